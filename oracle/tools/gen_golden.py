@@ -248,17 +248,17 @@ def gen_traj():
             for s, d in enumerate(spec["regs"][mode]):
                 dual = rng.uniform(size=shapes[mode])
                 arrays[f"dual_in_m{mode}_{s}"] = dual
-                dual_init = split_rows(dual, row_ptr) if mode == 1 else dual
+                dual_init = split_rows(dual, row_ptr) if mode == 1 else dual.copy()  # the reference mutates aux/dual inits in place
                 if d["kind"] == "parafac2":
                     P = pack_rows([np.eye(J, r) for _ in range(I)])
                     Delta = rng.uniform(size=(r, r))
                     arrays[f"aux_in_m{mode}_{s}_P"] = P
                     arrays[f"aux_in_m{mode}_{s}_Delta"] = Delta
-                    aux_init = (split_rows(P, row_ptr), Delta)
+                    aux_init = (split_rows(P, row_ptr), Delta.copy())
                 else:
                     aux = rng.uniform(size=shapes[mode])
                     arrays[f"aux_in_m{mode}_{s}"] = aux
-                    aux_init = split_rows(aux, row_ptr) if mode == 1 else aux
+                    aux_init = split_rows(aux, row_ptr) if mode == 1 else aux.copy()
                 regs[mode].append(make_ref_penalty(d, aux_init=aux_init, dual_init=dual_init))
         cmf, admm_vars, diag = ref_dec.cmf_aoadmm(
             matrices, r, init=(None, (A0.copy(), split_rows(B0, row_ptr), C0.copy())), regs=regs,
