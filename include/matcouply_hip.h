@@ -1,0 +1,132 @@
+/*
+ * matcouply_hip.h - C ABI of the MI355X-native AO-ADMM engine (libmatcouply_hip.so).
+ *
+ * The reference (MarieRoald/matcouply) is pure Python and has no FFI: its "operator interface" for the
+ * hot path is the set of Python functions in src/matcouply/decomposition.py.  Each entry point below
+ * replaces one of them; the Python front end `matcouply_amd` (and any other host)
+ * binds these symbols with ctypes.  Plain pointers and sizes only - no torch/NumPy types cross the ABI.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; mcl_last_error() gives the message;
+ *   - the caller owns EVERY buffer (data, factors, aux/dual variables, workspace); the library never
+ *     allocates device memory and never synchronises the stream, except where stated;
+ *   - all device work is enqueued on the HIP stream given to mcl_create();
+ *   - one context per (device, stream); a context is not thread-safe;
+ *   - all matrices are row-major fp32; the I coupled matrices X_i (J_i x K) and every B-mode variable are
+ *     PACKED along rows: X[sum J_i, K], B[sum J_i, r], slab i = rows row_ptr[i] .. row_ptr[i+1].
+ */
+#ifndef MATCOUPLY_HIP_H
+#define MATCOUPLY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mcl_context mcl_context;
+
+#define MCL_MAX_REGS 4   /* penalties per mode */
+#define MCL_MAX_RANK 64
+
+/* Proximal operators with a native kernel (reference: src/matcouply/penalties.py). */
+enum mcl_penalty_kind {
+    MCL_PEN_NN = 1,       /* NonNegativity   penalties.py:488-508  */
+    MCL_PEN_BOX = 2,      /* Box             penalties.py:511-542  */
+    MCL_PEN_L1 = 3,       /* L1Penalty       penalties.py:545-592  */
+    MCL_PEN_L2BALL = 4,   /* L2Ball          penalties.py:844-925  */
+    MCL_PEN_UNIMODAL = 5, /* Unimodality     penalties.py:983-1015 */
+    MCL_PEN_PARAFAC2 = 6, /* Parafac2        penalties.py:1018-1324 (mode 1 only) */
+    MCL_PEN_EXTERNAL = 7  /* user prox evaluated by the host between mcl_*_solve and mcl_*_dual */
+};
+
+typedef struct {
+    int32_t kind;           /* enum mcl_penalty_kind */
+    int32_t non_negativity; /* L1 / L2Ball / Unimodality: also clip at 0 */
+    double p0;              /* Box: min_val; L1: reg_strength; L2Ball: norm_bound */
+    double p1;              /* Box: max_val */
+    float *aux;             /* [rows, r] auxiliary variable; PARAFAC2: packed orthogonal bases P_i */
+    float *dual;            /* [rows, r] scaled dual variable */
+    float *aux2;            /* PARAFAC2: coordinate matrix Delta [r, r]; otherwise NULL */
+} mcl_penalty_desc;
+
+typedef struct {
+    double feasibility_penalty_scale; /* decomposition.py:678 */
+    double l2_penalty[3];             /* per mode; None -> 0 (decomposition.py:876-877) */
+    int32_t inner_n_iter_max;         /* decomposition.py:689 */
+    int32_t constant_A;               /* constant_feasibility_penalty for mode 0 (decomposition.py:937-939) */
+    int32_t constant_B;               /* ... for mode 1 (decomposition.py:940-942) */
+    int32_t reserved;
+} mcl_options;
+
+/* Layout of the fp64 vector written by mcl_diagnostics(). */
+#define MCL_DIAG_NORM_SQ 0     /* [3] ||A||^2, ||B||^2, ||C||^2 */
+#define MCL_DIAG_INNER 3       /* <X, M>  = sum_i rhs_i . a_i            (decomposition.py:448) */
+#define MCL_DIAG_MODEL_SQ 4    /* ||M||^2 = sum_i a_i^T Q_i a_i          (decomposition.py:449) */
+#define MCL_DIAG_X_SQ 5        /* ||X||^2 of this context's slabs        (decomposition.py:906) */
+#define MCL_DIAG_REG 8         /* + (mode*MCL_MAX_REGS + k)*2 : {||aux - factor||^2, sum |factor|} */
+#define MCL_DIAG_LEN (8 + 3 * MCL_MAX_REGS * 2)
+
+/* ---- life cycle ------------------------------------------------------------------------------------ */
+int mcl_create(mcl_context **out, int device, void *hip_stream);
+void mcl_destroy(mcl_context *ctx);
+const char *mcl_last_error(const mcl_context *ctx); /* ctx may be NULL: last mcl_create() failure */
+int mcl_version(void);
+
+/* ---- problem definition (replaces the `matrices`, `rank` arguments of cmf_aoadmm, decomposition.py:662) */
+/* X: device [row_ptr[I], K]; row_ptr: HOST int64[I+1], non-decreasing, row_ptr[0] = 0. */
+int mcl_set_problem(mcl_context *ctx, const float *X, const int64_t *row_ptr, int64_t I, int64_t K, int32_t rank);
+int mcl_set_options(mcl_context *ctx, const mcl_options *opt);
+/* Factors of the CMF (decomposition.py:133,235,307): A [I, r], B packed [sum J_i, r], C [K, r]; updated in place. */
+int mcl_set_factors(mcl_context *ctx, float *A, float *B, float *C);
+/* Penalty list of one mode, in the order of decomposition.py:571-612; descs are copied. */
+int mcl_set_penalties(mcl_context *ctx, int32_t mode, int32_t n, const mcl_penalty_desc *descs);
+/* Scratch memory: call after the four setters above; bytes needed for the current problem. */
+int64_t mcl_workspace_bytes(mcl_context *ctx);
+int mcl_set_workspace(mcl_context *ctx, void *workspace, int64_t bytes);
+
+/* ---- phase calls: one per reference function -------------------------------------------------------- */
+/* admm_update_B (decomposition.py:222-292) */
+int mcl_update_B(mcl_context *ctx);
+/* admm_update_C (decomposition.py:295-344), split at the cross-slab reduction so that a multi-GPU host can
+ * all-reduce the normal equations:  local -> [all-reduce over ranks of mcl_c_normal_equations()] -> finish. */
+int mcl_update_C_local(mcl_context *ctx);
+float *mcl_c_normal_equations(mcl_context *ctx, int64_t *count); /* device [G (r x r) | R (K x r)], fp32 */
+int mcl_update_C_finish(mcl_context *ctx);
+/* admm_update_A (decomposition.py:120-219); also leaves (rhses, cross_products) for the fast error formula. */
+int mcl_update_A(mcl_context *ctx);
+/* compute_feasibility_gaps + _cmf_reconstruction_error + penalty sums (decomposition.py:351-452, 916-921):
+ * writes MCL_DIAG_LEN fp64 partial sums of THIS context's slabs to device memory `out`.
+ * include_replicated = 0 leaves the C-mode entries (identical on every rank) at zero so that a SUM all-reduce
+ * over ranks is exact.  If no A-phase by-products are current, they are recomputed with a pass over X
+ * (decomposition.py:430-444). */
+int mcl_diagnostics(mcl_context *ctx, double *out, int32_t include_replicated);
+/* n outer iterations B -> C -> A on ONE device (decomposition.py:945-988); if diag_ring != NULL,
+ * MCL_DIAG_LEN doubles are appended per iteration (device memory, n * MCL_DIAG_LEN doubles). */
+int mcl_iterate(mcl_context *ctx, int32_t n_iter, int32_t update_A, int32_t update_B, int32_t update_C,
+                double *diag_ring);
+
+/* ---- step calls (constant feasibility penalty / PARAFAC2 / EXTERNAL penalties on several devices) ---- */
+/* B-phase prologue: CtC, rhs_i, rho_i; returns pointer to this rank's max rho (device fp32[1]) for a MAX all-reduce */
+int mcl_B_begin(mcl_context *ctx);
+float *mcl_B_rho_max(mcl_context *ctx);
+int mcl_B_factor(mcl_context *ctx);          /* build and invert the r x r systems (decomposition.py:252-256) */
+int mcl_B_solve(mcl_context *ctx);           /* one normal-equation solve (decomposition.py:266-273) */
+int mcl_B_prox_local(mcl_context *ctx, int32_t k);  /* prox of penalty k; PARAFAC2: bases + local Delta sums */
+float *mcl_B_prox_reduce_buffer(mcl_context *ctx, int32_t k, int64_t *count); /* PARAFAC2: [sum rho P^T Y | sum rho] */
+int mcl_B_prox_finish(mcl_context *ctx, int32_t k); /* PARAFAC2: Delta; all: dual update (decomposition.py:282-285) */
+int mcl_A_begin(mcl_context *ctx);           /* X C, rhs_i, Q_i, rho_i (decomposition.py:136-162) */
+float *mcl_A_rho_max(mcl_context *ctx);
+int mcl_A_finish(mcl_context *ctx);          /* systems, inner ADMM loop, by-products (decomposition.py:163-219) */
+
+/* ---- introspection for tests / profiling ------------------------------------------------------------- */
+/* device pointers to internal by-products: 0 rhses [I, r], 1 cross_products [I, r, r], 2 X C [sum J_i, r],
+ * 3 rho_B [I], 4 rho_A [I], 5 rho_C [1] */
+float *mcl_internal_buffer(mcl_context *ctx, int32_t which, int64_t *count);
+/* name of the dominant kernel variant chosen for the current problem (for bench.py's roofline block) */
+const char *mcl_kernel_variant(mcl_context *ctx, int32_t which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MATCOUPLY_HIP_H */

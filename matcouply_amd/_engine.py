@@ -1,0 +1,271 @@
+"""ctypes binding of libmatcouply_hip.so (the C ABI in include/matcouply_hip.h).
+
+PyTorch is used for plumbing only: device memory (`torch.empty(..., device="cuda")`), the current HIP stream
+and `torch.distributed`.  All arithmetic of the AO-ADMM hot path runs in the HIP library; there is NO CPU or
+eager-PyTorch fallback - if the library is missing or no MI355X is visible, construction raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmatcouply_hip.so")
+
+MCL_MAX_REGS = 4
+MCL_MAX_RANK = 64
+DIAG_NORM_SQ, DIAG_INNER, DIAG_MODEL_SQ, DIAG_X_SQ, DIAG_REG = 0, 3, 4, 5, 8
+DIAG_LEN = 8 + 3 * MCL_MAX_REGS * 2
+
+PEN_NN, PEN_BOX, PEN_L1, PEN_L2BALL, PEN_UNIMODAL, PEN_PARAFAC2, PEN_EXTERNAL = 1, 2, 3, 4, 5, 6, 7
+
+# every symbol include/matcouply_hip.h declares (checked by tests/test_cabi_symbols.py)
+EXPORTED_SYMBOLS = [
+    "mcl_create", "mcl_destroy", "mcl_last_error", "mcl_version", "mcl_set_problem", "mcl_set_options",
+    "mcl_set_factors", "mcl_set_penalties", "mcl_workspace_bytes", "mcl_set_workspace", "mcl_update_B",
+    "mcl_update_C_local", "mcl_c_normal_equations", "mcl_update_C_finish", "mcl_update_A", "mcl_diagnostics",
+    "mcl_iterate", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
+    "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
+    "mcl_internal_buffer", "mcl_kernel_variant",
+]
+
+
+class PenaltyDesc(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("non_negativity", ctypes.c_int32), ("p0", ctypes.c_double),
+                ("p1", ctypes.c_double), ("aux", ctypes.c_void_p), ("dual", ctypes.c_void_p),
+                ("aux2", ctypes.c_void_p)]
+
+
+class Options(ctypes.Structure):
+    _fields_ = [("feasibility_penalty_scale", ctypes.c_double), ("l2_penalty", ctypes.c_double * 3),
+                ("inner_n_iter_max", ctypes.c_int32), ("constant_A", ctypes.c_int32), ("constant_B", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libmatcouply_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP engine has not been built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `python matcouply_amd/_build.py`). matcouply_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    P, I32, I64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    sig = {
+        "mcl_create": (ctypes.c_int, [ctypes.POINTER(P), ctypes.c_int, P]),
+        "mcl_destroy": (None, [P]),
+        "mcl_last_error": (ctypes.c_char_p, [P]),
+        "mcl_version": (ctypes.c_int, []),
+        "mcl_set_problem": (ctypes.c_int, [P, P, ctypes.POINTER(I64), I64, I64, I32]),
+        "mcl_set_options": (ctypes.c_int, [P, ctypes.POINTER(Options)]),
+        "mcl_set_factors": (ctypes.c_int, [P, P, P, P]),
+        "mcl_set_penalties": (ctypes.c_int, [P, I32, I32, ctypes.POINTER(PenaltyDesc)]),
+        "mcl_workspace_bytes": (I64, [P]),
+        "mcl_set_workspace": (ctypes.c_int, [P, P, I64]),
+        "mcl_update_B": (ctypes.c_int, [P]),
+        "mcl_update_C_local": (ctypes.c_int, [P]),
+        "mcl_c_normal_equations": (P, [P, ctypes.POINTER(I64)]),
+        "mcl_update_C_finish": (ctypes.c_int, [P]),
+        "mcl_update_A": (ctypes.c_int, [P]),
+        "mcl_diagnostics": (ctypes.c_int, [P, P, I32]),
+        "mcl_iterate": (ctypes.c_int, [P, I32, I32, I32, I32, P]),
+        "mcl_B_begin": (ctypes.c_int, [P]),
+        "mcl_B_rho_max": (P, [P]),
+        "mcl_B_factor": (ctypes.c_int, [P]),
+        "mcl_B_solve": (ctypes.c_int, [P]),
+        "mcl_B_prox_local": (ctypes.c_int, [P, I32]),
+        "mcl_B_prox_reduce_buffer": (P, [P, I32, ctypes.POINTER(I64)]),
+        "mcl_B_prox_finish": (ctypes.c_int, [P, I32]),
+        "mcl_A_begin": (ctypes.c_int, [P]),
+        "mcl_A_rho_max": (P, [P]),
+        "mcl_A_finish": (ctypes.c_int, [P]),
+        "mcl_internal_buffer": (P, [P, I32, ctypes.POINTER(I64)]),
+        "mcl_kernel_variant": (ctypes.c_char_p, [P, I32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class NativeReg:
+    """One penalty as the engine sees it: kind + parameters + device tensors of its ADMM variables."""
+
+    def __init__(self, kind, aux, dual, aux2=None, non_negativity=False, p0=0.0, p1=0.0):
+        self.kind, self.aux, self.dual, self.aux2 = kind, aux, dual, aux2
+        self.non_negativity, self.p0, self.p1 = bool(non_negativity), float(p0), float(p1)
+
+
+class HipEngine:
+    """Owns one `mcl_context` bound to torch's current HIP stream on `device`.
+
+    X: float32 CUDA tensor [sum J_i, K] (packed slabs), row_ptr: int64 array [I+1],
+    A/B/C: float32 CUDA tensors (updated in place), regs: [[NativeReg]*n0, [..]*n1, [..]*n2].
+    """
+
+    def __init__(self, X, row_ptr, rank, A, B, C, regs, l2_penalty=(0.0, 0.0, 0.0), inner_n_iter_max=5,
+                 feasibility_penalty_scale=1.0, constant_A=False, constant_B=False):
+        import torch
+
+        self._torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise EngineError("no HIP device visible: matcouply_amd needs an MI355X (gfx950); there is no CPU fallback")
+        for name, t in (("X", X), ("A", A), ("B", B), ("C", C)):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise EngineError(f"{name} must be a contiguous float32 CUDA tensor")
+        self.device = X.device
+        self.X, self.A, self.B, self.C = X, A, B, C
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        self.I, self.K, self.N, self.r = len(self.row_ptr) - 1, int(X.shape[1]), int(X.shape[0]), int(rank)
+        if A.shape != (self.I, self.r) or B.shape != (self.N, self.r) or C.shape != (self.K, self.r):
+            raise EngineError("factor shapes do not match the problem")
+        self.regs = regs
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self.lib.mcl_create(ctypes.byref(self._h), self.device.index or 0, ctypes.c_void_p(stream))
+        if rc != 0:
+            raise EngineError(self.lib.mcl_last_error(None).decode())
+        self._check(self.lib.mcl_set_problem(self._h, X.data_ptr(), self.row_ptr.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                             self.I, self.K, self.r))
+        opt = Options()
+        opt.feasibility_penalty_scale = float(feasibility_penalty_scale)
+        for m in range(3):
+            opt.l2_penalty[m] = float(l2_penalty[m] or 0.0)
+        opt.inner_n_iter_max = int(inner_n_iter_max)
+        opt.constant_A, opt.constant_B = int(bool(constant_A)), int(bool(constant_B))
+        self._check(self.lib.mcl_set_options(self._h, ctypes.byref(opt)))
+        self._check(self.lib.mcl_set_factors(self._h, A.data_ptr(), B.data_ptr(), C.data_ptr()))
+        for mode in range(3):
+            n = len(regs[mode])
+            arr = (PenaltyDesc * max(n, 1))()
+            for k, reg in enumerate(regs[mode]):
+                for t in (reg.aux, reg.dual) + ((reg.aux2,) if reg.aux2 is not None else ()):
+                    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                        raise EngineError("aux/dual variables must be contiguous float32 CUDA tensors")
+                arr[k].kind, arr[k].non_negativity = reg.kind, int(reg.non_negativity)
+                arr[k].p0, arr[k].p1 = reg.p0, reg.p1
+                arr[k].aux, arr[k].dual = reg.aux.data_ptr(), reg.dual.data_ptr()
+                arr[k].aux2 = reg.aux2.data_ptr() if reg.aux2 is not None else None
+            self._check(self.lib.mcl_set_penalties(self._h, mode, n, arr))
+        nbytes = self.lib.mcl_workspace_bytes(self._h)
+        if nbytes < 0:
+            raise EngineError("mcl_workspace_bytes failed")
+        self.workspace = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.device)
+        self._ws_off = (-self.workspace.data_ptr()) % 256
+        self._check(self.lib.mcl_set_workspace(self._h, self.workspace.data_ptr() + self._ws_off, nbytes))
+
+    # -- plumbing -----------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(self.lib.mcl_last_error(self._h).decode())
+
+    def _view(self, ptr, count, dtype):
+        """torch view of `count` elements at device address `ptr` inside the workspace."""
+        torch = self._torch
+        off = ptr - self.workspace.data_ptr()
+        nb = count * torch.empty(0, dtype=dtype).element_size()
+        assert 0 <= off and off + nb <= self.workspace.numel()
+        return self.workspace[off : off + nb].view(dtype)
+
+    def close(self):
+        if self._h:
+            self.lib.mcl_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- phases ---------------------------------------------------------------------------------------
+    def update_B(self):
+        self._check(self.lib.mcl_update_B(self._h))
+
+    def update_C_local(self):
+        """Returns the fp32 device tensor [G | R] (r*r + K*r) to be all-reduced over ranks."""
+        self._check(self.lib.mcl_update_C_local(self._h))
+        return self.c_normal_equations()
+
+    def c_normal_equations(self):
+        n = ctypes.c_int64()
+        p = self.lib.mcl_c_normal_equations(self._h, ctypes.byref(n))
+        return self._view(p, n.value, self._torch.float32)
+
+    def update_C_finish(self):
+        self._check(self.lib.mcl_update_C_finish(self._h))
+
+    def update_A(self):
+        self._check(self.lib.mcl_update_A(self._h))
+
+    def diagnostics(self, include_replicated=True, out=None):
+        torch = self._torch
+        if out is None:
+            out = torch.empty(DIAG_LEN, dtype=torch.float64, device=self.device)
+        self._check(self.lib.mcl_diagnostics(self._h, out.data_ptr(), int(include_replicated)))
+        return out
+
+    def iterate(self, n_iter, update_A=True, update_B=True, update_C=True, diag_ring=None):
+        ptr = diag_ring.data_ptr() if diag_ring is not None else None
+        self._check(self.lib.mcl_iterate(self._h, int(n_iter), int(update_A), int(update_B), int(update_C), ptr))
+
+    # -- step calls -----------------------------------------------------------------------------------
+    def B_begin(self):
+        self._check(self.lib.mcl_B_begin(self._h))
+
+    def B_rho_max(self):
+        return self._view(self.lib.mcl_B_rho_max(self._h), 1, self._torch.float32)
+
+    def B_factor(self):
+        self._check(self.lib.mcl_B_factor(self._h))
+
+    def B_solve(self):
+        self._check(self.lib.mcl_B_solve(self._h))
+
+    def B_prox_local(self, k):
+        self._check(self.lib.mcl_B_prox_local(self._h, k))
+
+    def B_prox_reduce_buffer(self, k):
+        n = ctypes.c_int64()
+        p = self.lib.mcl_B_prox_reduce_buffer(self._h, k, ctypes.byref(n))
+        return None if not p else self._view(p, n.value, self._torch.float32)
+
+    def B_prox_finish(self, k):
+        self._check(self.lib.mcl_B_prox_finish(self._h, k))
+
+    def A_begin(self):
+        self._check(self.lib.mcl_A_begin(self._h))
+
+    def A_rho_max(self):
+        return self._view(self.lib.mcl_A_rho_max(self._h), 1, self._torch.float32)
+
+    def A_finish(self):
+        self._check(self.lib.mcl_A_finish(self._h))
+
+    # -- introspection ------------------------------------------------------------------------------------
+    def internal(self, which):
+        n = ctypes.c_int64()
+        p = self.lib.mcl_internal_buffer(self._h, which, ctypes.byref(n))
+        return self._view(p, n.value, self._torch.float32)
+
+    def rhses(self):
+        return self.internal(0).view(self.I, self.r)
+
+    def cross_products(self):
+        return self.internal(1).view(self.I, self.r, self.r)
+
+    def kernel_variant(self, which):
+        return self.lib.mcl_kernel_variant(self._h, which).decode()

@@ -1,0 +1,176 @@
+"""Coupled-matrix-factorization container and dense converters.
+
+Mirrors /root/reference/src/matcouply/coupled_matrices.py: `CoupledMatrixFactorization` (:8-240), `_validate_cmf`
+(:243-362), `cmf_to_matrix` / `cmf_to_matrices` / `cmf_to_tensor` / `cmf_to_unfolded` / `cmf_to_vec` (:365-799).
+Factors may be NumPy arrays or torch tensors (host or MI355X memory)."""
+import numpy as np
+
+from ._utils import is_tensor, is_torch, shape
+
+
+class CoupledMatrixFactorization:
+    """(weights, (A, [B_0, ..., B_{I-1}], C)); matrix i is B_i diag(weights * a_i) C^T.  Behaves like a 2-tuple."""
+
+    def __init__(self, cmf_matrices):
+        self.shape, self.rank = _validate_cmf(cmf_matrices)
+        weights, factors = cmf_matrices
+        self.weights = weights
+        self.factors = factors
+
+    def __getitem__(self, item):
+        if item == 0:
+            return self.weights
+        elif item == 1:
+            return self.factors
+        raise IndexError(
+            "You tried to access index {} of a coupled matrix factorization.\n"
+            "You can only access index 0 and 1 of a coupled matrix factorization"
+            "(corresponding respectively to the weights and factors)".format(item)
+        )
+
+    def __iter__(self):
+        yield self.weights
+        yield self.factors
+
+    def __len__(self):
+        return 2
+
+    def __repr__(self):
+        return "(weights, factors) : rank-{} CoupledMatrixFactorization of shape {}".format(self.rank, self.shape)
+
+    def to_tensor(self):
+        return cmf_to_tensor(self)
+
+    def to_vec(self, pad=True):
+        return cmf_to_vec(self, pad=pad)
+
+    def to_unfolded(self, mode, pad=True):
+        return cmf_to_unfolded(self, mode, pad=pad)
+
+    def to_matrices(self):
+        return cmf_to_matrices(self)
+
+    def to_matrix(self, matrix_idx):
+        return cmf_to_matrix(self, matrix_idx)
+
+
+def _validate_cmf(cmf):
+    """Returns (shapes, rank) or raises TypeError / ValueError with the reference's conditions (:296-362)."""
+    if isinstance(cmf, CoupledMatrixFactorization):
+        return cmf.shape, cmf.rank
+    weights, (A, B_is, C) = cmf
+    if not (is_tensor(weights) or weights is None):
+        raise TypeError("Weights should be a first order tensor of length rank, not {}".format(type(weights)))
+    elif weights is not None and len(shape(weights)) != 1:
+        raise ValueError("Weights should be a first order tensor. However weights has shape {}".format(shape(weights)))
+    if not is_tensor(A):
+        raise TypeError(
+            "The first factor matrix, A, should be a second order tensor of size (I, rank)), not {}".format(type(A)))
+    elif len(shape(A)) != 2:
+        raise ValueError(
+            "The first factor matrix, A, should be a second order tensor. However A has shape {}".format(shape(A)))
+    if not is_tensor(C):
+        raise TypeError(
+            "The last factor matrix, C, should be a second order tensor of size (K, rank)), not {}".format(type(C)))
+    elif len(shape(C)) != 2:
+        raise ValueError(
+            "The last factor matrix, C, should be a second order tensor. However C has shape {}".format(shape(C)))
+    rank = int(shape(A)[1])
+    if shape(C)[1] != rank:
+        raise ValueError(
+            "All the factors of a coupled matrix factorization should have the same number of columns."
+            "However, A.shape[1]={} but C.shape[1]={}.".format(rank, shape(C)[1]))
+    shapes = []
+    for i, B_i in enumerate(B_is):
+        if not is_tensor(B_i):
+            raise TypeError(
+                "The B_is[{}] factor matrix should be second order tensor of size (J_i, rank)), not {}".format(i, type(B_i)))
+        elif len(shape(B_i)) != 2:
+            raise ValueError(
+                "The B_is[{}] factor matrix should be second order tensor. However B_is[{}] has shape {}".format(
+                    i, i, shape(B_i)))
+        if shape(B_i)[1] != rank:
+            raise ValueError(
+                "All the factors of a coupled matrix factorization should have the same number of columns."
+                "However, A.shape[1]={} but B_is[{}].shape[1]={}.".format(rank, i, shape(B_i)[1]))
+        shapes.append((shape(B_i)[0], shape(C)[0]))
+    if weights is not None and shape(weights)[0] != rank:
+        raise ValueError(
+            "Given factors for a rank-{} coupled matrix factorization but len(weights)={}.".format(rank, shape(weights)[0]))
+    if shape(A)[0] != len(B_is):
+        raise ValueError(
+            "The number of rows in A should be the same as the number of B_i matrices"
+            "However, tl.shape(A)[0]={}, but len(B_is)={}".format(shape(A)[0], len(B_is)))
+    return tuple(shapes), rank
+
+
+def cmf_to_matrix(cmf, matrix_idx, validate=True):
+    """Dense matrix i: (B_i * a_i) C^T (:365-423)."""
+    if validate:
+        cmf = CoupledMatrixFactorization(cmf)
+    weights, (A, B_is, C) = cmf
+    a = A[matrix_idx]
+    if weights is not None:
+        a = a * weights
+    B_i = B_is[matrix_idx]
+    Ct = C.T if not is_torch(C) else C.t()
+    return (B_i * a) @ Ct
+
+
+def cmf_to_slice(cmf, slice_idx, validate=True):
+    return cmf_to_matrix(cmf, slice_idx, validate=validate)
+
+
+def cmf_to_matrices(cmf, validate=True):
+    """List of all dense matrices (:446-497)."""
+    if validate:
+        cmf = CoupledMatrixFactorization(cmf)
+    weights, (A, B_is, C) = cmf
+    if weights is not None:
+        A = A * weights
+        weights = None
+    decomposition = weights, (A, B_is, C)
+    return [cmf_to_matrix(decomposition, i, validate=False) for i in range(len(B_is))]
+
+
+def cmf_to_slices(cmf, validate=True):
+    return cmf_to_matrices(cmf, validate=validate)
+
+
+def cmf_to_tensor(cmf, validate=True):
+    """Zero-padded third-order tensor of the matrices (:520-600)."""
+    if validate:
+        cmf = CoupledMatrixFactorization(cmf)
+    _, (A, B_is, C) = cmf
+    matrices = cmf_to_matrices(cmf, validate=False)
+    lengths = [B_i.shape[0] for B_i in B_is]
+    if is_torch(C):
+        tensor = C.new_zeros((A.shape[0], max(lengths), C.shape[0]))
+    else:
+        tensor = np.zeros((A.shape[0], max(lengths), C.shape[0]), dtype=matrices[0].dtype)
+    for i, (matrix_, length) in enumerate(zip(matrices, lengths)):
+        tensor[i, :length] = matrix_
+    return tensor
+
+
+def cmf_to_unfolded(cmf, mode, pad=True, validate=True):
+    """:603-720"""
+    if pad:
+        t = cmf_to_tensor(cmf, validate=validate)
+        moved = t.movedim(mode, 0) if is_torch(t) else np.moveaxis(t, mode, 0)
+        return moved.reshape(t.shape[mode], -1)
+    if mode == 2:
+        mats = cmf_to_matrices(cmf, validate=validate)
+        cat = __import__("torch").cat(mats, 0).t() if is_torch(mats[0]) else np.concatenate(mats, axis=0).T
+        return cat
+    raise ValueError(f"Cannot unfold along mode {mode} without padding. ")
+
+
+def cmf_to_vec(cmf, pad=True, validate=True):
+    """:723-799"""
+    if pad:
+        return cmf_to_tensor(cmf, validate=validate).reshape(-1)
+    mats = cmf_to_matrices(cmf, validate=validate)
+    if is_torch(mats[0]):
+        return __import__("torch").cat([m.reshape(-1) for m in mats])
+    return np.concatenate([m.reshape(-1) for m in mats])

@@ -1,0 +1,530 @@
+// C ABI of libmatcouply_hip.so: context, workspace carve-up and the orchestration of the kernels per phase.
+// One function per reference entry point (see include/matcouply_hip.h for the file:line each one replaces).
+#include <algorithm>
+#include <cstring>
+
+#include "mcl_internal.h"
+
+int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k);   // generic.hip
+int mcl_launch_generic_prox_finish(mcl_context *c, int mode, int k);  // generic.hip
+int mcl_rows_fused_dispatch(mcl_context *c, int mode, double *diag);  // admm.hip
+
+static std::string g_create_error;
+
+namespace {
+
+struct Bump {
+    char *base;
+    int64_t off = 0;
+    template <typename T>
+    T *take(int64_t count) {
+        off = (off + 255) & ~int64_t(255);
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += (int64_t)sizeof(T) * std::max<int64_t>(count, 1);
+        return p;
+    }
+};
+
+bool has_kind(const mcl_context *c, int kind) {
+    for (int m = 0; m < 3; ++m)
+        for (int k = 0; k < c->regs[m].n; ++k)
+            if (c->regs[m].kind[k] == kind) return true;
+    return false;
+}
+
+int xc_chunks(const mcl_context *c) {
+    int kc = (int)((c->K + 63) / 64);
+    if (kc & 1) kc += 1;
+    return kc;
+}
+
+// Assign every workspace pointer; returns the number of bytes needed.
+int64_t plan(mcl_context *c, char *base) {
+    Bump b{base};
+    const int64_t I = c->I, K = c->K, N = c->N, r = c->r;
+    const int64_t E = K * r + r * r;
+    c->slab_of_row = b.take<int>(N);
+    c->row_ptr_dev = b.take<int>(I + 1);
+    auto tm = [&](TileMap &t, size_t n) {
+        t.n_tiles = (int)n;
+        t.slab = b.take<int>((int64_t)n);
+        t.row0 = b.take<int>((int64_t)n);
+        t.nrows = b.take<int>((int64_t)n);
+    };
+    tm(c->tilesB, c->h_tile_slab.size());
+    tm(c->tilesC, c->h_ctile_slab.size());
+    tm(c->tilesA, c->h_atile_slab.size());
+    c->ext_A = b.take<int>(2);
+    c->ext_C = b.take<int>(2);
+    c->XC = b.take<float>(N * r);
+    c->Cfrag = b.take<float>((int64_t)xc_chunks(c) * 4 * c->NB * 256);
+    c->CtC = b.take<float>(r * r);
+    c->rhoB = b.take<float>(I);
+    c->LinvB = b.take<float>(I * r * r);
+    c->rho_max = b.take<float>(2);
+    c->partials = b.take<float>((int64_t)mcl_contract_n_partials(c) * E);
+    c->GR = b.take<float>(E);
+    c->rhoC = b.take<float>(1);
+    c->LinvC = b.take<float>(r * r);
+    c->rhsA = b.take<float>(I * r);
+    c->BtB = b.take<float>(I * r * r);
+    c->rhoA = b.take<float>(I);
+    c->LinvA = b.take<float>(I * r * r);
+    c->e1 = b.take<double>(2 * I);
+    c->diagA_row = b.take<double>(I * DIAG_COLS);
+    c->diagA_tile = b.take<double>((int64_t)c->tilesA.n_tiles * DIAG_COLS);
+    c->diagB_tile = b.take<double>((int64_t)c->tilesB.n_tiles * DIAG_COLS);
+    c->diagC_tile = b.take<double>((int64_t)c->tilesC.n_tiles * DIAG_COLS);
+    c->diag_sums = b.take<double>(3 * DIAG_COLS + 2);
+    c->xsq_part = b.take<double>(1024);
+    c->x_sq = b.take<double>(1);
+    // generic (non row-separable) path scratch
+    const int64_t maxrows = std::max<int64_t>(N, std::max<int64_t>(I, K));
+    c->colsq = b.take<double>(std::max<int64_t>(I, 1) * r);
+    if (has_kind(c, MCL_PEN_UNIMODAL)) {
+        c->uni_f64 = b.take<double>(8 * (maxrows + std::max<int64_t>(I, 1)) * r);
+        c->uni_i32 = b.take<int>(2 * maxrows * r);
+    } else {
+        c->uni_f64 = nullptr;
+        c->uni_i32 = nullptr;
+    }
+    if (has_kind(c, MCL_PEN_PARAFAC2)) {
+        c->pf2_S = b.take<double>(I * r * r);
+        c->pf2_T = b.take<float>(I * r * r);
+        c->pf2_acc = b.take<double>(I * (r * r + 1));
+        c->pf2_red = b.take<float>(r * r + 1);
+    } else {
+        c->pf2_S = nullptr, c->pf2_T = nullptr, c->pf2_acc = nullptr, c->pf2_red = nullptr;
+    }
+    return (b.off + 255) & ~int64_t(255);
+}
+
+int fail(mcl_context *c, const std::string &msg) {
+    c->err = msg;
+    return 1;
+}
+
+int ready(mcl_context *c) {
+    if (!c->has_problem) return fail(c, "mcl_set_problem has not been called");
+    if (!c->has_factors) return fail(c, "mcl_set_factors has not been called");
+    if (!c->has_workspace) return fail(c, "mcl_set_workspace has not been called");
+    return 0;
+}
+
+int ensure_ctc(mcl_context *c) {
+    if (!c->ctc_valid) {
+        if (int rc = mcl_launch_ctc(c)) return rc;
+        c->ctc_valid = true;
+    }
+    return 0;
+}
+
+int ensure_xc(mcl_context *c) {
+    if (!c->xc_valid) {
+        if (int rc = mcl_launch_build_cfrag(c)) return rc;
+        if (int rc = mcl_launch_contract_xc(c)) return rc;
+        c->xc_valid = true;
+    }
+    return 0;
+}
+
+// generic inner loop of mode m: solve, then per penalty prox (+ reduction) and dual update
+int generic_inner_loop(mcl_context *c, int mode) {
+    const int n_it = (c->regs[mode].n == 0) ? std::min(1, (int)c->opt.inner_n_iter_max) : c->opt.inner_n_iter_max;
+    for (int it = 0; it < n_it; ++it) {
+        if (mode == 0) {
+            if (int rc = mcl_launch_A_rows_solve(c)) return rc;
+        } else {
+            if (int rc = mcl_launch_rows_solve(c, mode)) return rc;
+        }
+        for (int k = 0; k < c->regs[mode].n; ++k) {
+            if (int rc = mcl_launch_generic_prox_local(c, mode, k)) return rc;
+            if (int rc = mcl_launch_generic_prox_finish(c, mode, k)) return rc;
+        }
+    }
+    c->diag_valid[mode] = false;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcl_version(void) { return 100; }
+
+const char *mcl_last_error(const mcl_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mcl_create(mcl_context **out, int device, void *hip_stream) {
+    if (!out) return 1;
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        return 1;
+    }
+    if (device < 0 || device >= n_dev) {
+        g_create_error = "device index out of range";
+        return 1;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return 1;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("libmatcouply_hip is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName;
+        return 1;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return 1;
+    }
+    mcl_context *c = new mcl_context();
+    c->device = device;
+    c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    c->opt.feasibility_penalty_scale = 1.0;
+    c->opt.inner_n_iter_max = 5;
+    *out = c;
+    return 0;
+}
+
+void mcl_destroy(mcl_context *ctx) { delete ctx; }
+
+int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int64_t I, int64_t K, int32_t rank) {
+    if (!c) return 1;
+    if (I < 0 || K < 1) return fail(c, "mcl_set_problem: need I >= 0 and K >= 1");
+    if (rank < 1 || rank > MCL_MAX_RANK) return fail(c, "mcl_set_problem: rank must be in [1, 64]");
+    if (!row_ptr || row_ptr[0] != 0) return fail(c, "mcl_set_problem: row_ptr[0] must be 0");
+    for (int64_t i = 0; i < I; ++i)
+        if (row_ptr[i + 1] < row_ptr[i]) return fail(c, "mcl_set_problem: row_ptr must be non-decreasing");
+    const int64_t N = row_ptr[I];
+    if (N >= (int64_t(1) << 31) - 64) return fail(c, "mcl_set_problem: more than 2^31 packed rows are not supported");
+    if (N > 0 && !X) return fail(c, "mcl_set_problem: X is NULL");
+    c->X = X;
+    c->row_ptr.assign(row_ptr, row_ptr + I + 1);
+    c->I = I, c->K = K, c->N = N, c->r = rank;
+    c->RP = mcl_pad_rank(rank);
+    c->NB = (rank + 15) / 16;
+    if (c->NB == 3) c->NB = 4;
+    c->h_slab_of_row.resize((size_t)N);
+    c->h_tile_slab.clear(), c->h_tile_row0.clear(), c->h_tile_nrows.clear();
+    for (int64_t i = 0; i < I; ++i) {
+        for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; ++j) c->h_slab_of_row[(size_t)j] = (int)i;
+        for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; j += 64) {
+            c->h_tile_slab.push_back((int)i);
+            c->h_tile_row0.push_back((int)j);
+            c->h_tile_nrows.push_back((int)std::min<int64_t>(64, row_ptr[i + 1] - j));
+        }
+    }
+    auto single = [](int64_t rows, std::vector<int> &s, std::vector<int> &r0, std::vector<int> &nr) {
+        s.clear(), r0.clear(), nr.clear();
+        for (int64_t j = 0; j < rows; j += 64) {
+            s.push_back(0);
+            r0.push_back((int)j);
+            nr.push_back((int)std::min<int64_t>(64, rows - j));
+        }
+    };
+    single(K, c->h_ctile_slab, c->h_ctile_row0, c->h_ctile_nrows);
+    single(I, c->h_atile_slab, c->h_atile_row0, c->h_atile_nrows);
+    c->has_problem = true;
+    c->has_workspace = false;
+    c->xc_valid = c->ctc_valid = c->e1_valid = c->xsq_valid = false;
+    c->diag_valid[0] = c->diag_valid[1] = c->diag_valid[2] = false;
+    return 0;
+}
+
+int mcl_set_options(mcl_context *c, const mcl_options *opt) {
+    if (!c || !opt) return 1;
+    if (opt->inner_n_iter_max < 0) return fail(c, "mcl_set_options: inner_n_iter_max must be >= 0");
+    c->opt = *opt;
+    return 0;
+}
+
+int mcl_set_factors(mcl_context *c, float *A, float *B, float *C) {
+    if (!c) return 1;
+    if (!c->has_problem) return fail(c, "mcl_set_factors: call mcl_set_problem first");
+    if ((c->I > 0 && !A) || (c->N > 0 && !B) || !C) return fail(c, "mcl_set_factors: NULL factor pointer");
+    c->A = A, c->B = B, c->C = C;
+    c->has_factors = true;
+    c->xc_valid = c->ctc_valid = c->e1_valid = false;
+    c->diag_valid[0] = c->diag_valid[1] = c->diag_valid[2] = false;
+    return 0;
+}
+
+int mcl_set_penalties(mcl_context *c, int32_t mode, int32_t n, const mcl_penalty_desc *descs) {
+    if (!c) return 1;
+    if (mode < 0 || mode > 2) return fail(c, "mcl_set_penalties: mode must be 0, 1 or 2");
+    if (n < 0 || n > MCL_MAX_REGS) return fail(c, "mcl_set_penalties: at most 4 penalties per mode");
+    RegSet rs{};
+    rs.n = n;
+    for (int k = 0; k < n; ++k) {
+        const mcl_penalty_desc &d = descs[k];
+        if (d.kind < MCL_PEN_NN || d.kind > MCL_PEN_EXTERNAL) return fail(c, "mcl_set_penalties: unknown penalty kind");
+        if (d.kind == MCL_PEN_PARAFAC2 && mode != 1)
+            return fail(c, "mcl_set_penalties: PARAFAC2 constraint can only be imposed with mode=1");
+        if (d.kind == MCL_PEN_PARAFAC2 && !d.aux2) return fail(c, "mcl_set_penalties: PARAFAC2 needs the coordinate matrix");
+        if (d.kind == MCL_PEN_L1 && d.p0 < 0) return fail(c, "mcl_set_penalties: L1 strength must be non-negative");
+        if (d.kind == MCL_PEN_L2BALL && d.p0 <= 0) return fail(c, "mcl_set_penalties: L2 ball bound must be positive");
+        if (!d.aux || !d.dual) return fail(c, "mcl_set_penalties: NULL aux/dual pointer");
+        rs.kind[k] = d.kind;
+        rs.nonneg[k] = d.non_negativity;
+        rs.p0[k] = (float)d.p0;
+        rs.p1[k] = (float)d.p1;
+        rs.aux[k] = d.aux;
+        rs.dual[k] = d.dual;
+        rs.aux2[k] = d.aux2;
+    }
+    c->regs[mode] = rs;
+    c->has_workspace = false;  // scratch requirements may have changed
+    c->diag_valid[mode] = false;
+    c->e1_valid = false;
+    return 0;
+}
+
+int64_t mcl_workspace_bytes(mcl_context *c) {
+    if (!c || !c->has_problem) return -1;
+    return plan(c, nullptr);
+}
+
+int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
+    if (!c) return 1;
+    if (!c->has_problem) return fail(c, "mcl_set_workspace: call mcl_set_problem first");
+    const int64_t need = plan(c, nullptr);
+    if (!workspace || bytes < need) return fail(c, "mcl_set_workspace: workspace too small");
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(c, "mcl_set_workspace: workspace must be 256-byte aligned");
+    c->ws = static_cast<char *>(workspace);
+    c->ws_bytes = bytes;
+    plan(c, c->ws);
+    hipStream_t s = c->stream;
+    MCL_CHECK_HIP(c, hipMemsetAsync(c->ws, 0, (size_t)need, s));
+    auto up = [&](int *dst, const std::vector<int> &src) -> hipError_t {
+        if (src.empty()) return hipSuccess;
+        return hipMemcpyAsync(dst, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice, s);
+    };
+    MCL_CHECK_HIP(c, up(c->slab_of_row, c->h_slab_of_row));
+    c->h_row_ptr32.assign(c->row_ptr.begin(), c->row_ptr.end());
+    MCL_CHECK_HIP(c, up(c->row_ptr_dev, c->h_row_ptr32));
+    MCL_CHECK_HIP(c, up(c->tilesB.slab, c->h_tile_slab));
+    MCL_CHECK_HIP(c, up(c->tilesB.row0, c->h_tile_row0));
+    MCL_CHECK_HIP(c, up(c->tilesB.nrows, c->h_tile_nrows));
+    MCL_CHECK_HIP(c, up(c->tilesC.slab, c->h_ctile_slab));
+    MCL_CHECK_HIP(c, up(c->tilesC.row0, c->h_ctile_row0));
+    MCL_CHECK_HIP(c, up(c->tilesC.nrows, c->h_ctile_nrows));
+    MCL_CHECK_HIP(c, up(c->tilesA.slab, c->h_atile_slab));
+    MCL_CHECK_HIP(c, up(c->tilesA.row0, c->h_atile_row0));
+    MCL_CHECK_HIP(c, up(c->tilesA.nrows, c->h_atile_nrows));
+    c->h_ext = {0, (int)c->I, 0, (int)c->K};
+    MCL_CHECK_HIP(c, hipMemcpyAsync(c->ext_A, c->h_ext.data(), 2 * sizeof(int), hipMemcpyHostToDevice, s));
+    MCL_CHECK_HIP(c, hipMemcpyAsync(c->ext_C, c->h_ext.data() + 2, 2 * sizeof(int), hipMemcpyHostToDevice, s));
+    // the host vectors must outlive the async copies: they are members of the context
+    c->has_workspace = true;
+    c->xc_valid = c->ctc_valid = c->e1_valid = c->xsq_valid = false;
+    c->diag_valid[0] = c->diag_valid[1] = c->diag_valid[2] = false;
+    return 0;
+}
+
+// ---- B-phase -------------------------------------------------------------------------------------------
+int mcl_B_begin(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    if (int rc = ensure_ctc(c)) return rc;
+    if (int rc = ensure_xc(c)) return rc;
+    if (c->opt.constant_B)
+        if (int rc = mcl_launch_B_rho(c)) return rc;
+    return 0;
+}
+
+float *mcl_B_rho_max(mcl_context *c) { return c ? c->rho_max : nullptr; }
+
+int mcl_B_factor(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    return mcl_launch_B_systems(c);
+}
+
+int mcl_B_solve(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    c->e1_valid = false;
+    c->diag_valid[1] = false;
+    return mcl_launch_rows_solve(c, 1);
+}
+
+int mcl_B_prox_local(mcl_context *c, int32_t k) {
+    if (int rc = ready(c)) return rc;
+    if (k < 0 || k >= c->regs[1].n) return fail(c, "mcl_B_prox_local: penalty index out of range");
+    return mcl_launch_generic_prox_local(c, 1, k);
+}
+
+float *mcl_B_prox_reduce_buffer(mcl_context *c, int32_t k, int64_t *count) {
+    if (!c || k < 0 || k >= c->regs[1].n || c->regs[1].kind[k] != MCL_PEN_PARAFAC2) {
+        if (count) *count = 0;
+        return nullptr;
+    }
+    if (count) *count = (int64_t)c->r * c->r + 1;
+    return c->pf2_red;
+}
+
+int mcl_B_prox_finish(mcl_context *c, int32_t k) {
+    if (int rc = ready(c)) return rc;
+    if (k < 0 || k >= c->regs[1].n) return fail(c, "mcl_B_prox_finish: penalty index out of range");
+    return mcl_launch_generic_prox_finish(c, 1, k);
+}
+
+int mcl_update_B(mcl_context *c) {
+    if (int rc = mcl_B_begin(c)) return rc;
+    if (int rc = mcl_B_factor(c)) return rc;
+    c->e1_valid = false;
+    if (c->opt.inner_n_iter_max <= 0) return 0;
+    if (mcl_mode_is_row_separable(c, 1)) {
+        const int rc = mcl_launch_rows_fused(c, 1);
+        if (rc == 0) {
+            c->diag_valid[1] = true;
+            return 0;
+        }
+        if (rc > 0) return rc;
+    }
+    return generic_inner_loop(c, 1);
+}
+
+// ---- C-phase -------------------------------------------------------------------------------------------
+int mcl_update_C_local(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    if (int rc = mcl_launch_contract_xt(c)) return rc;
+    return mcl_launch_reduce_partials(c);
+}
+
+float *mcl_c_normal_equations(mcl_context *c, int64_t *count) {
+    if (!c || !c->has_workspace) {
+        if (count) *count = 0;
+        return nullptr;
+    }
+    if (count) *count = c->K * c->r + (int64_t)c->r * c->r;
+    return c->GR;
+}
+
+int mcl_update_C_finish(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    if (int rc = mcl_launch_C_prepare(c)) return rc;
+    if (c->opt.inner_n_iter_max <= 0) return 0;
+    c->xc_valid = c->ctc_valid = c->e1_valid = false;
+    if (mcl_mode_is_row_separable(c, 2)) {
+        const int rc = mcl_launch_rows_fused(c, 2);
+        if (rc == 0) {
+            c->diag_valid[2] = true;
+            return 0;
+        }
+        if (rc > 0) return rc;
+    }
+    return generic_inner_loop(c, 2);
+}
+
+// ---- A-phase -------------------------------------------------------------------------------------------
+int mcl_A_begin(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    if (int rc = ensure_ctc(c)) return rc;
+    if (int rc = ensure_xc(c)) return rc;
+    if (int rc = mcl_launch_slab_gram(c)) return rc;
+    c->e1_valid = false;
+    if (c->opt.constant_A)
+        if (int rc = mcl_launch_A_rho(c)) return rc;
+    return 0;
+}
+
+float *mcl_A_rho_max(mcl_context *c) { return c ? c->rho_max + 1 : nullptr; }
+
+int mcl_A_finish(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    if (c->opt.inner_n_iter_max <= 0) return 0;
+    if (mcl_mode_is_row_separable(c, 0)) {
+        if (int rc = mcl_launch_A_finish(c, true)) return rc;
+    } else {
+        if (!c->opt.constant_A)
+            return fail(c, "matrix penalties on mode 0 need constant_feasibility_penalty (the reference raises "
+                           "AttributeError: no factor_matrix_row_update)");
+        if (int rc = mcl_launch_A_finish(c, false)) return rc;
+        if (int rc = generic_inner_loop(c, 0)) return rc;
+        if (int rc = mcl_launch_A_e1(c, true)) return rc;
+    }
+    c->e1_valid = true;
+    c->e1_from_raw_gram = false;  // the BtB buffer now holds Q_i (cross_products)
+    c->diag_valid[0] = true;
+    return 0;
+}
+
+int mcl_update_A(mcl_context *c) {
+    if (int rc = mcl_A_begin(c)) return rc;
+    return mcl_A_finish(c);
+}
+
+// ---- diagnostics ---------------------------------------------------------------------------------------
+int mcl_diagnostics(mcl_context *c, double *out, int32_t include_replicated) {
+    if (int rc = ready(c)) return rc;
+    if (!out) return fail(c, "mcl_diagnostics: out is NULL");
+    if (!c->xsq_valid) {
+        if (int rc = mcl_launch_x_sq(c)) return rc;
+        c->xsq_valid = true;
+    }
+    if (!c->diag_valid[1])
+        if (int rc = mcl_launch_rows_diag(c, 1)) return rc;
+    if (!c->diag_valid[2])
+        if (int rc = mcl_launch_rows_diag(c, 2)) return rc;
+    c->diag_valid[1] = c->diag_valid[2] = true;
+    if (!c->e1_valid) {
+        // no current A-phase by-products: full formula with a pass over X (decomposition.py:430-444)
+        if (int rc = ensure_ctc(c)) return rc;
+        if (int rc = ensure_xc(c)) return rc;
+        if (int rc = mcl_launch_slab_gram(c)) return rc;
+        if (int rc = mcl_launch_A_e1(c, false)) return rc;
+        c->e1_valid = true;
+        c->e1_from_raw_gram = true;
+    } else if (!c->diag_valid[0]) {
+        if (int rc = mcl_launch_A_e1(c, !c->e1_from_raw_gram)) return rc;
+    }
+    c->diag_valid[0] = true;
+    return mcl_launch_diag_final(c, out, include_replicated, true);
+}
+
+int mcl_iterate(mcl_context *c, int32_t n_iter, int32_t update_A, int32_t update_B, int32_t update_C,
+                double *diag_ring) {
+    if (int rc = ready(c)) return rc;
+    for (int it = 0; it < n_iter; ++it) {
+        if (update_B)
+            if (int rc = mcl_update_B(c)) return rc;
+        if (update_C) {
+            if (int rc = mcl_update_C_local(c)) return rc;
+            if (int rc = mcl_update_C_finish(c)) return rc;
+        }
+        if (update_A)
+            if (int rc = mcl_update_A(c)) return rc;
+        if (diag_ring)
+            if (int rc = mcl_diagnostics(c, diag_ring + (int64_t)it * MCL_DIAG_LEN, 1)) return rc;
+    }
+    return 0;
+}
+
+float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {
+    if (!c || !c->has_workspace) return nullptr;
+    float *p = nullptr;
+    int64_t n = 0;
+    switch (which) {
+        case 0: p = c->rhsA, n = c->I * c->r; break;
+        case 1: p = c->BtB, n = c->I * c->r * c->r; break;
+        case 2: p = c->XC, n = c->N * c->r; break;
+        case 3: p = c->rhoB, n = c->I; break;
+        case 4: p = c->rhoA, n = c->I; break;
+        case 5: p = c->rhoC, n = 1; break;
+        case 6: p = c->CtC, n = (int64_t)c->r * c->r; break;
+        case 7: p = c->LinvB, n = c->I * c->r * c->r; break;
+        default: break;
+    }
+    if (count) *count = n;
+    return p;
+}
+
+const char *mcl_kernel_variant(mcl_context *c, int32_t which) {
+    if (!c || which < 0 || which > 3) return "";
+    return c->variant[which].c_str();
+}
+
+}  // extern "C"

@@ -1,0 +1,540 @@
+// The two passes over X per outer AO-ADMM iteration, as fp32-input MFMA kernels for gfx950 (CDNA4).
+//
+//   k_contract_xt : [G | R] partials,  R = sum_i X_i^T (B_i o a_i),  G = sum_i (B_i o a_i)^T (B_i o a_i)
+//                   (reference: decomposition.py:312-315, sites C1 of SURVEY.md 2.3)
+//   k_contract_xc : XC = X C  (rows of all slabs at once; reference: decomposition.py:147-152 and,
+//                   through rhs_i = (X_i C) o a_i, decomposition.py:242)
+//   k_slab_gram   : rhs_i = diag(B_i^T X_i C), B_i^T B_i per slab (decomposition.py:155-158)
+//
+// Both X passes are HBM-bound (r/2 flop per byte); v_mfma_f32_16x16x4_f32 does the contraction so that the
+// VALU stays free for address/guard work, and every global load of X is a 16-byte-per-lane load of
+// 256-byte row segments (4 rows per wave instruction).
+#include "mcl_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+static __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// ---------------------------------------------------------------------------------------------------------
+// k_contract_xt
+//   lane l = (rsub = l>>4, c16 = l&15).  One "group" = 4 consecutive packed rows; lane loads
+//   X[4g+rsub][kbase + 64kb + 4c16 .. +3] (a 256-B row segment per 16 lanes) for kb < KB.
+//   MFMA (kb, m): A-operand = component m of that float4  -> output row index i <-> k = kbase+64kb+4i+m,
+//                 B-operand = (B o a)[4g+rsub][16nb + c16]; reduction index (l>>4) <-> the 4 rows of the group.
+//   Accumulator (kb, m, nb), lane l, reg v  <->  R[kbase + 64kb + 4(4(l>>4)+v) + m][16nb + (l&15)].
+// ---------------------------------------------------------------------------------------------------------
+template <int KB, int NB, int VEC, int DEPTH>
+__global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X, const float *__restrict__ B,
+                                                     const float *__restrict__ A, const int *__restrict__ slab_of_row,
+                                                     long N, int K, int r, long groups_per_wave, long n_groups,
+                                                     float *__restrict__ part, int part_stride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rsub = lane >> 4, c16 = lane & 15;
+    const int kbase = blockIdx.y * (64 * KB);
+    const long w = (long)blockIdx.x * 4 + wave;
+    const long g0 = w * groups_per_wave;
+    long g1 = g0 + groups_per_wave;
+    if (g1 > n_groups) g1 = n_groups;
+    const bool doG = (blockIdx.y == 0);
+
+    int kcol[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) kcol[kb] = kbase + 64 * kb + 4 * c16;
+
+    f32x4 acc[KB][4][NB];
+    f32x4 accG[NB][NB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[kb][m][nb] = zero4();
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) accG[a][b] = zero4();
+
+    f32x4 fx[DEPTH][KB];
+    float fb[DEPTH][NB];
+
+    auto load = [&](int d, long g) {
+        const long j = g * 4 + rsub;
+        const bool ok = (g < g1) && (j < N);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            if (VEC == 4) {
+                f32x4 v = zero4();
+                if (ok && kcol[kb] < K) v = *reinterpret_cast<const f32x4 *>(X + j * K + kcol[kb]);
+                fx[d][kb] = v;
+            } else {
+                f32x4 v = zero4();
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    if (ok && kcol[kb] + m < K) v[m] = X[j * K + kcol[kb] + m];
+                fx[d][kb] = v;
+            }
+        }
+        const int s = ok ? slab_of_row[j] : 0;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = nb * 16 + c16;
+            float v = 0.f;
+            if (ok && col < r) v = B[j * r + col] * A[(long)s * r + col];
+            fb[d][nb] = v;
+        }
+    };
+
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load(d, g0 + d);
+
+    for (long g = g0; g < g1; g += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[kb][m][nb] = MFMA16(fx[d][kb][m], fb[d][nb], acc[kb][m][nb]);
+            if (doG) {
+#pragma unroll
+                for (int a = 0; a < NB; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) accG[a][b] = MFMA16(fb[d][a], fb[d][b], accG[a][b]);
+            }
+            load(d, g + DEPTH + d);
+        }
+    }
+
+    // deterministic cross-wave reduction through LDS, then one partial slab per block
+    constexpr int W = 16 * NB;
+    __shared__ float lds[64 * KB * W + W * W];
+    float *ldsG = lds + 64 * KB * W;
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int kl = 64 * kb + 4 * (4 * rsub + v) + m;
+                            const int idx = kl * W + 16 * nb + c16;
+                            lds[idx] = (wv == 0) ? acc[kb][m][nb][v] : lds[idx] + acc[kb][m][nb][v];
+                        }
+            if (doG) {
+#pragma unroll
+                for (int a = 0; a < NB; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int idx = (16 * a + 4 * rsub + v) * W + 16 * b + c16;
+                            ldsG[idx] = (wv == 0) ? accG[a][b][v] : ldsG[idx] + accG[a][b][v];
+                        }
+            }
+        }
+        __syncthreads();
+    }
+    float *out = part + (long)blockIdx.x * part_stride;
+    for (int e = threadIdx.x; e < 64 * KB * W; e += 256) {
+        const int kl = e / W, n = e - kl * W;
+        const int k = kbase + kl;
+        if (k < K && n < r) out[r * r + k * r + n] = lds[e];
+    }
+    if (doG) {
+        for (int e = threadIdx.x; e < W * W; e += 256) {
+            const int a = e / W, b = e - a * W;
+            if (a < r && b < r) out[a * r + b] = ldsG[e];
+        }
+    }
+}
+
+// GR[e] = sum_p part[p][e]; fixed summation order (deterministic, identical on every rank for identical input)
+__global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict__ part, int n_part, int E,
+                                                         float *__restrict__ out) {
+    __shared__ float sm[4][64];
+    const int el = threadIdx.x & 63, pc = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    float s = 0.f;
+    if (e < E) {
+        int p = pc;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (; p + 12 < n_part; p += 16) {
+            s0 += part[(long)p * E + e];
+            s1 += part[(long)(p + 4) * E + e];
+            s2 += part[(long)(p + 8) * E + e];
+            s3 += part[(long)(p + 12) * E + e];
+        }
+        for (; p < n_part; p += 4) s0 += part[(long)p * E + e];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    sm[pc][el] = s;
+    __syncthreads();
+    if (pc == 0 && e < E) out[e] = (sm[0][el] + sm[1][el]) + (sm[2][el] + sm[3][el]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// C in MFMA-fragment order for k_contract_xc:
+//   Cfrag[(((kc*4 + kq)*NB + nb)*64 + lane)*4 + m] = C[64kc + 16kq + 4(lane>>4) + m][16nb + (lane&15)]  (0 outside)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_build_cfrag(const float *__restrict__ C, int K, int r, int KC, int NB, float *__restrict__ Cfrag) {
+    const long total = (long)KC * 4 * NB * 256;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int m = idx & 3, lane = (idx >> 2) & 63;
+    long t = idx >> 8;
+    const int nb = t % NB;
+    t /= NB;
+    const int kq = t & 3, kc = t >> 2;
+    const int k = 64 * kc + 16 * kq + 4 * (lane >> 4) + m, col = 16 * nb + (lane & 15);
+    Cfrag[idx] = (k < K && col < r) ? C[(long)k * r + col] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_contract_xc : XC = X C.  A wave owns blocks of 16 packed rows and walks K in chunks of 64 columns.
+//   global -> registers: lane (rsub, c16), t<4: X[j0 + 4t + rsub][64kc + 4c16 .. +3]   (256-B row segments)
+//   registers -> LDS   : wave-private 16 x 64 fp32 tile, 16-B slot index XORed with the row (conflict-free)
+//   LDS -> fragments   : lane (q = l>>4, i = l&15), kq<4: X[j0 + i][64kc + 16kq + 4q .. +3]
+//   MFMA (kq, m)       : A = component m (row i, k = 64kc+16kq+4q+m), B = Cfrag(kc,kq,nb)[m]
+//   accumulator nb, lane l, reg v <-> XC[j0 + 4(l>>4) + v][16nb + (l&15)]
+// KCT > 0: K <= 64*KCT and the C fragments live in registers; KCT == 0: runtime (even) chunk count,
+// fragments re-read from the L1/L2-resident Cfrag buffer each chunk.
+// ---------------------------------------------------------------------------------------------------------
+template <int NB, int VEC, int KCT>
+__global__ __launch_bounds__(256) void k_contract_xc(const float *__restrict__ X, const float *__restrict__ Cfrag,
+                                                     float *__restrict__ XC, long N, int K, int r, int KCrt,
+                                                     long blocks_per_wave, long n_blocks16) {
+    __shared__ float lds_all[4][16 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, i16 = lane & 15;
+    float *L = lds_all[wave];
+    const int KC = (KCT > 0) ? KCT : KCrt;
+    const long w = (long)blockIdx.x * 4 + wave;
+    const long b0 = w * blocks_per_wave;
+    long b1 = b0 + blocks_per_wave;
+    if (b1 > n_blocks16) b1 = n_blocks16;
+    if (b0 >= b1) return;
+
+    constexpr int CR = (KCT > 0) ? KCT : 1;
+    f32x4 creg[CR][4][NB];
+    if (KCT > 0) {
+#pragma unroll
+        for (int kc = 0; kc < CR; ++kc)
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    creg[kc][kq][nb] =
+                        *reinterpret_cast<const f32x4 *>(Cfrag + ((((long)kc * 4 + kq) * NB + nb) * 64 + lane) * 4);
+    }
+
+    f32x4 xr[2][4];
+    // stage the 16 x 64 chunk (blk, kc) into ring slot `slot` (zeros outside the matrix)
+    auto issue = [&](int slot, long blk, int kc) {
+        const bool in = blk < b1;
+        const int col = 64 * kc + 4 * i16;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long j = blk * 16 + 4 * t + q;
+            f32x4 v = zero4();
+            if (VEC == 4) {
+                if (in && j < N && col < K) v = *reinterpret_cast<const f32x4 *>(X + j * K + col);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    if (in && j < N && col + m < K) v[m] = X[j * K + col + m];
+            }
+            xr[slot][t] = v;
+        }
+    };
+
+    f32x4 acc[NB];
+    auto step = [&](int slot, long blk, int kc, long nblk, int nkc, const f32x4 (&cf)[4][NB]) {
+        if (kc == 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = zero4();
+        }
+        // registers -> LDS (row = 4t + q, slot = c16 ^ row)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = 4 * t + q;
+            *reinterpret_cast<f32x4 *>(L + row * 64 + ((i16 ^ row) << 2)) = xr[slot][t];
+        }
+        f32x4 fr[4];
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) fr[kq] = *reinterpret_cast<const f32x4 *>(L + i16 * 64 + (((4 * kq + q) ^ i16) << 2));
+        issue(slot, nblk, nkc);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA16(fr[kq][m], cf[kq][nb][m], acc[nb]);
+        if (kc == KC - 1) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const long j = blk * 16 + 4 * q + v;
+                    const int col = 16 * nb + i16;
+                    if (j < N && col < r) XC[j * r + col] = acc[nb][v];
+                }
+        }
+    };
+
+    issue(0, b0, 0);
+    issue(1, (KC > 1) ? b0 : b0 + 1, (KC > 1) ? 1 : 0);
+    if (KCT > 0) {
+        for (long blk = b0; blk < b1; ++blk) {
+#pragma unroll
+            for (int kc = 0; kc < CR; ++kc) {
+                const int nk = kc + 2;
+                const long nblk = blk + nk / CR;
+                step(kc & 1, blk, kc, nblk, nk % CR, creg[kc]);
+            }
+        }
+    } else {
+        // KCrt is even (host pads), so ring slot = kc & 1 is static in the 2-unrolled loop
+        for (long blk = b0; blk < b1; ++blk) {
+            for (int kc = 0; kc < KC; kc += 2) {
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    f32x4 cf[4][NB];
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            cf[kq][nb] = *reinterpret_cast<const f32x4 *>(
+                                Cfrag + ((((long)(kc + d) * 4 + kq) * NB + nb) * 64 + lane) * 4);
+                    int nk = kc + d + 2;
+                    long nblk = blk;
+                    if (nk >= KC) {
+                        nk -= KC;
+                        nblk += 1;
+                    }
+                    step(d, blk, kc + d, nblk, nk, cf);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_slab_gram : one workgroup per slab.  rhs_i[c] = sum_j B[j][c] XC[j][c];  BtB_i = B_i^T B_i (MFMA).
+// ---------------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256) void k_slab_gram(const float *__restrict__ B, const float *__restrict__ XC,
+                                                   const int *__restrict__ row_ptr, int r, float *__restrict__ rhsA,
+                                                   float *__restrict__ BtB) {
+    constexpr int W = 16 * NB;
+    __shared__ float ldsG[W * W];
+    __shared__ float ldsP[4][W];
+    const int slab = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rsub = lane >> 4, c16 = lane & 15;
+    const int s = row_ptr[slab], e = row_ptr[slab + 1];
+    const int n_groups = (e - s + 3) >> 2;
+    float p[NB];
+    f32x4 accG[NB][NB];
+#pragma unroll
+    for (int a = 0; a < NB; ++a) {
+        p[a] = 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) accG[a][b] = zero4();
+    }
+    for (int g = wave; g < n_groups; g += 4) {
+        const long j = (long)s + 4 * g + rsub;
+        float bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = 16 * nb + c16;
+            float b = 0.f, x = 0.f;
+            if (j < e && col < r) {
+                b = B[j * r + col];
+                x = XC[j * r + col];
+            }
+            bv[nb] = b;
+            p[nb] += b * x;
+        }
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) accG[a][b] = MFMA16(bv[a], bv[b], accG[a][b]);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        p[nb] += __shfl_xor(p[nb], 16);
+        p[nb] += __shfl_xor(p[nb], 32);
+        if (rsub == 0) ldsP[wave][16 * nb + c16] = p[nb];
+    }
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int idx = (16 * a + 4 * rsub + v) * W + 16 * b + c16;
+                        ldsG[idx] = (wv == 0) ? accG[a][b][v] : ldsG[idx] + accG[a][b][v];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < W * W; t += 256) {
+        const int a = t / W, b = t - a * W;
+        if (a < r && b < r) BtB[((long)slab * r + a) * r + b] = ldsG[t];
+    }
+    if (threadIdx.x < W && (int)threadIdx.x < r)
+        rhsA[(long)slab * r + threadIdx.x] =
+            (ldsP[0][threadIdx.x] + ldsP[1][threadIdx.x]) + (ldsP[2][threadIdx.x] + ldsP[3][threadIdx.x]);
+}
+
+// =========================================================================================================
+// host launchers
+// =========================================================================================================
+static inline int xt_KB(const mcl_context *c) {
+    int kb = 4 / c->NB;
+    if (kb < 1) kb = 1;
+    const int need = (int)((c->K + 63) / 64);
+    return need < kb ? (need <= 1 ? 1 : (need <= 2 ? 2 : 4)) : kb;
+}
+
+static inline void xt_geometry(const mcl_context *c, long *n_groups, long *gpw, int *n_blocks) {
+    *n_groups = (c->N + 3) / 4;
+    const long target_waves = 2048;  // 256 CUs x 8 waves
+    long g = (*n_groups + target_waves - 1) / target_waves;
+    if (g < 4) g = 4;  // at least one prefetch ring of work per wave
+    *gpw = g;
+    const long waves = (*n_groups + g - 1) / g;
+    long nb = (waves + 3) / 4;
+    if (nb < 1) nb = 1;
+    *n_blocks = (int)nb;
+}
+
+int mcl_contract_n_partials(const mcl_context *c) {
+    long ng, gpw;
+    int nb;
+    xt_geometry(c, &ng, &gpw, &nb);
+    return nb;
+}
+
+template <int KB, int NB>
+static int launch_xt(mcl_context *c) {
+    long ng, gpw;
+    int nb;
+    xt_geometry(c, &ng, &gpw, &nb);
+    const int E = (int)(c->K * c->r + c->r * c->r);
+    dim3 grid(nb, (unsigned)((c->K + 64 * KB - 1) / (64 * KB)));
+    const bool vec = (c->K % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->X) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL((k_contract_xt<KB, NB, 4, 4>), grid, dim3(256), 0, c->stream, c->X, c->B, c->A,
+                           c->slab_of_row, (long)c->N, (int)c->K, c->r, gpw, ng, c->partials, E);
+    else
+        hipLaunchKernelGGL((k_contract_xt<KB, NB, 1, 2>), grid, dim3(256), 0, c->stream, c->X, c->B, c->A,
+                           c->slab_of_row, (long)c->N, (int)c->K, c->r, gpw, ng, c->partials, E);
+    c->n_part = nb;
+    char buf[96];
+    snprintf(buf, sizeof buf, "k_contract_xt<KB=%d,NB=%d,VEC=%d>", KB, NB, vec ? 4 : 1);
+    c->variant[1] = buf;
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int mcl_launch_contract_xt(mcl_context *c) {
+    const int KB = xt_KB(c);
+    switch (c->NB) {
+        case 1:
+            if (KB == 4) return launch_xt<4, 1>(c);
+            if (KB == 2) return launch_xt<2, 1>(c);
+            return launch_xt<1, 1>(c);
+        case 2:
+            if (KB >= 2) return launch_xt<2, 2>(c);
+            return launch_xt<1, 2>(c);
+        default:
+            return launch_xt<1, 4>(c);
+    }
+}
+
+int mcl_launch_reduce_partials(mcl_context *c) {
+    const int E = (int)(c->K * c->r + c->r * c->r);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((E + 63) / 64), dim3(256), 0, c->stream, c->partials, c->n_part, E,
+                       c->GR);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+static inline int xc_KC(const mcl_context *c) {
+    int kc = (int)((c->K + 63) / 64);
+    if (kc & 1) kc += 1;  // even chunk count (ring slot parity is static)
+    return kc;
+}
+
+int mcl_launch_build_cfrag(mcl_context *c) {
+    const int KC = xc_KC(c);
+    const long total = (long)KC * 4 * c->NB * 256;
+    hipLaunchKernelGGL(k_build_cfrag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->C, (int)c->K,
+                       c->r, KC, c->NB, c->Cfrag);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+template <int NB>
+static int launch_xc(mcl_context *c) {
+    const int KC = xc_KC(c);
+    const long nblk = (c->N + 15) / 16;
+    const long target_waves = 2048;
+    long bpw = (nblk + target_waves - 1) / target_waves;
+    if (bpw < 1) bpw = 1;
+    const long waves = (nblk + bpw - 1) / bpw;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    if (grid == 0) return 0;
+    const bool vec = (c->K % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->X) & 15) == 0);
+    const int creg_budget = 4 / NB;  // chunks whose C fragments fit in 64 VGPRs
+    int kct = 0;
+    if (KC <= creg_budget) kct = KC;  // KC is even: 2 or 4
+#define MCL_XC(NB_, VEC_, KCT_)                                                                                     \
+    hipLaunchKernelGGL((k_contract_xc<NB_, VEC_, KCT_>), dim3(grid), dim3(256), 0, c->stream, c->X, c->Cfrag, c->XC, \
+                       (long)c->N, (int)c->K, c->r, KC, bpw, nblk)
+    if (vec) {
+        if (kct == 4) MCL_XC(NB, 4, 4);
+        else if (kct == 2) MCL_XC(NB, 4, 2);
+        else MCL_XC(NB, 4, 0);
+    } else {
+        MCL_XC(NB, 1, 0);
+        kct = 0;
+    }
+#undef MCL_XC
+    char buf[96];
+    snprintf(buf, sizeof buf, "k_contract_xc<NB=%d,VEC=%d,KCT=%d>", NB, vec ? 4 : 1, kct);
+    c->variant[0] = buf;
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int mcl_launch_contract_xc(mcl_context *c) {
+    if (c->NB == 1) return launch_xc<1>(c);
+    if (c->NB == 2) return launch_xc<2>(c);
+    return launch_xc<4>(c);
+}
+
+int mcl_launch_slab_gram(mcl_context *c) {
+    if (c->I == 0) return 0;
+    dim3 grid((unsigned)c->I);
+    if (c->NB == 1)
+        hipLaunchKernelGGL(k_slab_gram<1>, grid, dim3(256), 0, c->stream, c->B, c->XC, c->row_ptr_dev, c->r, c->rhsA,
+                           c->BtB);
+    else if (c->NB == 2)
+        hipLaunchKernelGGL(k_slab_gram<2>, grid, dim3(256), 0, c->stream, c->B, c->XC, c->row_ptr_dev, c->r, c->rhsA,
+                           c->BtB);
+    else
+        hipLaunchKernelGGL(k_slab_gram<4>, grid, dim3(256), 0, c->stream, c->B, c->XC, c->row_ptr_dev, c->r, c->rhsA,
+                           c->BtB);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,142 @@
+// Internal declarations shared by the translation units of libmatcouply_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/matcouply_hip.h"
+
+#define DIAG_COLS (2 + MCL_MAX_REGS)
+
+#define MCL_CHECK_HIP(ctx, expr)                                                                      \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                           \
+            return 1;                                                                                 \
+        }                                                                                             \
+    } while (0)
+
+// Descriptor of one mode's penalty list as the kernels see it (passed by value).
+struct RegSet {
+    int n;
+    int kind[MCL_MAX_REGS];
+    int nonneg[MCL_MAX_REGS];
+    float p0[MCL_MAX_REGS];
+    float p1[MCL_MAX_REGS];
+    float *aux[MCL_MAX_REGS];
+    float *dual[MCL_MAX_REGS];
+    float *aux2[MCL_MAX_REGS];
+};
+
+// Row tiling of a packed [rows, r] matrix: every wave tile holds <= 64 rows of ONE slab.
+struct TileMap {
+    int n_tiles = 0;
+    int *slab = nullptr;   // device int32[n_tiles]
+    int *row0 = nullptr;   // device int32[n_tiles]
+    int *nrows = nullptr;  // device int32[n_tiles]
+};
+
+struct mcl_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // problem
+    const float *X = nullptr;
+    std::vector<int64_t> row_ptr;  // host
+    int64_t I = 0, K = 0, N = 0;
+    int r = 0;
+    int RP = 0;  // rank padded to 4/8/16/32/64 (register tiles)
+    int NB = 0;  // number of 16-wide MFMA column blocks = ceil(r/16)
+    mcl_options opt{};
+    float *A = nullptr, *B = nullptr, *C = nullptr;
+    RegSet regs[3]{};
+    bool has_problem = false, has_factors = false, has_workspace = false;
+
+    // host-side tile maps (uploaded into the workspace)
+    std::vector<int> h_slab_of_row, h_tile_slab, h_tile_row0, h_tile_nrows;
+    std::vector<int> h_ctile_slab, h_ctile_row0, h_ctile_nrows;  // C-mode: one slab of K rows
+    std::vector<int> h_atile_slab, h_atile_row0, h_atile_nrows;  // A-mode: one slab of I rows
+
+    // workspace carve-up (device pointers)
+    char *ws = nullptr;
+    int64_t ws_bytes = 0;
+    int *slab_of_row = nullptr;
+    int *row_ptr_dev = nullptr;  // int32[I+1]
+    TileMap tilesB, tilesC, tilesA;
+    float *XC = nullptr;        // [N, r]   X C  (cached between the A-phase and the next B-phase)
+    float *Cfrag = nullptr;     // C in MFMA-fragment order for the X C kernel
+    float *CtC = nullptr;       // [r, r]
+    float *rhoB = nullptr;      // [I]
+    float *LinvB = nullptr;     // [I, r, r]
+    float *rho_max = nullptr;   // [2]  (0: B-phase, 1: A-phase)
+    float *partials = nullptr;  // [n_part, K*r + r*r]
+    float *GR = nullptr;        // [r*r + K*r]
+    float *rhoC = nullptr;      // [1]
+    float *LinvC = nullptr;     // [r, r]
+    float *rhsA = nullptr;      // [I, r]
+    float *BtB = nullptr;       // [I, r, r]  -> overwritten by Q_i = BtB_i o CtC (cross_products)
+    float *rhoA = nullptr;      // [I]
+    float *LinvA = nullptr;     // [I, r, r]
+    double *e1 = nullptr;       // [I, 2]   per-slab <X_i, M_i>, ||M_i||^2
+    double *diagA_row = nullptr;   // [I, DIAG_COLS]        per-row sums of mode 0 (A-phase kernels)
+    double *diagA_tile = nullptr;  // [tilesA, DIAG_COLS]
+    double *diagB_tile = nullptr;  // [tilesB, DIAG_COLS]   per-tile ||F||^2, sum|F|, ||Z_k - F||^2
+    double *diagC_tile = nullptr;  // [tilesC, DIAG_COLS]
+    double *diag_sums = nullptr;   // [3*DIAG_COLS + 2]
+    double *xsq_part = nullptr;    // [1024]
+    int *ext_A = nullptr, *ext_C = nullptr;  // int32[2] slab extents {0, I} / {0, K} for the single-slab modes
+    double *x_sq = nullptr;     // [1]
+    double *colsq = nullptr;    // [max(I,1), r]   per-slab column sums of squares (L2Ball)
+    double *uni_f64 = nullptr;  // unimodal regression scratch: 8 fp64 arrays of (rows + slabs) * r
+    int *uni_i32 = nullptr;     //                              2 int32 arrays of rows * r
+    double *pf2_S = nullptr;    // [I, r, r]  Y_i^T Y_i (fp64)
+    float *pf2_T = nullptr;     // [I, r, r]  P_i = Y_i T_i
+    double *pf2_acc = nullptr;  // [I, r*r + 1] per-slab rho_i P_i^T Y_i | rho_i
+    float *pf2_red = nullptr;   // [r*r + 1]  sum over this context's slabs (all-reduced by a multi-GPU host)
+    std::vector<int> h_row_ptr32, h_ext;
+    bool e1_from_raw_gram = false;  // BtB buffer holds B_i^T B_i (true) or Q_i = B_i^T B_i o CtC (false)
+    int n_part = 0;
+
+    // validity of cached by-products
+    bool xc_valid = false;      // XC == X @ C for the current C
+    bool ctc_valid = false;     // CtC == C^T C for the current C
+    bool e1_valid = false;      // e1/rhsA/BtB consistent with the current factors (A-phase just ran)
+    bool diag_valid[3] = {false, false, false};  // per-mode diag tables consistent with factors/aux
+    bool diagA_from_rows = false;
+    bool xsq_valid = false;
+    bool b_begun = false;
+
+    std::string variant[4];
+};
+
+static inline int mcl_pad_rank(int r) { return r <= 4 ? 4 : r <= 8 ? 8 : r <= 16 ? 16 : r <= 32 ? 32 : 64; }
+
+// ---- launchers implemented in contract.hip ---------------------------------------------------------
+int mcl_launch_build_cfrag(mcl_context *c);
+int mcl_launch_contract_xc(mcl_context *c);                      // XC = X @ C
+int mcl_launch_contract_xt(mcl_context *c);                      // partials of [G | R]
+int mcl_launch_reduce_partials(mcl_context *c);                  // GR = sum of partials
+int mcl_launch_slab_gram(mcl_context *c);                        // rhsA, BtB from B and XC
+int mcl_contract_n_partials(const mcl_context *c);
+
+// ---- launchers implemented in admm.hip ---------------------------------------------------------------
+int mcl_launch_ctc(mcl_context *c);
+int mcl_launch_B_rho(mcl_context *c);
+int mcl_launch_B_systems(mcl_context *c);
+int mcl_launch_rows_fused(mcl_context *c, int mode);             // fused inner ADMM loop, row-separable penalties
+int mcl_launch_rows_solve(mcl_context *c, int mode);
+int mcl_launch_rows_prox(mcl_context *c, int mode, int k);       // generic prox step of penalty k (local part)
+int mcl_launch_rows_prox_finish(mcl_context *c, int mode, int k);
+int mcl_launch_C_prepare(mcl_context *c);
+int mcl_launch_A_rho(mcl_context *c);
+int mcl_launch_A_finish(mcl_context *c, bool fused_inner);
+int mcl_launch_A_rows_solve(mcl_context *c);
+int mcl_launch_A_e1(mcl_context *c, bool btb_is_q);
+int mcl_launch_rows_diag(mcl_context *c, int mode);
+int mcl_launch_diag_final(mcl_context *c, double *out, int include_replicated, bool a_from_rows);
+int mcl_launch_x_sq(mcl_context *c);
+bool mcl_mode_is_row_separable(const mcl_context *c, int mode);
