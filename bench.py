@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py - AO-ADMM outer iterations/s of the MI355X engine on BASELINE.json's metric configuration.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE outer AO-ADMM iteration (B-phase -> C-phase -> A-phase + per-iteration diagnostics, i.e.
+`return_errors=True` as in the reference's default loop) of `cmf_aoadmm(non_negative=True, l1_penalty={2: 0.1})`
+on synthetic data of config 3 (I=1024, J_i=512, K=256, rank 16), inputs resident in HBM.
+With N > 1 the I slabs are sharded contiguously over the ranks (fixed total problem -> "strong" scaling, as
+BASELINE.json's metric "@1/2/4/8 GPU" states); per step there is one RCCL all-reduce of the C-mode normal
+equations [G | R] and one of the fp64 diagnostic sums.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      dominant kernel's algorithmic bytes / HIP-event time (events recorded inside the library on the
+                kernel's own stream) against the 8 TB/s HBM peak
+  cpu_baseline  the NumPy oracle (oracle/aoadmm_oracle.py, a restatement of the reference pinned by goldens)
+                timed on this box's host cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+CONFIGS = {
+    # name: (I, J, K, r, regs per mode as descriptor lists)
+    "c2": dict(I=256, J=256, K=128, r=8, regs=[[{"kind": "nn"}], [{"kind": "nn"}], [{"kind": "nn"}]],
+               desc="c2: I=256 J_i=256 K=128 rank=8, non_negative on all modes"),
+    "c3": dict(I=1024, J=512, K=256, r=16,
+               regs=[[{"kind": "nn"}], [{"kind": "nn"}], [{"kind": "l1", "reg_strength": 0.1, "non_negativity": True}]],
+               desc="c3: I=1024 J_i=512 K=256 rank=16, non_negative + L1(0.1) on C"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_shard(cfg, rank, world, device, seed=0):
+    """Synthetic X_i = B_i* diag(a_i*) C*^T + 0.05 N(0,1) for this rank's contiguous slab range."""
+    import torch
+
+    I, J, K, r = cfg["I"], cfg["J"], cfg["K"], cfg["r"]
+    lo, hi = (I * rank) // world, (I * (rank + 1)) // world
+    I_loc = hi - lo
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    C_true = torch.rand((K, r), generator=g, device=device)
+    g.manual_seed(seed + 1000 + rank)
+    A_true = torch.rand((I_loc, r), generator=g, device=device) + 0.1
+    B_true = torch.rand((I_loc, J, r), generator=g, device=device)
+    X = torch.einsum("ijr,ir,kr->ijk", B_true, A_true, C_true)
+    X += 0.05 * torch.randn(X.shape, generator=g, device=device)
+    X = X.reshape(I_loc * J, K).contiguous()
+    row_ptr = np.arange(I_loc + 1, dtype=np.int64) * J
+    return X, row_ptr, I_loc
+
+
+def make_engine(cfg, X, row_ptr, I_loc, rank, device, seed=1):
+    import torch
+    from matcouply_amd._engine import HipEngine, NativeReg
+    from tests.helpers import KIND
+
+    K, r, N = cfg["K"], cfg["r"], X.shape[0]
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)  # replicated quantities (C and its ADMM variables) are drawn identically on all ranks
+    C = torch.rand((K, r), generator=g, device=device)
+    shapes = {0: (I_loc, r), 1: (N, r), 2: (K, r)}
+    c_vars = [(torch.rand((K, r), generator=g, device=device), torch.rand((K, r), generator=g, device=device))
+              for _ in cfg["regs"][2]]
+    g.manual_seed(seed + 1000 + rank)
+    A = torch.rand((I_loc, r), generator=g, device=device)
+    B = torch.rand((N, r), generator=g, device=device)
+    regs = [[], [], []]
+    for m in range(3):
+        for k, d in enumerate(cfg["regs"][m]):
+            if m == 2:
+                aux, dual = c_vars[k]
+            else:
+                aux = torch.rand(shapes[m], generator=g, device=device)
+                dual = torch.rand(shapes[m], generator=g, device=device)
+            regs[m].append(NativeReg(KIND[d["kind"]], aux, dual, non_negativity=d.get("non_negativity", False),
+                                     p0=d.get("reg_strength", d.get("norm_bound", 0.0))))
+    return HipEngine(X, row_ptr, r, A, B, C, regs)
+
+
+def cpu_baseline(cfg, budget_s=15.0):
+    """Oracle (NumPy, fp64 like the reference) on the host cores, bounded sample: a subset of the slabs, >= 1 iteration."""
+    from oracle import aoadmm_oracle as orc
+
+    cores = os.cpu_count() or 1
+    I, J, K, r = cfg["I"], cfg["J"], cfg["K"], cfg["r"]
+
+    def timed(I_s, iters):
+        X, row_ptr = orc.synthetic_problem(I_s, J, K, r, seed=0, dtype=np.float64)
+        st = orc.random_state_for(X, row_ptr, r, cfg["regs"], seed=1)
+        st.update_B(); st.update_C(); st.update_A()  # warm-up iteration (BLAS thread pool, page faults)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            st.update_B(); st.update_C(); st.update_A()
+            st.feasibility_gaps(); st.loss(st.rec_error_from_A_byproducts())
+        return (time.perf_counter() - t0) / iters
+
+    I_probe = min(I, 64)
+    t_probe = timed(I_probe, 1)
+    per_slab = t_probe / I_probe
+    I_s = int(min(I, max(I_probe, budget_s / 3.0 / max(per_slab, 1e-9))))
+    iters = 2
+    t_iter = timed(I_s, iters)
+    value = 1.0 / (t_iter * I / I_s)
+    return dict(value=value, unit="outer-iters/s", cores=cores, kind="port",
+                sample=f"{iters} outer iterations (after 1 warm-up) of the NumPy fp64 oracle on the first {I_s} of {I} slabs "
+                       f"of the same synthetic workload, BLAS threads = {cores}; value scaled by {I_s}/{I}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    cfg = CONFIGS[args.config]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    X, row_ptr, I_loc = make_shard(cfg, rank, world, device)
+    eng = make_engine(cfg, X, row_ptr, I_loc, rank, device)
+    from matcouply_amd._engine import DIAG_LEN
+
+    ring = torch.zeros((args.steps + args.warmup, DIAG_LEN), dtype=torch.float64, device=device)
+
+    def step(it):
+        eng.update_B()
+        gr = eng.update_C_local()
+        if world > 1:
+            dist.all_reduce(gr)
+        eng.update_C_finish()
+        eng.update_A()
+        eng.diagnostics(include_replicated=(rank == 0), out=ring[it])
+        if world > 1:
+            dist.all_reduce(ring[it])
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        step(it)
+    sync()
+    eng.profile_enable(args.steps)
+    sync()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        step(args.warmup + it)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # live roofline of the dominant kernel (HIP events inside the library, same stream as the kernels)
+    prof = []
+    names = {0: "X C pass", 1: "X^T (B o a) pass", 2: "fused B-phase rows"}
+    N_loc, K, r = X.shape[0], cfg["K"], cfg["r"]
+    S_X, S_B = 4.0 * N_loc * K, 4.0 * N_loc * r
+    n_B = len(cfg["regs"][1])
+    alg_bytes = {0: S_X + S_B, 1: S_X + S_B, 2: (2 + 4 * n_B) * S_B}  # per launch: reads + writes of that kernel
+    for slot in range(3):
+        tot_ms, n = eng.profile_read(slot)
+        if n:
+            prof.append((tot_ms / n, slot, n))
+    roofline = None
+    if prof:
+        avg_ms, slot, n = max(prof)
+        achieved = alg_bytes[slot] / (avg_ms * 1e-3) / 1e9
+        roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, kernel=eng.kernel_variant(slot),
+                        kernel_role=names[slot], avg_us=round(avg_ms * 1e3, 2), launches=n,
+                        algorithmic_bytes_per_launch=int(alg_bytes[slot]),
+                        all_kernels_avg_us={names[s]: round(a * 1e3, 2) for a, s, _ in prof})
+
+    final = ring[args.warmup + args.steps - 1].cpu().numpy() if args.steps else None
+    if rank == 0:
+        its = args.steps / elapsed
+        S_X_tot, S_B_tot = 4.0 * cfg["I"] * cfg["J"] * K, 4.0 * cfg["I"] * cfg["J"] * r
+        bytes_iter = 2 * S_X_tot + (5 + 4 * n_B) * S_B_tot
+        out = {
+            "metric": "AO-ADMM outer-iters/sec", "value": round(its, 2), "unit": "outer-iters/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["desc"], "I": cfg["I"], "J": cfg["J"], "K": K, "rank": r,
+                       "inner_n_iter_max": 5, "diagnostics_every_iteration": True,
+                       "sharding": f"{world} x contiguous slab ranges" if world > 1 else "single device"},
+            "algorithmic_bytes_per_iter": int(bytes_iter),
+            "hbm_gbps_algorithmic": round(bytes_iter * its / 1e9, 1),
+            "roofline": roofline,
+        }
+        if final is not None:
+            xsq, inner, model = final[5], final[3], final[4]
+            out["final_rel_rec_error"] = round(float(np.sqrt(max(0.0, xsq - 2 * inner + model) / xsq)), 6)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_budget)
+        elif world > 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,8 +123,13 @@ int mcl_A_finish(mcl_context *ctx);          /* systems, inner ADMM loop, by-pro
 /* device pointers to internal by-products: 0 rhses [I, r], 1 cross_products [I, r, r], 2 X C [sum J_i, r],
  * 3 rho_B [I], 4 rho_A [I], 5 rho_C [1] */
 float *mcl_internal_buffer(mcl_context *ctx, int32_t which, int64_t *count);
-/* name of the dominant kernel variant chosen for the current problem (for bench.py's roofline block) */
+/* name of the kernel variant chosen for the current problem: which = 0 X C pass, 1 X^T B pass, 2 fused B-phase rows */
 const char *mcl_kernel_variant(mcl_context *ctx, int32_t which);
+/* HIP-event timing of the named kernels on the context's stream (for bench.py's roofline block).
+ * mcl_profile_enable(ctx, capacity): record up to `capacity` launches per kernel slot (0 disables and frees);
+ * mcl_profile_read(ctx, which, &total_ms, &count): synchronises the recorded events of slot `which` and resets it. */
+int mcl_profile_enable(mcl_context *ctx, int32_t capacity);
+int mcl_profile_read(mcl_context *ctx, int32_t which, double *total_ms, int32_t *count);
 
 #ifdef __cplusplus
 }

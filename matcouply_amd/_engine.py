@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "mcl_update_C_local", "mcl_c_normal_equations", "mcl_update_C_finish", "mcl_update_A", "mcl_diagnostics",
     "mcl_iterate", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
-    "mcl_internal_buffer", "mcl_kernel_variant",
+    "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_read",
 ]
 
 
@@ -86,6 +86,8 @@ def load_library():
         "mcl_A_finish": (ctypes.c_int, [P]),
         "mcl_internal_buffer": (P, [P, I32, ctypes.POINTER(I64)]),
         "mcl_kernel_variant": (ctypes.c_char_p, [P, I32]),
+        "mcl_profile_enable": (ctypes.c_int, [P, I32]),
+        "mcl_profile_read": (ctypes.c_int, [P, I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -266,6 +268,15 @@ class HipEngine:
 
     def cross_products(self):
         return self.internal(1).view(self.I, self.r, self.r)
+
+    def profile_enable(self, capacity):
+        self._check(self.lib.mcl_profile_enable(self._h, int(capacity)))
+
+    def profile_read(self, which):
+        """(total_ms, launches) of kernel slot `which` (0: X C pass, 1: X^T B pass, 2: fused B rows); synchronises."""
+        tot, n = ctypes.c_double(), ctypes.c_int32()
+        self._check(self.lib.mcl_profile_read(self._h, which, ctypes.byref(tot), ctypes.byref(n)))
+        return tot.value, n.value
 
     def kernel_variant(self, which):
         return self.lib.mcl_kernel_variant(self._h, which).decode()

@@ -16,26 +16,37 @@ static __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// In-place Gauss-Jordan inverse of the SPD r x r matrix M (fp64, LDS, row-major) by ONE wave (64 threads).
-// SPD => no pivoting needed.  colp: r doubles of LDS scratch.  Replaces the reference's SVD-based solve
-// `(v (U/s)) Uh` (decomposition.py:172,194) - identical for symmetric positive definite systems.
-static __device__ void gj_inverse(double *M, double *colp, int r, int lane) {
-    for (int p = 0; p < r; ++p) {
-        __syncthreads();
-        const double piv = 1.0 / M[p * r + p];
-        for (int i = lane; i < r; i += 64) colp[i] = M[i * r + p];
-        __syncthreads();
-        for (int c = lane; c < r; c += 64) M[p * r + c] = (c == p) ? piv : M[p * r + c] * piv;
-        __syncthreads();
-        for (int e = lane; e < r * r; e += 64) {
-            const int i = e / r, c = e - i * r;
-            if (i != p) {
-                const double f = colp[i];
-                M[e] = (c == p) ? -f * piv : M[e] - f * M[p * r + c];
+// Gauss-Jordan inverse of an SPD r x r matrix held ONE COLUMN PER LANE in registers (fp64): lane c (< r) owns
+// col[i] = M[i][c]; lanes >= r and rows >= r hold identity padding.  Pivot column entries are fetched with
+// v_readlane (compile-time lane index), so there is no LDS traffic and no barrier.  SPD => no pivoting.
+// Replaces the reference's SVD-based solve `(v (U/s)) Uh` (decomposition.py:172,194) - identical for SPD systems.
+static __device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+static __device__ __forceinline__ float readlane_f32(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+template <int RP>
+static __device__ __forceinline__ void gj_inverse_reg(double (&col)[RP], int r, int lane) {
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+        if (p < r) {
+            double cp[RP];
+#pragma unroll
+            for (int i = 0; i < RP; ++i) cp[i] = readlane_f64(col[i], p);  // M[i][p]
+            const double piv = 1.0 / cp[p];
+            const double myp = (lane == p) ? piv : col[p] * piv;  // scaled pivot-row entry of this column
+#pragma unroll
+            for (int i = 0; i < RP; ++i) {
+                if (i != p) col[i] = (lane == p) ? -cp[i] * piv : col[i] - cp[i] * myp;
             }
+            col[p] = myp;
         }
     }
-    __syncthreads();
 }
 
 static __device__ __forceinline__ float prox_elem(int kind, int nonneg, float p0, float p1, float thr, float y) {
@@ -55,33 +66,21 @@ static __device__ __forceinline__ float prox_elem(int kind, int nonneg, float p0
 // ---------------------------------------------------------------------------------------------------------
 // CtC = C^T C  (fp64 accumulation, one workgroup; C staged through LDS in row chunks)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ctc(const float *__restrict__ C, int K, int r, float *__restrict__ CtC) {
-    extern __shared__ float smf[];
-    const int chunk_rows = 8192 / r;  // <= 32 KB of LDS
-    const int npairs = r * r;
-    double acc[16];                   // r*r <= 4096 pairs / 256 threads
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = 0.0;
-    for (int k0 = 0; k0 < K; k0 += chunk_rows) {
-        const int rows = min(chunk_rows, K - k0);
-        __syncthreads();
-        for (int e = threadIdx.x; e < rows * r; e += 256) smf[e] = C[(long)k0 * r + e];
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int pr = threadIdx.x + 256 * t;
-            if (pr < npairs) {
-                const int a = pr / r, b = pr - a * r;
-                double s = 0.0;
-                for (int k = 0; k < rows; ++k) s += (double)smf[k * r + a] * (double)smf[k * r + b];
-                acc[t] += s;
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int pr = threadIdx.x + 256 * t;
-        if (pr < npairs) CtC[pr] = (float)acc[t];
+__global__ __launch_bounds__(256) void k_ctc(const float *__restrict__ C, int K, int r, int RP,
+                                               float *__restrict__ CtC) {
+    // block a computes row a of CtC; thread (b = t % RP, ks = t / RP) strides over k
+    __shared__ double sm[256];
+    const int a = blockIdx.x;
+    const int b = threadIdx.x % RP, ks = threadIdx.x / RP, nks = 256 / RP;
+    double acc = 0.0;
+    if (b < r)
+        for (int k = ks; k < K; k += nks) acc += (double)C[(long)k * r + a] * (double)C[(long)k * r + b];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < RP && b < r) {
+        double t = 0.0;
+        for (int q = 0; q < nks; ++q) t += sm[q * RP + b];
+        CtC[a * r + b] = (float)t;
     }
 }
 
@@ -102,56 +101,79 @@ __global__ void k_B_rho(const float *__restrict__ CtC, const float *__restrict__
     atomicMax(reinterpret_cast<int *>(rho_max), __float_as_int(rho));  // rho >= 0: int order == float order
 }
 
-__global__ __launch_bounds__(64) void k_B_systems(const float *__restrict__ CtC, const float *__restrict__ A, int r,
-                                                  float scale, float l2, int n_regs, int constant,
-                                                  const float *__restrict__ rho_max, float *__restrict__ rhoB,
-                                                  float *__restrict__ Linv) {
-    extern __shared__ double smd[];
-    double *M = smd, *colp = smd + r * r;
-    const int i = blockIdx.x, lane = threadIdx.x;
+template <int RP>
+__global__ __launch_bounds__(256) void k_B_systems(const float *__restrict__ CtC, const float *__restrict__ A, int I,
+                                                   int r, float scale, float l2, int n_regs, int constant,
+                                                   const float *__restrict__ rho_max, float *__restrict__ rhoB,
+                                                   float *__restrict__ Linv) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per slab
+    if (i >= I) return;
     const float *a = A + (long)i * r;
     double tr = 0.0;
     for (int c = 0; c < r; ++c) tr += (double)CtC[c * r + c] * (double)a[c] * (double)a[c];
     float rho = (float)(0.5 * tr * scale);
     if (constant) rho = rho_max[0];
     const double shift = (double)rho * n_regs + (double)l2;
-    for (int e = lane; e < r * r; e += 64) {
-        const int c = e / r, d = e - c * r;
-        M[e] = (double)CtC[e] * (double)a[c] * (double)a[d] + (c == d ? shift : 0.0);
+    const bool act = lane < r;
+    const double ac = act ? (double)a[lane] : 0.0;
+    double col[RP];
+#pragma unroll
+    for (int d = 0; d < RP; ++d) {
+        double v = (d == lane) ? 1.0 : 0.0;
+        if (act && d < r) v = (double)CtC[d * r + lane] * (double)a[d] * ac + (d == lane ? shift : 0.0);
+        col[d] = v;
     }
-    gj_inverse(M, colp, r, lane);
-    for (int e = lane; e < r * r; e += 64) Linv[(long)i * r * r + e] = (float)M[e];
+    gj_inverse_reg<RP>(col, r, lane);
+#pragma unroll
+    for (int d = 0; d < RP; ++d)
+        if (act && d < r) Linv[((long)i * r + d) * r + lane] = (float)col[d];
     if (lane == 0) rhoB[i] = rho;
 }
 
 // C-phase system from the (all-reduced) normal equations [G | R]
+template <int RP>
 __global__ __launch_bounds__(64) void k_C_prepare(const float *__restrict__ GR, int r, float scale, float l2,
                                                   int n_regs, float *__restrict__ rhoC, float *__restrict__ LinvC) {
-    extern __shared__ double smd[];
-    double *M = smd, *colp = smd + r * r;
     const int lane = threadIdx.x;
     double tr = 0.0;
     for (int c = 0; c < r; ++c) tr += (double)GR[c * r + c];
     const float rho = (float)(0.5 * tr * scale);
     const double shift = (double)rho * n_regs + (double)l2;
-    for (int e = lane; e < r * r; e += 64) {
-        const int c = e / r, d = e - c * r;
-        M[e] = (double)GR[e] + (c == d ? shift : 0.0);
+    const bool act = lane < r;
+    double col[RP];
+#pragma unroll
+    for (int d = 0; d < RP; ++d) {
+        double v = (d == lane) ? 1.0 : 0.0;
+        if (act && d < r) v = (double)GR[d * r + lane] + (d == lane ? shift : 0.0);
+        col[d] = v;
     }
-    gj_inverse(M, colp, r, lane);
-    for (int e = lane; e < r * r; e += 64) LinvC[e] = (float)M[e];
+    gj_inverse_reg<RP>(col, r, lane);
+#pragma unroll
+    for (int d = 0; d < RP; ++d)
+        if (act && d < r) LinvC[d * r + lane] = (float)col[d];
     if (lane == 0) rhoC[0] = rho;
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Fused inner ADMM loop for row-separable penalties (NN / Box / L1): one lane per packed row, the whole
-// `inner` iterations in registers; reads rhs/aux/dual once, writes factor/aux/dual once.
+// Fused inner ADMM loop for row-separable penalties (NN / Box / L1), `inner` iterations in registers:
 //   t   = rhs + rho * sum_k (z_k - u_k)            decomposition.py:269-273 / 328-331
-//   f   = t L^-1                                   (L^-1 is wave-uniform: scalar loads)
+//   f   = t L^-1                                   as v_mfma_f32_16x16x4_f32 on the TRANSPOSED problem
 //   z_k = prox_k(f + u_k, rho) ; u_k = f - (z_k - u_k)     decomposition.py:278-285 / 337-338
+// A wave owns a tile of <= 64 rows of one slab = 4 blocks of 16 rows.  Lane l = (row = l&15, g = l>>4) holds,
+// for every 16-column block h, the 4 consecutive columns 16h + 4g .. +3 of its row (one 16-B load; the 64
+// lanes of a wave cover 16 full rows = one contiguous 1 KB region when r = 16).
+// MFMA (h', h, kq):  D[c'][row] += A[c'][kk] * B[kk][row]  with  kk = g,  k = 16h + 4g + kq:
+//     A (lane (c' = l&15, g)) = L^-1[k][16h' + c']        B (lane (row = l&15, g)) = t[row][k]
+//     D (lane l, reg v)       = f[row = l&15][16h' + 4g + v]
+// i.e. the k-permutation is chosen so that the INPUT fragment layout equals the OUTPUT layout: the inner
+// iterations need no cross-lane data movement at all.
 // Per-tile diagnostics (fp64): ||f||^2, sum|f|, ||z_k - f||^2.
 // ---------------------------------------------------------------------------------------------------------
-template <int RP, int NREG>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int NBR, int NREG, bool VEC>
 __global__ __launch_bounds__(256) void k_rows_fused(const int *__restrict__ tile_slab, const int *__restrict__ tile_row0,
                                                     const int *__restrict__ tile_nrows, int n_tiles,
                                                     const float *__restrict__ rhs_src, const float *__restrict__ Arows,
@@ -164,127 +186,135 @@ __global__ __launch_bounds__(256) void k_rows_fused(const int *__restrict__ tile
     const int slab = __builtin_amdgcn_readfirstlane(tile_slab[tile]);
     const int row0 = __builtin_amdgcn_readfirstlane(tile_row0[tile]);
     const int nrows = __builtin_amdgcn_readfirstlane(tile_nrows[tile]);
-    const bool valid = lane < nrows;
-    const long j = (long)row0 + (valid ? lane : 0);
+    const int row16 = lane & 15, g = lane >> 4;
     const float rho = rho_arr[slab];
     const float *__restrict__ Li = Linv + (long)slab * r * r;
-    const bool vec = (RP >= 4) && (r == RP);
-
-    float rhs[RP];
-    if (vec) {
-#pragma unroll
-        for (int c = 0; c < RP; c += 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(rhs_src + j * r + c);
-            rhs[c] = v.x, rhs[c + 1] = v.y, rhs[c + 2] = v.z, rhs[c + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < RP; ++c) rhs[c] = (c < r) ? rhs_src[j * r + c] : 0.f;
-    }
-    if (Arows != nullptr) {
-        const float *__restrict__ a = Arows + (long)slab * r;
-#pragma unroll
-        for (int c = 0; c < RP; ++c)
-            if (c < r) rhs[c] *= a[c];
-    }
-
     constexpr int NR = NREG > 0 ? NREG : 1;
-    float z[NR][RP], u[NR][RP], thr[NR];
-#pragma unroll
-    for (int k = 0; k < NREG; ++k) {
-        thr[k] = regs.p0[k] / rho;
-        if (vec) {
-#pragma unroll
-            for (int c = 0; c < RP; c += 4) {
-                const float4 a = *reinterpret_cast<const float4 *>(regs.aux[k] + j * r + c);
-                const float4 d = *reinterpret_cast<const float4 *>(regs.dual[k] + j * r + c);
-                z[k][c] = a.x, z[k][c + 1] = a.y, z[k][c + 2] = a.z, z[k][c + 3] = a.w;
-                u[k][c] = d.x, u[k][c + 1] = d.y, u[k][c + 2] = d.z, u[k][c + 3] = d.w;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < RP; ++c) {
-                z[k][c] = (c < r) ? regs.aux[k][j * r + c] : 0.f;
-                u[k][c] = (c < r) ? regs.dual[k][j * r + c] : 0.f;
-            }
-        }
-    }
 
-    float f[RP];
-    const int n_it = (NREG == 0 && inner > 1) ? 1 : inner;  // without penalties every inner solve is identical
-    for (int it = 0; it < n_it; ++it) {
-        float t[RP];
+    // A-operand fragments of (L^-1)^T
+    float LT[NBR][NBR][4];
 #pragma unroll
-        for (int c = 0; c < RP; ++c) {
-            float s = 0.f;
+    for (int hp = 0; hp < NBR; ++hp)
 #pragma unroll
-            for (int k = 0; k < NREG; ++k) s += z[k][c] - u[k][c];
-            t[c] = (NREG > 0) ? fmaf(rho, s, rhs[c]) : rhs[c];
-            f[c] = 0.f;
-        }
+        for (int h = 0; h < NBR; ++h)
 #pragma unroll
-        for (int c = 0; c < RP; ++c) {
-            if (c < r) {
-#pragma unroll
-                for (int d = 0; d < RP; ++d)
-                    if (d < r) f[d] = fmaf(t[c], Li[c * r + d], f[d]);
+            for (int kq = 0; kq < 4; ++kq) {
+                const int k = 16 * h + 4 * g + kq, c = 16 * hp + row16;
+                LT[hp][h][kq] = (k < r && c < r) ? Li[k * r + c] : 0.f;
             }
-        }
+    float av[NBR][4];
 #pragma unroll
-        for (int k = 0; k < NREG; ++k) {
-            const int kind = regs.kind[k], nn = regs.nonneg[k];
-            const float p0 = regs.p0[k], p1 = regs.p1[k];
+    for (int h = 0; h < NBR; ++h)
 #pragma unroll
-            for (int c = 0; c < RP; ++c) {
-                const float y = f[c] + u[k][c];
-                const float zn = prox_elem(kind, nn, p0, p1, thr[k], y);
-                u[k][c] = f[c] - (zn - u[k][c]);
-                z[k][c] = zn;
-            }
+        for (int v = 0; v < 4; ++v) {
+            const int col = 16 * h + 4 * g + v;
+            av[h][v] = (Arows != nullptr && col < r) ? Arows[(long)slab * r + col] : 1.f;
         }
-    }
+    float thr[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) thr[k] = (k < NREG) ? regs.p0[k] / rho : 0.f;
 
-    if (valid) {
-        if (vec) {
-#pragma unroll
-            for (int c = 0; c < RP; c += 4) {
-                *reinterpret_cast<float4 *>(F + j * r + c) = make_float4(f[c], f[c + 1], f[c + 2], f[c + 3]);
-#pragma unroll
-                for (int k = 0; k < NREG; ++k) {
-                    *reinterpret_cast<float4 *>(regs.aux[k] + j * r + c) =
-                        make_float4(z[k][c], z[k][c + 1], z[k][c + 2], z[k][c + 3]);
-                    *reinterpret_cast<float4 *>(regs.dual[k] + j * r + c) =
-                        make_float4(u[k][c], u[k][c + 1], u[k][c + 2], u[k][c + 3]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < RP; ++c) {
-                if (c < r) {
-                    F[j * r + c] = f[c];
-#pragma unroll
-                    for (int k = 0; k < NREG; ++k) {
-                        regs.aux[k][j * r + c] = z[k][c];
-                        regs.dual[k][j * r + c] = u[k][c];
-                    }
-                }
-            }
-        }
-    }
-    // per-tile diagnostics
     double nf = 0.0, na = 0.0, gap[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) gap[k] = 0.0;
-    if (valid) {
+
+    auto ld4 = [&](const float *__restrict__ base, long j, int col, bool ok) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (VEC) {
+            if (ok && col < r) v = *reinterpret_cast<const f32x4 *>(base + j * r + col);
+        } else {
 #pragma unroll
-        for (int c = 0; c < RP; ++c) {
-            if (c < r) {
-                nf += (double)f[c] * (double)f[c];
-                na += fabs((double)f[c]);
+            for (int q = 0; q < 4; ++q)
+                if (ok && col + q < r) v[q] = base[j * r + col + q];
+        }
+        return v;
+    };
+    auto st4 = [&](float *__restrict__ base, long j, int col, bool ok, f32x4 v) {
+        if (VEC) {
+            if (ok && col < r) *reinterpret_cast<f32x4 *>(base + j * r + col) = v;
+        } else {
 #pragma unroll
-                for (int k = 0; k < NREG; ++k) {
-                    const double dlt = (double)z[k][c] - (double)f[c];
-                    gap[k] += dlt * dlt;
+            for (int q = 0; q < 4; ++q)
+                if (ok && col + q < r) base[j * r + col + q] = v[q];
+        }
+    };
+
+    const int n_it = (NREG == 0 && inner > 1) ? 1 : inner;  // without penalties every inner solve is identical
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        if (16 * rb >= nrows) break;  // wave-uniform
+        const bool ok = 16 * rb + row16 < nrows;
+        const long j = (long)row0 + 16 * rb + (ok ? row16 : 0);
+        f32x4 rhs[NBR], z[NR][NBR], u[NR][NBR], f[NBR];
+#pragma unroll
+        for (int h = 0; h < NBR; ++h) {
+            const int col = 16 * h + 4 * g;
+            rhs[h] = ld4(rhs_src, j, col, ok);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) rhs[h][v] *= av[h][v];
+#pragma unroll
+            for (int k = 0; k < NREG; ++k) {
+                z[k][h] = ld4(regs.aux[k], j, col, ok);
+                u[k][h] = ld4(regs.dual[k], j, col, ok);
+            }
+            f[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int it = 0; it < n_it; ++it) {
+            f32x4 t[NBR];
+#pragma unroll
+            for (int h = 0; h < NBR; ++h) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NREG; ++k) s += z[k][h][v] - u[k][h][v];
+                    t[h][v] = (NREG > 0) ? fmaf(rho, s, rhs[h][v]) : rhs[h][v];
+                }
+            }
+#pragma unroll
+            for (int hp = 0; hp < NBR; ++hp) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq) acc = MFMA16(LT[hp][h][kq], t[h][kq], acc);
+                f[hp] = acc;
+            }
+#pragma unroll
+            for (int k = 0; k < NREG; ++k) {
+                const int kind = regs.kind[k], nn = regs.nonneg[k];
+                const float p0 = regs.p0[k], p1 = regs.p1[k];
+#pragma unroll
+                for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float y = f[h][v] + u[k][h][v];
+                        const float zn = prox_elem(kind, nn, p0, p1, thr[k], y);
+                        u[k][h][v] = f[h][v] - (zn - u[k][h][v]);
+                        z[k][h][v] = zn;
+                    }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NBR; ++h) {
+            const int col = 16 * h + 4 * g;
+            st4(F, j, col, ok, f[h]);
+#pragma unroll
+            for (int k = 0; k < NREG; ++k) {
+                st4(regs.aux[k], j, col, ok, z[k][h]);
+                st4(regs.dual[k], j, col, ok, u[k][h]);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if (ok && col + v < r) {
+                    const double fv = (double)f[h][v];
+                    nf += fv * fv;
+                    na += fabs(fv);
+#pragma unroll
+                    for (int k = 0; k < NREG; ++k) {
+                        const double dlt = (double)z[k][h][v] - fv;
+                        gap[k] += dlt * dlt;
+                    }
                 }
             }
         }
@@ -303,67 +333,84 @@ __global__ __launch_bounds__(256) void k_rows_fused(const int *__restrict__ tile
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// A-phase finish, one wave per slab i (decomposition.py:155-219):
-//   Q_i = BtB_i o CtC (stored as cross_products), rho_i, L_i^-1 (fp64), fused inner loop on row a_i with
-//   row-separable penalties, and the per-slab terms of the fast reconstruction-error formula (:445-449).
-// fused_inner == 0: only Q_i, rho_i and L_i^-1 are produced (generic inner loop follows).
+// A-phase finish, one wave per slab i (decomposition.py:155-219), everything in registers:
+//   lane c owns column c of Q_i = BtB_i o CtC (stored back as cross_products) and of L_i = Q_i + (rho n + l2) I;
+//   L_i^-1 by the register Gauss-Jordan; fused inner loop on the row a_i with row-separable penalties
+//   (a_c = sum_d t_d L^-1[d][c], t_d fetched with v_readlane); per-slab terms of the fast reconstruction-error
+//   formula (:445-449) and the mode-0 diagnostics.
+// fused_inner == 0: only Q_i, rho_i and L_i^-1 are produced (the generic inner loop follows).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_A_finish(const float *__restrict__ rhsA, float *__restrict__ BtB,
-                                                 const float *__restrict__ CtC, int r, float scale, float l2,
-                                                 int constant, const float *__restrict__ rho_max,
-                                                 float *__restrict__ rhoA, float *__restrict__ LinvA,
-                                                 float *__restrict__ A, RegSet regs, int inner, int fused_inner,
-                                                 double *__restrict__ e1, double *__restrict__ diag_row) {
-    extern __shared__ double smd[];
-    double *M = smd, *colp = smd + r * r, *Q = colp + r, *tS = Q + r * r;
-    const int i = blockIdx.x, lane = threadIdx.x;
-    for (int e = lane; e < r * r; e += 64) {
-        const double qv = (double)BtB[(long)i * r * r + e] * (double)CtC[e];
-        Q[e] = qv;
-        BtB[(long)i * r * r + e] = (float)qv;
-    }
-    __syncthreads();
+template <int RP>
+__global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA, float *__restrict__ BtB,
+                                                  const float *__restrict__ CtC, int I, int r, float scale, float l2,
+                                                  int constant, const float *__restrict__ rho_max,
+                                                  float *__restrict__ rhoA, float *__restrict__ LinvA,
+                                                  float *__restrict__ A, RegSet regs, int inner, int fused_inner,
+                                                  double *__restrict__ e1, double *__restrict__ diag_row) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= I) return;
+    const bool act = lane < r;
+    const int c = act ? lane : 0;
+    float qcol[RP];
+    double col[RP];
     double tr = 0.0;
-    for (int c = 0; c < r; ++c) tr += Q[c * r + c];
+#pragma unroll
+    for (int d = 0; d < RP; ++d) {
+        float q = 0.f;
+        if (act && d < r) {
+            q = (float)((double)BtB[((long)i * r + d) * r + c] * (double)CtC[d * r + c]);
+            BtB[((long)i * r + d) * r + c] = q;
+        }
+        qcol[d] = q;
+        if (d == lane) tr = (double)q;
+    }
+    tr = wave_sum(act ? tr : 0.0);
     float rho = (float)(0.5 * tr * scale);
     if (constant) rho = rho_max[1];
     const int n = regs.n;
     const double shift = (double)rho * n + (double)l2;
-    for (int e = lane; e < r * r; e += 64) {
-        const int c = e / r, d = e - c * r;
-        M[e] = Q[e] + (c == d ? shift : 0.0);
+#pragma unroll
+    for (int d = 0; d < RP; ++d) {
+        double v = (d == lane) ? 1.0 : 0.0;
+        if (act && d < r) v = (double)qcol[d] + (d == lane ? shift : 0.0);
+        col[d] = v;
     }
-    gj_inverse(M, colp, r, lane);
+    gj_inverse_reg<RP>(col, r, lane);
     if (lane == 0) rhoA[i] = rho;
     if (!fused_inner) {
-        for (int e = lane; e < r * r; e += 64) LinvA[(long)i * r * r + e] = (float)M[e];
+#pragma unroll
+        for (int d = 0; d < RP; ++d)
+            if (act && d < r) LinvA[((long)i * r + d) * r + c] = (float)col[d];
         return;
     }
-    const bool act = lane < r;
-    const int c = act ? lane : 0;
-    const float rhs = rhsA[(long)i * r + c];
+    const float rhs = act ? rhsA[(long)i * r + c] : 0.f;
     float z[MCL_MAX_REGS], u[MCL_MAX_REGS], thr[MCL_MAX_REGS];
 #pragma unroll
     for (int k = 0; k < MCL_MAX_REGS; ++k) {
         z[k] = u[k] = thr[k] = 0.f;
-        if (k < n) {
+        if (k < n && act) {
             z[k] = regs.aux[k][(long)i * r + c];
             u[k] = regs.dual[k][(long)i * r + c];
-            thr[k] = regs.p0[k] / rho;
         }
+        if (k < n) thr[k] = regs.p0[k] / rho;
     }
-    float a = A[(long)i * r + c];
+    float a = act ? A[(long)i * r + c] : 0.f;
     const int n_it = (n == 0 && inner > 1) ? 1 : inner;
     for (int it = 0; it < n_it; ++it) {
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < MCL_MAX_REGS; ++k)
             if (k < n) s += z[k] - u[k];
-        __syncthreads();
-        if (act) tS[c] = (double)((n > 0) ? fmaf(rho, s, rhs) : rhs);
-        __syncthreads();
+        const float t = (n > 0) ? fmaf(rho, s, rhs) : rhs;
         double acc = 0.0;
-        for (int d = 0; d < r; ++d) acc += tS[d] * M[d * r + c];
+#pragma unroll
+        for (int d = 0; d < RP; ++d) {
+            if (d < r) {
+                const float td = readlane_f32(t, d);
+                acc += (double)td * col[d];
+            }
+        }
         a = (float)acc;
 #pragma unroll
         for (int k = 0; k < MCL_MAX_REGS; ++k) {
@@ -385,19 +432,19 @@ __global__ __launch_bounds__(64) void k_A_finish(const float *__restrict__ rhsA,
             }
         }
     }
-    // <X_i, M_i> = rhs_i . a_i ;  ||M_i||^2 = a_i^T Q_i a_i
-    __syncthreads();
-    if (act) tS[c] = (double)a;
-    __syncthreads();
+    // <X_i, M_i> = rhs_i . a_i ;  ||M_i||^2 = a_i^T Q_i a_i   (Q symmetric: column c of Q = row c)
     double qa = 0.0;
-    for (int d = 0; d < r; ++d) qa += Q[c * r + d] * tS[d];
-    double inner_i = act ? (double)rhs * (double)a : 0.0;
-    double model_i = act ? (double)a * qa : 0.0;
-    double nf = act ? (double)a * (double)a : 0.0, na = act ? fabs((double)a) : 0.0;
-    inner_i = wave_sum(inner_i);
-    model_i = wave_sum(model_i);
-    nf = wave_sum(nf);
-    na = wave_sum(na);
+#pragma unroll
+    for (int d = 0; d < RP; ++d) {
+        if (d < r) {
+            const float ad = readlane_f32(a, d);
+            qa += (double)qcol[d] * (double)ad;
+        }
+    }
+    const double inner_i = wave_sum(act ? (double)rhs * (double)a : 0.0);
+    const double model_i = wave_sum(act ? (double)a * qa : 0.0);
+    const double nf = wave_sum(act ? (double)a * (double)a : 0.0);
+    const double na = wave_sum(act ? fabs((double)a) : 0.0);
     double gap[MCL_MAX_REGS];
 #pragma unroll
     for (int k = 0; k < MCL_MAX_REGS; ++k) {
@@ -466,7 +513,10 @@ __global__ __launch_bounds__(64) void k_A_e1(const float *__restrict__ rhsA, con
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// diagnostics: ||X||^2 (once) and the final reduction of the per-tile / per-slab partial sums
+// diagnostics: ||X||^2 (once) and ONE launch that reduces every per-tile / per-slab table and assembles the
+// MCL_DIAG_LEN vector.  Block b < 3*DIAG_COLS reduces column (b % DIAG_COLS) of table (b / DIAG_COLS) in
+// {A rows, B tiles, C tiles}; the next two blocks reduce the e1 columns; the last block writes the constants.
+// Every output entry is written by exactly one block (fixed summation order: deterministic).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sumsq_partial(const float *__restrict__ x, long n, double *__restrict__ part) {
     __shared__ double sm[4];
@@ -496,45 +546,58 @@ __global__ __launch_bounds__(256) void k_sum_doubles(const double *__restrict__ 
     if (threadIdx.x == 0) out[0] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-// Column sums of a [n_rows, ncols] fp64 table (ncols <= 8): block b reduces column b.
-__global__ __launch_bounds__(256) void k_colsum_table(const double *__restrict__ tab, int n_rows, int ncols,
-                                                      double *__restrict__ out, int out_stride_is_one) {
-    __shared__ double sm[4];
-    const int col = blockIdx.x;
-    double s = 0.0;
-    for (int e = threadIdx.x; e < n_rows; e += 256) s += tab[(long)e * ncols + col];
-    s = wave_sum(s);
+
+struct DiagTables {
+    const double *tab[3];
+    int rows[3];
+    int nreg[3];
+    const double *e1;
+    int I;
+    const double *xsq;
+};
+
+static __device__ double block_colsum(const double *__restrict__ tab, int n_rows, int ncols, int col, double *sm) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int e = threadIdx.x;
+    for (; e + 768 < n_rows; e += 1024) {
+        s0 += tab[(long)e * ncols + col];
+        s1 += tab[(long)(e + 256) * ncols + col];
+        s2 += tab[(long)(e + 512) * ncols + col];
+        s3 += tab[(long)(e + 768) * ncols + col];
+    }
+    for (; e < n_rows; e += 256) s0 += tab[(long)e * ncols + col];
+    double s = wave_sum((s0 + s1) + (s2 + s3));
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[col] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-// Assemble the MCL_DIAG_LEN vector from the reduced tables (one thread; trivial)
-__global__ void k_diag_assemble(const double *__restrict__ sA, const double *__restrict__ sB,
-                                const double *__restrict__ sC, const double *__restrict__ sE,
-                                const double *__restrict__ xsq, int nA, int nB, int nC, int include_replicated,
-                                double *__restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int e = 0; e < MCL_DIAG_LEN; ++e) out[e] = 0.0;
-    out[MCL_DIAG_NORM_SQ + 0] = sA[0];
-    out[MCL_DIAG_NORM_SQ + 1] = sB[0];
-    out[MCL_DIAG_INNER] = sE[0];
-    out[MCL_DIAG_MODEL_SQ] = sE[1];
-    out[MCL_DIAG_X_SQ] = xsq[0];
-    for (int k = 0; k < nA; ++k) {
-        out[MCL_DIAG_REG + (0 * MCL_MAX_REGS + k) * 2] = sA[2 + k];
-        out[MCL_DIAG_REG + (0 * MCL_MAX_REGS + k) * 2 + 1] = sA[1];
-    }
-    for (int k = 0; k < nB; ++k) {
-        out[MCL_DIAG_REG + (1 * MCL_MAX_REGS + k) * 2] = sB[2 + k];
-        out[MCL_DIAG_REG + (1 * MCL_MAX_REGS + k) * 2 + 1] = sB[1];
-    }
-    if (include_replicated) {
-        out[MCL_DIAG_NORM_SQ + 2] = sC[0];
-        for (int k = 0; k < nC; ++k) {
-            out[MCL_DIAG_REG + (2 * MCL_MAX_REGS + k) * 2] = sC[2 + k];
-            out[MCL_DIAG_REG + (2 * MCL_MAX_REGS + k) * 2 + 1] = sC[1];
+__global__ __launch_bounds__(256) void k_diag_final(DiagTables T, int include_replicated, double *__restrict__ out) {
+    __shared__ double sm[4];
+    const int b = blockIdx.x;
+    if (b < 3 * DIAG_COLS) {
+        const int t = b / DIAG_COLS, col = b - t * DIAG_COLS;
+        const bool live = (t < 2) || include_replicated;
+        const double s = (live && T.rows[t] > 0) ? block_colsum(T.tab[t], T.rows[t], DIAG_COLS, col, sm) : 0.0;
+        if (threadIdx.x == 0) {
+            if (col == 0) {
+                out[MCL_DIAG_NORM_SQ + t] = s;
+            } else if (col == 1) {
+                for (int k = 0; k < MCL_MAX_REGS; ++k)
+                    out[MCL_DIAG_REG + (t * MCL_MAX_REGS + k) * 2 + 1] = (k < T.nreg[t]) ? s : 0.0;
+            } else {
+                const int k = col - 2;
+                out[MCL_DIAG_REG + (t * MCL_MAX_REGS + k) * 2] = (k < T.nreg[t]) ? s : 0.0;
+            }
         }
+    } else if (b < 3 * DIAG_COLS + 2) {
+        const int col = b - 3 * DIAG_COLS;
+        const double s = (T.I > 0) ? block_colsum(T.e1, T.I, 2, col, sm) : 0.0;
+        if (threadIdx.x == 0) out[col == 0 ? MCL_DIAG_INNER : MCL_DIAG_MODEL_SQ] = s;
+    } else if (threadIdx.x == 0) {
+        out[MCL_DIAG_X_SQ] = T.xsq[0];
+        out[6] = 0.0;
+        out[7] = 0.0;
     }
 }
 
@@ -596,8 +659,18 @@ bool mcl_mode_is_row_separable(const mcl_context *c, int mode) {
     return true;
 }
 
+#define DISPATCH_RP_T(c, KERNEL, grid, block, ...)                                                       \
+    switch ((c)->RP) {                                                                                   \
+        case 4: hipLaunchKernelGGL((KERNEL<4>), grid, block, 0, (c)->stream, __VA_ARGS__); break;         \
+        case 8: hipLaunchKernelGGL((KERNEL<8>), grid, block, 0, (c)->stream, __VA_ARGS__); break;         \
+        case 16: hipLaunchKernelGGL((KERNEL<16>), grid, block, 0, (c)->stream, __VA_ARGS__); break;       \
+        case 32: hipLaunchKernelGGL((KERNEL<32>), grid, block, 0, (c)->stream, __VA_ARGS__); break;       \
+        default: hipLaunchKernelGGL((KERNEL<64>), grid, block, 0, (c)->stream, __VA_ARGS__); break;       \
+    }
+
 int mcl_launch_ctc(mcl_context *c) {
-    hipLaunchKernelGGL(k_ctc, dim3(1), dim3(256), 32768, c->stream, c->C, (int)c->K, c->r, c->CtC);
+    const int RPc = c->RP < 4 ? 4 : c->RP;
+    hipLaunchKernelGGL(k_ctc, dim3((unsigned)c->r), dim3(256), 0, c->stream, c->C, (int)c->K, c->r, RPc, c->CtC);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
@@ -613,40 +686,47 @@ int mcl_launch_B_rho(mcl_context *c) {
 
 int mcl_launch_B_systems(mcl_context *c) {
     if (c->I == 0) return 0;
-    const size_t sm = sizeof(double) * (size_t)(c->r * c->r + c->r);
-    hipLaunchKernelGGL(k_B_systems, dim3((unsigned)c->I), dim3(64), sm, c->stream, c->CtC, c->A, c->r,
-                       (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[1], c->regs[1].n,
-                       c->opt.constant_B, c->rho_max, c->rhoB, c->LinvB);
+    dim3 grid((unsigned)((c->I + 3) / 4)), block(256);
+    DISPATCH_RP_T(c, k_B_systems, grid, block, c->CtC, c->A, (int)c->I, c->r, (float)c->opt.feasibility_penalty_scale,
+                  (float)c->opt.l2_penalty[1], c->regs[1].n, c->opt.constant_B, c->rho_max, c->rhoB, c->LinvB);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
 
 int mcl_launch_C_prepare(mcl_context *c) {
-    const size_t sm = sizeof(double) * (size_t)(c->r * c->r + c->r);
-    hipLaunchKernelGGL(k_C_prepare, dim3(1), dim3(64), sm, c->stream, c->GR, c->r,
-                       (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[2], c->regs[2].n, c->rhoC,
-                       c->LinvC);
+    dim3 grid(1), block(64);
+    DISPATCH_RP_T(c, k_C_prepare, grid, block, c->GR, c->r, (float)c->opt.feasibility_penalty_scale,
+                  (float)c->opt.l2_penalty[2], c->regs[2].n, c->rhoC, c->LinvC);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
 
-template <int RP, int NREG>
+template <int NBR, int NREG>
 static void launch_rows_fused_t(mcl_context *c, const TileMap &tm, const float *rhs, const float *Arows,
                                 const float *rho, const float *Linv, float *F, const RegSet &rs, double *diag) {
-    hipLaunchKernelGGL((k_rows_fused<RP, NREG>), dim3((unsigned)((tm.n_tiles + 3) / 4)), dim3(256), 0, c->stream,
-                       tm.slab, tm.row0, tm.nrows, tm.n_tiles, rhs, Arows, rho, Linv, F, rs, c->r,
-                       c->opt.inner_n_iter_max, diag);
+    bool vec = (c->r % 4 == 0) && ((reinterpret_cast<uintptr_t>(rhs) & 15) == 0) &&
+               ((reinterpret_cast<uintptr_t>(F) & 15) == 0);
+    for (int k = 0; k < rs.n; ++k)
+        vec = vec && ((reinterpret_cast<uintptr_t>(rs.aux[k]) & 15) == 0) && ((reinterpret_cast<uintptr_t>(rs.dual[k]) & 15) == 0);
+    dim3 grid((unsigned)((tm.n_tiles + 3) / 4)), block(256);
+    if (vec)
+        hipLaunchKernelGGL((k_rows_fused<NBR, NREG, true>), grid, block, 0, c->stream, tm.slab, tm.row0, tm.nrows,
+                           tm.n_tiles, rhs, Arows, rho, Linv, F, rs, c->r, c->opt.inner_n_iter_max, diag);
+    else
+        hipLaunchKernelGGL((k_rows_fused<NBR, NREG, false>), grid, block, 0, c->stream, tm.slab, tm.row0, tm.nrows,
+                           tm.n_tiles, rhs, Arows, rho, Linv, F, rs, c->r, c->opt.inner_n_iter_max, diag);
 }
 
-template <int RP>
+template <int NBR>
 static int launch_rows_fused_n(mcl_context *c, const TileMap &tm, const float *rhs, const float *Arows,
                                const float *rho, const float *Linv, float *F, const RegSet &rs, double *diag) {
     switch (rs.n) {
-        case 0: launch_rows_fused_t<RP, 0>(c, tm, rhs, Arows, rho, Linv, F, rs, diag); return 0;
-        case 1: launch_rows_fused_t<RP, 1>(c, tm, rhs, Arows, rho, Linv, F, rs, diag); return 0;
-        case 2:
-            if (RP <= 32) {
-                launch_rows_fused_t<(RP <= 32 ? RP : 32), 2>(c, tm, rhs, Arows, rho, Linv, F, rs, diag);
+        case 0: launch_rows_fused_t<NBR, 0>(c, tm, rhs, Arows, rho, Linv, F, rs, diag); return 0;
+        case 1: launch_rows_fused_t<NBR, 1>(c, tm, rhs, Arows, rho, Linv, F, rs, diag); return 0;
+        case 2: launch_rows_fused_t<NBR, 2>(c, tm, rhs, Arows, rho, Linv, F, rs, diag); return 0;
+        case 3:
+            if (NBR == 1) {
+                launch_rows_fused_t<1, 3>(c, tm, rhs, Arows, rho, Linv, F, rs, diag);
                 return 0;
             }
             return -1;
@@ -664,18 +744,24 @@ int mcl_rows_fused_dispatch(mcl_context *c, int mode, double *diag) {
     const float *rho = (mode == 1) ? c->rhoB : c->rhoC;
     const float *Linv = (mode == 1) ? c->LinvB : c->LinvC;
     float *F = (mode == 1) ? c->B : c->C;
-    switch (c->RP) {
-        case 4: return launch_rows_fused_n<4>(c, tm, rhs, Arows, rho, Linv, F, rs, diag);
-        case 8: return launch_rows_fused_n<8>(c, tm, rhs, Arows, rho, Linv, F, rs, diag);
-        case 16: return launch_rows_fused_n<16>(c, tm, rhs, Arows, rho, Linv, F, rs, diag);
-        case 32: return launch_rows_fused_n<32>(c, tm, rhs, Arows, rho, Linv, F, rs, diag);
-        default: return launch_rows_fused_n<64>(c, tm, rhs, Arows, rho, Linv, F, rs, diag);
-    }
+    if (c->r <= 16) return launch_rows_fused_n<1>(c, tm, rhs, Arows, rho, Linv, F, rs, diag);
+    if (c->r <= 32) return launch_rows_fused_n<2>(c, tm, rhs, Arows, rho, Linv, F, rs, diag);
+    if (rs.n <= 1) return launch_rows_fused_n<4>(c, tm, rhs, Arows, rho, Linv, F, rs, diag);
+    return -1;
 }
 
 int mcl_launch_rows_fused(mcl_context *c, int mode) {
     double *diag = (mode == 1) ? c->diagB_tile : c->diagC_tile;
-    const int rc = mcl_rows_fused_dispatch(c, mode, diag);
+    int rc;
+    if (mode == 1) {
+        ProfScope prof(c, 2);
+        rc = mcl_rows_fused_dispatch(c, mode, diag);
+        char buf[64];
+        snprintf(buf, sizeof buf, "k_rows_fused<NBR=%d,NREG=%d>", c->r <= 16 ? 1 : (c->r <= 32 ? 2 : 4), c->regs[1].n);
+        c->variant[2] = buf;
+    } else {
+        rc = mcl_rows_fused_dispatch(c, mode, diag);
+    }
     if (rc < 0) return rc;
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
@@ -692,11 +778,11 @@ int mcl_launch_A_rho(mcl_context *c) {
 
 int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     if (c->I == 0) return 0;
-    const size_t sm = sizeof(double) * (size_t)(2 * c->r * c->r + 2 * c->r);
-    hipLaunchKernelGGL(k_A_finish, dim3((unsigned)c->I), dim3(64), sm, c->stream, c->rhsA, c->BtB, c->CtC, c->r,
-                       (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[0], c->opt.constant_A,
-                       c->rho_max, c->rhoA, c->LinvA, c->A, c->regs[0], c->opt.inner_n_iter_max, fused_inner ? 1 : 0,
-                       c->e1, c->diagA_row);
+    dim3 grid((unsigned)((c->I + 3) / 4)), block(256);
+    DISPATCH_RP_T(c, k_A_finish, grid, block, c->rhsA, c->BtB, c->CtC, (int)c->I, c->r,
+                  (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[0], c->opt.constant_A, c->rho_max,
+                  c->rhoA, c->LinvA, c->A, c->regs[0], c->opt.inner_n_iter_max, fused_inner ? 1 : 0, c->e1,
+                  c->diagA_row);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
@@ -729,25 +815,15 @@ int mcl_launch_x_sq(mcl_context *c) {
     return 0;
 }
 
-// Final reduction: column sums of the per-tile/per-row tables, then assembly of the MCL_DIAG_LEN vector.
-// a_rows_table: mode-0 sums come from diagA_row [I] (A-phase kernels) or diagA_tile (k_rows_diag).
 int mcl_launch_diag_final(mcl_context *c, double *out, int include_replicated, bool a_from_rows) {
-    double *s = c->diag_sums;  // [3*DIAG_COLS + 2]
-    MCL_CHECK_HIP(c, hipMemsetAsync(s, 0, sizeof(double) * (3 * DIAG_COLS + 2), c->stream));
-    const int nA = a_from_rows ? (int)c->I : c->tilesA.n_tiles;
-    if (nA > 0)
-        hipLaunchKernelGGL(k_colsum_table, dim3(DIAG_COLS), dim3(256), 0, c->stream,
-                           a_from_rows ? c->diagA_row : c->diagA_tile, nA, DIAG_COLS, s, 1);
-    if (c->tilesB.n_tiles > 0)
-        hipLaunchKernelGGL(k_colsum_table, dim3(DIAG_COLS), dim3(256), 0, c->stream, c->diagB_tile, c->tilesB.n_tiles,
-                           DIAG_COLS, s + DIAG_COLS, 1);
-    if (c->tilesC.n_tiles > 0)
-        hipLaunchKernelGGL(k_colsum_table, dim3(DIAG_COLS), dim3(256), 0, c->stream, c->diagC_tile, c->tilesC.n_tiles,
-                           DIAG_COLS, s + 2 * DIAG_COLS, 1);
-    if (c->I > 0)
-        hipLaunchKernelGGL(k_colsum_table, dim3(2), dim3(256), 0, c->stream, c->e1, (int)c->I, 2, s + 3 * DIAG_COLS, 1);
-    hipLaunchKernelGGL(k_diag_assemble, dim3(1), dim3(64), 0, c->stream, s, s + DIAG_COLS, s + 2 * DIAG_COLS,
-                       s + 3 * DIAG_COLS, c->x_sq, c->regs[0].n, c->regs[1].n, c->regs[2].n, include_replicated, out);
+    DiagTables T;
+    T.tab[0] = a_from_rows ? c->diagA_row : c->diagA_tile;
+    T.rows[0] = a_from_rows ? (int)c->I : c->tilesA.n_tiles;
+    T.tab[1] = c->diagB_tile, T.rows[1] = c->tilesB.n_tiles;
+    T.tab[2] = c->diagC_tile, T.rows[2] = c->tilesC.n_tiles;
+    for (int m = 0; m < 3; ++m) T.nreg[m] = c->regs[m].n;
+    T.e1 = c->e1, T.I = (int)c->I, T.xsq = c->x_sq;
+    hipLaunchKernelGGL(k_diag_final, dim3(3 * DIAG_COLS + 3), dim3(256), 0, c->stream, T, include_replicated, out);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

@@ -191,7 +191,12 @@ int mcl_create(mcl_context **out, int device, void *hip_stream) {
     return 0;
 }
 
-void mcl_destroy(mcl_context *ctx) { delete ctx; }
+void mcl_destroy(mcl_context *ctx) {
+    if (!ctx) return;
+    for (int s = 0; s < 3; ++s)
+        for (hipEvent_t e : ctx->prof_ev[s]) hipEventDestroy(e);
+    delete ctx;
+}
 
 int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int64_t I, int64_t K, int32_t rank) {
     if (!c) return 1;
@@ -520,6 +525,39 @@ float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {
     }
     if (count) *count = n;
     return p;
+}
+
+int mcl_profile_enable(mcl_context *c, int32_t capacity) {
+    if (!c) return 1;
+    for (int s = 0; s < 3; ++s) {
+        for (hipEvent_t e : c->prof_ev[s]) hipEventDestroy(e);
+        c->prof_ev[s].clear();
+        c->prof_used[s] = 0;
+    }
+    c->prof_capacity = 0;
+    if (capacity <= 0) return 0;
+    for (int s = 0; s < 3; ++s) {
+        c->prof_ev[s].resize((size_t)2 * capacity);
+        for (auto &e : c->prof_ev[s]) MCL_CHECK_HIP(c, hipEventCreate(&e));
+    }
+    c->prof_capacity = capacity;
+    return 0;
+}
+
+int mcl_profile_read(mcl_context *c, int32_t which, double *total_ms, int32_t *count) {
+    if (!c || which < 0 || which > 2 || !total_ms || !count) return 1;
+    double tot = 0.0;
+    const int n = c->prof_used[which];
+    for (int i = 0; i < n; ++i) {
+        MCL_CHECK_HIP(c, hipEventSynchronize(c->prof_ev[which][2 * i + 1]));
+        float ms = 0.f;
+        MCL_CHECK_HIP(c, hipEventElapsedTime(&ms, c->prof_ev[which][2 * i], c->prof_ev[which][2 * i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *count = n;
+    c->prof_used[which] = 0;
+    return 0;
 }
 
 const char *mcl_kernel_variant(mcl_context *c, int32_t which) {

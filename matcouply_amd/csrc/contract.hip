@@ -432,6 +432,7 @@ static int launch_xt(mcl_context *c) {
     const int E = (int)(c->K * c->r + c->r * c->r);
     dim3 grid(nb, (unsigned)((c->K + 64 * KB - 1) / (64 * KB)));
     const bool vec = (c->K % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->X) & 15) == 0);
+    ProfScope prof(c, 1);
     if (vec)
         hipLaunchKernelGGL((k_contract_xt<KB, NB, 4, 4>), grid, dim3(256), 0, c->stream, c->X, c->B, c->A,
                            c->slab_of_row, (long)c->N, (int)c->K, c->r, gpw, ng, c->partials, E);
@@ -496,6 +497,7 @@ static int launch_xc(mcl_context *c) {
     if (grid == 0) return 0;
     const bool vec = (c->K % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->X) & 15) == 0);
     const int creg_budget = 4 / NB;  // chunks whose C fragments fit in 64 VGPRs
+    ProfScope prof(c, 0);
     int kct = 0;
     if (KC <= creg_budget) kct = KC;  // KC is even: 2 or 4
 #define MCL_XC(NB_, VEC_, KCT_)                                                                                     \

@@ -111,6 +111,30 @@ struct mcl_context {
     bool b_begun = false;
 
     std::string variant[4];
+
+    // optional HIP-event timing of kernel slots (0: X C pass, 1: X^T B pass, 2: fused B rows)
+    int prof_capacity = 0;
+    std::vector<hipEvent_t> prof_ev[3];
+    int prof_used[3] = {0, 0, 0};
+};
+
+// RAII helper: records start/stop events around a launch when profiling is enabled
+struct ProfScope {
+    mcl_context *c;
+    int slot;
+    bool on;
+    ProfScope(mcl_context *ctx, int s) : c(ctx), slot(s), on(false) {
+        if (c->prof_capacity > 0 && c->prof_used[slot] < c->prof_capacity) {
+            on = true;
+            (void)hipEventRecord(c->prof_ev[slot][2 * c->prof_used[slot]], c->stream);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(c->prof_ev[slot][2 * c->prof_used[slot] + 1], c->stream);
+            c->prof_used[slot] += 1;
+        }
+    }
 };
 
 static inline int mcl_pad_rank(int r) { return r <= 4 ? 4 : r <= 8 ? 8 : r <= 16 ? 16 : r <= 32 ? 32 : 64; }
