@@ -3,6 +3,8 @@
 //
 // Reference sites: B1/B3-B5 (decomposition.py:240-256), B6-B9 (:259-285), C2-C3 (:319-338),
 // A1/A3-A6 (:138,155-213), E1-E3 (:404-417, 445-452, 916-921), prox: penalties.py:503-586.
+#include <cstdlib>
+
 #include "mcl_internal.h"
 
 #define FULL_TILE 64
@@ -180,12 +182,14 @@ __global__ __launch_bounds__(256) void k_rows_fused(const int *__restrict__ tile
                                                     const float *__restrict__ rho_arr, const float *__restrict__ Linv,
                                                     float *__restrict__ F, RegSet regs, int r, int inner,
                                                     double *__restrict__ diag_tile) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= n_tiles) return;
+    __shared__ double dsm[4][DIAG_COLS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile_raw = blockIdx.x * 4 + wave;
+    const bool live = tile_raw < n_tiles;       // wave-uniform; dead waves do no memory traffic (nrows = 0)
+    const int tile = live ? tile_raw : n_tiles - 1;
     const int slab = __builtin_amdgcn_readfirstlane(tile_slab[tile]);
     const int row0 = __builtin_amdgcn_readfirstlane(tile_row0[tile]);
-    const int nrows = __builtin_amdgcn_readfirstlane(tile_nrows[tile]);
+    const int nrows = live ? __builtin_amdgcn_readfirstlane(tile_nrows[tile]) : 0;
     const int row16 = lane & 15, g = lane >> 4;
     const float rho = rho_arr[slab];
     const float *__restrict__ Li = Linv + (long)slab * r * r;
@@ -324,12 +328,15 @@ __global__ __launch_bounds__(256) void k_rows_fused(const int *__restrict__ tile
 #pragma unroll
     for (int k = 0; k < NREG; ++k) gap[k] = wave_sum(gap[k]);
     if (lane == 0) {
-        double *o = diag_tile + (long)tile * DIAG_COLS;
-        o[0] = nf;
-        o[1] = na;
+        dsm[wave][0] = nf;
+        dsm[wave][1] = na;
 #pragma unroll
-        for (int k = 0; k < NREG; ++k) o[2 + k] = gap[k];
+        for (int k = 0; k < NREG; ++k) dsm[wave][2 + k] = gap[k];
     }
+    __syncthreads();
+    if (threadIdx.x < 2 + NREG)  // one diagnostics row per BLOCK (4 tiles), fixed summation order
+        diag_tile[(long)blockIdx.x * DIAG_COLS + threadIdx.x] =
+            (dsm[0][threadIdx.x] + dsm[1][threadIdx.x]) + (dsm[2][threadIdx.x] + dsm[3][threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -346,7 +353,9 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
                                                   int constant, const float *__restrict__ rho_max,
                                                   float *__restrict__ rhoA, float *__restrict__ LinvA,
                                                   float *__restrict__ A, RegSet regs, int inner, int fused_inner,
-                                                  double *__restrict__ e1, double *__restrict__ diag_row) {
+                                                  double *__restrict__ e1, double *__restrict__ diag_row,
+                                                  int next_B, float l2_B, int n_regs_B, float *__restrict__ rhoB,
+                                                  float *__restrict__ LinvB) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= I) return;
@@ -459,6 +468,32 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
         o[1] = na;
 #pragma unroll
         for (int k = 0; k < MCL_MAX_REGS; ++k) o[2 + k] = gap[k];
+    }
+    if (next_B) {
+        // The next B-phase's systems depend only on the a_i just computed and on CtC (unchanged until the next
+        // C-phase): L_i = CtC o a_i a_i^T + (rho_i n_B + l2_B) I (decomposition.py:243-256) - build and invert here.
+        double trb = 0.0;
+#pragma unroll
+        for (int d = 0; d < RP; ++d) {
+            const float ad = (d < r) ? readlane_f32(a, d) : 0.f;
+            double v = (d == lane) ? 1.0 : 0.0;
+            if (act && d < r) v = (double)CtC[d * r + c] * (double)ad * (double)a;
+            if (d == lane && act) trb = v;
+            col[d] = v;
+        }
+        trb = wave_sum(act ? trb : 0.0);
+        const float rb = (float)(0.5 * trb * scale);
+        const double shiftb = (double)rb * n_regs_B + (double)l2_B;
+        if (act) {
+#pragma unroll
+            for (int d = 0; d < RP; ++d)
+                if (d == lane) col[d] += shiftb;
+        }
+        gj_inverse_reg<RP>(col, r, lane);
+#pragma unroll
+        for (int d = 0; d < RP; ++d)
+            if (act && d < r) LinvB[((long)i * r + d) * r + c] = (float)col[d];
+        if (lane == 0) rhoB[i] = rb;
     }
 }
 
@@ -763,6 +798,7 @@ int mcl_launch_rows_fused(mcl_context *c, int mode) {
         rc = mcl_rows_fused_dispatch(c, mode, diag);
     }
     if (rc < 0) return rc;
+    c->diag_rows[mode] = (((mode == 1) ? c->tilesB.n_tiles : c->tilesC.n_tiles) + 3) / 4;  // one row per block
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
@@ -778,12 +814,15 @@ int mcl_launch_A_rho(mcl_context *c) {
 
 int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     if (c->I == 0) return 0;
+    // also prepare the next B-phase's systems when that is exact: fused inner loop, per-slab rho for B
+    const int next_B = (fused_inner && !c->opt.constant_B && !getenv("MCL_NO_NEXT_B")) ? 1 : 0;
     dim3 grid((unsigned)((c->I + 3) / 4)), block(256);
     DISPATCH_RP_T(c, k_A_finish, grid, block, c->rhsA, c->BtB, c->CtC, (int)c->I, c->r,
                   (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[0], c->opt.constant_A, c->rho_max,
                   c->rhoA, c->LinvA, c->A, c->regs[0], c->opt.inner_n_iter_max, fused_inner ? 1 : 0, c->e1,
-                  c->diagA_row);
+                  c->diagA_row, next_B, (float)c->opt.l2_penalty[1], c->regs[1].n, c->rhoB, c->LinvB);
     MCL_CHECK_HIP(c, hipGetLastError());
+    c->b_systems_valid = (next_B != 0);
     return 0;
 }
 
@@ -802,6 +841,7 @@ int mcl_launch_rows_diag(mcl_context *c, int mode) {
     double *diag = (mode == 1) ? c->diagB_tile : (mode == 2 ? c->diagC_tile : c->diagA_tile);
     hipLaunchKernelGGL(k_rows_diag, dim3((unsigned)((tm.n_tiles + 3) / 4)), dim3(256), 0, c->stream, tm.row0, tm.nrows,
                        tm.n_tiles, F, c->regs[mode], c->r, diag);
+    c->diag_rows[mode] = tm.n_tiles;  // one row per tile
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
@@ -819,8 +859,8 @@ int mcl_launch_diag_final(mcl_context *c, double *out, int include_replicated, b
     DiagTables T;
     T.tab[0] = a_from_rows ? c->diagA_row : c->diagA_tile;
     T.rows[0] = a_from_rows ? (int)c->I : c->tilesA.n_tiles;
-    T.tab[1] = c->diagB_tile, T.rows[1] = c->tilesB.n_tiles;
-    T.tab[2] = c->diagC_tile, T.rows[2] = c->tilesC.n_tiles;
+    T.tab[1] = c->diagB_tile, T.rows[1] = c->diag_rows[1];
+    T.tab[2] = c->diagC_tile, T.rows[2] = c->diag_rows[2];
     for (int m = 0; m < 3; ++m) T.nreg[m] = c->regs[m].n;
     T.e1 = c->e1, T.I = (int)c->I, T.xsq = c->x_sq;
     hipLaunchKernelGGL(k_diag_final, dim3(3 * DIAG_COLS + 3), dim3(256), 0, c->stream, T, include_replicated, out);

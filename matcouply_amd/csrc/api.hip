@@ -32,11 +32,7 @@ bool has_kind(const mcl_context *c, int kind) {
     return false;
 }
 
-int xc_chunks(const mcl_context *c) {
-    int kc = (int)((c->K + 63) / 64);
-    if (kc & 1) kc += 1;
-    return kc;
-}
+int xc_chunks(const mcl_context *c) { return mcl_xc_chunks(c, nullptr); }
 
 // Assign every workspace pointer; returns the number of bytes needed.
 int64_t plan(mcl_context *c, char *base) {
@@ -54,6 +50,7 @@ int64_t plan(mcl_context *c, char *base) {
     tm(c->tilesB, c->h_tile_slab.size());
     tm(c->tilesC, c->h_ctile_slab.size());
     tm(c->tilesA, c->h_atile_slab.size());
+    tm(c->segs, c->h_seg_slab.size());
     c->ext_A = b.take<int>(2);
     c->ext_C = b.take<int>(2);
     c->XC = b.take<float>(N * r);
@@ -216,7 +213,13 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     if (c->NB == 3) c->NB = 4;
     c->h_slab_of_row.resize((size_t)N);
     c->h_tile_slab.clear(), c->h_tile_row0.clear(), c->h_tile_nrows.clear();
+    c->h_seg_slab.clear(), c->h_seg_row0.clear(), c->h_seg_nrows.clear();
     for (int64_t i = 0; i < I; ++i) {
+        for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; j += MCL_SEG_ROWS) {
+            c->h_seg_slab.push_back((int)i);
+            c->h_seg_row0.push_back((int)j);
+            c->h_seg_nrows.push_back((int)std::min<int64_t>(MCL_SEG_ROWS, row_ptr[i + 1] - j));
+        }
         for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; ++j) c->h_slab_of_row[(size_t)j] = (int)i;
         for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; j += 64) {
             c->h_tile_slab.push_back((int)i);
@@ -245,6 +248,7 @@ int mcl_set_options(mcl_context *c, const mcl_options *opt) {
     if (!c || !opt) return 1;
     if (opt->inner_n_iter_max < 0) return fail(c, "mcl_set_options: inner_n_iter_max must be >= 0");
     c->opt = *opt;
+    c->b_systems_valid = false;
     return 0;
 }
 
@@ -254,6 +258,7 @@ int mcl_set_factors(mcl_context *c, float *A, float *B, float *C) {
     if ((c->I > 0 && !A) || (c->N > 0 && !B) || !C) return fail(c, "mcl_set_factors: NULL factor pointer");
     c->A = A, c->B = B, c->C = C;
     c->has_factors = true;
+    c->b_systems_valid = false;
     c->xc_valid = c->ctc_valid = c->e1_valid = false;
     c->diag_valid[0] = c->diag_valid[1] = c->diag_valid[2] = false;
     return 0;
@@ -283,6 +288,7 @@ int mcl_set_penalties(mcl_context *c, int32_t mode, int32_t n, const mcl_penalty
         rs.aux2[k] = d.aux2;
     }
     c->regs[mode] = rs;
+    c->b_systems_valid = false;
     c->has_workspace = false;  // scratch requirements may have changed
     c->diag_valid[mode] = false;
     c->e1_valid = false;
@@ -321,6 +327,9 @@ int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
     MCL_CHECK_HIP(c, up(c->tilesA.slab, c->h_atile_slab));
     MCL_CHECK_HIP(c, up(c->tilesA.row0, c->h_atile_row0));
     MCL_CHECK_HIP(c, up(c->tilesA.nrows, c->h_atile_nrows));
+    MCL_CHECK_HIP(c, up(c->segs.slab, c->h_seg_slab));
+    MCL_CHECK_HIP(c, up(c->segs.row0, c->h_seg_row0));
+    MCL_CHECK_HIP(c, up(c->segs.nrows, c->h_seg_nrows));
     c->h_ext = {0, (int)c->I, 0, (int)c->K};
     MCL_CHECK_HIP(c, hipMemcpyAsync(c->ext_A, c->h_ext.data(), 2 * sizeof(int), hipMemcpyHostToDevice, s));
     MCL_CHECK_HIP(c, hipMemcpyAsync(c->ext_C, c->h_ext.data() + 2, 2 * sizeof(int), hipMemcpyHostToDevice, s));
@@ -345,6 +354,10 @@ float *mcl_B_rho_max(mcl_context *c) { return c ? c->rho_max : nullptr; }
 
 int mcl_B_factor(mcl_context *c) {
     if (int rc = ready(c)) return rc;
+    if (c->b_systems_valid) {  // built by the preceding A-finish from the same a_i and CtC
+        c->b_systems_valid = false;
+        return 0;
+    }
     return mcl_launch_B_systems(c);
 }
 
@@ -413,6 +426,7 @@ int mcl_update_C_finish(mcl_context *c) {
     if (int rc = mcl_launch_C_prepare(c)) return rc;
     if (c->opt.inner_n_iter_max <= 0) return 0;
     c->xc_valid = c->ctc_valid = c->e1_valid = false;
+    c->b_systems_valid = false;
     if (mcl_mode_is_row_separable(c, 2)) {
         const int rc = mcl_launch_rows_fused(c, 2);
         if (rc == 0) {

@@ -9,6 +9,8 @@
 // Both X passes are HBM-bound (r/2 flop per byte); v_mfma_f32_16x16x4_f32 does the contraction so that the
 // VALU stays free for address/guard work, and every global load of X is a 16-byte-per-lane load of
 // 256-byte row segments (4 rows per wave instruction).
+#include <cstdlib>
+
 #include "mcl_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -19,29 +21,45 @@ static __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.
 
 // ---------------------------------------------------------------------------------------------------------
 // k_contract_xt
-//   lane l = (rsub = l>>4, c16 = l&15).  One "group" = 4 consecutive packed rows; lane loads
-//   X[4g+rsub][kbase + 64kb + 4c16 .. +3] (a 256-B row segment per 16 lanes) for kb < KB.
+//   Work unit = SEGMENT: <= 256 consecutive packed rows of ONE slab (host-built table), so a_i is loaded once per
+//   segment and the pipelined inner loop over 4-row groups is branch-free.
+//   lane l = (rsub = l>>4, c16 = l&15).  One "group" = 4 consecutive rows; lane loads
+//   X[row][kbase + 64kb + 4c16 .. +3] (a 256-B row segment per 16 lanes) for kb < KB.
 //   MFMA (kb, m): A-operand = component m of that float4  -> output row index i <-> k = kbase+64kb+4i+m,
-//                 B-operand = (B o a)[4g+rsub][16nb + c16]; reduction index (l>>4) <-> the 4 rows of the group.
+//                 B-operand = (B o a)[row][16nb + c16]; reduction index (l>>4) <-> the 4 rows of the group.
 //   Accumulator (kb, m, nb), lane l, reg v  <->  R[kbase + 64kb + 4(4(l>>4)+v) + m][16nb + (l&15)].
+// Every load in the inner loop is UNCONDITIONAL (row/column indices clamped into the segment / matrix) so that
+// the compiler keeps DEPTH groups in flight with counted s_waitcnt vmcnt(N): rows past the segment end get a
+// zero B-operand, columns past K land in accumulator rows that are never written out.
 // ---------------------------------------------------------------------------------------------------------
 template <int KB, int NB, int VEC, int DEPTH>
 __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X, const float *__restrict__ B,
-                                                     const float *__restrict__ A, const int *__restrict__ slab_of_row,
-                                                     long N, int K, int r, long groups_per_wave, long n_groups,
-                                                     float *__restrict__ part, int part_stride) {
+                                                     const float *__restrict__ A, const int *__restrict__ seg_slab,
+                                                     const int *__restrict__ seg_row0, const int *__restrict__ seg_rows,
+                                                     int n_segs, int segs_per_wave, int K, int r,
+                                                     float *__restrict__ part, int part_stride, int dbg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rsub = lane >> 4, c16 = lane & 15;
     const int kbase = blockIdx.y * (64 * KB);
-    const long w = (long)blockIdx.x * 4 + wave;
-    const long g0 = w * groups_per_wave;
-    long g1 = g0 + groups_per_wave;
-    if (g1 > n_groups) g1 = n_groups;
+    const int w = blockIdx.x * 4 + wave;
+    const int s0 = w * segs_per_wave;
+    const int s1 = min(s0 + segs_per_wave, n_segs);
     const bool doG = (blockIdx.y == 0);
 
     int kcol[KB];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) kcol[kb] = kbase + 64 * kb + 4 * c16;
+    for (int kb = 0; kb < KB; ++kb) {
+        int kc = kbase + 64 * kb + 4 * c16;
+        if (VEC == 4) kc = min(kc, K - 4);  // clamped: results for k >= K are discarded
+        kcol[kb] = kc;
+    }
+    int bcol[NB];
+    bool bok[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        bok[nb] = (16 * nb + c16) < r;
+        bcol[nb] = min(16 * nb + c16, r - 1);
+    }
 
     f32x4 acc[KB][4][NB];
     f32x4 accG[NB][NB];
@@ -56,55 +74,65 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
 #pragma unroll
         for (int b = 0; b < NB; ++b) accG[a][b] = zero4();
 
-    f32x4 fx[DEPTH][KB];
-    float fb[DEPTH][NB];
+    for (int sg = s0; sg < s1; ++sg) {
+        const int slab = __builtin_amdgcn_readfirstlane(seg_slab[sg]);
+        const long row0 = __builtin_amdgcn_readfirstlane(seg_row0[sg]);
+        const int nrows = __builtin_amdgcn_readfirstlane(seg_rows[sg]);
+        const int ng = (nrows + 3) >> 2;
+        float a_val[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) a_val[nb] = bok[nb] ? A[(long)slab * r + bcol[nb]] : 0.f;
 
-    auto load = [&](int d, long g) {
-        const long j = g * 4 + rsub;
-        const bool ok = (g < g1) && (j < N);
+        f32x4 fx[DEPTH][KB];
+        float fb[DEPTH][NB], fa[DEPTH][NB];
+        auto load = [&](int d, int g) {
+            const int rl = 4 * g + rsub;
+            const long j = row0 + min(rl, nrows - 1);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            if (VEC == 4) {
-                f32x4 v = zero4();
-                if (ok && kcol[kb] < K) v = *reinterpret_cast<const f32x4 *>(X + j * K + kcol[kb]);
-                fx[d][kb] = v;
-            } else {
-                f32x4 v = zero4();
+            for (int kb = 0; kb < KB; ++kb) {
+                if (VEC == 4) {
+                    fx[d][kb] = *reinterpret_cast<const f32x4 *>(X + j * K + kcol[kb]);
+                } else {
+                    f32x4 v;
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    if (ok && kcol[kb] + m < K) v[m] = X[j * K + kcol[kb] + m];
-                fx[d][kb] = v;
+                    for (int m = 0; m < 4; ++m) v[m] = X[j * K + min(kcol[kb] + m, K - 1)];
+                    fx[d][kb] = v;
+                }
             }
-        }
-        const int s = ok ? slab_of_row[j] : 0;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int col = nb * 16 + c16;
-            float v = 0.f;
-            if (ok && col < r) v = B[j * r + col] * A[(long)s * r + col];
-            fb[d][nb] = v;
-        }
-    };
-
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) load(d, g0 + d);
-
-    for (long g = g0; g < g1; g += DEPTH) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[kb][m][nb] = MFMA16(fx[d][kb][m], fb[d][nb], acc[kb][m][nb]);
-            if (doG) {
-#pragma unroll
-                for (int a = 0; a < NB; ++a)
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) accG[a][b] = MFMA16(fb[d][a], fb[d][b], accG[a][b]);
+            for (int nb = 0; nb < NB; ++nb) {
+                fb[d][nb] = B[j * r + bcol[nb]];
+                fa[d][nb] = (rl < nrows) ? a_val[nb] : 0.f;
             }
-            load(d, g + DEPTH + d);
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) load(d, d);
+        for (int g = 0; g < ng; g += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                float ba[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) ba[nb] = fb[d][nb] * fa[d][nb];
+                if (dbg & 1) {  // timing experiment: loads only
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) acc[kb][0][0] += fx[d][kb] * ba[0];
+                    load(d, g + DEPTH + d);
+                    continue;
+                }
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) acc[kb][m][nb] = MFMA16(fx[d][kb][m], ba[nb], acc[kb][m][nb]);
+                if (doG) {
+#pragma unroll
+                    for (int a = 0; a < NB; ++a)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) accG[a][b] = MFMA16(ba[a], ba[b], accG[a][b]);
+                }
+                load(d, g + DEPTH + d);
+            }
         }
     }
 
@@ -197,18 +225,21 @@ __global__ void k_build_cfrag(const float *__restrict__ C, int K, int r, int KC,
 
 // ---------------------------------------------------------------------------------------------------------
 // k_contract_xc : XC = X C.  A wave owns blocks of 16 packed rows and walks K in chunks of 64 columns.
-//   global -> registers: lane (rsub, c16), t<4: X[j0 + 4t + rsub][64kc + 4c16 .. +3]   (256-B row segments)
+//   global -> registers: lane (q = l>>4, i16 = l&15), t<4: X[j0 + 4t + q][64kc + 4 i16 .. +3]  (256-B row segments)
 //   registers -> LDS   : wave-private 16 x 64 fp32 tile, 16-B slot index XORed with the row (conflict-free)
-//   LDS -> fragments   : lane (q = l>>4, i = l&15), kq<4: X[j0 + i][64kc + 16kq + 4q .. +3]
-//   MFMA (kq, m)       : A = component m (row i, k = 64kc+16kq+4q+m), B = Cfrag(kc,kq,nb)[m]
+//   LDS -> fragments   : lane (q, i16), kq<4: X[j0 + i16][64kc + 16kq + 4q .. +3]
+//   MFMA (kq, m)       : A = component m (row i16, k = 64kc+16kq+4q+m), B = Cfrag(kc,kq,nb)[m]
 //   accumulator nb, lane l, reg v <-> XC[j0 + 4(l>>4) + v][16nb + (l&15)]
-// KCT > 0: K <= 64*KCT and the C fragments live in registers; KCT == 0: runtime (even) chunk count,
-// fragments re-read from the L1/L2-resident Cfrag buffer each chunk.
+// The (block, chunk) steps of a wave are flattened and software-pipelined through a 4-slot register ring:
+// loads are UNCONDITIONAL (addresses clamped; columns >= K meet zero C fragments, rows >= N are never stored),
+// so 4 chunks (16 KB per wave) stay in flight under counted s_waitcnt vmcnt(N).
+// KCT in {2, 4}: K <= 64*KCT, C fragments live in registers.  KCT == 0: runtime chunk count (multiple of 4, the
+// host pads Cfrag with zeros), fragments re-read from the L1/L2-resident Cfrag buffer each chunk.
 // ---------------------------------------------------------------------------------------------------------
 template <int NB, int VEC, int KCT>
 __global__ __launch_bounds__(256) void k_contract_xc(const float *__restrict__ X, const float *__restrict__ Cfrag,
                                                      float *__restrict__ XC, long N, int K, int r, int KCrt,
-                                                     long blocks_per_wave, long n_blocks16) {
+                                                     long blocks_per_wave, long n_blocks16, int dbg) {
     __shared__ float lds_all[4][16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, i16 = lane & 15;
@@ -233,77 +264,91 @@ __global__ __launch_bounds__(256) void k_contract_xc(const float *__restrict__ X
                         *reinterpret_cast<const f32x4 *>(Cfrag + ((((long)kc * 4 + kq) * NB + nb) * 64 + lane) * 4);
     }
 
-    f32x4 xr[2][4];
-    // stage the 16 x 64 chunk (blk, kc) into ring slot `slot` (zeros outside the matrix)
+    f32x4 xr[4][4];
+    // stage the 16 x 64 chunk (blk, kc) into ring slot `slot`
     auto issue = [&](int slot, long blk, int kc) {
-        const bool in = blk < b1;
-        const int col = 64 * kc + 4 * i16;
+        const long bc = min(blk, b1 - 1);
+        int col = 64 * kc + 4 * i16;
+        if (VEC == 4) col = min(col, K - 4);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const long j = blk * 16 + 4 * t + q;
-            f32x4 v = zero4();
+            const long j = min(bc * 16 + 4 * t + q, N - 1);
             if (VEC == 4) {
-                if (in && j < N && col < K) v = *reinterpret_cast<const f32x4 *>(X + j * K + col);
+                xr[slot][t] = *reinterpret_cast<const f32x4 *>(X + j * K + col);
             } else {
+                f32x4 v;
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    if (in && j < N && col + m < K) v[m] = X[j * K + col + m];
+                for (int m = 0; m < 4; ++m) v[m] = X[j * K + min(col + m, K - 1)];
+                xr[slot][t] = v;
             }
-            xr[slot][t] = v;
         }
     };
 
     f32x4 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = zero4();
     auto step = [&](int slot, long blk, int kc, long nblk, int nkc, const f32x4 (&cf)[4][NB]) {
-        if (kc == 0) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = zero4();
-        }
-        // registers -> LDS (row = 4t + q, slot = c16 ^ row)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int row = 4 * t + q;
-            *reinterpret_cast<f32x4 *>(L + row * 64 + ((i16 ^ row) << 2)) = xr[slot][t];
-        }
+        // registers -> LDS (row = 4t + q, slot = i16 ^ row)
         f32x4 fr[4];
+        if (dbg & 2) {  // timing experiment: no LDS staging (wrong results)
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) fr[kq] = *reinterpret_cast<const f32x4 *>(L + i16 * 64 + (((4 * kq + q) ^ i16) << 2));
+            for (int kq = 0; kq < 4; ++kq) fr[kq] = xr[slot][kq];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = 4 * t + q;
+                *reinterpret_cast<f32x4 *>(L + row * 64 + ((i16 ^ row) << 2)) = xr[slot][t];
+            }
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq)
+                fr[kq] = *reinterpret_cast<const f32x4 *>(L + i16 * 64 + (((4 * kq + q) ^ i16) << 2));
+        }
         issue(slot, nblk, nkc);
+        if (dbg & 1) {  // timing experiment: no MFMA
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq)
+            for (int kq = 0; kq < 4; ++kq) acc[0] += fr[kq] * cf[kq][0];
+        } else {
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA16(fr[kq][m], cf[kq][nb][m], acc[nb]);
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA16(fr[kq][m], cf[kq][nb][m], acc[nb]);
+        }
         if (kc == KC - 1) {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+            for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const long j = blk * 16 + 4 * q + v;
                     const int col = 16 * nb + i16;
                     if (j < N && col < r) XC[j * r + col] = acc[nb][v];
                 }
+                acc[nb] = zero4();
+            }
         }
     };
 
-    issue(0, b0, 0);
-    issue(1, (KC > 1) ? b0 : b0 + 1, (KC > 1) ? 1 : 0);
     if (KCT > 0) {
-        for (long blk = b0; blk < b1; ++blk) {
+        // 4 flattened steps per trip: (blk + d / KCT, d % KCT)
+        constexpr int BPT = 4 / CR;  // blocks per trip
 #pragma unroll
-            for (int kc = 0; kc < CR; ++kc) {
-                const int nk = kc + 2;
-                const long nblk = blk + nk / CR;
-                step(kc & 1, blk, kc, nblk, nk % CR, creg[kc]);
+        for (int d = 0; d < 4; ++d) issue(d, b0 + d / CR, d % CR);
+        for (long blk = b0; blk < b1; blk += BPT) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const long cb = blk + d / CR;
+                if (cb < b1) step(d, cb, d % CR, cb + BPT, d % CR, creg[d % CR]);
             }
         }
     } else {
-        // KCrt is even (host pads), so ring slot = kc & 1 is static in the 2-unrolled loop
-        for (long blk = b0; blk < b1; ++blk) {
-            for (int kc = 0; kc < KC; kc += 2) {
+        // KCrt is a multiple of 4
 #pragma unroll
-                for (int d = 0; d < 2; ++d) {
+        for (int d = 0; d < 4; ++d) issue(d, b0, d);
+        for (long blk = b0; blk < b1; ++blk) {
+            for (int kc = 0; kc < KC; kc += 4) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
                     f32x4 cf[4][NB];
 #pragma unroll
                     for (int kq = 0; kq < 4; ++kq)
@@ -311,7 +356,7 @@ __global__ __launch_bounds__(256) void k_contract_xc(const float *__restrict__ X
                         for (int nb = 0; nb < NB; ++nb)
                             cf[kq][nb] = *reinterpret_cast<const f32x4 *>(
                                 Cfrag + ((((long)(kc + d) * 4 + kq) * NB + nb) * 64 + lane) * 4);
-                    int nk = kc + d + 2;
+                    int nk = kc + d + 4;
                     long nblk = blk;
                     if (nk >= KC) {
                         nk -= KC;
@@ -320,6 +365,105 @@ __global__ __launch_bounds__(256) void k_contract_xc(const float *__restrict__ X
                     step(d, blk, kc + d, nblk, nk, cf);
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_contract_xc_row : XC = X C for K % 256 == 0.  Same MFMA mapping as k_contract_xc, but the global access is
+// ROW-CONTIGUOUS: a wave stages a 16-row x 256-column super-chunk with 16 wave-loads of ONE 1 KB row segment each
+// (lane l reads columns 4l..4l+3), i.e. the same access geometry as a plain streaming copy; for K = 256 the
+// 16 loads cover one contiguous 16 KB region.  The tile lives in a wave-private 16 KB LDS image whose 16-B slot
+// index is XORed with the row (conflict-free ds_write_b128 / ds_read_b128).  The next super-chunk's 16 loads are
+// in flight while the current one is multiplied (16 KB per wave outstanding).
+// CREG: K == 256 and the 64 C-fragment registers per NB fit (NB == 1): fragments stay in registers.
+// ---------------------------------------------------------------------------------------------------------
+template <int NB, bool CREG>
+__global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict__ X, const float *__restrict__ Cfrag,
+                                                         float *__restrict__ XC, long N, int K, int r,
+                                                         long blocks_per_wave, long n_blocks16) {
+    extern __shared__ float lds_dyn[];  // 4 waves x 16 rows x 256 floats
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, i16 = lane & 15;
+    float *L = lds_dyn + wave * (16 * 256);
+    const int SC = K >> 8;  // super-chunks per row block
+    const long w = (long)blockIdx.x * 4 + wave;
+    const long b0 = w * blocks_per_wave;
+    long b1 = b0 + blocks_per_wave;
+    if (b1 > n_blocks16) b1 = n_blocks16;
+    if (b0 >= b1) return;
+
+    constexpr int CR = CREG ? 4 : 1;
+    f32x4 creg[CR][4][NB];
+    if (CREG) {
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    creg[kc][kq][nb] =
+                        *reinterpret_cast<const f32x4 *>(Cfrag + ((((long)kc * 4 + kq) * NB + nb) * 64 + lane) * 4);
+    }
+
+    f32x4 xr[16];
+    auto issue = [&](long blk, int sc) {
+        const long bc = min(blk, b1 - 1);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const long j = min(bc * 16 + t, N - 1);
+            xr[t] = *reinterpret_cast<const f32x4 *>(X + j * K + 256 * sc + 4 * lane);
+        }
+    };
+
+    f32x4 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = zero4();
+
+    issue(b0, 0);
+    for (long blk = b0; blk < b1; ++blk) {
+        for (int sc = 0; sc < SC; ++sc) {
+            // registers -> LDS: row t, logical 16-B slot = lane, physical slot = lane ^ t
+#pragma unroll
+            for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4 *>(L + t * 256 + ((lane ^ t) << 2)) = xr[t];
+            // prefetch the next super-chunk
+            int nsc = sc + 1;
+            long nblk = blk;
+            if (nsc == SC) nsc = 0, nblk = blk + 1;
+            issue(nblk, nsc);
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                f32x4 fr[4];
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq)
+                    fr[kq] = *reinterpret_cast<const f32x4 *>(L + i16 * 256 + (((16 * kc + 4 * kq + q) ^ i16) << 2));
+                f32x4 cf[4][NB];
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        if (CREG) cf[kq][nb] = creg[kc][kq][nb];
+                        else
+                            cf[kq][nb] = *reinterpret_cast<const f32x4 *>(
+                                Cfrag + ((((long)(4 * sc + kc) * 4 + kq) * NB + nb) * 64 + lane) * 4);
+                    }
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA16(fr[kq][m], cf[kq][nb][m], acc[nb]);
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const long j = blk * 16 + 4 * q + v;
+                const int col = 16 * nb + i16;
+                if (j < N && col < r) XC[j * r + col] = acc[nb][v];
+            }
+            acc[nb] = zero4();
         }
     }
 }
@@ -405,40 +549,53 @@ static inline int xt_KB(const mcl_context *c) {
     return need < kb ? (need <= 1 ? 1 : (need <= 2 ? 2 : 4)) : kb;
 }
 
-static inline void xt_geometry(const mcl_context *c, long *n_groups, long *gpw, int *n_blocks) {
-    *n_groups = (c->N + 3) / 4;
-    const long target_waves = 2048;  // 256 CUs x 8 waves
-    long g = (*n_groups + target_waves - 1) / target_waves;
-    if (g < 4) g = 4;  // at least one prefetch ring of work per wave
-    *gpw = g;
-    const long waves = (*n_groups + g - 1) / g;
-    long nb = (waves + 3) / 4;
+static inline void xt_geometry(const mcl_context *c, int *segs_per_wave, int *n_blocks) {
+    const int n_segs = c->segs.n_tiles;
+    int target_waves = 1024;  // 256 CUs x 4 waves: measured best (one 256-thread block per CU)
+    if (const char *e = getenv("MCL_XT_WAVES")) target_waves = atoi(e);
+    int spw = (n_segs + target_waves - 1) / target_waves;
+    if (spw < 1) spw = 1;
+    const int waves = (n_segs + spw - 1) / spw;
+    int nb = (waves + 3) / 4;
     if (nb < 1) nb = 1;
-    *n_blocks = (int)nb;
+    *segs_per_wave = spw;
+    *n_blocks = nb;
 }
 
 int mcl_contract_n_partials(const mcl_context *c) {
-    long ng, gpw;
-    int nb;
-    xt_geometry(c, &ng, &gpw, &nb);
+    int spw, nb;
+    xt_geometry(c, &spw, &nb);
     return nb;
 }
 
 template <int KB, int NB>
 static int launch_xt(mcl_context *c) {
-    long ng, gpw;
-    int nb;
-    xt_geometry(c, &ng, &gpw, &nb);
+    int spw, nb;
+    xt_geometry(c, &spw, &nb);
     const int E = (int)(c->K * c->r + c->r * c->r);
+    if (c->segs.n_tiles == 0) {  // no rows: the partial slab is all zeros
+        MCL_CHECK_HIP(c, hipMemsetAsync(c->partials, 0, sizeof(float) * (size_t)E, c->stream));
+        c->n_part = 1;
+        return 0;
+    }
     dim3 grid(nb, (unsigned)((c->K + 64 * KB - 1) / (64 * KB)));
     const bool vec = (c->K % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->X) & 15) == 0);
     ProfScope prof(c, 1);
-    if (vec)
-        hipLaunchKernelGGL((k_contract_xt<KB, NB, 4, 4>), grid, dim3(256), 0, c->stream, c->X, c->B, c->A,
-                           c->slab_of_row, (long)c->N, (int)c->K, c->r, gpw, ng, c->partials, E);
-    else
-        hipLaunchKernelGGL((k_contract_xt<KB, NB, 1, 2>), grid, dim3(256), 0, c->stream, c->X, c->B, c->A,
-                           c->slab_of_row, (long)c->N, (int)c->K, c->r, gpw, ng, c->partials, E);
+    int dbg = 0, depth = 4;
+    if (const char *e = getenv("MCL_XT_DBG")) dbg = atoi(e);
+    if (const char *e = getenv("MCL_XT_DEPTH")) depth = atoi(e);
+#define MCL_XT(VEC_, DEPTH_)                                                                                          \
+    hipLaunchKernelGGL((k_contract_xt<KB, NB, VEC_, DEPTH_>), grid, dim3(256), 0, c->stream, c->X, c->B, c->A,        \
+                       c->segs.slab, c->segs.row0, c->segs.nrows, c->segs.n_tiles, spw, (int)c->K, c->r, c->partials, \
+                       E, dbg)
+    if (vec) {
+        if (depth == 8 && KB * NB <= 4) MCL_XT(4, 8);
+        else if (depth == 2) MCL_XT(4, 2);
+        else MCL_XT(4, 4);
+    } else {
+        MCL_XT(1, 2);
+    }
+#undef MCL_XT
     c->n_part = nb;
     char buf[96];
     snprintf(buf, sizeof buf, "k_contract_xt<KB=%d,NB=%d,VEC=%d>", KB, NB, vec ? 4 : 1);
@@ -470,11 +627,7 @@ int mcl_launch_reduce_partials(mcl_context *c) {
     return 0;
 }
 
-static inline int xc_KC(const mcl_context *c) {
-    int kc = (int)((c->K + 63) / 64);
-    if (kc & 1) kc += 1;  // even chunk count (ring slot parity is static)
-    return kc;
-}
+static inline int xc_KC(const mcl_context *c) { return mcl_xc_chunks(c, nullptr); }
 
 int mcl_launch_build_cfrag(mcl_context *c) {
     const int KC = xc_KC(c);
@@ -489,27 +642,45 @@ template <int NB>
 static int launch_xc(mcl_context *c) {
     const int KC = xc_KC(c);
     const long nblk = (c->N + 15) / 16;
-    const long target_waves = 2048;
+    long target_waves = 2048;
+    if (const char *e = getenv("MCL_XC_WAVES")) target_waves = atol(e);
+    int dbg = 0;
+    if (const char *e = getenv("MCL_XC_DBG")) dbg = atoi(e);
     long bpw = (nblk + target_waves - 1) / target_waves;
     if (bpw < 1) bpw = 1;
     const long waves = (nblk + bpw - 1) / bpw;
     const unsigned grid = (unsigned)((waves + 3) / 4);
     if (grid == 0) return 0;
     const bool vec = (c->K % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->X) & 15) == 0);
-    const int creg_budget = 4 / NB;  // chunks whose C fragments fit in 64 VGPRs
     ProfScope prof(c, 0);
     int kct = 0;
-    if (KC <= creg_budget) kct = KC;  // KC is even: 2 or 4
+    mcl_xc_chunks(c, &kct);
+    if (vec && (c->K % 256 == 0) && !getenv("MCL_XC_NOROW")) {
+        const size_t sm = sizeof(float) * 4 * 16 * 256;
+        const bool creg = (c->K == 256) && (NB == 1);
+        if (creg)
+            hipLaunchKernelGGL((k_contract_xc_row<NB, true>), dim3(grid), dim3(256), sm, c->stream, c->X, c->Cfrag, c->XC,
+                               (long)c->N, (int)c->K, c->r, bpw, nblk);
+        else
+            hipLaunchKernelGGL((k_contract_xc_row<NB, false>), dim3(grid), dim3(256), sm, c->stream, c->X, c->Cfrag,
+                               c->XC, (long)c->N, (int)c->K, c->r, bpw, nblk);
+        char buf[96];
+        snprintf(buf, sizeof buf, "k_contract_xc_row<NB=%d,CREG=%d>", NB, creg ? 1 : 0);
+        c->variant[0] = buf;
+        MCL_CHECK_HIP(c, hipGetLastError());
+        return 0;
+    }
 #define MCL_XC(NB_, VEC_, KCT_)                                                                                     \
     hipLaunchKernelGGL((k_contract_xc<NB_, VEC_, KCT_>), dim3(grid), dim3(256), 0, c->stream, c->X, c->Cfrag, c->XC, \
-                       (long)c->N, (int)c->K, c->r, KC, bpw, nblk)
+                       (long)c->N, (int)c->K, c->r, KC, bpw, nblk, dbg)
     if (vec) {
         if (kct == 4) MCL_XC(NB, 4, 4);
         else if (kct == 2) MCL_XC(NB, 4, 2);
         else MCL_XC(NB, 4, 0);
     } else {
-        MCL_XC(NB, 1, 0);
-        kct = 0;
+        if (kct == 4) MCL_XC(NB, 1, 4);
+        else if (kct == 2) MCL_XC(NB, 1, 2);
+        else MCL_XC(NB, 1, 0);
     }
 #undef MCL_XC
     char buf[96];

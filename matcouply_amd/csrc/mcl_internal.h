@@ -9,6 +9,7 @@
 #include "../../include/matcouply_hip.h"
 
 #define DIAG_COLS (2 + MCL_MAX_REGS)
+#define MCL_SEG_ROWS 256
 
 #define MCL_CHECK_HIP(ctx, expr)                                                                      \
     do {                                                                                              \
@@ -60,6 +61,7 @@ struct mcl_context {
     std::vector<int> h_slab_of_row, h_tile_slab, h_tile_row0, h_tile_nrows;
     std::vector<int> h_ctile_slab, h_ctile_row0, h_ctile_nrows;  // C-mode: one slab of K rows
     std::vector<int> h_atile_slab, h_atile_row0, h_atile_nrows;  // A-mode: one slab of I rows
+    std::vector<int> h_seg_slab, h_seg_row0, h_seg_nrows;
 
     // workspace carve-up (device pointers)
     char *ws = nullptr;
@@ -67,6 +69,7 @@ struct mcl_context {
     int *slab_of_row = nullptr;
     int *row_ptr_dev = nullptr;  // int32[I+1]
     TileMap tilesB, tilesC, tilesA;
+    TileMap segs;  // <= MCL_SEG_ROWS-row segments of one slab each: work units of the X^T (B o a) pass
     float *XC = nullptr;        // [N, r]   X C  (cached between the A-phase and the next B-phase)
     float *Cfrag = nullptr;     // C in MFMA-fragment order for the X C kernel
     float *CtC = nullptr;       // [r, r]
@@ -108,6 +111,8 @@ struct mcl_context {
     bool diag_valid[3] = {false, false, false};  // per-mode diag tables consistent with factors/aux
     bool diagA_from_rows = false;
     bool xsq_valid = false;
+    bool b_systems_valid = false;  // rhoB/LinvB already hold the systems of the coming B-phase (built by A-finish)
+    int diag_rows[3] = {0, 0, 0};  // rows currently valid in diagA_row / diagB_tile / diagC_tile
     bool b_begun = false;
 
     std::string variant[4];
@@ -136,6 +141,19 @@ struct ProfScope {
         }
     }
 };
+
+// Chunk count (64 columns each) of the X C kernel: 2 or 4 when the C fragments fit in registers (KCT template
+// argument), otherwise a multiple of 4 (runtime loop; Cfrag is zero-padded).
+static inline int mcl_xc_chunks(const mcl_context *c, int *kct) {
+    const int raw = (int)((c->K + 63) / 64);
+    const int budget = 4 / c->NB;  // chunks whose fragments fit in 64 VGPRs
+    int kc, t;
+    if (raw <= 2 && budget >= 2) kc = 2, t = 2;
+    else if (raw <= 4 && budget >= 4) kc = 4, t = 4;
+    else kc = (raw + 3) & ~3, t = 0;
+    if (kct) *kct = t;
+    return kc;
+}
 
 static inline int mcl_pad_rank(int r) { return r <= 4 ? 4 : r <= 8 ? 8 : r <= 16 ? 16 : r <= 32 ? 32 : 64; }
 
