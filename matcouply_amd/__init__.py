@@ -6,4 +6,5 @@ hand-written HIP kernels (libmatcouply_hip.so, C ABI in include/matcouply_hip.h)
 """
 __version__ = "0.1.0"
 
-# (submodules are imported below once they exist)
+from . import coupled_matrices, data, decomposition, penalties, random  # noqa: F401,E402
+from .decomposition import PackedMatrices  # noqa: F401,E402

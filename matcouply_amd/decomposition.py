@@ -1,0 +1,696 @@
+"""`cmf_aoadmm` / `parafac2_aoadmm` on the MI355X engine.
+
+Same signature, defaults, return types, error behaviour and stopping rules as
+/root/reference/src/matcouply/decomposition.py (`cmf_aoadmm` :662-1100, `parafac2_aoadmm` :1103-1179,
+`compute_feasibility_gaps` :351-417, `ADMMVars` :643-645, `DiagnosticMetrics` :648-659).  The host side only
+parses arguments, draws the initial state with the reference's RNG order (:35-37, :904-905), keeps the loss /
+stopping bookkeeping (:990-1053) and converts results; every per-mode ADMM update runs in the HIP library
+(matcouply_amd/_engine.py -> libmatcouply_hip.so).  There is no CPU fallback.
+
+Extensions (keyword-only, not in the reference): `group=` a torch.distributed process group - every rank passes
+ITS OWN contiguous range of the I matrices; the replicated C-mode normal equations and the diagnostic sums are
+all-reduced over the group (RCCL on MI355X, gloo in the CPU tests).
+"""
+from copy import copy
+from typing import NamedTuple, Optional
+
+import numpy as np
+
+from . import _engine, penalties
+from ._utils import check_random_state, get_svd, is_iterable, is_tensor, is_torch, shape, torch
+from .coupled_matrices import CoupledMatrixFactorization
+
+__all__ = ["compute_feasibility_gaps", "ADMMVars", "DiagnosticMetrics", "cmf_aoadmm", "parafac2_aoadmm",
+           "PackedMatrices"]
+
+# factory of the compute engine; tests of the host / multi-GPU logic substitute a checker engine here
+_ENGINE_FACTORY = None
+
+
+class PackedMatrices:
+    """The I coupled matrices already packed along rows in device memory: X [sum J_i, K] float32 (torch CUDA
+    tensor) + row_ptr [I+1].  Behaves like the list of the I matrices (len / iteration / indexing give views),
+    and lets callers that keep their data in HBM skip the host-side packing."""
+
+    def __init__(self, X, row_ptr):
+        self.X = X
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        if self.row_ptr[0] != 0 or self.row_ptr[-1] != X.shape[0]:
+            raise ValueError("row_ptr must start at 0 and end at X.shape[0]")
+
+    def __len__(self):
+        return len(self.row_ptr) - 1
+
+    def __getitem__(self, i):
+        return self.X[self.row_ptr[i]: self.row_ptr[i + 1]]
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# initialisation (decomposition.py:18-89)
+# ------------------------------------------------------------------------------------------------------------
+def initialize_cmf(matrices, rank, init, svd_fun, random_state=None, init_params=None):
+    random_state = check_random_state(random_state)
+    if isinstance(init, (tuple, list, CoupledMatrixFactorization)):
+        weights, (A, B_is, C) = init
+        if weights is not None:
+            scaled_A = weights * A
+            return CoupledMatrixFactorization((None, (scaled_A, B_is, C)))
+        return CoupledMatrixFactorization(init)
+    if init == "random":
+        I = len(matrices)
+        K = shape(matrices[0])[1]
+        A = random_state.uniform(size=(I, rank))
+        C = random_state.uniform(size=(K, rank))
+        B_is = [random_state.uniform(size=(shape(matrix)[0], rank)) for matrix in matrices]
+        return CoupledMatrixFactorization((None, [A, B_is, C]))
+    if init == "svd" or init == "threshold_svd":
+        # one-off set-up on the host (decomposition.py:42-53)
+        from ._utils import to_numpy
+
+        mats = [np.asarray(to_numpy(m), dtype=np.float64) for m in matrices]
+        A = np.ones((len(mats), rank))
+        B_is = [svd_fun(m, n_eigenvecs=rank)[0] for m in mats]
+        C = svd_fun(np.concatenate(mats, 0), n_eigenvecs=rank)[2].T
+        if init == "threshold_svd":
+            B_is = [np.clip(B_i, 0, float("inf")) for B_i in B_is]
+            C = np.clip(C, 0, float("inf"))
+        return CoupledMatrixFactorization((None, [A, B_is, np.ascontiguousarray(C)]))
+    if init in ("parafac2_als", "cp_als", "parafac_als", "cp_hals", "parafac_hals"):
+        raise NotImplementedError(
+            f'init="{init}" delegates to TensorLy decompositions in the reference (decomposition.py:55-73) and is '
+            "out of scope of this engine; pass an explicit (weights, (A, B_is, C)) tuple instead.")
+    raise ValueError('Initialization method "{}" not recognized'.format(init))
+
+
+def initialize_aux(matrices, rank, reg, random_state):
+    A_aux_list = [A_reg.init_aux(matrices, rank, 0, random_state=random_state) for A_reg in reg[0]]
+    B_aux_list = [B_reg.init_aux(matrices, rank, 1, random_state=random_state) for B_reg in reg[1]]
+    C_aux_list = [C_reg.init_aux(matrices, rank, 2, random_state=random_state) for C_reg in reg[2]]
+    return A_aux_list, B_aux_list, C_aux_list
+
+
+def initialize_dual(matrices, rank, reg, random_state):
+    A_dual_list = [A_reg.init_dual(matrices, rank, 0, random_state=random_state) for A_reg in reg[0]]
+    B_dual_list = [B_reg.init_dual(matrices, rank, 1, random_state=random_state) for B_reg in reg[1]]
+    C_dual_list = [C_reg.init_dual(matrices, rank, 2, random_state=random_state) for C_reg in reg[2]]
+    return A_dual_list, B_dual_list, C_dual_list
+
+
+# ------------------------------------------------------------------------------------------------------------
+# public diagnostics helper (decomposition.py:347-417) on host/device arrays
+# ------------------------------------------------------------------------------------------------------------
+def _sq(x):
+    return float((x.double() ** 2).sum()) if is_torch(x) else float(np.sum(np.asarray(x, dtype=np.float64) ** 2))
+
+
+def _root_sum_squared_list(x_list):
+    return np.sqrt(sum(_sq(x) for x in x_list))
+
+
+def compute_feasibility_gaps(cmf, regs, A_aux_list, B_aux_list, C_aux_list):
+    r"""Feasibility gaps ||aux - x|| / ||x|| per penalty and mode; the B-mode gap pools all B_i (:404-417)."""
+    weights, (A, B_is, C) = cmf
+    A_norm = np.sqrt(_sq(A))
+    B_norm = _root_sum_squared_list(B_is)
+    C_norm = np.sqrt(_sq(C))
+    A_gaps = [np.sqrt(_sq(A_reg.subtract_from_aux(A_aux, A))) / A_norm for A_reg, A_aux in zip(regs[0], A_aux_list)]
+    B_gaps = [_root_sum_squared_list(B_reg.subtract_from_auxes(B_is_aux, B_is)) / B_norm
+              for B_reg, B_is_aux in zip(regs[1], B_aux_list)]
+    C_gaps = [np.sqrt(_sq(C_reg.subtract_from_aux(C_aux, C))) / C_norm for C_reg, C_aux in zip(regs[2], C_aux_list)]
+    return A_gaps, B_gaps, C_gaps
+
+
+# ------------------------------------------------------------------------------------------------------------
+# argument parsing (decomposition.py:455-614)
+# ------------------------------------------------------------------------------------------------------------
+def _listify(input_value, param_name):
+    if hasattr(input_value, "get"):
+        return [input_value.get(i, None) for i in range(3)]
+    elif not is_iterable(input_value):
+        return [input_value] * 3
+    else:
+        out = list(input_value)
+        if not len(out) == 3:
+            raise ValueError(
+                "All parameters must be a dictionary, non-iterable value or non-dictionary iterable of length 3."
+                f" {param_name} is iterable of length {len(out)}.")
+        return out
+
+
+def _parse_all_penalties(non_negative, lower_bound, upper_bound, l2_norm_bound, unimodal, parafac2, l1_penalty,
+                         tv_penalty, generalized_l2_penalty, svd, regs, dual_init, aux_init, verbose):
+    if regs is None:
+        regs = [[], [], []]
+    elif is_iterable(regs):
+        for modereg in regs:
+            if not is_iterable(modereg):
+                raise TypeError(
+                    "regs should contain an iterable of iterables containting "
+                    "matcouply.penalties.ADMMMPenalty instances at least one of the"
+                    f"elements in regs were not iterable (regs={regs})")
+            else:
+                for reg in modereg:
+                    if not isinstance(reg, penalties.ADMMPenalty):
+                        raise TypeError(
+                            "regs should contain an iterable of iterables containting "
+                            "matcouply.penalties.ADMMMPenalty instances at least one of the"
+                            f"elements in regs contained something other than an ADMMPenalty (regs={regs})")
+    regs = [copy(reg_list) for reg_list in regs]  # avoid side effects on the input lists
+
+    non_negative = _listify(non_negative, "non_negative")
+    upper_bound = _listify(upper_bound, "upper_bound")
+    lower_bound = _listify(lower_bound, "lower_bound")
+    l2_norm_bound = _listify(l2_norm_bound, "l2_norm_bound")
+    unimodal = _listify(unimodal, "unimodal")
+    parafac2 = [False, True, False] if parafac2 else [False, False, False]
+    l1_penalty = _listify(l1_penalty, "l1_penalty")
+    generalized_l2_penalty = _listify(generalized_l2_penalty, "generalized_l2_penalty")
+    tv_penalty = _listify(tv_penalty, "tv_penalty")
+
+    for mode in range(3):
+        parsed_regs = _parse_mode_penalties(
+            non_negative=non_negative[mode], lower_bound=lower_bound[mode], upper_bound=upper_bound[mode],
+            l2_norm_bound=l2_norm_bound[mode], unimodal=unimodal[mode], parafac2=parafac2[mode],
+            l1_penalty=l1_penalty[mode], tv_penalty=tv_penalty[mode],
+            generalized_l2_penalty=generalized_l2_penalty[mode], svd=svd, dual_init=dual_init, aux_init=aux_init)
+        regs[mode] = parsed_regs + regs[mode]
+
+    if verbose:
+        print("All regularization penalties (including regs list):")
+        for mode, reg in enumerate(regs):
+            print(f"* Mode {mode}:")
+            if len(reg) == 0:
+                print("   - (no regularization added)")
+            for single_reg in reg:
+                print(f"   - {single_reg}")
+    return regs
+
+
+def _parse_mode_penalties(non_negative, lower_bound, upper_bound, l2_norm_bound, unimodal, parafac2, l1_penalty,
+                          tv_penalty, generalized_l2_penalty, svd, dual_init, aux_init):
+    """Order: Parafac2, Unimodality, (GeneralizedL2), L2Ball, (TV), L1, Box, NonNegativity (decomposition.py:571-612)."""
+    if not l1_penalty:
+        l1_penalty = 0
+    regs = []
+    skip_non_negative = False
+    if parafac2:
+        regs.append(penalties.Parafac2(svd=svd, aux_init=aux_init, dual_init=dual_init))
+    if unimodal:
+        regs.append(penalties.Unimodality(non_negativity=non_negative, aux_init=aux_init, dual_init=dual_init))
+        skip_non_negative = True
+    if generalized_l2_penalty is not None and generalized_l2_penalty is not False:
+        raise NotImplementedError("generalized_l2_penalty is out of scope of this engine (SURVEY.md 2.1)")
+    if l2_norm_bound:
+        regs.append(penalties.L2Ball(l2_norm_bound, non_negativity=non_negative, aux_init=aux_init, dual_init=dual_init))
+        skip_non_negative = True
+    if tv_penalty:
+        raise NotImplementedError("tv_penalty needs the GPL condat_tv library in the reference and is out of scope here")
+    if l1_penalty:
+        regs.append(penalties.L1Penalty(l1_penalty, non_negativity=non_negative, aux_init=aux_init, dual_init=dual_init))
+        skip_non_negative = True
+    if lower_bound is not None or upper_bound is not None:
+        if lower_bound is None:
+            lower_bound = -float("inf")
+        if non_negative:
+            lower_bound = max(lower_bound, 0)
+        regs.append(penalties.Box(lower_bound, upper_bound, aux_init=aux_init, dual_init=dual_init))
+        skip_non_negative = True
+    if non_negative and not skip_non_negative:
+        regs.append(penalties.NonNegativity(aux_init=aux_init, dual_init=dual_init))
+    return regs
+
+
+def _check_feasibility(feasibility_gaps, feasibility_tol):
+    A_gaps, B_gaps, C_gaps = feasibility_gaps
+    max_feasibility_gap = -float("inf")
+    if len(A_gaps):
+        max_feasibility_gap = max((max(A_gaps), max_feasibility_gap))
+    if len(B_gaps):
+        max_feasibility_gap = max((max(B_gaps), max_feasibility_gap))
+    if len(C_gaps):
+        max_feasibility_gap = max((max(C_gaps), max_feasibility_gap))
+    return max_feasibility_gap < feasibility_tol
+
+
+class ADMMVars(NamedTuple):
+    auxes: tuple  #: Length three tuple containing a list of auxiliary factor matrices for each mode
+    duals: tuple  #: Length three tuple containing a list of dual variables for each mode
+
+
+class DiagnosticMetrics(NamedTuple):
+    rec_errors: list  #: reconstruction errors, one per iteration plus the initial one
+    feasibility_gaps: list  #: feasibility gaps, one per iteration plus the initial one
+    regularized_loss: list  #: regularized loss, one per iteration plus the initial one
+    satisfied_stopping_condition: Optional[bool]  #: None if no tolerance is set
+    satisfied_feasibility_condition: Optional[bool]  #: None if no tolerance is set
+    n_iter: int  #: Number of iterations ran
+    message: str  #: Convergence message
+
+
+# ------------------------------------------------------------------------------------------------------------
+# host <-> device plumbing
+# ------------------------------------------------------------------------------------------------------------
+def _device():
+    if torch is None or not torch.cuda.is_available():
+        raise _engine.EngineError(
+            "no HIP device visible: matcouply_amd runs the AO-ADMM updates on an MI355X (gfx950); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _dtype():
+    """float32 on the device; a substituted checker engine (tests) may ask for float64 state."""
+    return getattr(_ENGINE_FACTORY, "dtype", torch.float32) if _ENGINE_FACTORY is not None else torch.float32
+
+
+def _to_dev(x, device):
+    if is_torch(x):
+        return x.detach().to(device=device, dtype=_dtype()).contiguous().clone()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x)), device=device).to(_dtype()).contiguous()
+
+
+def _pack(matrices, device):
+    """-> (X [N, K] float32 on device, row_ptr int64 [I+1])"""
+    if isinstance(matrices, PackedMatrices):
+        X = matrices.X
+        if not (is_torch(X) and X.is_cuda and X.dtype == torch.float32 and X.is_contiguous()):
+            raise TypeError("PackedMatrices.X must be a contiguous float32 CUDA tensor")
+        return X, matrices.row_ptr
+    mats = list(matrices)
+    K = shape(mats[0])[1]
+    for m in mats:
+        if len(shape(m)) != 2 or shape(m)[1] != K:
+            raise ValueError("All matrices must be second order tensors with the same number of columns")
+    rows = [shape(m)[0] for m in mats]
+    row_ptr = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    if all(is_torch(m) for m in mats):
+        X = torch.cat([m.detach().to(device=device, dtype=torch.float32) for m in mats], 0).contiguous()
+    else:
+        host = np.empty((int(row_ptr[-1]), K), dtype=np.float32)
+        for i, m in enumerate(mats):
+            host[row_ptr[i]: row_ptr[i + 1]] = m.detach().cpu().numpy() if is_torch(m) else np.asarray(m)
+        X = torch.from_numpy(host).to(device)
+    return X, row_ptr
+
+
+def _pack_rows(list_of_matrices, device):
+    if len(list_of_matrices) == 0:
+        return torch.zeros((0, 0), dtype=torch.float32, device=device)
+    if all(is_torch(m) for m in list_of_matrices):
+        return torch.cat([m.detach().to(device=device, dtype=_dtype()) for m in list_of_matrices], 0).contiguous()
+    return _to_dev(np.concatenate([m.detach().cpu().numpy() if is_torch(m) else np.asarray(m)
+                                   for m in list_of_matrices], 0), device)
+
+
+class _Out:
+    """Converts device results back to the array type / dtype / device of the caller's matrices."""
+
+    def __init__(self, matrices):
+        first = matrices.X if isinstance(matrices, PackedMatrices) else matrices[0]
+        self.torch_out = is_torch(first)
+        self.dtype = first.dtype
+        self.device = first.device if self.torch_out else None
+
+    def __call__(self, t):
+        if self.torch_out:
+            return t.detach().to(device=self.device, dtype=self.dtype).clone()
+        return t.detach().cpu().numpy().astype(self.dtype if np.issubdtype(self.dtype, np.floating) else np.float64)
+
+    def split(self, t, row_ptr):
+        full = self(t)
+        return [full[row_ptr[i]: row_ptr[i + 1]] for i in range(len(row_ptr) - 1)]
+
+
+def _default_engine_factory(**kw):
+    return _engine.HipEngine(**kw)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the solver
+# ------------------------------------------------------------------------------------------------------------
+def cmf_aoadmm(
+    matrices,
+    rank,
+    init="random",
+    n_iter_max=1000,
+    l2_penalty=None,
+    tv_penalty=None,
+    l1_penalty=None,
+    non_negative=None,
+    unimodal=None,
+    generalized_l2_penalty=None,
+    l2_norm_bound=None,
+    lower_bound=None,
+    upper_bound=None,
+    parafac2=None,
+    regs=None,
+    feasibility_penalty_scale=1,
+    constant_feasibility_penalty=False,
+    aux_init="random_uniform",
+    dual_init="random_uniform",
+    svd="truncated_svd",
+    init_params=None,
+    random_state=None,
+    tol=1e-8,
+    absolute_tol=1e-10,
+    feasibility_tol=1e-4,
+    inner_tol=None,
+    inner_n_iter_max=5,
+    update_A=True,
+    update_B_is=True,
+    update_C=True,
+    return_admm_vars=False,
+    return_errors=False,
+    verbose=False,
+    *,
+    group=None,
+):
+    r"""Fit a regularized coupled matrix factorization model with AO-ADMM on an MI355X.
+
+    Parameters, defaults, return values (``cmf`` or ``(cmf[, ADMMVars][, DiagnosticMetrics])``) and stopping rules are
+    those of ``matcouply.decomposition.cmf_aoadmm`` (reference decomposition.py:662-1100): regularization parameters may
+    be ``None``, a scalar (all modes), a length-3 list, or a ``{mode: value}`` dict; mode 0 is A, mode 1 the B_i, mode 2 C.
+
+    ``matrices`` is a list of I arrays (NumPy or torch, J_i x K) or a :class:`PackedMatrices` already in HBM.  The
+    arithmetic runs in fp32 on the device (rank x rank systems and all reductions in fp64); results are returned in the
+    array type and dtype of the input.  Not supported (out of scope, raise ``NotImplementedError``): ``tv_penalty``,
+    ``generalized_l2_penalty``, TensorLy-ALS initialisations, ``inner_tol``, user-defined penalty subclasses.
+
+    >>> import numpy as np, matcouply_amd
+    >>> len(matcouply_amd.decomposition._listify({1: 0.5}, "l1_penalty"))
+    3
+    """
+    random_state = check_random_state(random_state)
+    svd_fun = get_svd(svd)
+    cmf = initialize_cmf(matrices, rank, init, svd_fun=svd_fun, random_state=random_state, init_params=init_params)
+
+    l2_penalty = _listify(l2_penalty, "l2_penalty")
+    l2_penalty = [l2 if l2 is not None else 0 for l2 in l2_penalty]
+
+    regs = _parse_all_penalties(
+        non_negative=non_negative, lower_bound=lower_bound, upper_bound=upper_bound, l2_norm_bound=l2_norm_bound,
+        unimodal=unimodal, parafac2=parafac2, l1_penalty=l1_penalty, tv_penalty=tv_penalty,
+        generalized_l2_penalty=generalized_l2_penalty, svd=svd, regs=regs, dual_init=dual_init, aux_init=aux_init,
+        verbose=verbose)
+    if not update_A:
+        regs[0] = []
+    if not update_B_is:
+        regs[1] = []
+    if not update_C:
+        regs[2] = []
+    if inner_tol:
+        raise NotImplementedError("inner_tol (early exit of the inner ADMM loops) is not supported by the fused kernels; "
+                                  "the default inner_tol=None runs inner_n_iter_max iterations as the reference does")
+    if isinstance(constant_feasibility_penalty, str) and constant_feasibility_penalty not in {"A", "B"}:
+        raise ValueError(
+            f"If `constant_feasibility_penalty` is a string, it must be 'A' or 'B', not {constant_feasibility_penalty}")
+    constant_A = (constant_feasibility_penalty and not isinstance(constant_feasibility_penalty, str)
+                  ) or constant_feasibility_penalty == "A"
+    constant_B = (constant_feasibility_penalty and not isinstance(constant_feasibility_penalty, str)
+                  ) or constant_feasibility_penalty == "B"
+
+    # ---- initial ADMM state with the reference's draw order (aux of modes 0,1,2 then duals of modes 0,1,2) ----
+    A_aux_list, B_aux_list, C_aux_list = initialize_aux(matrices, rank, regs, random_state=random_state)
+    A_dual_list, B_dual_list, C_dual_list = initialize_dual(matrices, rank, regs, random_state=random_state)
+
+    # ---- move everything to the device -----------------------------------------------------------------------
+    factory = _ENGINE_FACTORY or _default_engine_factory
+    device = _device() if _ENGINE_FACTORY is None else getattr(_ENGINE_FACTORY, "device", torch.device("cpu"))
+    X, row_ptr = _pack(matrices, device) if _ENGINE_FACTORY is None else _ENGINE_FACTORY.pack(matrices)
+    out = _Out(matrices)
+    _, (A0, B0_is, C0) = cmf
+    A, B, C = _to_dev(A0, device), _pack_rows(B0_is, device), _to_dev(C0, device)
+    if B.shape != (X.shape[0], rank):
+        raise ValueError("The B_i matrices of `init` do not match the shapes of `matrices`")
+
+    native = [[], [], []]
+    aux_lists, dual_lists = (A_aux_list, B_aux_list, C_aux_list), (A_dual_list, B_dual_list, C_dual_list)
+    for mode in range(3):
+        for reg, aux, dual in zip(regs[mode], aux_lists[mode], dual_lists[mode]):
+            desc = reg._native_descriptor()
+            if desc is None:
+                raise NotImplementedError(
+                    f"{type(reg).__name__} has no native HIP kernel; user-defined / non-default penalties need the "
+                    "EXTERNAL step path, which is not available yet")
+            kind, nonneg, p0, p1 = desc
+            dual_t = _pack_rows(dual, device) if mode == 1 else _to_dev(dual, device)
+            if kind == _engine.PEN_PARAFAC2:
+                P_is, Delta = aux
+                native[mode].append(_engine.NativeReg(kind, _pack_rows(P_is, device), dual_t,
+                                                      aux2=_to_dev(Delta, device)))
+            else:
+                aux_t = _pack_rows(aux, device) if mode == 1 else _to_dev(aux, device)
+                native[mode].append(_engine.NativeReg(kind, aux_t, dual_t, non_negativity=nonneg, p0=p0, p1=p1))
+
+    eng = factory(X=X, row_ptr=row_ptr, rank=rank, A=A, B=B, C=C, regs=native, l2_penalty=l2_penalty,
+                  inner_n_iter_max=inner_n_iter_max, feasibility_penalty_scale=feasibility_penalty_scale,
+                  constant_A=constant_A, constant_B=constant_B)
+    world = 1
+    dist = None
+    if group is not None:
+        import torch.distributed as dist  # noqa: F811
+
+        world = dist.get_world_size(group)
+        rank_id = dist.get_rank(group)
+    else:
+        rank_id = 0
+    needs_B_steps = world > 1 and (constant_B or any(r.kind == _engine.PEN_PARAFAC2 for r in native[1]))
+    needs_A_steps = world > 1 and constant_A
+    if world > 1 and not all(r.kind in (_engine.PEN_NN, _engine.PEN_BOX, _engine.PEN_L1) for r in native[0]):
+        raise NotImplementedError("matrix penalties on mode 0 couple rows that live on different ranks; "
+                                  "not supported with group=")
+
+    def all_reduce(t, op=None):
+        if world > 1:
+            dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=group)
+
+    def do_update_B():
+        if not needs_B_steps:
+            eng.update_B()
+            return
+        eng.B_begin()
+        if constant_B:
+            all_reduce(eng.B_rho_max(), dist.ReduceOp.MAX)
+        eng.B_factor()
+        n_it = inner_n_iter_max if native[1] else min(1, inner_n_iter_max)
+        for _ in range(n_it):
+            eng.B_solve()
+            for k, reg in enumerate(native[1]):
+                eng.B_prox_local(k)
+                if reg.kind == _engine.PEN_PARAFAC2:
+                    all_reduce(eng.B_prox_reduce_buffer(k))
+                eng.B_prox_finish(k)
+
+    def do_update_C():
+        gr = eng.update_C_local()
+        all_reduce(gr)
+        eng.update_C_finish()
+
+    def do_update_A():
+        if not needs_A_steps:
+            eng.update_A()
+            return
+        eng.A_begin()
+        all_reduce(eng.A_rho_max(), dist.ReduceOp.MAX)
+        eng.A_finish()
+
+    def read_diag(vec):
+        """MCL_DIAG vector (already all-reduced) -> (rec_error, (A_gaps, B_gaps, C_gaps), reg_penalty + l2)"""
+        d = vec.detach().cpu().numpy() if is_torch(vec) else np.asarray(vec)
+        xsq, inner, model = d[_engine.DIAG_X_SQ], d[_engine.DIAG_INNER], d[_engine.DIAG_MODEL_SQ]
+        norm_matrices = np.sqrt(xsq)
+        rec_error = np.sqrt(max(0.0, xsq - 2 * inner + model)) / norm_matrices
+        gaps, reg_penalty = [], 0.0
+        for mode in range(3):
+            fnorm = np.sqrt(d[_engine.DIAG_NORM_SQ + mode])
+            mode_gaps = []
+            for k, reg in enumerate(regs[mode]):
+                base = _engine.DIAG_REG + (mode * _engine.MCL_MAX_REGS + k) * 2
+                mode_gaps.append(np.sqrt(d[base]) / fnorm)
+                if isinstance(reg, penalties.L1Penalty):
+                    reg_penalty += reg.reg_strength * d[base + 1]
+            gaps.append(mode_gaps)
+            if l2_penalty[mode]:
+                reg_penalty += 0.5 * l2_penalty[mode] * d[_engine.DIAG_NORM_SQ + mode]
+        return rec_error, tuple(gaps), reg_penalty
+
+    def diagnostics():
+        vec = eng.diagnostics(include_replicated=(rank_id == 0))
+        all_reduce(vec)
+        return read_diag(vec)
+
+    rec_errors, feasibility_gaps, losses = [], [], []
+    rec_error, gaps0, reg0 = diagnostics()
+    rec_errors.append(rec_error)
+    losses.append(0.5 * rec_error ** 2 + reg0)
+    A_gaps, B_gaps, C_gaps = gaps0
+    feasibility_gaps.append(gaps0)
+    if verbose and verbose > 0:
+        print("Feasibility gaps for A: {}".format(A_gaps))
+        print("Feasibility gaps for the Bi-matrices: {}".format(B_gaps))
+        print("Feasibility gaps for C: {}".format(C_gaps))
+
+    satisfied_stopping_condition = False
+    message = "MAXIMUM NUMBER OF ITERATIONS REACHED"
+    feasibility_criterion = None
+
+    it = -1  # Needed if n_iter_max <= 0
+    fast_path = (not (tol or absolute_tol)) and world == 1 and not verbose and n_iter_max > 0
+    if fast_path:
+        # fixed iteration count: the whole outer loop runs natively, diagnostics stay on the device until the end
+        ring = None
+        if return_errors:
+            ring = torch.zeros((n_iter_max, _engine.DIAG_LEN), dtype=torch.float64, device=device)
+        eng.iterate(n_iter_max, update_A=update_A, update_B=update_B_is, update_C=update_C, diag_ring=ring)
+        it = n_iter_max - 1
+        if return_errors:
+            host_ring = ring.cpu().numpy()
+            for row in host_ring:
+                rec_error, gaps, reg = read_diag(row)
+                feasibility_gaps.append(gaps)
+                rec_errors.append(rec_error)
+                losses.append(0.5 * rec_error ** 2 + reg)
+    else:
+        for it in range(n_iter_max):
+            if update_B_is:
+                do_update_B()
+            if update_C:
+                do_update_C()
+            if update_A:
+                do_update_A()
+
+            if tol or absolute_tol or return_errors:
+                rec_error, curr_feasibility_gaps, reg_pen = diagnostics()
+                feasibility_gaps.append(curr_feasibility_gaps)
+
+                if tol or absolute_tol:
+                    feasibility_criterion = feasibility_tol and _check_feasibility(curr_feasibility_gaps, feasibility_tol)
+                    if not feasibility_criterion and not return_errors:
+                        A_gaps, B_gaps, C_gaps = curr_feasibility_gaps
+                        if verbose and it % verbose == 0 and verbose > 0:
+                            print("Coupled matrix factorization iteration={}, ".format(it)
+                                  + "reconstruction error=NOT COMPUTED, "
+                                  + "regularized loss=NOT COMPUTED, "
+                                  + "regularized loss variation=NOT COMPUTED.")
+                            print("Feasibility gaps for A: {}".format(A_gaps))
+                            print("Feasibility gaps for the Bi-matrices: {}".format(B_gaps))
+                            print("Feasibility gaps for C: {}".format(C_gaps))
+                        continue
+
+                rec_errors.append(rec_error)
+                losses.append(0.5 * rec_error ** 2 + reg_pen)
+
+                if verbose and it % verbose == 0 and verbose > 0:
+                    A_gaps, B_gaps, C_gaps = curr_feasibility_gaps
+                    print("Coupled matrix factorization iteration={}, ".format(it)
+                          + "reconstruction error={}, ".format(rec_errors[-1])
+                          + "regularized loss={} ".format(losses[-1])
+                          + "regularized loss variation={}.".format(abs(losses[-2] - losses[-1]) / losses[-2]))
+                    print("Feasibility gaps for A: {}".format(A_gaps))
+                    print("Feasibility gaps for the Bi-matrices: {}".format(B_gaps))
+                    print("Feasibility gaps for C: {}".format(C_gaps))
+
+                if tol:
+                    rel_loss_criterion = abs(losses[-2] - losses[-1]) < (tol * losses[-2])
+                    abs_loss_criterion = losses[-1] < absolute_tol
+                    if feasibility_criterion and rel_loss_criterion:
+                        satisfied_stopping_condition = True
+                        message = "FEASIBILITY GAP CRITERION AND RELATIVE LOSS CRITERION SATISFIED"
+                        if verbose:
+                            print("converged in {} iterations: {}".format(it, message))
+                        break
+                    elif feasibility_criterion and abs_loss_criterion:
+                        satisfied_stopping_condition = True
+                        message = "FEASIBILITY GAP CRITERION AND ABSOLUTE LOSS CRITERION SATISFIED"
+                        if verbose:
+                            print("converged in {} iterations: {}".format(it, message))
+                        break
+            elif verbose and it % verbose == 0 and verbose > 0:
+                print("Coupled matrix factorization iteration={}".format(it))
+        else:
+            if verbose:
+                print("REACHED MAXIMUM NUMBER OF ITERATIONS")
+
+    if feasibility_tol and return_errors:
+        _, final_gaps, _ = diagnostics()
+        feasibility_criterion = _check_feasibility(final_gaps, feasibility_tol)
+    elif not feasibility_tol:
+        feasibility_criterion = None
+
+    # ---- results back in the caller's array type ------------------------------------------------------------------
+    cmf = CoupledMatrixFactorization((None, (out(eng.A), out.split(eng.B, row_ptr), out(eng.C))))
+    result = [cmf]
+    if return_admm_vars:
+        auxes, duals = [[], [], []], [[], [], []]
+        for mode in range(3):
+            for reg in native[mode]:
+                if reg.kind == _engine.PEN_PARAFAC2:
+                    auxes[mode].append((out.split(reg.aux, row_ptr), out(reg.aux2)))
+                else:
+                    auxes[mode].append(out.split(reg.aux, row_ptr) if mode == 1 else out(reg.aux))
+                duals[mode].append(out.split(reg.dual, row_ptr) if mode == 1 else out(reg.dual))
+        result.append(ADMMVars(auxes=tuple(auxes), duals=tuple(duals)))
+    if return_errors:
+        if not satisfied_stopping_condition and not (tol or absolute_tol):
+            satisfied_stopping_condition = None
+        result.append(DiagnosticMetrics(
+            rec_errors=rec_errors, feasibility_gaps=feasibility_gaps, regularized_loss=losses,
+            satisfied_stopping_condition=satisfied_stopping_condition,
+            satisfied_feasibility_condition=feasibility_criterion, message=message, n_iter=it + 1))
+    if hasattr(eng, "close"):
+        eng.close()
+    if len(result) == 1:
+        return result[0]
+    return tuple(result)
+
+
+def parafac2_aoadmm(
+    matrices,
+    rank,
+    init="random",
+    n_iter_max=1000,
+    l2_penalty=0,
+    tv_penalty=None,
+    l1_penalty=None,
+    non_negative=None,
+    unimodal=None,
+    generalized_l2_penalty=None,
+    l2_norm_bound=None,
+    lower_bound=None,
+    upper_bound=None,
+    regs=None,
+    feasibility_penalty_scale=1,
+    constant_feasibility_penalty=False,
+    aux_init="random_uniform",
+    dual_init="random_uniform",
+    svd="truncated_svd",
+    init_params=None,
+    random_state=None,
+    tol=1e-8,
+    absolute_tol=1e-10,
+    feasibility_tol=1e-4,
+    inner_tol=None,
+    inner_n_iter_max=5,
+    update_A=True,
+    update_B_is=True,
+    update_C=True,
+    return_errors=False,
+    return_admm_vars=False,
+    verbose=False,
+    *,
+    group=None,
+):
+    """Alias for cmf_aoadmm with the PARAFAC2 constraint on mode 1 (reference decomposition.py:1103-1179)."""
+    return cmf_aoadmm(
+        matrices=matrices, rank=rank, init=init, n_iter_max=n_iter_max, l2_penalty=l2_penalty, tv_penalty=tv_penalty,
+        l1_penalty=l1_penalty, non_negative=non_negative, unimodal=unimodal,
+        generalized_l2_penalty=generalized_l2_penalty, l2_norm_bound=l2_norm_bound, lower_bound=lower_bound,
+        upper_bound=upper_bound, parafac2=True, regs=regs, feasibility_penalty_scale=feasibility_penalty_scale,
+        constant_feasibility_penalty=constant_feasibility_penalty, aux_init=aux_init, dual_init=dual_init, svd=svd,
+        init_params=init_params, random_state=random_state, tol=tol, absolute_tol=absolute_tol,
+        feasibility_tol=feasibility_tol, inner_tol=inner_tol, inner_n_iter_max=inner_n_iter_max, update_A=update_A,
+        update_B_is=update_B_is, update_C=update_C, return_errors=return_errors, return_admm_vars=return_admm_vars,
+        verbose=verbose, group=group)

@@ -1,0 +1,136 @@
+"""CPU, world_size 2 over gloo: the product's sharded driver (`cmf_aoadmm(..., group=...)`: slabs split over ranks,
+all-reduce of the C-mode normal equations / diagnostics / PARAFAC2 coordinate sums / constant-rho maxima) must
+reproduce the single-process run.  The checker engine stands in for the HIP engine (no GPU here)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = {
+    "c3_nn_l1C": dict(non_negative=True, l1_penalty={2: 0.1}),
+    "pf2_ball_constant": dict(parafac2=True, l2_norm_bound={1: 1.0}, non_negative={0: True},
+                              constant_feasibility_penalty=True),
+}
+
+
+def _problem():
+    rng = np.random.RandomState(5)
+    I, K, r = 6, 9, 3
+    J = [7, 4, 9, 5, 8, 6]
+    A, C = rng.uniform(0.1, 1.1, (I, r)), rng.uniform(size=(K, r))
+    mats = [(rng.uniform(size=(j, r)) * A[i]) @ C.T + 0.05 * rng.standard_normal((j, K)) for i, j in enumerate(J)]
+    init = (None, (rng.uniform(size=(I, r)), [rng.uniform(size=(j, r)) for j in J], rng.uniform(size=(K, r))))
+    return mats, init, r
+
+
+def _explicit_state(case, mats, r, seed=9):
+    """explicit aux/dual so that the sharded and the single run start from identical states"""
+    from matcouply_amd import penalties as pen
+
+    rng = np.random.RandomState(seed)
+    I, K = len(mats), mats[0].shape[1]
+    kw = CASES[case]
+    regs = [[], [], []]
+    mk = lambda shp: rng.uniform(size=shp)
+    if case == "c3_nn_l1C":
+        regs[0] = [("nn", mk((I, r)), mk((I, r)))]
+        regs[1] = [("nn", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
+        regs[2] = [("l1nn", mk((K, r)), mk((K, r)))]
+    else:
+        regs[0] = [("nn", mk((I, r)), mk((I, r)))]
+        regs[1] = [("pf2", ([np.eye(m.shape[0], r) for m in mats], mk((r, r))), [mk((m.shape[0], r)) for m in mats]),
+                   ("ball", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
+    return regs, kw
+
+
+def _build(regs_spec, lo, hi):
+    from matcouply_amd import penalties as pen
+
+    out = [[], [], []]
+    for m in range(3):
+        for kind, aux, dual in regs_spec[m]:
+            if m == 0:
+                aux, dual = aux[lo:hi].copy(), dual[lo:hi].copy()
+            elif m == 1:
+                dual = [d.copy() for d in dual[lo:hi]]
+                aux = ([p.copy() for p in aux[0][lo:hi]], aux[1].copy()) if kind == "pf2" else [a.copy() for a in aux[lo:hi]]
+            else:
+                aux, dual = aux.copy(), dual.copy()
+            if kind == "nn":
+                out[m].append(pen.NonNegativity(aux_init=aux, dual_init=dual))
+            elif kind == "l1nn":
+                out[m].append(pen.L1Penalty(0.1, non_negativity=True, aux_init=aux, dual_init=dual))
+            elif kind == "pf2":
+                out[m].append(pen.Parafac2(aux_init=aux, dual_init=dual))
+            elif kind == "ball":
+                out[m].append(pen.L2Ball(1.0, aux_init=aux, dual_init=dual))
+    return out
+
+
+def _run(case, lo, hi, group):
+    from matcouply_amd import decomposition as dec
+    from tests.oracle_engine import OracleEngineFactory
+
+    previous, dec._ENGINE_FACTORY = dec._ENGINE_FACTORY, OracleEngineFactory()
+    try:
+        return _run_with_checker(dec, case, lo, hi, group)
+    finally:
+        dec._ENGINE_FACTORY = previous
+
+
+def _run_with_checker(dec, case, lo, hi, group):
+    mats, init, r = _problem()
+    regs_spec, kw = _explicit_state(case, mats, r)
+    const = kw.get("constant_feasibility_penalty", False)
+    w, (A0, B0, C0) = init
+    cmf, diag = dec.cmf_aoadmm(mats[lo:hi], r, init=(None, (A0[lo:hi].copy(), [b.copy() for b in B0[lo:hi]], C0.copy())),
+                               regs=_build(regs_spec, lo, hi), n_iter_max=6, tol=None, absolute_tol=None,
+                               return_errors=True, constant_feasibility_penalty=const, group=group)
+    return cmf, diag
+
+
+def _worker(rank, world, port, case, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bounds = [0, 4, 6]  # uneven split of the 6 slabs
+    cmf, diag = _run(case, bounds[rank], bounds[rank + 1], dist.group.WORLD)
+    q.put((rank, cmf[1][0], np.concatenate(cmf[1][1]), cmf[1][2], diag.rec_errors, diag.regularized_loss,
+           [[list(map(float, g)) for g in it] for it in diag.feasibility_gaps]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_two_rank_sharded_run_equals_single_process(case):
+    sys.path.insert(0, REPO)
+    ref_cmf, ref_diag = _run(case, 0, 6, None)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(rk, 2, port, case, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    A = np.concatenate([res[1] for res in results])
+    B = np.concatenate([res[2] for res in results])
+    np.testing.assert_allclose(A, ref_cmf[1][0], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(B, np.concatenate(ref_cmf[1][1]), rtol=1e-9, atol=1e-12)
+    for res in results:  # replicated quantities identical on every rank
+        np.testing.assert_allclose(res[3], ref_cmf[1][2], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(res[4], ref_diag.rec_errors, rtol=1e-9)
+        np.testing.assert_allclose(res[5], ref_diag.regularized_loss, rtol=1e-9)
+        ref_gaps = [[list(map(float, g)) for g in it] for it in ref_diag.feasibility_gaps]
+        for got_it, ref_it in zip(res[6], ref_gaps):
+            for g, rg in zip(got_it, ref_it):
+                np.testing.assert_allclose(g, rg, rtol=1e-8, atol=1e-12)
+    np.testing.assert_array_equal(results[0][3], results[1][3])
