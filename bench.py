@@ -37,6 +37,9 @@ CONFIGS = {
                regs=[[{"kind": "nn"}], [{"kind": "nn"}], [{"kind": "l1", "reg_strength": 0.1, "non_negativity": True}]],
                desc="c3: I=1024 J_i=512 K=256 rank=16, non_negative + L1(0.1) on C"),
 }
+CONFIGS["c4"] = dict(I=1024, J="ragged", K=256, r=16,
+                     regs=[[], [{"kind": "parafac2"}, {"kind": "l2ball", "norm_bound": 1.0}], []],
+                     desc="c4: I=1024 ragged J_i in [128,1024] K=256 rank=16, parafac2 + L2Ball(1.0) on B")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -47,6 +50,8 @@ def make_shard(cfg, rank, world, device, seed=0):
     I, J, K, r = cfg["I"], cfg["J"], cfg["K"], cfg["r"]
     lo, hi = (I * rank) // world, (I * (rank + 1)) // world
     I_loc = hi - lo
+    if J == "ragged":
+        return make_ragged_shard(cfg, lo, hi, rank, device, seed)
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     C_true = torch.rand((K, r), generator=g, device=device)
@@ -58,6 +63,27 @@ def make_shard(cfg, rank, world, device, seed=0):
     X = X.reshape(I_loc * J, K).contiguous()
     row_ptr = np.arange(I_loc + 1, dtype=np.int64) * J
     return X, row_ptr, I_loc
+
+
+def make_ragged_shard(cfg, lo, hi, rank, device, seed):
+    """config 4: J_i = RandomState(0).randint(128, 1025, I)"""
+    import torch
+
+    K, r = cfg["K"], cfg["r"]
+    J_all = np.random.RandomState(0).randint(128, 1025, cfg["I"])
+    J = J_all[lo:hi]
+    row_ptr = np.concatenate([[0], np.cumsum(J)]).astype(np.int64)
+    N = int(row_ptr[-1])
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    C_true = torch.rand((K, r), generator=g, device=device)
+    g.manual_seed(seed + 1000 + rank)
+    A_true = torch.rand((hi - lo, r), generator=g, device=device) + 0.1
+    slab = torch.repeat_interleave(torch.arange(hi - lo, device=device), torch.as_tensor(J, device=device))
+    B_true = torch.rand((N, r), generator=g, device=device)
+    X = (B_true * A_true[slab]) @ C_true.T
+    X += 0.05 * torch.randn(X.shape, generator=g, device=device)
+    return X.contiguous(), row_ptr, hi - lo
 
 
 def make_engine(cfg, X, row_ptr, I_loc, rank, device, seed=1):
@@ -78,12 +104,22 @@ def make_engine(cfg, X, row_ptr, I_loc, rank, device, seed=1):
     regs = [[], [], []]
     for m in range(3):
         for k, d in enumerate(cfg["regs"][m]):
+            aux2 = None
             if m == 2:
                 aux, dual = c_vars[k]
+            elif d["kind"] == "parafac2":
+                aux = torch.zeros(shapes[m], device=device)  # P_i = eye(J_i, r)
+                rp = torch.as_tensor(row_ptr[:-1], device=device)
+                for cc in range(r):
+                    aux[rp + cc, cc] = 1.0
+                dual = torch.rand(shapes[m], generator=g, device=device)
+                g2 = torch.Generator(device=device)
+                g2.manual_seed(seed + 7)  # Delta is replicated: identical on all ranks
+                aux2 = torch.rand((r, r), generator=g2, device=device)
             else:
                 aux = torch.rand(shapes[m], generator=g, device=device)
                 dual = torch.rand(shapes[m], generator=g, device=device)
-            regs[m].append(NativeReg(KIND[d["kind"]], aux, dual, non_negativity=d.get("non_negativity", False),
+            regs[m].append(NativeReg(KIND[d["kind"]], aux, dual, aux2=aux2, non_negativity=d.get("non_negativity", False),
                                      p0=d.get("reg_strength", d.get("norm_bound", 0.0))))
     return HipEngine(X, row_ptr, r, A, B, C, regs)
 
@@ -150,8 +186,24 @@ def main():
 
     ring = torch.zeros((args.steps + args.warmup, DIAG_LEN), dtype=torch.float64, device=device)
 
+    pf2 = [k for k, d in enumerate(cfg["regs"][1]) if d["kind"] == "parafac2"]
+
+    def update_B():
+        if world == 1 or not pf2:
+            eng.update_B()
+            return
+        eng.B_begin()
+        eng.B_factor()
+        for _ in range(5):
+            eng.B_solve()
+            for k in range(len(cfg["regs"][1])):
+                eng.B_prox_local(k)
+                if k in pf2:
+                    dist.all_reduce(eng.B_prox_reduce_buffer(k))
+                eng.B_prox_finish(k)
+
     def step(it):
-        eng.update_B()
+        update_B()
         gr = eng.update_C_local()
         if world > 1:
             dist.all_reduce(gr)
@@ -185,6 +237,11 @@ def main():
     prof = []
     names = {0: "X C pass", 1: "X^T (B o a) pass", 2: "fused B-phase rows"}
     N_loc, K, r = X.shape[0], cfg["K"], cfg["r"]
+    N_tot = N_loc
+    if world > 1:
+        t = torch.tensor([N_loc], dtype=torch.float64, device=device)
+        dist.all_reduce(t)
+        N_tot = int(t.item())
     S_X, S_B = 4.0 * N_loc * K, 4.0 * N_loc * r
     n_B = len(cfg["regs"][1])
     alg_bytes = {0: S_X + S_B, 1: S_X + S_B, 2: (2 + 4 * n_B) * S_B}  # per launch: reads + writes of that kernel
@@ -192,12 +249,28 @@ def main():
         tot_ms, n = eng.profile_read(slot)
         if n:
             prof.append((tot_ms / n, slot, n))
+    def pmc_traffic(kernel_variant):
+        """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), if the
+        profile was taken on this configuration; counters are collected in separate runs, never inside this one."""
+        path = os.path.join(REPO, "profiles", f"r1_{args.config}_pmc_traffic.json")
+        if world != 1 or not os.path.exists(path):
+            return None
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+        base = kernel_variant.split("<")[0]
+        for name, v in kernels.items():
+            if name.split("<")[0] == base:
+                return int(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
+        return None
+
     roofline = None
     if prof:
         avg_ms, slot, n = max(prof)
         achieved = alg_bytes[slot] / (avg_ms * 1e-3) / 1e9
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, kernel=eng.kernel_variant(slot),
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(eng.kernel_variant(slot)),
+                        traffic_source="profiles/r1_%s_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % args.config,
+                        kernel=eng.kernel_variant(slot),
                         kernel_role=names[slot], avg_us=round(avg_ms * 1e3, 2), launches=n,
                         algorithmic_bytes_per_launch=int(alg_bytes[slot]),
                         all_kernels_avg_us={names[s]: round(a * 1e3, 2) for a, s, _ in prof})
@@ -205,13 +278,13 @@ def main():
     final = ring[args.warmup + args.steps - 1].cpu().numpy() if args.steps else None
     if rank == 0:
         its = args.steps / elapsed
-        S_X_tot, S_B_tot = 4.0 * cfg["I"] * cfg["J"] * K, 4.0 * cfg["I"] * cfg["J"] * r
+        S_X_tot, S_B_tot = 4.0 * N_tot * K, 4.0 * N_tot * r
         bytes_iter = 2 * S_X_tot + (5 + 4 * n_B) * S_B_tot
         out = {
             "metric": "AO-ADMM outer-iters/sec", "value": round(its, 2), "unit": "outer-iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["desc"], "I": cfg["I"], "J": cfg["J"], "K": K, "rank": r,
+            "config": {"workload": cfg["desc"], "I": cfg["I"], "J": cfg["J"], "sum_J": N_tot, "K": K, "rank": r,
                        "inner_n_iter_max": 5, "diagnostics_every_iteration": True,
                        "sharding": f"{world} x contiguous slab ranges" if world > 1 else "single device"},
             "algorithmic_bytes_per_iter": int(bytes_iter),

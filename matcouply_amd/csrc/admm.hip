@@ -175,24 +175,15 @@ __global__ __launch_bounds__(64) void k_C_prepare(const float *__restrict__ GR, 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// One wave's share of the fused inner loop: a tile of <= 64 rows [row0, row0 + nrows) of one slab.
+// Li: the slab's L^-1 (global or LDS), Arow: the slab's a_i or nullptr, Fcopy: optional second destination (LDS).
+// Returns the tile's diagnostic sums (already reduced over the wave) in dg[0..1+NREG].
 template <int NBR, int NREG, bool VEC>
-__global__ __launch_bounds__(256) void k_rows_fused(const int *__restrict__ tile_slab, const int *__restrict__ tile_row0,
-                                                    const int *__restrict__ tile_nrows, int n_tiles,
-                                                    const float *__restrict__ rhs_src, const float *__restrict__ Arows,
-                                                    const float *__restrict__ rho_arr, const float *__restrict__ Linv,
-                                                    float *__restrict__ F, RegSet regs, int r, int inner,
-                                                    double *__restrict__ diag_tile) {
-    __shared__ double dsm[4][DIAG_COLS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile_raw = blockIdx.x * 4 + wave;
-    const bool live = tile_raw < n_tiles;       // wave-uniform; dead waves do no memory traffic (nrows = 0)
-    const int tile = live ? tile_raw : n_tiles - 1;
-    const int slab = __builtin_amdgcn_readfirstlane(tile_slab[tile]);
-    const int row0 = __builtin_amdgcn_readfirstlane(tile_row0[tile]);
-    const int nrows = live ? __builtin_amdgcn_readfirstlane(tile_nrows[tile]) : 0;
+static __device__ __forceinline__ void rows_fused_tile(int lane, long row0, int nrows, float rho, const float *Li,
+                                                       const float *Arow, const float *__restrict__ rhs_src,
+                                                       float *__restrict__ F, float *Fcopy, const RegSet &regs, int r,
+                                                       int inner, double *dg) {
     const int row16 = lane & 15, g = lane >> 4;
-    const float rho = rho_arr[slab];
-    const float *__restrict__ Li = Linv + (long)slab * r * r;
     constexpr int NR = NREG > 0 ? NREG : 1;
 
     // A-operand fragments of (L^-1)^T
@@ -212,7 +203,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const int *__restrict__ tile
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int col = 16 * h + 4 * g + v;
-            av[h][v] = (Arows != nullptr && col < r) ? Arows[(long)slab * r + col] : 1.f;
+            av[h][v] = (Arow != nullptr && col < r) ? Arow[col] : 1.f;
         }
     float thr[NR];
 #pragma unroll
@@ -303,6 +294,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const int *__restrict__ tile
         for (int h = 0; h < NBR; ++h) {
             const int col = 16 * h + 4 * g;
             st4(F, j, col, ok, f[h]);
+            if (Fcopy != nullptr) st4(Fcopy, j, col, ok, f[h]);
 #pragma unroll
             for (int k = 0; k < NREG; ++k) {
                 st4(regs.aux[k], j, col, ok, z[k][h]);
@@ -323,20 +315,117 @@ __global__ __launch_bounds__(256) void k_rows_fused(const int *__restrict__ tile
             }
         }
     }
-    nf = wave_sum(nf);
-    na = wave_sum(na);
+    dg[0] = wave_sum(nf);
+    dg[1] = wave_sum(na);
 #pragma unroll
-    for (int k = 0; k < NREG; ++k) gap[k] = wave_sum(gap[k]);
+    for (int k = 0; k < NREG; ++k) dg[2 + k] = wave_sum(gap[k]);
+}
+
+template <int NBR, int NREG, bool VEC>
+__global__ __launch_bounds__(256) void k_rows_fused(const int *__restrict__ tile_slab, const int *__restrict__ tile_row0,
+                                                    const int *__restrict__ tile_nrows, int n_tiles,
+                                                    const float *__restrict__ rhs_src, const float *__restrict__ Arows,
+                                                    const float *__restrict__ rho_arr, const float *__restrict__ Linv,
+                                                    float *__restrict__ F, RegSet regs, int r, int inner,
+                                                    double *__restrict__ diag_tile) {
+    __shared__ double dsm[4][DIAG_COLS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile_raw = blockIdx.x * 4 + wave;
+    const bool live = tile_raw < n_tiles;       // wave-uniform; dead waves do no memory traffic (nrows = 0)
+    const int tile = live ? tile_raw : n_tiles - 1;
+    const int slab = __builtin_amdgcn_readfirstlane(tile_slab[tile]);
+    const int row0 = __builtin_amdgcn_readfirstlane(tile_row0[tile]);
+    const int nrows = live ? __builtin_amdgcn_readfirstlane(tile_nrows[tile]) : 0;
+    double dg[DIAG_COLS];
+    rows_fused_tile<NBR, NREG, VEC>(lane, row0, nrows, rho_arr[slab], Linv + (long)slab * r * r,
+                                    Arows ? Arows + (long)slab * r : nullptr, rhs_src, F, nullptr, regs, r, inner, dg);
     if (lane == 0) {
-        dsm[wave][0] = nf;
-        dsm[wave][1] = na;
 #pragma unroll
-        for (int k = 0; k < NREG; ++k) dsm[wave][2 + k] = gap[k];
+        for (int k = 0; k < 2 + NREG; ++k) dsm[wave][k] = dg[k];
     }
     __syncthreads();
     if (threadIdx.x < 2 + NREG)  // one diagnostics row per BLOCK (4 tiles), fixed summation order
         diag_tile[(long)blockIdx.x * DIAG_COLS + threadIdx.x] =
             (dsm[0][threadIdx.x] + dsm[1][threadIdx.x]) + (dsm[2][threadIdx.x] + dsm[3][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Whole C-side finish in ONE workgroup (K <= 1024 rows): system from the all-reduced [G | R] (decomposition.py:319-321)
+// -> fused inner loop on the rows of C (:325-338) -> CtC = C^T C (fp64) and the MFMA-fragment image of C for the
+// next X C pass.  Replaces four dependent launches (k_C_prepare, k_rows_fused, k_ctc, k_build_cfrag).
+// LDS: L^-1 [r*r] | C [K*r] (fp32).
+// ---------------------------------------------------------------------------------------------------------
+template <int NBR, int NREG, bool VEC>
+__global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict__ GR, int K, int r, float scale, float l2,
+                                                         float *__restrict__ rhoC, float *__restrict__ LinvC,
+                                                         float *__restrict__ C, RegSet regs, int inner,
+                                                         float *__restrict__ CtC, float *__restrict__ Cfrag, int KC,
+                                                         int NBc, double *__restrict__ diag_row) {
+    extern __shared__ float smc[];
+    __shared__ double dsm[16][DIAG_COLS];
+    __shared__ float rho_s;
+    float *Ls = smc, *Cs = smc + r * r;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    constexpr int RP = 16 * NBR;
+    if (wave == 0) {
+        double tr = 0.0;
+        for (int c = 0; c < r; ++c) tr += (double)GR[c * r + c];
+        const float rho = (float)(0.5 * tr * scale);
+        const double shift = (double)rho * NREG + (double)l2;
+        const bool act = lane < r;
+        double col[RP];
+#pragma unroll
+        for (int d = 0; d < RP; ++d) {
+            double v = (d == lane) ? 1.0 : 0.0;
+            if (act && d < r) v = (double)GR[d * r + lane] + (d == lane ? shift : 0.0);
+            col[d] = v;
+        }
+        gj_inverse_reg<RP>(col, r, lane);
+#pragma unroll
+        for (int d = 0; d < RP; ++d) {
+            if (act && d < r) {
+                Ls[d * r + lane] = (float)col[d];
+                LinvC[d * r + lane] = (float)col[d];
+            }
+        }
+        if (lane == 0) {
+            rho_s = rho;
+            rhoC[0] = rho;
+        }
+    }
+    __syncthreads();
+    const long row0 = 64L * wave;
+    const int nrows = min(64, K - 64 * wave);
+    double dg[DIAG_COLS];
+    rows_fused_tile<NBR, NREG, VEC>(lane, row0, nrows, rho_s, Ls, nullptr, GR + (long)r * r, C, Cs, regs, r, inner, dg);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 2 + NREG; ++k) dsm[wave][k] = dg[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 + NREG) {
+        double t = 0.0;
+        for (int wv = 0; wv < n_waves; ++wv) t += dsm[wv][threadIdx.x];
+        diag_row[threadIdx.x] = t;
+    }
+    // CtC from the LDS copy of the new C (fp64 accumulation)
+    for (int pr = threadIdx.x; pr < r * r; pr += blockDim.x) {
+        const int a = pr / r, b = pr - a * r;
+        double acc = 0.0;
+        for (int k = 0; k < K; ++k) acc += (double)Cs[k * r + a] * (double)Cs[k * r + b];
+        CtC[pr] = (float)acc;
+    }
+    // fragment image of C for the X C kernels (see k_build_cfrag)
+    const long total = (long)KC * 4 * NBc * 256;
+    for (long idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int m = idx & 3, ln = (idx >> 2) & 63;
+        long t = idx >> 8;
+        const int nb = t % NBc;
+        t /= NBc;
+        const int kq = t & 3, kc = t >> 2;
+        const int k = 64 * kc + 16 * kq + 4 * (ln >> 4) + m, col = 16 * nb + (ln & 15);
+        Cfrag[idx] = (k < K && col < r) ? Cs[(long)k * r + col] : 0.f;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -355,7 +444,9 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
                                                   float *__restrict__ A, RegSet regs, int inner, int fused_inner,
                                                   double *__restrict__ e1, double *__restrict__ diag_row,
                                                   int next_B, float l2_B, int n_regs_B, float *__restrict__ rhoB,
-                                                  float *__restrict__ LinvB) {
+                                                  float *__restrict__ LinvB, const int *__restrict__ slab_seg_ptr,
+                                                  const float *__restrict__ seg_rhs, const float *__restrict__ seg_btb,
+                                                  float *__restrict__ rhsA_out) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= I) return;
@@ -364,11 +455,23 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
     float qcol[RP];
     double col[RP];
     double tr = 0.0;
+    int sg0 = 0, sg1 = 0;
+    if (seg_btb != nullptr) {
+        sg0 = slab_seg_ptr[i];
+        sg1 = slab_seg_ptr[i + 1];
+    }
 #pragma unroll
     for (int d = 0; d < RP; ++d) {
         float q = 0.f;
         if (act && d < r) {
-            q = (float)((double)BtB[((long)i * r + d) * r + c] * (double)CtC[d * r + c]);
+            float btb;
+            if (seg_btb != nullptr) {  // sum the per-segment partial Grams of this slab (fixed order)
+                btb = 0.f;
+                for (int sg = sg0; sg < sg1; ++sg) btb += seg_btb[((long)sg * r + d) * r + c];
+            } else {
+                btb = BtB[((long)i * r + d) * r + c];
+            }
+            q = (float)((double)btb * (double)CtC[d * r + c]);
             BtB[((long)i * r + d) * r + c] = q;
         }
         qcol[d] = q;
@@ -393,7 +496,15 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
             if (act && d < r) LinvA[((long)i * r + d) * r + c] = (float)col[d];
         return;
     }
-    const float rhs = act ? rhsA[(long)i * r + c] : 0.f;
+    float rhs = 0.f;
+    if (act) {
+        if (seg_rhs != nullptr) {
+            for (int sg = sg0; sg < sg1; ++sg) rhs += seg_rhs[(long)sg * r + c];
+            rhsA_out[(long)i * r + c] = rhs;  // keep the `rhses` by-product available
+        } else {
+            rhs = rhsA[(long)i * r + c];
+        }
+    }
     float z[MCL_MAX_REGS], u[MCL_MAX_REGS], thr[MCL_MAX_REGS];
 #pragma unroll
     for (int k = 0; k < MCL_MAX_REGS; ++k) {
@@ -803,6 +914,59 @@ int mcl_launch_rows_fused(mcl_context *c, int mode) {
     return 0;
 }
 
+template <int NBR, int NREG>
+static int launch_C_fused_t(mcl_context *c) {
+    const RegSet &rs = c->regs[2];
+    const float *rhs = c->GR + (long)c->r * c->r;
+    bool vec = (c->r % 4 == 0) && ((reinterpret_cast<uintptr_t>(rhs) & 15) == 0) &&
+               ((reinterpret_cast<uintptr_t>(c->C) & 15) == 0) && ((c->r * c->r) % 4 == 0);
+    for (int k = 0; k < rs.n; ++k)
+        vec = vec && ((reinterpret_cast<uintptr_t>(rs.aux[k]) & 15) == 0) && ((reinterpret_cast<uintptr_t>(rs.dual[k]) & 15) == 0);
+    const int n_waves = (int)((c->K + 63) / 64);
+    const size_t sm = sizeof(float) * (size_t)(c->r * c->r + c->K * c->r);
+    int kct = 0;
+    const int KC = mcl_xc_chunks(c, &kct);
+#define MCL_CF(VEC_)                                                                                                  \
+    do {                                                                                                              \
+        if (sm > 65536)                                                                                               \
+            MCL_CHECK_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_C_finish_fused<NBR, NREG, VEC_>),   \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));               \
+        hipLaunchKernelGGL((k_C_finish_fused<NBR, NREG, VEC_>), dim3(1), dim3(64 * n_waves), sm, c->stream, c->GR,    \
+                           (int)c->K, c->r, (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[2],     \
+                           c->rhoC, c->LinvC, c->C, rs, c->opt.inner_n_iter_max, c->CtC, c->Cfrag, KC, c->NB,         \
+                           c->diagC_tile);                                                                            \
+    } while (0)
+    if (vec) MCL_CF(true);
+    else MCL_CF(false);
+#undef MCL_CF
+    MCL_CHECK_HIP(c, hipGetLastError());
+    c->diag_rows[2] = 1;
+    return 0;
+}
+
+// Single-workgroup C-side finish; returns -1 if the shape has no instantiation (caller uses the separate kernels)
+int mcl_launch_C_finish_fused(mcl_context *c) {
+    if (c->K > 1024 || getenv("MCL_NO_FUSED_C")) return -1;
+    if ((size_t)(c->r * c->r + c->K * c->r) * sizeof(float) > 150 * 1024) return -1;
+    const int n = c->regs[2].n;
+    if (c->r <= 16) {
+        switch (n) {
+            case 0: return launch_C_fused_t<1, 0>(c);
+            case 1: return launch_C_fused_t<1, 1>(c);
+            case 2: return launch_C_fused_t<1, 2>(c);
+            default: return -1;
+        }
+    }
+    if (c->r <= 32) {
+        switch (n) {
+            case 0: return launch_C_fused_t<2, 0>(c);
+            case 1: return launch_C_fused_t<2, 1>(c);
+            default: return -1;
+        }
+    }
+    return -1;
+}
+
 int mcl_launch_A_rho(mcl_context *c) {
     MCL_CHECK_HIP(c, hipMemsetAsync(c->rho_max + 1, 0, sizeof(float), c->stream));
     if (c->I == 0) return 0;
@@ -816,11 +980,14 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     if (c->I == 0) return 0;
     // also prepare the next B-phase's systems when that is exact: fused inner loop, per-slab rho for B
     const int next_B = (fused_inner && !c->opt.constant_B && !getenv("MCL_NO_NEXT_B")) ? 1 : 0;
+    const bool seg = c->use_seg_gram;
     dim3 grid((unsigned)((c->I + 3) / 4)), block(256);
     DISPATCH_RP_T(c, k_A_finish, grid, block, c->rhsA, c->BtB, c->CtC, (int)c->I, c->r,
                   (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[0], c->opt.constant_A, c->rho_max,
                   c->rhoA, c->LinvA, c->A, c->regs[0], c->opt.inner_n_iter_max, fused_inner ? 1 : 0, c->e1,
-                  c->diagA_row, next_B, (float)c->opt.l2_penalty[1], c->regs[1].n, c->rhoB, c->LinvB);
+                  c->diagA_row, next_B, (float)c->opt.l2_penalty[1], c->regs[1].n, c->rhoB, c->LinvB,
+                  (const int *)c->slab_seg_ptr, (const float *)(seg ? c->seg_rhs : nullptr),
+                  (const float *)(seg ? c->seg_btb : nullptr), c->rhsA);
     MCL_CHECK_HIP(c, hipGetLastError());
     c->b_systems_valid = (next_B != 0);
     return 0;

@@ -63,6 +63,9 @@ int64_t plan(mcl_context *c, char *base) {
     c->GR = b.take<float>(E);
     c->rhoC = b.take<float>(1);
     c->LinvC = b.take<float>(r * r);
+    c->seg_rhs = b.take<float>((int64_t)c->segs.n_tiles * r);
+    c->seg_btb = b.take<float>((int64_t)c->segs.n_tiles * r * r);
+    c->slab_seg_ptr = b.take<int>(I + 1);
     c->rhsA = b.take<float>(I * r);
     c->BtB = b.take<float>(I * r * r);
     c->rhoA = b.take<float>(I);
@@ -118,7 +121,10 @@ int ensure_ctc(mcl_context *c) {
 
 int ensure_xc(mcl_context *c) {
     if (!c->xc_valid) {
-        if (int rc = mcl_launch_build_cfrag(c)) return rc;
+        if (!c->cfrag_valid) {
+            if (int rc = mcl_launch_build_cfrag(c)) return rc;
+            c->cfrag_valid = true;
+        }
         if (int rc = mcl_launch_contract_xc(c)) return rc;
         c->xc_valid = true;
     }
@@ -214,7 +220,9 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     c->h_slab_of_row.resize((size_t)N);
     c->h_tile_slab.clear(), c->h_tile_row0.clear(), c->h_tile_nrows.clear();
     c->h_seg_slab.clear(), c->h_seg_row0.clear(), c->h_seg_nrows.clear();
+    c->h_slab_seg_ptr.assign((size_t)I + 1, 0);
     for (int64_t i = 0; i < I; ++i) {
+        c->h_slab_seg_ptr[(size_t)i] = (int)c->h_seg_slab.size();
         for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; j += MCL_SEG_ROWS) {
             c->h_seg_slab.push_back((int)i);
             c->h_seg_row0.push_back((int)j);
@@ -227,6 +235,7 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
             c->h_tile_nrows.push_back((int)std::min<int64_t>(64, row_ptr[i + 1] - j));
         }
     }
+    c->h_slab_seg_ptr[(size_t)I] = (int)c->h_seg_slab.size();
     auto single = [](int64_t rows, std::vector<int> &s, std::vector<int> &r0, std::vector<int> &nr) {
         s.clear(), r0.clear(), nr.clear();
         for (int64_t j = 0; j < rows; j += 64) {
@@ -259,6 +268,7 @@ int mcl_set_factors(mcl_context *c, float *A, float *B, float *C) {
     c->A = A, c->B = B, c->C = C;
     c->has_factors = true;
     c->b_systems_valid = false;
+    c->cfrag_valid = false;
     c->xc_valid = c->ctc_valid = c->e1_valid = false;
     c->diag_valid[0] = c->diag_valid[1] = c->diag_valid[2] = false;
     return 0;
@@ -330,11 +340,13 @@ int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
     MCL_CHECK_HIP(c, up(c->segs.slab, c->h_seg_slab));
     MCL_CHECK_HIP(c, up(c->segs.row0, c->h_seg_row0));
     MCL_CHECK_HIP(c, up(c->segs.nrows, c->h_seg_nrows));
+    MCL_CHECK_HIP(c, up(c->slab_seg_ptr, c->h_slab_seg_ptr));
     c->h_ext = {0, (int)c->I, 0, (int)c->K};
     MCL_CHECK_HIP(c, hipMemcpyAsync(c->ext_A, c->h_ext.data(), 2 * sizeof(int), hipMemcpyHostToDevice, s));
     MCL_CHECK_HIP(c, hipMemcpyAsync(c->ext_C, c->h_ext.data() + 2, 2 * sizeof(int), hipMemcpyHostToDevice, s));
     // the host vectors must outlive the async copies: they are members of the context
     c->has_workspace = true;
+    c->cfrag_valid = false;
     c->xc_valid = c->ctc_valid = c->e1_valid = c->xsq_valid = false;
     c->diag_valid[0] = c->diag_valid[1] = c->diag_valid[2] = false;
     return 0;
@@ -423,9 +435,23 @@ float *mcl_c_normal_equations(mcl_context *c, int64_t *count) {
 
 int mcl_update_C_finish(mcl_context *c) {
     if (int rc = ready(c)) return rc;
+    if (c->opt.inner_n_iter_max > 0 && mcl_mode_is_row_separable(c, 2)) {
+        // everything from the system solve to CtC / C fragments in one single-workgroup launch
+        const int rc = mcl_launch_C_finish_fused(c);
+        if (rc == 0) {
+            c->xc_valid = c->e1_valid = false;
+            c->b_systems_valid = false;
+            c->ctc_valid = true;
+            c->cfrag_valid = true;
+            c->diag_valid[2] = true;
+            return 0;
+        }
+        if (rc > 0) return rc;
+    }
     if (int rc = mcl_launch_C_prepare(c)) return rc;
     if (c->opt.inner_n_iter_max <= 0) return 0;
     c->xc_valid = c->ctc_valid = c->e1_valid = false;
+    c->cfrag_valid = false;
     c->b_systems_valid = false;
     if (mcl_mode_is_row_separable(c, 2)) {
         const int rc = mcl_launch_rows_fused(c, 2);
@@ -442,8 +468,20 @@ int mcl_update_C_finish(mcl_context *c) {
 int mcl_A_begin(mcl_context *c) {
     if (int rc = ready(c)) return rc;
     if (int rc = ensure_ctc(c)) return rc;
-    if (int rc = ensure_xc(c)) return rc;
-    if (int rc = mcl_launch_slab_gram(c)) return rc;
+    // When X C has to be recomputed anyway (C changed), the per-slab reductions ride in its epilogue; the
+    // constant-rho pre-pass (k_A_rho) needs the assembled per-slab Gram, so it keeps the separate kernel.
+    c->use_seg_gram = false;
+    if (!c->xc_valid && !c->opt.constant_A && !getenv("MCL_NO_FUSED_GRAM")) {
+        c->xc_with_gram = true;
+        const int rc = ensure_xc(c);
+        c->xc_with_gram = false;
+        if (rc) return rc;
+        c->use_seg_gram = c->xc_did_gram;
+    } else {
+        if (int rc = ensure_xc(c)) return rc;
+    }
+    if (!c->use_seg_gram)
+        if (int rc = mcl_launch_slab_gram(c)) return rc;
     c->e1_valid = false;
     if (c->opt.constant_A)
         if (int rc = mcl_launch_A_rho(c)) return rc;

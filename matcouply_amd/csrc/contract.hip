@@ -370,28 +370,36 @@ __global__ __launch_bounds__(256) void k_contract_xc(const float *__restrict__ X
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_contract_xc_row : XC = X C for K % 256 == 0.  Same MFMA mapping as k_contract_xc, but the global access is
-// ROW-CONTIGUOUS: a wave stages a 16-row x 256-column super-chunk with 16 wave-loads of ONE 1 KB row segment each
-// (lane l reads columns 4l..4l+3), i.e. the same access geometry as a plain streaming copy; for K = 256 the
-// 16 loads cover one contiguous 16 KB region.  The tile lives in a wave-private 16 KB LDS image whose 16-B slot
-// index is XORed with the row (conflict-free ds_write_b128 / ds_read_b128).  The next super-chunk's 16 loads are
-// in flight while the current one is multiplied (16 KB per wave outstanding).
-// CREG: K == 256 and the 64 C-fragment registers per NB fit (NB == 1): fragments stay in registers.
+// k_contract_xc_row : XC = X C for K % 256 == 0, optionally FUSED with the per-slab A-phase reductions.
+// Same MFMA mapping as k_contract_xc, but the global access is ROW-CONTIGUOUS: a wave stages a 16-row x 256-column
+// super-chunk with 16 wave-loads of ONE 1 KB row segment each (lane l reads columns 4l..4l+3), i.e. the access
+// geometry of a plain streaming copy; for K = 256 the 16 loads cover one contiguous 16 KB region.  The tile lives
+// in a wave-private 16 KB LDS image whose 16-B slot index is XORed with the row (conflict-free ds_write_b128 /
+// ds_read_b128).  The next super-chunk's 16 loads are in flight while the current one is multiplied.
+// Work unit = SEGMENT (<= 256 rows of one slab).  GRAM: while the XC block is still in the accumulators
+// (lane (q, i16) holds rows 4q+v, column i16), the same-layout block of B is loaded and
+//     rhs_seg[c]  += sum_rows B[row][c] * XC[row][c]           (decomposition.py:147-158: diag(B_i^T X_i C))
+//     BtB_seg     += B_blk^T B_blk   (4 MFMAs: A = B-operand = b[v], reduction index <-> the 4 lane quarters)
+// are accumulated per segment; k_A_finish sums the segments of its slab.  This removes the separate
+// k_slab_gram pass (a 2 S_B re-read and a launch).
+// CREG: K == 256 and NB == 1: the 64 C-fragment registers stay resident.
 // ---------------------------------------------------------------------------------------------------------
-template <int NB, bool CREG>
+template <int NB, bool CREG, bool GRAM>
 __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict__ X, const float *__restrict__ Cfrag,
-                                                         float *__restrict__ XC, long N, int K, int r,
-                                                         long blocks_per_wave, long n_blocks16) {
+                                                         float *__restrict__ XC, const float *__restrict__ B,
+                                                         const int *__restrict__ seg_row0,
+                                                         const int *__restrict__ seg_rows, int n_segs,
+                                                         int segs_per_wave, int K, int r,
+                                                         float *__restrict__ seg_rhs, float *__restrict__ seg_btb) {
     extern __shared__ float lds_dyn[];  // 4 waves x 16 rows x 256 floats
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, i16 = lane & 15;
     float *L = lds_dyn + wave * (16 * 256);
     const int SC = K >> 8;  // super-chunks per row block
-    const long w = (long)blockIdx.x * 4 + wave;
-    const long b0 = w * blocks_per_wave;
-    long b1 = b0 + blocks_per_wave;
-    if (b1 > n_blocks16) b1 = n_blocks16;
-    if (b0 >= b1) return;
+    const int w = blockIdx.x * 4 + wave;
+    const int s0 = w * segs_per_wave;
+    const int s1 = min(s0 + segs_per_wave, n_segs);
+    if (s0 >= s1) return;
 
     constexpr int CR = CREG ? 4 : 1;
     f32x4 creg[CR][4][NB];
@@ -407,12 +415,25 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
     }
 
     f32x4 xr[16];
-    auto issue = [&](long blk, int sc) {
-        const long bc = min(blk, b1 - 1);
+    float bnx[NB][4];  // B block (rows 4q+v, column 16nb+i16) of the block whose X loads are in flight
+    int bcolc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bcolc[nb] = min(16 * nb + i16, r - 1);
+    // stage rows [row0 + 16 blk, +16) x columns [256 sc, +256) of segment (row0, nrows); rows clamped into the segment
+    auto issue = [&](long row0, int nrows, int blk, int sc) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const long j = min(bc * 16 + t, N - 1);
+            const long j = row0 + min(16 * blk + t, nrows - 1);
             xr[t] = *reinterpret_cast<const f32x4 *>(X + j * K + 256 * sc + 4 * lane);
+        }
+        if (GRAM && sc == 0) {  // unconditional clamped loads; masked at use
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const long j = row0 + min(16 * blk + 4 * q + v, nrows - 1);
+                    bnx[nb][v] = B[j * r + bcolc[nb]];
+                }
         }
     };
 
@@ -420,51 +441,115 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = zero4();
 
-    issue(b0, 0);
-    for (long blk = b0; blk < b1; ++blk) {
-        for (int sc = 0; sc < SC; ++sc) {
-            // registers -> LDS: row t, logical 16-B slot = lane, physical slot = lane ^ t
-#pragma unroll
-            for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4 *>(L + t * 256 + ((lane ^ t) << 2)) = xr[t];
-            // prefetch the next super-chunk
-            int nsc = sc + 1;
-            long nblk = blk;
-            if (nsc == SC) nsc = 0, nblk = blk + 1;
-            issue(nblk, nsc);
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                f32x4 fr[4];
-#pragma unroll
-                for (int kq = 0; kq < 4; ++kq)
-                    fr[kq] = *reinterpret_cast<const f32x4 *>(L + i16 * 256 + (((16 * kc + 4 * kq + q) ^ i16) << 2));
-                f32x4 cf[4][NB];
-#pragma unroll
-                for (int kq = 0; kq < 4; ++kq)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        if (CREG) cf[kq][nb] = creg[kc][kq][nb];
-                        else
-                            cf[kq][nb] = *reinterpret_cast<const f32x4 *>(
-                                Cfrag + ((((long)(4 * sc + kc) * 4 + kq) * NB + nb) * 64 + lane) * 4);
-                    }
-#pragma unroll
-                for (int kq = 0; kq < 4; ++kq)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA16(fr[kq][m], cf[kq][nb][m], acc[nb]);
-            }
+    long row0 = __builtin_amdgcn_readfirstlane(seg_row0[s0]);
+    int nrows = __builtin_amdgcn_readfirstlane(seg_rows[s0]);
+    issue(row0, nrows, 0, 0);
+    for (int sg = s0; sg < s1; ++sg) {
+        const int nblk = (nrows + 15) >> 4;
+        // next segment (for the prefetch across the segment boundary)
+        long nrow0 = row0;
+        int nnrows = nrows;
+        if (sg + 1 < s1) {
+            nrow0 = __builtin_amdgcn_readfirstlane(seg_row0[sg + 1]);
+            nnrows = __builtin_amdgcn_readfirstlane(seg_rows[sg + 1]);
         }
+        float p[NB];
+        f32x4 accG[NB][NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
+        for (int a = 0; a < NB; ++a) {
+            p[a] = 0.f;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const long j = blk * 16 + 4 * q + v;
+            for (int b = 0; b < NB; ++b) accG[a][b] = zero4();
+        }
+        for (int blk = 0; blk < nblk; ++blk) {
+            float bcur[NB][4];
+            if (GRAM) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) bcur[nb][v] = bnx[nb][v];
+            }
+            for (int sc = 0; sc < SC; ++sc) {
+                // registers -> LDS: row t, logical 16-B slot = lane, physical slot = lane ^ t
+#pragma unroll
+                for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4 *>(L + t * 256 + ((lane ^ t) << 2)) = xr[t];
+                // prefetch the next super-chunk (possibly the first one of the next segment)
+                if (sc + 1 < SC) issue(row0, nrows, blk, sc + 1);
+                else if (blk + 1 < nblk) issue(row0, nrows, blk + 1, 0);
+                else issue(nrow0, nnrows, 0, 0);
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    f32x4 fr[4];
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq)
+                        fr[kq] = *reinterpret_cast<const f32x4 *>(L + i16 * 256 + (((16 * kc + 4 * kq + q) ^ i16) << 2));
+                    f32x4 cf[4][NB];
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            if (CREG) cf[kq][nb] = creg[kc][kq][nb];
+                            else
+                                cf[kq][nb] = *reinterpret_cast<const f32x4 *>(
+                                    Cfrag + ((((long)(4 * sc + kc) * 4 + kq) * NB + nb) * 64 + lane) * 4);
+                        }
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA16(fr[kq][m], cf[kq][nb][m], acc[nb]);
+                }
+            }
+            // epilogue of the 16-row block
+            float bv[NB][4];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
                 const int col = 16 * nb + i16;
-                if (j < N && col < r) XC[j * r + col] = acc[nb][v];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int rl = 16 * blk + 4 * q + v;
+                    const long j = row0 + rl;
+                    const bool ok = (rl < nrows) && (col < r);
+                    if (ok) XC[j * r + col] = acc[nb][v];
+                    if (GRAM) {
+                        const float b = ok ? bcur[nb][v] : 0.f;
+                        bv[nb][v] = b;
+                        p[nb] = fmaf(b, acc[nb][v], p[nb]);
+                    }
+                }
+                acc[nb] = zero4();
             }
-            acc[nb] = zero4();
+            if (GRAM) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int a = 0; a < NB; ++a)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) accG[a][b] = MFMA16(bv[a][v], bv[b][v], accG[a][b]);
+            }
         }
+        if (GRAM) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float t = p[nb];
+                t += __shfl_xor(t, 16);
+                t += __shfl_xor(t, 32);
+                const int col = 16 * nb + i16;
+                if (q == 0 && col < r) seg_rhs[(long)sg * r + col] = t;
+            }
+#pragma unroll
+            for (int a = 0; a < NB; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int ra = 16 * a + 4 * q + v, cb = 16 * b + i16;
+                        if (ra < r && cb < r) seg_btb[((long)sg * r + ra) * r + cb] = accG[a][b][v];
+                    }
+        }
+        row0 = nrow0;
+        nrows = nnrows;
     }
 }
 
@@ -642,7 +727,7 @@ template <int NB>
 static int launch_xc(mcl_context *c) {
     const int KC = xc_KC(c);
     const long nblk = (c->N + 15) / 16;
-    long target_waves = 2048;
+    long target_waves = 1024;  // measured best: one 256-thread block per CU
     if (const char *e = getenv("MCL_XC_WAVES")) target_waves = atol(e);
     int dbg = 0;
     if (const char *e = getenv("MCL_XC_DBG")) dbg = atoi(e);
@@ -658,18 +743,33 @@ static int launch_xc(mcl_context *c) {
     if (vec && (c->K % 256 == 0) && !getenv("MCL_XC_NOROW")) {
         const size_t sm = sizeof(float) * 4 * 16 * 256;
         const bool creg = (c->K == 256) && (NB == 1);
-        if (creg)
-            hipLaunchKernelGGL((k_contract_xc_row<NB, true>), dim3(grid), dim3(256), sm, c->stream, c->X, c->Cfrag, c->XC,
-                               (long)c->N, (int)c->K, c->r, bpw, nblk);
-        else
-            hipLaunchKernelGGL((k_contract_xc_row<NB, false>), dim3(grid), dim3(256), sm, c->stream, c->X, c->Cfrag,
-                               c->XC, (long)c->N, (int)c->K, c->r, bpw, nblk);
+        const int n_segs = c->segs.n_tiles;
+        int tw = (int)target_waves;
+        int spw = (n_segs + tw - 1) / tw;
+        if (spw < 1) spw = 1;
+        const unsigned g = (unsigned)(((n_segs + spw - 1) / spw + 3) / 4);
+        const bool gram = c->xc_with_gram;
+#define MCL_XCR(CREG_, GRAM_)                                                                                        \
+    hipLaunchKernelGGL((k_contract_xc_row<NB, CREG_, GRAM_>), dim3(g), dim3(256), sm, c->stream, c->X, c->Cfrag,     \
+                       c->XC, c->B, c->segs.row0, c->segs.nrows, n_segs, spw, (int)c->K, c->r, c->seg_rhs, c->seg_btb)
+        if (n_segs > 0) {
+            if (creg) {
+                if (gram) MCL_XCR(true, true);
+                else MCL_XCR(true, false);
+            } else {
+                if (gram) MCL_XCR(false, true);
+                else MCL_XCR(false, false);
+            }
+        }
+#undef MCL_XCR
+        c->xc_did_gram = gram;
         char buf[96];
-        snprintf(buf, sizeof buf, "k_contract_xc_row<NB=%d,CREG=%d>", NB, creg ? 1 : 0);
+        snprintf(buf, sizeof buf, "k_contract_xc_row<NB=%d,CREG=%d,GRAM=%d>", NB, creg ? 1 : 0, gram ? 1 : 0);
         c->variant[0] = buf;
         MCL_CHECK_HIP(c, hipGetLastError());
         return 0;
     }
+    c->xc_did_gram = false;
 #define MCL_XC(NB_, VEC_, KCT_)                                                                                     \
     hipLaunchKernelGGL((k_contract_xc<NB_, VEC_, KCT_>), dim3(grid), dim3(256), 0, c->stream, c->X, c->Cfrag, c->XC, \
                        (long)c->N, (int)c->K, c->r, KC, bpw, nblk, dbg)

@@ -80,6 +80,13 @@ struct mcl_context {
     float *GR = nullptr;        // [r*r + K*r]
     float *rhoC = nullptr;      // [1]
     float *LinvC = nullptr;     // [r, r]
+    float *seg_rhs = nullptr;   // [n_segs, r]     per-segment partial rhs_i (fused X C epilogue)
+    float *seg_btb = nullptr;   // [n_segs, r, r]  per-segment partial B_i^T B_i
+    int *slab_seg_ptr = nullptr;  // int32[I+1] first segment of every slab
+    std::vector<int> h_slab_seg_ptr;
+    bool xc_with_gram = false;  // request: the next X C launch also produces seg_rhs / seg_btb
+    bool xc_did_gram = false;   // the last X C launch produced them
+    bool use_seg_gram = false;  // k_A_finish sums seg_rhs / seg_btb instead of reading rhsA / BtB
     float *rhsA = nullptr;      // [I, r]
     float *BtB = nullptr;       // [I, r, r]  -> overwritten by Q_i = BtB_i o CtC (cross_products)
     float *rhoA = nullptr;      // [I]
@@ -107,6 +114,7 @@ struct mcl_context {
     // validity of cached by-products
     bool xc_valid = false;      // XC == X @ C for the current C
     bool ctc_valid = false;     // CtC == C^T C for the current C
+    bool cfrag_valid = false;   // Cfrag is the fragment image of the current C
     bool e1_valid = false;      // e1/rhsA/BtB consistent with the current factors (A-phase just ran)
     bool diag_valid[3] = {false, false, false};  // per-mode diag tables consistent with factors/aux
     bool diagA_from_rows = false;
@@ -174,6 +182,7 @@ int mcl_launch_rows_solve(mcl_context *c, int mode);
 int mcl_launch_rows_prox(mcl_context *c, int mode, int k);       // generic prox step of penalty k (local part)
 int mcl_launch_rows_prox_finish(mcl_context *c, int mode, int k);
 int mcl_launch_C_prepare(mcl_context *c);
+int mcl_launch_C_finish_fused(mcl_context *c);
 int mcl_launch_A_rho(mcl_context *c);
 int mcl_launch_A_finish(mcl_context *c, bool fused_inner);
 int mcl_launch_A_rows_solve(mcl_context *c);

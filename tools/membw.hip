@@ -38,6 +38,34 @@ __global__ __launch_bounds__(256) void k_read(const float* __restrict__ x, long 
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) acc += v[u];
         }
+    } else if (mode == 4) {
+        // the X^T(B o a) kernel's pattern: per step a wave reads 4 consecutive 1 KB rows as 4 loads of
+        // (4 rows x 256 B): lane (rsub = lane>>4, c16 = lane&15) reads row 4g+rsub, floats 64kb + 4c16
+        const long base = w * chunk_f4;              // in float4 units; a row = 64 float4
+        const long groups = chunk_f4 / 256;          // 4 rows per group
+        const int rsub = lane >> 4, c16 = lane & 15;
+        for (long g = 0; g < groups; g += UNROLL / 4) {
+            f32x4 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const long gg = g + u / 4;
+                const int kb = u & 3;
+                v[u] = p[base + (gg * 4 + rsub) * 64 + kb * 16 + c16];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) acc += v[u];
+        }
+    } else if (mode == 5) {
+        // as mode 1 (one full 1 KB row per load) but issued in bursts of 16 loads (the X C kernel's 16-row blocks)
+        const long base = w * chunk_f4;
+        const long rows = chunk_f4 / 64;
+        for (long r0 = 0; r0 < rows; r0 += 16) {
+            f32x4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[base + (r0 + u) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += v[u];
+        }
     } else {
         const long bchunk = chunk_f4 * 4;  // block region
         const long base = (long)blockIdx.x * bchunk;
@@ -60,8 +88,8 @@ int main() {
     hipMemset(x, 0, bytes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const long n_f4 = bytes / 16;
-    for (int mode = 0; mode < 4; ++mode) {
-        for (int blocks : {512, 1024, 2048}) {
+    for (int mode = 0; mode < 6; ++mode) {
+        for (int blocks : {256, 512, 1024}) {
             const long waves = (long)blocks * 4;
             const long chunk_f4 = n_f4 / waves;
             for (int rep = 0; rep < 3; ++rep) k_read<16><<<blocks, 256>>>(x, n_f4, mode, chunk_f4, out);
