@@ -6,6 +6,7 @@
 #include <cstdlib>
 
 #include "mcl_internal.h"
+#include "rows_mfma.h"
 
 #define FULL_TILE 64
 
@@ -172,8 +173,6 @@ __global__ __launch_bounds__(64) void k_C_prepare(const float *__restrict__ GR, 
 // iterations need no cross-lane data movement at all.
 // Per-tile diagnostics (fp64): ||f||^2, sum|f|, ||z_k - f||^2.
 // ---------------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // One wave's share of the fused inner loop: a tile of <= 64 rows [row0, row0 + nrows) of one slab.
 // Li: the slab's L^-1 (global or LDS), Arow: the slab's a_i or nullptr, Fcopy: optional second destination (LDS).
@@ -748,37 +747,59 @@ __global__ __launch_bounds__(256) void k_diag_final(DiagTables T, int include_re
 }
 
 // Per-tile diagnostics of a packed factor from memory (generic path / initial state):
-// ||F||^2, sum|F|, ||Z_k - F||^2 with Z_k = aux_k or P Delta (PARAFAC2).
+// ||F||^2, sum|F|, ||Z_k - F||^2 with Z_k = aux_k or P Delta (PARAFAC2; product on the MFMA).  Tile layout of rows_mfma.h.
+template <int NBR, bool VEC>
 __global__ __launch_bounds__(256) void k_rows_diag(const int *__restrict__ tile_row0, const int *__restrict__ tile_nrows,
                                                    int n_tiles, const float *__restrict__ F, RegSet regs, int r,
                                                    double *__restrict__ diag_tile) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= n_tiles) return;
-    const int row0 = tile_row0[tile], nrows = tile_nrows[tile];
-    const bool valid = lane < nrows;
-    const long j = (long)row0 + (valid ? lane : 0);
+    const long row0 = __builtin_amdgcn_readfirstlane(tile_row0[tile]);
+    const int nrows = __builtin_amdgcn_readfirstlane(tile_nrows[tile]);
+    const int row16 = lane & 15, g = lane >> 4;
+    int kpf2 = -1;
+    for (int k = 0; k < regs.n; ++k)
+        if (regs.kind[k] == MCL_PEN_PARAFAC2) kpf2 = k;
+    RowMat<NBR> D;
+    if (kpf2 >= 0) D.load(regs.aux2[kpf2], r, lane);
     double nf = 0.0, na = 0.0, gap[MCL_MAX_REGS];
 #pragma unroll
     for (int k = 0; k < MCL_MAX_REGS; ++k) gap[k] = 0.0;
-    if (valid) {
-        for (int c = 0; c < r; ++c) {
-            const double f = F[j * r + c];
-            nf += f * f;
-            na += fabs(f);
 #pragma unroll
-            for (int k = 0; k < MCL_MAX_REGS; ++k) {
-                if (k < regs.n) {
-                    double zv;
-                    if (regs.kind[k] == MCL_PEN_PARAFAC2) {
-                        float acc = 0.f;
-                        for (int d = 0; d < r; ++d) acc = fmaf(regs.aux[k][j * r + d], regs.aux2[k][d * r + c], acc);
-                        zv = acc;
-                    } else {
-                        zv = regs.aux[k][j * r + c];
-                    }
-                    gap[k] += (zv - f) * (zv - f);
+    for (int rb = 0; rb < 4; ++rb) {
+        if (16 * rb >= nrows) break;
+        const bool ok = 16 * rb + row16 < nrows;
+        const long j = row0 + 16 * rb + (ok ? row16 : 0);
+        f32x4 f[NBR];
+#pragma unroll
+        for (int h = 0; h < NBR; ++h) {
+            f[h] = row_ld4<VEC>(F, j, 16 * h + 4 * g, ok, r);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                nf += (double)f[h][v] * (double)f[h][v];
+                na += fabs((double)f[h][v]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) {
+            if (k < regs.n) {
+                f32x4 z[NBR];
+#pragma unroll
+                for (int h = 0; h < NBR; ++h) z[h] = row_ld4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r);
+                if (k == kpf2) {
+                    f32x4 pz[NBR];
+                    D.apply(z, pz);
+#pragma unroll
+                    for (int h = 0; h < NBR; ++h) z[h] = pz[h];
                 }
+#pragma unroll
+                for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const double dlt = (double)z[h][v] - (double)f[h][v];  // padded / invalid entries are 0 - 0
+                        gap[k] += dlt * dlt;
+                    }
             }
         }
     }
@@ -1006,8 +1027,23 @@ int mcl_launch_rows_diag(mcl_context *c, int mode) {
     if (tm.n_tiles == 0) return 0;
     const float *F = (mode == 1) ? c->B : (mode == 2 ? c->C : c->A);
     double *diag = (mode == 1) ? c->diagB_tile : (mode == 2 ? c->diagC_tile : c->diagA_tile);
-    hipLaunchKernelGGL(k_rows_diag, dim3((unsigned)((tm.n_tiles + 3) / 4)), dim3(256), 0, c->stream, tm.row0, tm.nrows,
-                       tm.n_tiles, F, c->regs[mode], c->r, diag);
+    bool vec = (c->r % 4 == 0) && ((reinterpret_cast<uintptr_t>(F) & 15) == 0);
+    for (int k = 0; k < c->regs[mode].n; ++k) vec = vec && ((reinterpret_cast<uintptr_t>(c->regs[mode].aux[k]) & 15) == 0);
+    dim3 grid((unsigned)((tm.n_tiles + 3) / 4)), block(256);
+#define MCL_RD(NBR_, VEC_)                                                                                       \
+    hipLaunchKernelGGL((k_rows_diag<NBR_, VEC_>), grid, block, 0, c->stream, tm.row0, tm.nrows, tm.n_tiles, F,   \
+                       c->regs[mode], c->r, diag)
+    const int nbr = c->r <= 16 ? 1 : (c->r <= 32 ? 2 : 4);
+    if (vec) {
+        if (nbr == 1) MCL_RD(1, true);
+        else if (nbr == 2) MCL_RD(2, true);
+        else MCL_RD(4, true);
+    } else {
+        if (nbr == 1) MCL_RD(1, false);
+        else if (nbr == 2) MCL_RD(2, false);
+        else MCL_RD(4, false);
+    }
+#undef MCL_RD
     c->diag_rows[mode] = tm.n_tiles;  // one row per tile
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;

@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "mcl_internal.h"
+#include "rows_mfma.h"
 
 static __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -49,66 +50,74 @@ static ModeView view_of(mcl_context *c, int mode) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// solve:  F = (rhs (o a) + rho sum_k (Z_k - U_k)) L^-1   for every row of a slab-tiled matrix (modes 1, 2)
+// All row kernels below use the tile / fragment layout of rows_mfma.h (coalesced 16-B accesses); products with a
+// wave-uniform r x r matrix (L^-1, Delta, T_i) run on the fp32 MFMA.
 // ---------------------------------------------------------------------------------------------------------
-template <int RP>
+#define TILE_PROLOGUE()                                                                                      \
+    const int lane = threadIdx.x & 63;                                                                       \
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);                                                    \
+    if (tile >= mv.n_tiles) return;                                                                          \
+    const int slab = __builtin_amdgcn_readfirstlane(mv.tile_slab[tile]);                                     \
+    const long row0 = __builtin_amdgcn_readfirstlane(mv.tile_row0[tile]);                                    \
+    const int nrows = __builtin_amdgcn_readfirstlane(mv.tile_nrows[tile]);                                   \
+    const int row16 = lane & 15, g = lane >> 4;                                                              \
+    (void)slab; (void)row16; (void)g
+
+#define FOR_ROW_BLOCKS()                                                                                     \
+    _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)                                                         \
+        if (16 * rb < nrows)
+
+// solve:  F = (rhs (o a) + rho sum_k (Z_k - U_k)) L^-1   (decomposition.py:266-273 / 328-331)
+template <int NBR, bool VEC>
 __global__ __launch_bounds__(256) void k_rows_solve(ModeView mv, const float *__restrict__ rhs_src,
                                                     const float *__restrict__ Arows, const float *__restrict__ Linv,
                                                     RegSet regs, int r) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= mv.n_tiles) return;
-    const int slab = __builtin_amdgcn_readfirstlane(mv.tile_slab[tile]);
-    const int row0 = __builtin_amdgcn_readfirstlane(mv.tile_row0[tile]);
-    const int nrows = __builtin_amdgcn_readfirstlane(mv.tile_nrows[tile]);
-    const bool valid = lane < nrows;
-    const long j = (long)row0 + (valid ? lane : 0);
+    TILE_PROLOGUE();
     const float rho = mv.rho[slab];
-    const float *__restrict__ Li = Linv + (long)slab * r * r;
-    float t[RP], f[RP];
+    RowMat<NBR> L, D;
+    L.load(Linv + (long)slab * r * r, r, lane);
+    int kpf2 = -1;
+    for (int k = 0; k < regs.n; ++k)
+        if (regs.kind[k] == MCL_PEN_PARAFAC2) kpf2 = k;
+    if (kpf2 >= 0) D.load(regs.aux2[kpf2], r, lane);
+    float av[NBR][4];
 #pragma unroll
-    for (int c = 0; c < RP; ++c) {
-        float v = 0.f;
-        if (c < r) {
-            v = rhs_src[j * r + c];
-            if (Arows) v *= Arows[(long)slab * r + c];
+    for (int h = 0; h < NBR; ++h)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int col = 16 * h + 4 * g + v;
+            av[h][v] = (Arows != nullptr && col < r) ? Arows[(long)slab * r + col] : 1.f;
         }
-        t[c] = v;
-        f[c] = 0.f;
-    }
-    for (int k = 0; k < regs.n; ++k) {
-        if (regs.kind[k] == MCL_PEN_PARAFAC2) {
-            float p[RP];
+    FOR_ROW_BLOCKS() {
+        const bool ok = 16 * rb + row16 < nrows;
+        const long j = row0 + 16 * rb + (ok ? row16 : 0);
+        f32x4 t[NBR], f[NBR];
 #pragma unroll
-            for (int c = 0; c < RP; ++c) p[c] = (c < r) ? regs.aux[k][j * r + c] : 0.f;
+        for (int h = 0; h < NBR; ++h) {
+            t[h] = row_ld4<VEC>(rhs_src, j, 16 * h + 4 * g, ok, r);
 #pragma unroll
-            for (int c = 0; c < RP; ++c) {
-                if (c < r) {
-                    float z = 0.f;
+            for (int v = 0; v < 4; ++v) t[h][v] *= av[h][v];
+        }
+        for (int k = 0; k < regs.n; ++k) {
+            f32x4 z[NBR];
 #pragma unroll
-                    for (int d = 0; d < RP; ++d)
-                        if (d < r) z = fmaf(p[d], regs.aux2[k][d * r + c], z);
-                    t[c] = fmaf(rho, z - regs.dual[k][j * r + c], t[c]);
-                }
+            for (int h = 0; h < NBR; ++h) z[h] = row_ld4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r);
+            if (k == kpf2) {
+                f32x4 pz[NBR];
+                D.apply(z, pz);
+#pragma unroll
+                for (int h = 0; h < NBR; ++h) z[h] = pz[h];
             }
-        } else {
 #pragma unroll
-            for (int c = 0; c < RP; ++c)
-                if (c < r) t[c] = fmaf(rho, regs.aux[k][j * r + c] - regs.dual[k][j * r + c], t[c]);
+            for (int h = 0; h < NBR; ++h) {
+                const f32x4 u = row_ld4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) t[h][v] = fmaf(rho, z[h][v] - u[v], t[h][v]);
+            }
         }
-    }
+        L.apply(t, f);
 #pragma unroll
-    for (int c = 0; c < RP; ++c) {
-        if (c < r) {
-#pragma unroll
-            for (int d = 0; d < RP; ++d)
-                if (d < r) f[d] = fmaf(t[c], Li[c * r + d], f[d]);
-        }
-    }
-    if (valid) {
-#pragma unroll
-        for (int c = 0; c < RP; ++c)
-            if (c < r) mv.F[j * r + c] = f[c];
+        for (int h = 0; h < NBR; ++h) row_st4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r, f[h]);
     }
 }
 
@@ -130,24 +139,28 @@ __global__ __launch_bounds__(64) void k_A_rows_solve(const float *__restrict__ r
     if (act) A[(long)i * r + c] = a;
 }
 
-// ---------------------------------------------------------------------------------------------------------
 // row-separable prox + dual update of penalty k (generic path)
-// ---------------------------------------------------------------------------------------------------------
+template <int NBR, bool VEC>
 __global__ __launch_bounds__(256) void k_rows_prox_rowsep(ModeView mv, RegSet regs, int k, int r) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= mv.n_tiles) return;
-    const int slab = mv.tile_slab[tile];
-    const int nrows = mv.tile_nrows[tile];
-    if (lane >= nrows) return;
-    const long j = (long)mv.tile_row0[tile] + lane;
+    TILE_PROLOGUE();
     const float rho = mv.rho[slab];
     const float thr = regs.p0[k] / rho;
-    for (int c = 0; c < r; ++c) {
-        const float f = mv.F[j * r + c], u = regs.dual[k][j * r + c];
-        const float z = prox_elem_g(regs.kind[k], regs.nonneg[k], regs.p0[k], regs.p1[k], thr, f + u);
-        regs.aux[k][j * r + c] = z;
-        regs.dual[k][j * r + c] = f - (z - u);
+    FOR_ROW_BLOCKS() {
+        const bool ok = 16 * rb + row16 < nrows;
+        const long j = row0 + 16 * rb + (ok ? row16 : 0);
+#pragma unroll
+        for (int h = 0; h < NBR; ++h) {
+            const int col = 16 * h + 4 * g;
+            const f32x4 f = row_ld4<VEC>(mv.F, j, col, ok, r);
+            f32x4 u = row_ld4<VEC>(regs.dual[k], j, col, ok, r), z;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                z[v] = prox_elem_g(regs.kind[k], regs.nonneg[k], regs.p0[k], regs.p1[k], thr, f[v] + u[v]);
+                u[v] = f[v] - (z[v] - u[v]);
+            }
+            row_st4<VEC>(regs.aux[k], j, col, ok, r, z);
+            row_st4<VEC>(regs.dual[k], j, col, ok, r, u);
+        }
     }
 }
 
@@ -178,23 +191,38 @@ __global__ __launch_bounds__(256) void k_slab_colsq(const int *__restrict__ ext,
     }
 }
 
+template <int NBR, bool VEC>
 __global__ __launch_bounds__(256) void k_rows_l2ball(ModeView mv, RegSet regs, int k, int r,
                                                      const double *__restrict__ colsq) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= mv.n_tiles) return;
-    const int slab = mv.tile_slab[tile];
-    if (lane >= mv.tile_nrows[tile]) return;
-    const long j = (long)mv.tile_row0[tile] + lane;
+    TILE_PROLOGUE();
     const float bound = regs.p0[k];
-    for (int c = 0; c < r; ++c) {
-        const float f = mv.F[j * r + c], u = regs.dual[k][j * r + c];
-        float y = f + u;
-        if (regs.nonneg[k]) y = fmaxf(y, 0.f);
-        const float nrm = (float)sqrt(colsq[(long)slab * r + c]);
-        const float z = y * bound / fmaxf(nrm, bound);
-        regs.aux[k][j * r + c] = z;
-        regs.dual[k][j * r + c] = f - (z - u);
+    float scale[NBR][4];
+#pragma unroll
+    for (int h = 0; h < NBR; ++h)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int col = 16 * h + 4 * g + v;
+            const float nrm = (col < r) ? (float)sqrt(colsq[(long)slab * r + col]) : 1.f;
+            scale[h][v] = bound / fmaxf(nrm, bound);
+        }
+    FOR_ROW_BLOCKS() {
+        const bool ok = 16 * rb + row16 < nrows;
+        const long j = row0 + 16 * rb + (ok ? row16 : 0);
+#pragma unroll
+        for (int h = 0; h < NBR; ++h) {
+            const int col = 16 * h + 4 * g;
+            const f32x4 f = row_ld4<VEC>(mv.F, j, col, ok, r);
+            f32x4 u = row_ld4<VEC>(regs.dual[k], j, col, ok, r), z;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float y = f[v] + u[v];
+                if (regs.nonneg[k]) y = fmaxf(y, 0.f);
+                z[v] = y * scale[h][v];
+                u[v] = f[v] - (z[v] - u[v]);
+            }
+            row_st4<VEC>(regs.aux[k], j, col, ok, r, z);
+            row_st4<VEC>(regs.dual[k], j, col, ok, r, u);
+        }
     }
 }
 
@@ -291,35 +319,56 @@ __global__ __launch_bounds__(64) void k_slab_unimodal(const int *__restrict__ ex
 // Gram route in fp64:  S_i = Y_i^T Y_i,  G_i = Delta S_i Delta^T = V L V^T,  W_i = V L^-1/2 V^T,
 //                      T_i = Delta^T W_i,  P_i = Y_i T_i,  P_i^T Y_i = T_i^T S_i.
 // ---------------------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// S_i = Y_i^T Y_i on the fp64 MFMA (v_mfma_f64_16x16x4_f64): one workgroup per slab, lane (rsub = l>>4, c16 = l&15)
+// reads Y[4g + rsub][16nb + c16] (256 contiguous bytes per wave-load for r = 16); fp32 x fp32 products are exact in
+// fp64, so only the final rounding of the sums remains.  D layout of the f64 form: col = l&15, row = (l>>4) + 4 reg.
+template <int NB>
 __global__ __launch_bounds__(256) void k_pf2_gram(const int *__restrict__ ext, const float *__restrict__ F,
                                                   const float *__restrict__ U, int r, double *__restrict__ S) {
-    extern __shared__ float ytile[];  // [64, r]
+    constexpr int W = 16 * NB;
+    __shared__ double sm[W * W];
     const int slab = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rsub = lane >> 4, c16 = lane & 15;
     const int s = ext[slab], e = ext[slab + 1];
-    const int npairs = r * r;
-    double acc[16];
+    const int n_groups = (e - s + 3) >> 2;
+    f64x4 acc[NB][NB];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = 0.0;
-    for (int j0 = s; j0 < e; j0 += 64) {
-        const int rows = min(64, e - j0);
-        __syncthreads();
-        for (int q = threadIdx.x; q < rows * r; q += 256) ytile[q] = F[(long)j0 * r + q] + U[(long)j0 * r + q];
-        __syncthreads();
+    for (int a = 0; a < NB; ++a)
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int pr = threadIdx.x + 256 * t;
-            if (pr < npairs) {
-                const int a = pr / r, b = pr - a * r;
-                double sum = 0.0;
-                for (int q = 0; q < rows; ++q) sum += (double)ytile[q * r + a] * (double)ytile[q * r + b];
-                acc[t] += sum;
-            }
+        for (int b = 0; b < NB; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int gq = wave; gq < n_groups; gq += 4) {
+        const long j = (long)s + 4 * gq + rsub;
+        double y[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = 16 * nb + c16;
+            y[nb] = (j < e && col < r) ? (double)(F[j * r + col] + U[j * r + col]) : 0.0;
         }
-    }
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int pr = threadIdx.x + 256 * t;
-        if (pr < npairs) S[(long)slab * npairs + pr] = acc[t];
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[a], y[b], acc[a][b], 0, 0, 0);
+    }
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int idx = (16 * a + rsub + 4 * v) * W + 16 * b + c16;
+                        sm[idx] = (wv == 0) ? acc[a][b][v] : sm[idx] + acc[a][b][v];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < W * W; t += 256) {
+        const int a = t / W, b = t - a * W;
+        if (a < r && b < r) S[((long)slab * r + a) * r + b] = sm[t];
     }
 }
 
@@ -429,45 +478,40 @@ __global__ __launch_bounds__(64) void k_pf2_algebra(const double *__restrict__ S
     if (lane == 0) acc_out[(long)slab * (n2 + 1) + n2] = rh;
 }
 
-// P = Y T_slab  (one lane per row)
-template <int RP>
+// P = Y T_slab
+template <int NBR, bool VEC>
 __global__ __launch_bounds__(256) void k_pf2_apply(ModeView mv, const float *__restrict__ U, const float *__restrict__ T,
                                                    float *__restrict__ P, int r) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= mv.n_tiles) return;
-    const int slab = __builtin_amdgcn_readfirstlane(mv.tile_slab[tile]);
-    const int nrows = __builtin_amdgcn_readfirstlane(mv.tile_nrows[tile]);
-    const bool valid = lane < nrows;
-    const long j = (long)mv.tile_row0[tile] + (valid ? lane : 0);
-    const float *__restrict__ Ts = T + (long)slab * r * r;
-    float y[RP], p[RP];
+    TILE_PROLOGUE();
+    RowMat<NBR> Ts;
+    Ts.load(T + (long)slab * r * r, r, lane);
+    FOR_ROW_BLOCKS() {
+        const bool ok = 16 * rb + row16 < nrows;
+        const long j = row0 + 16 * rb + (ok ? row16 : 0);
+        f32x4 y[NBR], p[NBR];
 #pragma unroll
-    for (int c = 0; c < RP; ++c) {
-        y[c] = (c < r) ? mv.F[j * r + c] + U[j * r + c] : 0.f;
-        p[c] = 0.f;
-    }
-#pragma unroll
-    for (int c = 0; c < RP; ++c) {
-        if (c < r) {
-#pragma unroll
-            for (int d = 0; d < RP; ++d)
-                if (d < r) p[d] = fmaf(y[c], Ts[c * r + d], p[d]);
+        for (int h = 0; h < NBR; ++h) {
+            const f32x4 f = row_ld4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r);
+            const f32x4 u = row_ld4<VEC>(U, j, 16 * h + 4 * g, ok, r);
+            y[h] = f + u;
         }
-    }
-    if (valid) {
+        Ts.apply(y, p);
 #pragma unroll
-        for (int c = 0; c < RP; ++c)
-            if (c < r) P[j * r + c] = p[c];
+        for (int h = 0; h < NBR; ++h) row_st4<VEC>(P, j, 16 * h + 4 * g, ok, r, p[h]);
     }
 }
 
-__global__ void k_pf2_sum(const double *__restrict__ acc, int n_slabs, int n_el, float *__restrict__ red) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_el) return;
+// red[e] = sum_i acc[i][e]: one workgroup per element, fixed summation order
+__global__ __launch_bounds__(256) void k_pf2_sum(const double *__restrict__ acc, int n_slabs, int n_el,
+                                                 float *__restrict__ red) {
+    __shared__ double sm[4];
+    const int e = blockIdx.x;
     double s = 0.0;
-    for (int i = 0; i < n_slabs; ++i) s += acc[(long)i * n_el + e];
-    red[e] = (float)s;
+    for (int i = threadIdx.x; i < n_slabs; i += 256) s += acc[(long)i * n_el + e];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) red[e] = (float)((sm[0] + sm[1]) + (sm[2] + sm[3]));
 }
 
 __global__ void k_pf2_delta(const float *__restrict__ red, int r, float *__restrict__ Delta) {
@@ -476,26 +520,26 @@ __global__ void k_pf2_delta(const float *__restrict__ red, int r, float *__restr
 }
 
 // dual update of the PARAFAC2 penalty: U = F - (P Delta - U)
-template <int RP>
+template <int NBR, bool VEC>
 __global__ __launch_bounds__(256) void k_rows_pf2_dual(ModeView mv, RegSet regs, int k, int r) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= mv.n_tiles) return;
-    if (lane >= mv.tile_nrows[tile]) return;
-    const long j = (long)mv.tile_row0[tile] + lane;
-    const float *__restrict__ D = regs.aux2[k];
-    float p[RP];
+    TILE_PROLOGUE();
+    RowMat<NBR> D;
+    D.load(regs.aux2[k], r, lane);
+    FOR_ROW_BLOCKS() {
+        const bool ok = 16 * rb + row16 < nrows;
+        const long j = row0 + 16 * rb + (ok ? row16 : 0);
+        f32x4 p[NBR], z[NBR];
 #pragma unroll
-    for (int c = 0; c < RP; ++c) p[c] = (c < r) ? regs.aux[k][j * r + c] : 0.f;
+        for (int h = 0; h < NBR; ++h) p[h] = row_ld4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r);
+        D.apply(p, z);
 #pragma unroll
-    for (int c = 0; c < RP; ++c) {
-        if (c < r) {
-            float z = 0.f;
+        for (int h = 0; h < NBR; ++h) {
+            const int col = 16 * h + 4 * g;
+            const f32x4 f = row_ld4<VEC>(mv.F, j, col, ok, r);
+            f32x4 u = row_ld4<VEC>(regs.dual[k], j, col, ok, r);
 #pragma unroll
-            for (int d = 0; d < RP; ++d)
-                if (d < r) z = fmaf(p[d], D[d * r + c], z);
-            const float f = mv.F[j * r + c], u = regs.dual[k][j * r + c];
-            regs.dual[k][j * r + c] = f - (z - u);
+            for (int v = 0; v < 4; ++v) u[v] = f[v] - (z[h][v] - u[v]);
+            row_st4<VEC>(regs.dual[k], j, col, ok, r, u);
         }
     }
 }
@@ -503,14 +547,27 @@ __global__ __launch_bounds__(256) void k_rows_pf2_dual(ModeView mv, RegSet regs,
 // =========================================================================================================
 // host launchers
 // =========================================================================================================
-#define DISPATCH_RP(c, KERNEL, grid, block, ...)                                                         \
-    switch ((c)->RP) {                                                                                   \
-        case 4: hipLaunchKernelGGL((KERNEL<4>), grid, block, 0, (c)->stream, __VA_ARGS__); break;         \
-        case 8: hipLaunchKernelGGL((KERNEL<8>), grid, block, 0, (c)->stream, __VA_ARGS__); break;         \
-        case 16: hipLaunchKernelGGL((KERNEL<16>), grid, block, 0, (c)->stream, __VA_ARGS__); break;       \
-        case 32: hipLaunchKernelGGL((KERNEL<32>), grid, block, 0, (c)->stream, __VA_ARGS__); break;       \
-        default: hipLaunchKernelGGL((KERNEL<64>), grid, block, 0, (c)->stream, __VA_ARGS__); break;       \
-    }
+static bool rows_vec_ok(const mcl_context *c, const ModeView &mv, const RegSet &rs, const float *extra) {
+    bool vec = (c->r % 4 == 0) && ((reinterpret_cast<uintptr_t>(mv.F) & 15) == 0) &&
+               ((reinterpret_cast<uintptr_t>(extra) & 15) == 0);
+    for (int k = 0; k < rs.n; ++k)
+        vec = vec && ((reinterpret_cast<uintptr_t>(rs.aux[k]) & 15) == 0) && ((reinterpret_cast<uintptr_t>(rs.dual[k]) & 15) == 0);
+    return vec;
+}
+
+#define DISPATCH_ROWS(c, vec, KERNEL, grid, block, ...)                                                       \
+    do {                                                                                                      \
+        const int nbr_ = (c)->r <= 16 ? 1 : ((c)->r <= 32 ? 2 : 4);                                           \
+        if (vec) {                                                                                            \
+            if (nbr_ == 1) hipLaunchKernelGGL((KERNEL<1, true>), grid, block, 0, (c)->stream, __VA_ARGS__);   \
+            else if (nbr_ == 2) hipLaunchKernelGGL((KERNEL<2, true>), grid, block, 0, (c)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<4, true>), grid, block, 0, (c)->stream, __VA_ARGS__);             \
+        } else {                                                                                              \
+            if (nbr_ == 1) hipLaunchKernelGGL((KERNEL<1, false>), grid, block, 0, (c)->stream, __VA_ARGS__);  \
+            else if (nbr_ == 2) hipLaunchKernelGGL((KERNEL<2, false>), grid, block, 0, (c)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<4, false>), grid, block, 0, (c)->stream, __VA_ARGS__);            \
+        }                                                                                                     \
+    } while (0)
 
 int mcl_launch_rows_solve(mcl_context *c, int mode) {
     ModeView mv = view_of(c, mode);
@@ -519,7 +576,8 @@ int mcl_launch_rows_solve(mcl_context *c, int mode) {
     const float *Arows = (mode == 1) ? c->A : nullptr;
     const float *Linv = (mode == 1) ? c->LinvB : c->LinvC;
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
-    DISPATCH_RP(c, k_rows_solve, grid, block, mv, rhs, Arows, Linv, c->regs[mode], c->r);
+    const bool vec = rows_vec_ok(c, mv, c->regs[mode], rhs);
+    DISPATCH_ROWS(c, vec, k_rows_solve, grid, block, mv, rhs, Arows, Linv, c->regs[mode], c->r);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
@@ -548,16 +606,17 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
     if (mv.n_tiles == 0) return 0;
     const RegSet &rs = c->regs[mode];
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
+    const bool vec = rows_vec_ok(c, mv, rs, nullptr);
     switch (rs.kind[k]) {
         case MCL_PEN_NN:
         case MCL_PEN_BOX:
         case MCL_PEN_L1:
-            hipLaunchKernelGGL(k_rows_prox_rowsep, grid, block, 0, c->stream, mv, rs, k, c->r);
+            DISPATCH_ROWS(c, vec, k_rows_prox_rowsep, grid, block, mv, rs, k, c->r);
             break;
         case MCL_PEN_L2BALL:
             hipLaunchKernelGGL(k_slab_colsq, dim3((unsigned)mv.n_slabs), dim3(256), 0, c->stream, mv.ext, mv.F,
                                rs.dual[k], rs.nonneg[k], c->r, c->RP, c->colsq);
-            hipLaunchKernelGGL(k_rows_l2ball, grid, block, 0, c->stream, mv, rs, k, c->r, c->colsq);
+            DISPATCH_ROWS(c, vec, k_rows_l2ball, grid, block, mv, rs, k, c->r, (const double *)c->colsq);
             break;
         case MCL_PEN_UNIMODAL: {
             const long nthreads = (long)mv.n_slabs * c->r;
@@ -571,8 +630,12 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                 return 1;
             }
             const int r = c->r, n2 = r * r;
-            hipLaunchKernelGGL(k_pf2_gram, dim3((unsigned)c->I), dim3(256), sizeof(float) * 64 * r, c->stream, mv.ext,
-                               mv.F, rs.dual[k], r, c->pf2_S);
+            if (c->NB == 1)
+                hipLaunchKernelGGL(k_pf2_gram<1>, dim3((unsigned)c->I), dim3(256), 0, c->stream, mv.ext, mv.F, rs.dual[k], r, c->pf2_S);
+            else if (c->NB == 2)
+                hipLaunchKernelGGL(k_pf2_gram<2>, dim3((unsigned)c->I), dim3(256), 0, c->stream, mv.ext, mv.F, rs.dual[k], r, c->pf2_S);
+            else
+                hipLaunchKernelGGL(k_pf2_gram<4>, dim3((unsigned)c->I), dim3(256), 0, c->stream, mv.ext, mv.F, rs.dual[k], r, c->pf2_S);
             const size_t sm = sizeof(double) * (size_t)(4 * n2 + r);
             if (sm > 65536) {
                 MCL_CHECK_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pf2_algebra),
@@ -580,9 +643,9 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
             }
             hipLaunchKernelGGL(k_pf2_algebra, dim3((unsigned)c->I), dim3(64), sm, c->stream, c->pf2_S, rs.aux2[k],
                                c->rhoB, r, c->pf2_T, c->pf2_acc);
-            DISPATCH_RP(c, k_pf2_apply, grid, block, mv, (const float *)rs.dual[k], (const float *)c->pf2_T, rs.aux[k], r);
-            hipLaunchKernelGGL(k_pf2_sum, dim3((unsigned)((n2 + 1 + 255) / 256)), dim3(256), 0, c->stream, c->pf2_acc,
-                               (int)c->I, n2 + 1, c->pf2_red);
+            DISPATCH_ROWS(c, vec, k_pf2_apply, grid, block, mv, (const float *)rs.dual[k], (const float *)c->pf2_T, rs.aux[k], r);
+            hipLaunchKernelGGL(k_pf2_sum, dim3((unsigned)(n2 + 1)), dim3(256), 0, c->stream, c->pf2_acc, (int)c->I, n2 + 1,
+                               c->pf2_red);
             break;
         }
         default:
@@ -602,7 +665,8 @@ int mcl_launch_generic_prox_finish(mcl_context *c, int mode, int k) {
     hipLaunchKernelGGL(k_pf2_delta, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->pf2_red, c->r,
                        rs.aux2[k]);
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
-    DISPATCH_RP(c, k_rows_pf2_dual, grid, block, mv, rs, k, c->r);
+    const bool vec = rows_vec_ok(c, mv, rs, nullptr);
+    DISPATCH_ROWS(c, vec, k_rows_pf2_dual, grid, block, mv, rs, k, c->r);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

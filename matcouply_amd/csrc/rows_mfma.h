@@ -1,0 +1,69 @@
+// Row-tile helpers shared by the fused and the generic ADMM kernels (gfx950).
+//
+// A wave owns a tile of <= 64 rows of one slab = 4 blocks of 16 rows.  Lane l = (row16 = l&15, g = l>>4) holds, for
+// every 16-column block h, the 4 consecutive columns 16h + 4g .. +3 of its row: one 16-B access per (row block, h);
+// the 64 lanes of a wave cover 16 full rows = one contiguous 1 KB region when r = 16.
+//
+// out = t M (M: r x r, wave-uniform) as v_mfma_f32_16x16x4_f32 on the TRANSPOSED problem, with the k-permutation
+// k = 16h + 4g + kq that makes the input fragment layout equal to the output layout:
+//     A (lane (c' = l&15, g)) = M[k][16h' + c']      B (lane (row = l&15, g)) = t[row][k]
+//     D (lane l, reg v)       = out[row = l&15][16h' + 4g + v]
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef MFMA16
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
+
+template <int NBR>
+struct RowMat {
+    float m[NBR][NBR][4];  // m[h'][h][kq] = M[16h + 4g + kq][16h' + row16]
+    __device__ __forceinline__ void load(const float *M, int r, int lane) {
+        const int row16 = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int hp = 0; hp < NBR; ++hp)
+#pragma unroll
+            for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) {
+                    const int k = 16 * h + 4 * g + kq, c = 16 * hp + row16;
+                    m[hp][h][kq] = (k < r && c < r) ? M[k * r + c] : 0.f;
+                }
+    }
+    __device__ __forceinline__ void apply(const f32x4 (&t)[NBR], f32x4 (&out)[NBR]) const {
+#pragma unroll
+        for (int hp = 0; hp < NBR; ++hp) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) acc = MFMA16(m[hp][h][kq], t[h][kq], acc);
+            out[hp] = acc;
+        }
+    }
+};
+
+template <bool VEC>
+static __device__ __forceinline__ f32x4 row_ld4(const float *__restrict__ base, long j, int col, bool ok, int r) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (VEC) {
+        if (ok && col < r) v = *reinterpret_cast<const f32x4 *>(base + j * r + col);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (ok && col + q < r) v[q] = base[j * r + col + q];
+    }
+    return v;
+}
+
+template <bool VEC>
+static __device__ __forceinline__ void row_st4(float *__restrict__ base, long j, int col, bool ok, int r, f32x4 v) {
+    if (VEC) {
+        if (ok && col < r) *reinterpret_cast<f32x4 *>(base + j * r + col) = v;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (ok && col + q < r) base[j * r + col + q] = v[q];
+    }
+}
