@@ -93,7 +93,9 @@ int64_t plan(mcl_context *c, char *base) {
         c->pf2_T = b.take<float>(I * r * r);
         c->pf2_acc = b.take<double>(I * (r * r + 1));
         c->pf2_red = b.take<float>(r * r + 1);
+        c->pf2_status = b.take<int>(I);
     } else {
+        c->pf2_status = nullptr;
         c->pf2_S = nullptr, c->pf2_T = nullptr, c->pf2_acc = nullptr, c->pf2_red = nullptr;
     }
     return (b.off + 255) & ~int64_t(255);
@@ -573,6 +575,9 @@ float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {
         case 5: p = c->rhoC, n = 1; break;
         case 6: p = c->CtC, n = (int64_t)c->r * c->r; break;
         case 7: p = c->LinvB, n = c->I * c->r * c->r; break;
+        case 9: p = reinterpret_cast<float *>(c->pf2_acc), n = c->pf2_acc ? 2 * c->I * ((int64_t)c->r * c->r + 1) : 0; break;
+        case 10: p = reinterpret_cast<float *>(c->pf2_S), n = c->pf2_S ? 2 * c->I * (int64_t)c->r * c->r : 0; break;
+        case 8: p = reinterpret_cast<float *>(c->pf2_status), n = c->pf2_status ? c->I : 0; break;  // int32 bits
         default: break;
     }
     if (count) *count = n;

@@ -5,6 +5,7 @@
 // plus the row-separable ones when they share a mode with the above.  Used for all three modes: A and C are
 // treated as a single slab (tile maps tilesA / tilesC, extents ext_A / ext_C).
 #include <algorithm>
+#include <cstdlib>
 
 #include "mcl_internal.h"
 #include "rows_mfma.h"
@@ -374,8 +375,10 @@ __global__ __launch_bounds__(256) void k_pf2_gram(const int *__restrict__ ext, c
 
 __global__ __launch_bounds__(64) void k_pf2_algebra(const double *__restrict__ S, const float *__restrict__ Delta,
                                                     const float *__restrict__ rho, int r, float *__restrict__ T,
-                                                    double *__restrict__ acc_out) {
+                                                    double *__restrict__ acc_out, const int *__restrict__ status) {
     extern __shared__ double smd[];
+    if (status != nullptr && status[blockIdx.x] <= 0) return;  // already done by the Newton-Schulz kernel (-iterations)
+    if (status != nullptr && status[blockIdx.x] == 77) return;  // debugging hook
     double *Sm = smd, *G = smd + r * r, *V = G + r * r, *lam = V + r * r, *D = lam + r;  // D: Delta in fp64 [r*r]
     const int slab = blockIdx.x, lane = threadIdx.x;
     const int n2 = r * r;
@@ -475,6 +478,206 @@ __global__ __launch_bounds__(64) void k_pf2_algebra(const double *__restrict__ S
         acc_out[(long)slab * (n2 + 1) + e] = rh * sum;
         T[(long)slab * n2 + e] = (float)V[e];
     }
+    if (lane == 0) acc_out[(long)slab * (n2 + 1) + n2] = rh;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// PARAFAC2 r x r algebra on the fp64 MFMA (one wave per slab), replacing the Jacobi eigen-solver in the common case:
+//   G = Delta S Delta^T,  s = tr G,  Newton-Schulz:  Y_0 = G/s, Z_0 = I,  T = (3I - Z Y)/2,  Y <- Y T,  Z <- T Z
+//   -> Z = (G/s)^-1/2,  W = Z / sqrt(s),  T_i = Delta^T W,  acc_i = rho_i T_i^T S.
+// The D layout of v_mfma_f64_16x16x4_f64 (lane l, reg v: row = (l>>4) + 4v, col = l&15) is directly the B-operand
+// layout (B[k = (l>>4) + 4 step][n = l&15], step = v) and, read as an A operand (A[i = l&15][k = (l>>4) + 4 step]),
+// supplies the TRANSPOSE: two accumulator-layout matrices M1, M2 give M1^T M2 with no data movement.  The iterates
+// are symmetric only up to rounding, and treating them as exactly symmetric destabilises Newton-Schulz for
+// cond(G) > ~1e3; so every iterate is carried together with its transpose (Y, Yt, Z, Zt) and both are advanced with
+// the products that are available (6 small matmuls per iteration) - stable up to cond(G) ~ 1e11 (tools/ check).
+// status[slab] = 1 if the iteration did not converge (rank-deficient / extremely ill-conditioned Y_i Delta^T, or
+// J_i < r): those slabs are redone by k_pf2_algebra (Jacobi, pseudo-inverse square root).
+// ---------------------------------------------------------------------------------------------------------
+template <int NB>
+struct SymTiles {
+    f64x4 t[NB][NB];
+};
+
+// C = A^T B for A and B in D layout; result in D layout
+template <int NB>
+static __device__ __forceinline__ void mm_t(const SymTiles<NB> &A, const SymTiles<NB> &B, SymTiles<NB> &C) {
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A.t[kb][a][st], B.t[kb][b][st], acc, 0, 0, 0);
+            C.t[a][b] = acc;
+        }
+}
+
+template <int NB>
+__global__ __launch_bounds__(64) void k_pf2_algebra_ns(const double *__restrict__ S, const float *__restrict__ Delta,
+                                                       const float *__restrict__ rho, const int *__restrict__ ext, int r,
+                                                       float *__restrict__ T, double *__restrict__ acc_out,
+                                                       int *__restrict__ status) {
+    const int slab = blockIdx.x, lane = threadIdx.x;
+    const int q = lane >> 4, c16 = lane & 15;
+    const int n2 = r * r;
+    const double *Ss = S + (long)slab * n2;
+    auto Sat = [&](int i, int j) -> double { return (i < r && j < r) ? Ss[i * r + j] : 0.0; };
+    auto Dat = [&](int i, int j) -> double { return (i < r && j < r) ? (double)Delta[i * r + j] : 0.0; };
+    if (ext[slab + 1] - ext[slab] < r) {  // fewer rows than columns: rank-deficient by construction
+        if (lane == 0) status[slab] = 1;
+        return;
+    }
+    // U1 = S Delta^T   (A = S, symmetric: A[i][k] = S[k][i];  B[k][n] = Delta[n][k])
+    SymTiles<NB> U1, G;
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int k = 16 * kb + q + 4 * st;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Sat(k, 16 * a + c16), Dat(16 * b + c16, k), acc, 0, 0, 0);
+                }
+            U1.t[a][b] = acc;
+        }
+    // G = Delta U1 (A[i][k] = Delta[i][k];  B = U1 in D layout)  and  Gt = G^T = U1^T Delta^T (A = U1 as A-operand,
+    // B[k][n] = Delta[n][k])
+    SymTiles<NB> Gt;
+    double tr = 0.0;
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acct = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int k = 16 * kb + q + 4 * st;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Dat(16 * a + c16, k), U1.t[kb][b][st], acc, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f64_16x16x4f64(U1.t[kb][a][st], Dat(16 * b + c16, k), acct, 0, 0, 0);
+                }
+            G.t[a][b] = acc;
+            Gt.t[a][b] = acct;
+            if (a == b) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (q + 4 * v == c16 && 16 * a + c16 < r) tr += acc[v];
+            }
+        }
+    tr = wave_sum_d(tr);
+    if (!(tr > 0.0)) {
+        if (lane == 0) status[slab] = 1;
+        return;
+    }
+    // Newton-Schulz for the inverse square root of G / tr (padding rows/cols >= r carry the identity)
+    SymTiles<NB> Y, Yt, Z, Zt, P, Pt, Tm, Tmt, N1, N2, N3, N4;
+    const double inv_s = 1.0 / tr;
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = 16 * a + q + 4 * v, col = 16 * b + c16;
+                const double id = (row == col) ? 1.0 : 0.0;
+                const bool in = (row < r && col < r);
+                Y.t[a][b][v] = in ? G.t[a][b][v] * inv_s : id;
+                Yt.t[a][b][v] = in ? Gt.t[a][b][v] * inv_s : id;
+                Z.t[a][b][v] = id;
+                Zt.t[a][b][v] = id;
+            }
+    bool converged = false;
+    double prev = 1e300;
+    int it_used = 0;
+    for (int it = 0; it < 100; ++it) {
+        it_used = it;
+        mm_t<NB>(Zt, Y, P);   // P  = Z Y
+        mm_t<NB>(Y, Zt, Pt);  // Pt = Y^T Z^T = P^T
+        double res = 0.0;
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = 16 * a + q + 4 * v, col = 16 * b + c16;
+                    const double id = (row == col) ? 1.0 : 0.0;
+                    const double d = id - P.t[a][b][v];
+                    res += d * d;
+                    Tm.t[a][b][v] = 0.5 * (3.0 * id - P.t[a][b][v]);
+                    Tmt.t[a][b][v] = 0.5 * (3.0 * id - Pt.t[a][b][v]);
+                }
+        res = wave_sum_d(res);
+        // converged: ||I - Z Y||_F < 1e-12 sqrt(r), or stagnation at the fp64 round-off floor of an ill-conditioned G
+        // (the floor grows with cond(G); 1e-8 in ||I - ZY|| still leaves W accurate far beyond the fp32 data)
+        if (res < 1e-24 * r || (res < 1e-16 && res > 0.25 * prev)) {
+            converged = true;
+            break;
+        }
+        prev = res;
+        mm_t<NB>(Yt, Tm, N1);   // Y  <- Y T
+        mm_t<NB>(Tm, Yt, N2);   // Yt <- T^T Y^T
+        mm_t<NB>(Tmt, Z, N3);   // Z  <- T Z
+        mm_t<NB>(Z, Tmt, N4);   // Zt <- Z^T T^T
+        Y = N1;
+        Yt = N2;
+        Z = N3;
+        Zt = N4;
+    }
+    if (!converged) {
+        if (lane == 0) {
+            status[slab] = 1;
+            acc_out[(long)slab * (n2 + 1)] = prev;      // diagnostics only: the Jacobi kernel overwrites these
+            acc_out[(long)slab * (n2 + 1) + 1] = tr;
+        }
+        return;
+    }
+    if (lane == 0) status[slab] = -it_used;  // <= 0: converged (number of Newton-Schulz iterations, for diagnostics)
+    const double wscale = 1.0 / sqrt(tr);  // W = Z / sqrt(tr)
+    // T = Delta^T W  (A[i][k] = Delta[k][i];  B = W in D layout), then acc = rho T^T S (A = T^T: A[i][k] = T[k][i] = D layout of T)
+    SymTiles<NB> Tt;
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Dat(16 * kb + q + 4 * st, 16 * a + c16), Z.t[kb][b][st] * wscale, acc, 0, 0, 0);
+            Tt.t[a][b] = acc;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = 16 * a + q + 4 * v, col = 16 * b + c16;
+                if (row < r && col < r) T[(long)slab * n2 + row * r + col] = (float)acc[v];
+            }
+        }
+    const double rh = (double)rho[slab];
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Tt.t[kb][a][st], Sat(16 * kb + q + 4 * st, 16 * b + c16), acc, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = 16 * a + q + 4 * v, col = 16 * b + c16;
+                if (row < r && col < r) acc_out[(long)slab * (n2 + 1) + row * r + col] = rh * acc[v];
+            }
+        }
     if (lane == 0) acc_out[(long)slab * (n2 + 1) + n2] = rh;
 }
 
@@ -641,8 +844,18 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                 MCL_CHECK_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pf2_algebra),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
             }
+            const int *status = nullptr;
+            if (c->NB <= 2 && !getenv("MCL_PF2_JACOBI")) {
+                status = c->pf2_status;
+                if (c->NB == 1)
+                    hipLaunchKernelGGL(k_pf2_algebra_ns<1>, dim3((unsigned)c->I), dim3(64), 0, c->stream, c->pf2_S, rs.aux2[k],
+                                       c->rhoB, mv.ext, r, c->pf2_T, c->pf2_acc, c->pf2_status);
+                else
+                    hipLaunchKernelGGL(k_pf2_algebra_ns<2>, dim3((unsigned)c->I), dim3(64), 0, c->stream, c->pf2_S, rs.aux2[k],
+                                       c->rhoB, mv.ext, r, c->pf2_T, c->pf2_acc, c->pf2_status);
+            }
             hipLaunchKernelGGL(k_pf2_algebra, dim3((unsigned)c->I), dim3(64), sm, c->stream, c->pf2_S, rs.aux2[k],
-                               c->rhoB, r, c->pf2_T, c->pf2_acc);
+                               c->rhoB, r, c->pf2_T, c->pf2_acc, status);
             DISPATCH_ROWS(c, vec, k_pf2_apply, grid, block, mv, (const float *)rs.dual[k], (const float *)c->pf2_T, rs.aux[k], r);
             hipLaunchKernelGGL(k_pf2_sum, dim3((unsigned)(n2 + 1)), dim3(256), 0, c->stream, c->pf2_acc, (int)c->I, n2 + 1,
                                c->pf2_red);
