@@ -539,7 +539,28 @@ def cmf_aoadmm(
 
     it = -1  # Needed if n_iter_max <= 0
     fast_path = (not (tol or absolute_tol)) and world == 1 and not verbose and n_iter_max > 0
-    if fast_path:
+    lazy_diag = (not (tol or absolute_tol)) and world > 1 and not verbose and n_iter_max > 0
+    if lazy_diag:
+        # sharded, fixed iteration count: nothing depends on the diagnostics inside the loop, so their partial sums stay
+        # on the device and are all-reduced once for all iterations (one collective per iteration remains: [G | R])
+        ring = torch.zeros((n_iter_max, _engine.DIAG_LEN), dtype=torch.float64, device=device) if return_errors else None
+        for it in range(n_iter_max):
+            if update_B_is:
+                do_update_B()
+            if update_C:
+                do_update_C()
+            if update_A:
+                do_update_A()
+            if ring is not None:
+                eng.diagnostics(include_replicated=(rank_id == 0), out=ring[it])
+        if ring is not None:
+            all_reduce(ring)
+            for row in ring.cpu().numpy():
+                rec_error, gaps, reg = read_diag(row)
+                feasibility_gaps.append(gaps)
+                rec_errors.append(rec_error)
+                losses.append(0.5 * rec_error ** 2 + reg)
+    elif fast_path:
         # fixed iteration count: the whole outer loop runs natively, diagnostics stay on the device until the end
         ring = None
         if return_errors:
