@@ -118,6 +118,17 @@ int mcl_B_prox_finish(mcl_context *ctx, int32_t k); /* PARAFAC2: Delta; all: dua
 int mcl_A_begin(mcl_context *ctx);           /* X C, rhs_i, Q_i, rho_i (decomposition.py:136-162) */
 float *mcl_A_rho_max(mcl_context *ctx);
 int mcl_A_finish(mcl_context *ctx);          /* systems, inner ADMM loop, by-products (decomposition.py:163-219) */
+/* Host-evaluated (MCL_PEN_EXTERNAL) penalties on modes 0 / 2: the library does the linear algebra, the host the prox.
+ *   mode 0:  mcl_A_begin -> [MAX all-reduce] -> mcl_A_factor -> { mcl_A_solve -> host prox/dual }* -> mcl_A_end
+ *   mode 2:  mcl_update_C_local -> [all-reduce] -> mcl_C_begin -> { mcl_C_solve -> host prox/dual }* -> mcl_C_end
+ *   mode 1:  mcl_B_begin -> mcl_B_factor -> { mcl_B_solve -> per penalty: native mcl_B_prox_* or host prox/dual }*
+ * The aux buffer of an EXTERNAL penalty holds the auxiliary variable AS A MATRIX (aux_as_matrix of the reference). */
+int mcl_A_factor(mcl_context *ctx);          /* Q_i, rho_i, L_i^-1 (decomposition.py:162-172) */
+int mcl_A_solve(mcl_context *ctx);           /* one row solve for all rows (decomposition.py:184-195) */
+int mcl_A_end(mcl_context *ctx);             /* by-products for the fast error formula (decomposition.py:219, 445-449) */
+int mcl_C_begin(mcl_context *ctx);           /* rho, L^-1 from the reduced normal equations (decomposition.py:319-321) */
+int mcl_C_solve(mcl_context *ctx);           /* decomposition.py:328-331 */
+int mcl_C_end(mcl_context *ctx);             /* invalidates everything derived from C */
 
 /* ---- introspection for tests / profiling ------------------------------------------------------------- */
 /* device pointers to internal by-products: 0 rhses [I, r], 1 cross_products [I, r, r], 2 X C [sum J_i, r],

@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = [
     "mcl_update_C_local", "mcl_c_normal_equations", "mcl_update_C_finish", "mcl_update_A", "mcl_diagnostics",
     "mcl_iterate", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
+    "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
     "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_read",
 ]
 
@@ -84,6 +85,12 @@ def load_library():
         "mcl_A_begin": (ctypes.c_int, [P]),
         "mcl_A_rho_max": (P, [P]),
         "mcl_A_finish": (ctypes.c_int, [P]),
+        "mcl_A_factor": (ctypes.c_int, [P]),
+        "mcl_A_solve": (ctypes.c_int, [P]),
+        "mcl_A_end": (ctypes.c_int, [P]),
+        "mcl_C_begin": (ctypes.c_int, [P]),
+        "mcl_C_solve": (ctypes.c_int, [P]),
+        "mcl_C_end": (ctypes.c_int, [P]),
         "mcl_internal_buffer": (P, [P, I32, ctypes.POINTER(I64)]),
         "mcl_kernel_variant": (ctypes.c_char_p, [P, I32]),
         "mcl_profile_enable": (ctypes.c_int, [P, I32]),
@@ -256,6 +263,28 @@ class HipEngine:
 
     def A_finish(self):
         self._check(self.lib.mcl_A_finish(self._h))
+
+    def A_factor(self):
+        self._check(self.lib.mcl_A_factor(self._h))
+
+    def A_solve(self):
+        self._check(self.lib.mcl_A_solve(self._h))
+
+    def A_end(self):
+        self._check(self.lib.mcl_A_end(self._h))
+
+    def C_begin(self):
+        self._check(self.lib.mcl_C_begin(self._h))
+
+    def C_solve(self):
+        self._check(self.lib.mcl_C_solve(self._h))
+
+    def C_end(self):
+        self._check(self.lib.mcl_C_end(self._h))
+
+    def rho(self, mode):
+        """device fp32 feasibility penalties of the current phase: mode 0 -> [I], 1 -> [I], 2 -> [1]"""
+        return self.internal({0: 4, 1: 3, 2: 5}[mode])
 
     # -- introspection ------------------------------------------------------------------------------------
     def internal(self, which):

@@ -1,6 +1,7 @@
 // C ABI of libmatcouply_hip.so: context, workspace carve-up and the orchestration of the kernels per phase.
 // One function per reference entry point (see include/matcouply_hip.h for the file:line each one replaces).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "mcl_internal.h"
@@ -473,7 +474,7 @@ int mcl_A_begin(mcl_context *c) {
     // When X C has to be recomputed anyway (C changed), the per-slab reductions ride in its epilogue; the
     // constant-rho pre-pass (k_A_rho) needs the assembled per-slab Gram, so it keeps the separate kernel.
     c->use_seg_gram = false;
-    if (!c->xc_valid && !c->opt.constant_A && !getenv("MCL_NO_FUSED_GRAM")) {
+    if (!c->xc_valid && !c->opt.constant_A && mcl_mode_is_row_separable(c, 0) && !getenv("MCL_NO_FUSED_GRAM")) {
         c->xc_with_gram = true;
         const int rc = ensure_xc(c);
         c->xc_with_gram = false;
@@ -498,6 +499,9 @@ int mcl_A_finish(mcl_context *c) {
     if (mcl_mode_is_row_separable(c, 0)) {
         if (int rc = mcl_launch_A_finish(c, true)) return rc;
     } else {
+        for (int k = 0; k < c->regs[0].n; ++k)
+            if (c->regs[0].kind[k] == MCL_PEN_EXTERNAL)
+                return fail(c, "mode 0 has host-evaluated penalties: use mcl_A_factor / mcl_A_solve / mcl_A_end");
         if (!c->opt.constant_A)
             return fail(c, "matrix penalties on mode 0 need constant_feasibility_penalty (the reference raises "
                            "AttributeError: no factor_matrix_row_update)");
@@ -514,6 +518,53 @@ int mcl_A_finish(mcl_context *c) {
 int mcl_update_A(mcl_context *c) {
     if (int rc = mcl_A_begin(c)) return rc;
     return mcl_A_finish(c);
+}
+
+int mcl_A_factor(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    if (c->use_seg_gram) return fail(c, "internal: mcl_A_factor needs the assembled per-slab Gram");
+    c->b_systems_valid = false;
+    return mcl_launch_A_finish(c, false);
+}
+
+int mcl_A_solve(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    c->e1_valid = false;
+    c->diag_valid[0] = false;
+    c->b_systems_valid = false;
+    return mcl_launch_A_rows_solve(c);
+}
+
+int mcl_A_end(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    if (int rc = mcl_launch_A_e1(c, true)) return rc;
+    c->e1_valid = true;
+    c->e1_from_raw_gram = false;
+    c->diag_valid[0] = true;
+    return 0;
+}
+
+int mcl_C_begin(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    return mcl_launch_C_prepare(c);
+}
+
+int mcl_C_solve(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    c->xc_valid = c->ctc_valid = c->e1_valid = false;
+    c->cfrag_valid = false;
+    c->b_systems_valid = false;
+    c->diag_valid[2] = false;
+    return mcl_launch_rows_solve(c, 2);
+}
+
+int mcl_C_end(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    c->xc_valid = c->ctc_valid = c->e1_valid = false;
+    c->cfrag_valid = false;
+    c->b_systems_valid = false;
+    c->diag_valid[2] = false;
+    return 0;
 }
 
 // ---- diagnostics ---------------------------------------------------------------------------------------

@@ -324,6 +324,23 @@ class _Out:
         return [full[row_ptr[i]: row_ptr[i + 1]] for i in range(len(row_ptr) - 1)]
 
 
+def _aux_to_device(aux, device):
+    """Move an auxiliary variable in any parametrisation (array, list of arrays, tuple of those) to device tensors."""
+    if isinstance(aux, tuple):
+        return tuple(_aux_to_device(a, device) for a in aux)
+    if isinstance(aux, list):
+        return [_aux_to_device(a, device) for a in aux]
+    return _to_dev(aux, device)
+
+
+def _aux_out(aux, out):
+    if isinstance(aux, tuple):
+        return tuple(_aux_out(a, out) for a in aux)
+    if isinstance(aux, list):
+        return [_aux_out(a, out) for a in aux]
+    return out(aux)
+
+
 def _default_engine_factory(**kw):
     return _engine.HipEngine(**kw)
 
@@ -377,7 +394,9 @@ def cmf_aoadmm(
     ``matrices`` is a list of I arrays (NumPy or torch, J_i x K) or a :class:`PackedMatrices` already in HBM.  The
     arithmetic runs in fp32 on the device (rank x rank systems and all reductions in fp64); results are returned in the
     array type and dtype of the input.  Not supported (out of scope, raise ``NotImplementedError``): ``tv_penalty``,
-    ``generalized_l2_penalty``, TensorLy-ALS initialisations, ``inner_tol``, user-defined penalty subclasses.
+    ``generalized_l2_penalty``, TensorLy-ALS initialisations, ``inner_tol``.  Penalties without a native kernel (user
+    subclasses of ``matcouply_amd.penalties.ADMMPenalty``) are evaluated through their own Python methods on device
+    tensors between the native solve and dual-update steps.
 
     >>> import numpy as np, matcouply_amd
     >>> len(matcouply_amd.decomposition._listify({1: 0.5}, "l1_penalty"))
@@ -428,15 +447,24 @@ def cmf_aoadmm(
 
     native = [[], [], []]
     aux_lists, dual_lists = (A_aux_list, B_aux_list, C_aux_list), (A_dual_list, B_dual_list, C_dual_list)
+    # host-evaluated penalties: the Python object keeps the auxiliary variable in ITS parametrisation (on the device),
+    # the engine sees `aux_as_matrix` of it (reference penalties.py:311-343)
+    ext_aux = {}
     for mode in range(3):
-        for reg, aux, dual in zip(regs[mode], aux_lists[mode], dual_lists[mode]):
-            desc = reg._native_descriptor()
-            if desc is None:
-                raise NotImplementedError(
-                    f"{type(reg).__name__} has no native HIP kernel; user-defined / non-default penalties need the "
-                    "EXTERNAL step path, which is not available yet")
-            kind, nonneg, p0, p1 = desc
+        for k, (reg, aux, dual) in enumerate(zip(regs[mode], aux_lists[mode], dual_lists[mode])):
+            desc = getattr(reg, "_native_descriptor", lambda: None)()
             dual_t = _pack_rows(dual, device) if mode == 1 else _to_dev(dual, device)
+            if desc is None:
+                if mode == 1:
+                    obj = _aux_to_device(aux, device)
+                    mat = _pack_rows(reg.auxes_as_matrices(obj), device)
+                else:
+                    obj = _aux_to_device(aux, device)
+                    mat = _to_dev(reg.aux_as_matrix(obj), device)
+                ext_aux[(mode, k)] = obj
+                native[mode].append(_engine.NativeReg(_engine.PEN_EXTERNAL, mat, dual_t))
+                continue
+            kind, nonneg, p0, p1 = desc
             if kind == _engine.PEN_PARAFAC2:
                 P_is, Delta = aux
                 native[mode].append(_engine.NativeReg(kind, _pack_rows(P_is, device), dual_t,
@@ -463,9 +491,41 @@ def cmf_aoadmm(
         raise NotImplementedError("matrix penalties on mode 0 couple rows that live on different ranks; "
                                   "not supported with group=")
 
-    def all_reduce(t, op=None):
+    def all_reduce(t, op="sum"):
         if world > 1:
-            dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(t, op=(dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM), group=group)
+
+    has_ext = [any(r.kind == _engine.PEN_EXTERNAL for r in native[m]) for m in range(3)]
+    needs_B_steps = needs_B_steps or has_ext[1]
+    row_slices = [slice(int(row_ptr[i]), int(row_ptr[i + 1])) for i in range(len(row_ptr) - 1)]
+
+    def host_prox_B(k):
+        """user prox of penalty k on mode 1 (decomposition.py:276-285), evaluated on device tensors"""
+        reg, nat = regs[1][k], native[1][k]
+        rhos = [float(v) for v in eng.rho(1).cpu().numpy()]
+        shifted = [eng.B[sl] + nat.dual[sl] for sl in row_slices]
+        obj = reg.factor_matrices_update(shifted, rhos, ext_aux[(1, k)])
+        ext_aux[(1, k)] = obj
+        nat.aux.copy_(torch.cat([m.to(nat.aux.dtype) for m in reg.auxes_as_matrices(obj)], 0))
+        nat.dual.copy_(eng.B - (nat.aux - nat.dual))
+
+    def host_prox_matrix(mode, k, F, rho_rows, constant):
+        """user prox of penalty k on mode 0 / 2 (decomposition.py:197-213 / 333-338)"""
+        reg, nat = regs[mode][k], native[mode][k]
+        shifted = F + nat.dual
+        obj = ext_aux.get((mode, k))
+        if obj is None:  # native kind evaluated through its host method inside a host-driven mode
+            obj = nat.aux.clone()
+        if constant:
+            obj = reg.factor_matrix_update(shifted, float(rho_rows[0]), obj)
+        else:
+            obj = obj.clone() if is_torch(obj) else obj
+            for i in range(F.shape[0]):
+                obj[i] = reg.factor_matrix_row_update(shifted[i], float(rho_rows[i]), obj[i])
+        if (mode, k) in ext_aux:
+            ext_aux[(mode, k)] = obj
+        nat.aux.copy_(reg.aux_as_matrix(obj).to(nat.aux.dtype))
+        nat.dual.copy_(F - (nat.aux - nat.dual))
 
     def do_update_B():
         if not needs_B_steps:
@@ -473,12 +533,17 @@ def cmf_aoadmm(
             return
         eng.B_begin()
         if constant_B:
-            all_reduce(eng.B_rho_max(), dist.ReduceOp.MAX)
+            all_reduce(eng.B_rho_max(), "max")
         eng.B_factor()
         n_it = inner_n_iter_max if native[1] else min(1, inner_n_iter_max)
         for _ in range(n_it):
             eng.B_solve()
             for k, reg in enumerate(native[1]):
+                if reg.kind == _engine.PEN_EXTERNAL:
+                    if world > 1:
+                        raise NotImplementedError("host-evaluated penalties on mode 1 are not supported with group=")
+                    host_prox_B(k)
+                    continue
                 eng.B_prox_local(k)
                 if reg.kind == _engine.PEN_PARAFAC2:
                     all_reduce(eng.B_prox_reduce_buffer(k))
@@ -487,14 +552,37 @@ def cmf_aoadmm(
     def do_update_C():
         gr = eng.update_C_local()
         all_reduce(gr)
-        eng.update_C_finish()
+        if not has_ext[2]:
+            eng.update_C_finish()
+            return
+        eng.C_begin()
+        n_it = inner_n_iter_max if native[2] else min(1, inner_n_iter_max)
+        for _ in range(n_it):
+            eng.C_solve()
+            rho_c = eng.rho(2).cpu().numpy()
+            for k in range(len(native[2])):
+                host_prox_matrix(2, k, eng.C, rho_c, True)
+        eng.C_end()
 
     def do_update_A():
+        if has_ext[0]:
+            eng.A_begin()
+            if constant_A:
+                all_reduce(eng.A_rho_max(), "max")
+            eng.A_factor()
+            rho_a = eng.rho(0).cpu().numpy()
+            n_it = inner_n_iter_max if native[0] else min(1, inner_n_iter_max)
+            for _ in range(n_it):
+                eng.A_solve()
+                for k in range(len(native[0])):
+                    host_prox_matrix(0, k, eng.A, rho_a, constant_A)
+            eng.A_end()
+            return
         if not needs_A_steps:
             eng.update_A()
             return
         eng.A_begin()
-        all_reduce(eng.A_rho_max(), dist.ReduceOp.MAX)
+        all_reduce(eng.A_rho_max(), "max")
         eng.A_finish()
 
     def read_diag(vec):
@@ -512,6 +600,9 @@ def cmf_aoadmm(
                 mode_gaps.append(np.sqrt(d[base]) / fnorm)
                 if isinstance(reg, penalties.L1Penalty):
                     reg_penalty += reg.reg_strength * d[base + 1]
+                elif native[mode][k].kind == _engine.PEN_EXTERNAL:
+                    factor = [eng.B[sl] for sl in row_slices] if mode == 1 else (eng.A if mode == 0 else eng.C)
+                    reg_penalty += float(reg.penalty(factor))
             gaps.append(mode_gaps)
             if l2_penalty[mode]:
                 reg_penalty += 0.5 * l2_penalty[mode] * d[_engine.DIAG_NORM_SQ + mode]
@@ -538,7 +629,7 @@ def cmf_aoadmm(
     feasibility_criterion = None
 
     it = -1  # Needed if n_iter_max <= 0
-    fast_path = (not (tol or absolute_tol)) and world == 1 and not verbose and n_iter_max > 0
+    fast_path = (not (tol or absolute_tol)) and world == 1 and not verbose and n_iter_max > 0 and not any(has_ext)
     lazy_diag = (not (tol or absolute_tol)) and world > 1 and not verbose and n_iter_max > 0
     if lazy_diag:
         # sharded, fixed iteration count: nothing depends on the diagnostics inside the loop, so their partial sums stay
@@ -647,7 +738,11 @@ def cmf_aoadmm(
     if return_admm_vars:
         auxes, duals = [[], [], []], [[], [], []]
         for mode in range(3):
-            for reg in native[mode]:
+            for k, reg in enumerate(native[mode]):
+                if reg.kind == _engine.PEN_EXTERNAL:
+                    auxes[mode].append(_aux_out(ext_aux[(mode, k)], out))
+                    duals[mode].append(out.split(reg.dual, row_ptr) if mode == 1 else out(reg.dual))
+                    continue
                 if reg.kind == _engine.PEN_PARAFAC2:
                     auxes[mode].append((out.split(reg.aux, row_ptr), out(reg.aux2)))
                 else:
