@@ -139,6 +139,11 @@ SCALE_CASES = {
                            [{"kind": "parafac2"}, {"kind": "unimodal", "non_negativity": True},
                             {"kind": "l2ball", "norm_bound": 1.0, "non_negativity": True}],
                            [{"kind": "l1", "reg_strength": 0.1, "non_negativity": True}]]),
+    # config 5's matrix dimensions (K = 1024, rank 32: K-sliced X^T pass, fragment-streaming X C pass) with few slabs
+    "c5_dims": dict(I=6, J="c5dims", K=1024, r=32,
+                    regs=[[{"kind": "nn"}], [{"kind": "nn"}], [{"kind": "l1", "reg_strength": 0.1, "non_negativity": True}]]),
+    "k512": dict(I=10, J=300, K=512, r=16,
+                 regs=[[{"kind": "nn"}], [{"kind": "parafac2"}, {"kind": "nn"}], [{"kind": "nn"}]]),
     "odd_shapes": dict(I=9, J="odd", K=37, r=5, regs=[[{"kind": "box", "min_val": 0.0, "max_val": 0.9}],
                                                       [{"kind": "l1", "reg_strength": 0.05}], [{"kind": "nn"}]]),
     "r64": dict(I=8, J=96, K=80, r=64, regs=[[{"kind": "nn"}], [{"kind": "nn"}], []]),
@@ -153,6 +158,8 @@ def test_scale_parity_vs_oracle(name):
     J = cfg["J"]
     if J == "ragged":
         J = np.random.RandomState(0).randint(128, 1025, cfg["I"])
+    elif J == "c5dims":
+        J = np.array([2048, 700, 33, 1024, 515, 64])
     elif J == "odd":
         J = np.array([1, 3, 64, 65, 17, 130, 5, 63, 2])
     X, row_ptr = orc.synthetic_problem(cfg["I"], J, cfg["K"], cfg["r"], seed=0, dtype=np.float64)

@@ -1,0 +1,81 @@
+"""-m gpu: seeded random sweep of shapes / ranks / penalty stacks / options, two outer iterations on the GPU through
+the public API against the oracle.  Modes without any penalty are ill-conditioned by construction (see
+test_gpu_end_to_end.py), so every mode gets at least one penalty or an l2 term here and the 1e-5 bar applies."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_end_to_end import _compare, _run_both
+
+pytestmark = pytest.mark.gpu
+
+ROWSEP = [{"kind": "nn"}, {"kind": "l1", "reg_strength": 0.05}, {"kind": "l1", "reg_strength": 0.02, "non_negativity": True},
+          {"kind": "box", "min_val": -0.2, "max_val": 0.8}]
+MATRIX = [{"kind": "l2ball", "norm_bound": 0.7}, {"kind": "l2ball", "norm_bound": 1.5, "non_negativity": True},
+          {"kind": "unimodal"}, {"kind": "unimodal", "non_negativity": True}]
+
+
+def _draw_case(rng):
+    r = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 17, 24, 32, 40]))
+    K = int(rng.choice([r + 3, 33, 64, 100, 128, 200, 256, 300]))
+    I = int(rng.randint(2, 9))
+    J = rng.randint(max(r, 2), 150, size=I)
+    if rng.rand() < 0.3:
+        J[rng.randint(I)] = int(rng.choice([64, 65, 128, 256, 257]))
+    const = bool(rng.rand() < 0.3)
+    regs = [[], [], []]
+    # mode 0: row-separable (matrix penalties need a constant rho)
+    regs[0] = [dict(ROWSEP[rng.randint(len(ROWSEP))])] if rng.rand() < 0.8 else []
+    if const and rng.rand() < 0.5:
+        regs[0].append(dict(MATRIX[rng.randint(2)]))
+    # mode 1: any mix, optionally PARAFAC2 first (as the reference's parser orders it)
+    if rng.rand() < 0.4 and J.min() >= r:
+        regs[1].append({"kind": "parafac2"})
+    for _ in range(rng.randint(0, 3)):
+        pool = ROWSEP + MATRIX
+        regs[1].append(dict(pool[rng.randint(len(pool))]))
+    regs[1] = regs[1][:3]
+    # mode 2
+    for _ in range(rng.randint(0, 3)):
+        pool = ROWSEP + MATRIX
+        regs[2].append(dict(pool[rng.randint(len(pool))]))
+    l2 = [0.0 if regs[m] else float(rng.uniform(0.05, 0.5)) for m in range(3)]
+    if rng.rand() < 0.3:
+        l2 = [v + float(rng.uniform(0, 0.3)) for v in l2]
+    return dict(I=I, J=J, K=K, r=r, regs=regs, l2=l2, const=const, scale=float(rng.choice([0.5, 1.0, 2.0])),
+                inner=int(rng.choice([1, 3, 5])))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration(seed):
+    from oracle import aoadmm_oracle as orc
+
+    rng = np.random.RandomState(1000 + seed)
+    case = _draw_case(rng)
+    X, row_ptr = orc.synthetic_problem(case["I"], case["J"], case["K"], case["r"], seed=seed, dtype=np.float64)
+    X = X.astype(np.float32).astype(np.float64)
+    st = orc.random_state_for(X, row_ptr, case["r"], case["regs"], seed=seed + 1, l2=case["l2"],
+                              inner_n_iter_max=case["inner"], feasibility_penalty_scale=case["scale"],
+                              constant_A=case["const"], constant_B=case["const"])
+    tol, tol_rec = 1e-5, 1e-5
+    if any(len(m) == 0 for m in case["regs"]):
+        # penalty-free mode: un-shifted (or only l2-shifted) normal equations amplify fp32 rounding by their condition
+        # number; criterion = within 1e-5 or no worse than 3x NumPy's own float32 loss on the same algorithm
+        mk = lambda dt: orc.random_state_for(X, row_ptr, case["r"], case["regs"], seed=seed + 1, l2=case["l2"],
+                                             inner_n_iter_max=case["inner"], feasibility_penalty_scale=case["scale"],
+                                             constant_A=case["const"], constant_B=case["const"], dtype=dt)
+        s64, s32 = mk(np.float64), mk(np.float32)
+        for _ in range(2):
+            for s_ in (s64, s32):
+                s_.update_B(); s_.update_C(); s_.update_A()
+        from tests.helpers import rel_err
+        loss32 = max(rel_err(s32.A, s64.A), rel_err(s32.B, s64.B), rel_err(s32.C, s64.C))
+        for m in range(3):
+            for k, d in enumerate(case["regs"][m]):
+                z32, z64 = s32.aux[m][k], s64.aux[m][k]
+                loss32 = max(loss32, rel_err(z32[0], z64[0]) if isinstance(z32, tuple) else rel_err(z32, z64))
+        rec32 = abs(s32.rec_error_from_A_byproducts() - s64.rec_error_from_A_byproducts()) / s64.rec_error_from_A_byproducts()
+        tol, tol_rec = max(1e-5, 3 * loss32), max(1e-5, 3 * rec32)
+    cmf, admm, diag, res = _run_both(st, 2)
+    errs = _compare(cmf, admm, diag, st, res, tol, tol_rec)
+    print(seed, f"tol {tol:.1e}", {k: case[k] for k in ("I", "K", "r", "const", "inner")}, [[d["kind"] for d in m] for m in case["regs"]],
+          f"worst {max(errs.values()):.1e}")
