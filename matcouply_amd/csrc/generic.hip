@@ -316,6 +316,204 @@ __global__ __launch_bounds__(64) void k_slab_unimodal(const int *__restrict__ ex
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Unimodality, second version (default).  Same projection (Stout's prefix isotonic regression, both directions, best
+// split with the reference's tie rule, _unimodal_regression.py:27-104) with far less scratch traffic:
+//   * a block of the running fit is just (sum, count); the prefix error is kept incrementally as
+//         err = sum_j y_j^2 - sum_blocks q_b,   q_b = sum_b^2 / count_b  (0 for a block clamped at 0),
+//     so no per-position level / start / sum-of-squares arrays exist;
+//   * the block stack lives in a register window (top UW entries, static indexing by shifting) that spills to /
+//     refills from a column-interleaved global area only on overflow / underflow;
+//   * the right-to-left pass searches the split on the fly (t descending with '<=' == the reference's ascending scan
+//     with '<': smallest t among the minima), so only errL is stored;
+//   * the two fits are produced by re-running the pooling on [0, t) and on the reversed suffix and expanding the
+//     final block lists straight into aux (fp32); the dual update follows in a coalesced row kernel (k_rows_dual).
+// Arithmetic in fp64 as before.
+// ---------------------------------------------------------------------------------------------------------
+// Block stack of one lane: the top RC entries live in a lane-interleaved LDS ring (slot * 64 + lane: conflict-free
+// 8-byte accesses, dynamic indexing), older entries in a column-interleaved global spill area.
+#define RC 16
+struct UniRing {
+    double *sy, *sw, *sq;  // LDS [RC][64]
+    int h, cnt;            // ring index of the top entry, number of entries in the ring
+    long mem_n;            // entries spilled to global memory
+};
+
+static __device__ __forceinline__ void ur_push(UniRing &st, int lane, double sy, double sw, double q,
+                                               double *__restrict__ gsy, double *__restrict__ gsw,
+                                               double *__restrict__ gsq, long base, int r, int col) {
+    if (st.cnt == RC) {  // spill the bottom entry of the ring
+        const int b = ((st.h - RC + 1) & (RC - 1)) * 64 + lane;
+        const long idx = (base + st.mem_n) * r + col;
+        gsy[idx] = st.sy[b];
+        gsw[idx] = st.sw[b];
+        gsq[idx] = st.sq[b];
+        st.mem_n += 1;
+        st.cnt = RC - 1;
+    }
+    st.h = (st.h + 1) & (RC - 1);
+    const int t = st.h * 64 + lane;
+    st.sy[t] = sy;
+    st.sw[t] = sw;
+    st.sq[t] = q;
+    st.cnt += 1;
+}
+
+// returns false if the stack is empty; otherwise the top entry is at ring slot st.h
+static __device__ __forceinline__ bool ur_top(UniRing &st, int lane, const double *__restrict__ gsy,
+                                              const double *__restrict__ gsw, const double *__restrict__ gsq, long base,
+                                              int r, int col) {
+    if (st.cnt > 0) return true;
+    if (st.mem_n == 0) return false;
+    const int nref = st.mem_n >= 8 ? 8 : (int)st.mem_n;  // refill (independent loads, one latency)
+    for (int i = 0; i < nref; ++i) {
+        const long idx = (base + st.mem_n - 1 - i) * r + col;
+        const int t = ((st.h - i) & (RC - 1)) * 64 + lane;
+        st.sy[t] = gsy[idx];
+        st.sw[t] = gsw[idx];
+        st.sq[t] = gsq[idx];
+    }
+    st.mem_n -= nref;
+    st.cnt = nref;
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_slab_unimodal_v2(const int *__restrict__ ext, int n_slabs, float *__restrict__ F,
+                                                         RegSet regs, int k, int r, double *__restrict__ errL,
+                                                         double *__restrict__ ssy, double *__restrict__ ssw,
+                                                         double *__restrict__ ssq, int dbg) {
+    __shared__ double ring[3][RC * 64];
+    const int lane = threadIdx.x;
+    const long t = (long)blockIdx.x * 64 + threadIdx.x;
+    if (t >= (long)n_slabs * r) return;
+    const int slab = (int)(t / r), col = (int)(t - (long)slab * r);
+    const int s = ext[slab], e = ext[slab + 1], n = e - s;
+    if (n <= 0) return;
+    const int nonneg = regs.nonneg[k];
+    float *__restrict__ Z = regs.aux[k];
+    float *__restrict__ U = regs.dual[k];
+    const long eb = (long)s + slab;  // n + 1 error entries per slab
+    auto yat = [&](long pos) -> double { return (double)(F[pos * r + col] + U[pos * r + col]); };
+
+    UniRing st;
+    st.sy = ring[0], st.sw = ring[1], st.sq = ring[2];
+    double csy, csw, cq, cum2, Qb;
+    // one pooling step with element v: (csy, csw) is the top block with q = cq, st holds the blocks below it, Qb their q-sum
+    auto step = [&](double v, bool first) {
+        if (!first) {
+            Qb += cq;
+            ur_push(st, lane, csy, csw, cq, ssy, ssw, ssq, s, r, col);
+        }
+        csy = v;
+        csw = 1.0;
+        while (ur_top(st, lane, ssy, ssw, ssq, s, r, col)) {
+            const int tp = st.h * 64 + lane;
+            const double tsy = st.sy[tp], tsw = st.sw[tp];
+            if (!(csy * tsw <= tsy * csw)) break;  // mean(cur) > mean(top): done
+            Qb -= st.sq[tp];
+            csy += tsy;
+            csw += tsw;
+            st.h = (st.h - 1) & (RC - 1);
+            st.cnt -= 1;
+        }
+        cq = (nonneg && csy < 0.0) ? 0.0 : csy * csy / csw;
+    };
+    auto reset = [&]() {
+        st.h = 0;
+        st.cnt = 0;
+        st.mem_n = 0;
+        cum2 = 0.0;
+        Qb = 0.0;
+        csy = 0.0;
+        csw = 1.0;
+        cq = 0.0;
+    };
+
+    // The y loads are issued UB elements ahead (independent loads, one memory latency per batch instead of per element).
+    constexpr int UB = 8;
+    // pass 1: prefix errors, left to right
+    reset();
+    errL[eb * r + col] = 0.0;
+    for (int i0 = 0; i0 < ((dbg & 1) ? 0 : n); i0 += UB) {
+        double vb[UB];
+#pragma unroll
+        for (int j = 0; j < UB; ++j) vb[j] = yat((long)s + min(i0 + j, n - 1));
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+            const int i = i0 + j;
+            if (i < n) {
+                const double v = vb[j];
+                cum2 += v * v;
+                step(v, i == 0);
+                errL[(eb + i + 1) * r + col] = (nonneg && csy < 0.0) ? cum2 : cum2 - (Qb + cq);
+            }
+        }
+    }
+    // pass 2: suffix errors right to left + best split (smallest t among the minima)
+    reset();
+    double best = errL[(eb + n) * r + col];
+    int split = n;
+    for (int i0 = 0; i0 < ((dbg & 2) ? 0 : n); i0 += UB) {
+        double vb[UB], eb_l[UB];
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+            const int i = min(i0 + j, n - 1);
+            vb[j] = yat((long)e - 1 - i);
+            eb_l[j] = errL[(eb + (n - 1 - i)) * r + col];
+        }
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+            const int i = i0 + j;
+            if (i < n) {
+                const double v = vb[j];
+                cum2 += v * v;
+                step(v, i == 0);
+                const double er = (nonneg && csy < 0.0) ? cum2 : cum2 - (Qb + cq);
+                const double tot = eb_l[j] + er;
+                if (tot <= best) {
+                    best = tot;
+                    split = n - 1 - i;
+                }
+            }
+        }
+    }
+    // passes 3 / 4: the two fits; expand the final block lists into aux and update the dual
+    // store-only: the dual update U = F - (Z - U) is done afterwards by the coalesced k_rows_dual kernel
+    auto emit = [&](long pos, double lev) {
+        if (nonneg && lev < 0.0) lev = 0.0;
+        Z[pos * r + col] = (float)lev;
+    };
+    for (int side = 0; side < 2; ++side) {
+        const int len = side == 0 ? split : n - split;
+        if (len == 0) continue;
+        reset();
+        for (int i0 = 0; i0 < ((dbg & 4) ? 0 : len); i0 += UB) {
+            double vb[UB];
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                const int i = min(i0 + j, len - 1);
+                vb[j] = side == 0 ? yat((long)s + i) : yat((long)e - 1 - i);
+            }
+#pragma unroll
+            for (int j = 0; j < UB; ++j)
+                if (i0 + j < len) step(vb[j], i0 + j == 0);
+        }
+        long p = 0;
+        auto emit_block = [&](double sy, double sw) {
+            const double lev = sy / sw;
+            const long cnt = (long)sw;
+            if (dbg & 8) return;
+            for (long c = 0; c < cnt; ++c, ++p) emit(side == 0 ? (long)s + p : (long)e - 1 - p, lev);
+        };
+        for (long m = 0; m < st.mem_n; ++m) emit_block(ssy[((long)s + m) * r + col], ssw[((long)s + m) * r + col]);
+        for (int i = st.cnt - 1; i >= 0; --i) {  // ring entries, bottom first
+            const int tp = ((st.h - i) & (RC - 1)) * 64 + lane;
+            emit_block(st.sy[tp], st.sw[tp]);
+        }
+        emit_block(csy, csw);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // PARAFAC2 prox (mode 1):  Y_i = B_i + U_i,  P_i = polar(Y_i Delta^T),  Delta <- sum rho_i P_i^T Y_i / sum rho_i
 // Gram route in fp64:  S_i = Y_i^T Y_i,  G_i = Delta S_i Delta^T = V L V^T,  W_i = V L^-1/2 V^T,
 //                      T_i = Delta^T W_i,  P_i = Y_i T_i,  P_i^T Y_i = T_i^T S_i.
@@ -747,6 +945,26 @@ __global__ __launch_bounds__(256) void k_rows_pf2_dual(ModeView mv, RegSet regs,
     }
 }
 
+// plain dual update of penalty k: U = F - (Z - U)   (decomposition.py:282-285)
+template <int NBR, bool VEC>
+__global__ __launch_bounds__(256) void k_rows_dual(ModeView mv, RegSet regs, int k, int r) {
+    TILE_PROLOGUE();
+    FOR_ROW_BLOCKS() {
+        const bool ok = 16 * rb + row16 < nrows;
+        const long j = row0 + 16 * rb + (ok ? row16 : 0);
+#pragma unroll
+        for (int h = 0; h < NBR; ++h) {
+            const int col = 16 * h + 4 * g;
+            const f32x4 f = row_ld4<VEC>(mv.F, j, col, ok, r);
+            const f32x4 z = row_ld4<VEC>(regs.aux[k], j, col, ok, r);
+            f32x4 u = row_ld4<VEC>(regs.dual[k], j, col, ok, r);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) u[v] = f[v] - (z[v] - u[v]);
+            row_st4<VEC>(regs.dual[k], j, col, ok, r, u);
+        }
+    }
+}
+
 // =========================================================================================================
 // host launchers
 // =========================================================================================================
@@ -823,8 +1041,15 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
             break;
         case MCL_PEN_UNIMODAL: {
             const long nthreads = (long)mv.n_slabs * c->r;
-            hipLaunchKernelGGL(k_slab_unimodal, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, c->stream, mv.ext,
-                               mv.n_slabs, mv.F, rs, k, c->r, uni_scratch(c));
+            UniScratch sc = uni_scratch(c);
+            if (getenv("MCL_UNIMODAL_V1"))
+                hipLaunchKernelGGL(k_slab_unimodal, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, c->stream, mv.ext,
+                                   mv.n_slabs, mv.F, rs, k, c->r, sc);
+            else
+                hipLaunchKernelGGL(k_slab_unimodal_v2, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, c->stream,
+                                   mv.ext, mv.n_slabs, mv.F, rs, k, c->r, sc.eL, sc.sy, sc.sw, sc.sy2,
+                                   getenv("MCL_UNI_DBG") ? atoi(getenv("MCL_UNI_DBG")) : 0);
+            if (!getenv("MCL_UNIMODAL_V1")) DISPATCH_ROWS(c, vec, k_rows_dual, grid, block, mv, rs, k, c->r);
             break;
         }
         case MCL_PEN_PARAFAC2: {
