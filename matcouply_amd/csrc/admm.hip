@@ -407,12 +407,50 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict
         for (int wv = 0; wv < n_waves; ++wv) t += dsm[wv][threadIdx.x];
         diag_row[threadIdx.x] = t;
     }
-    // CtC from the LDS copy of the new C (fp64 accumulation)
-    for (int pr = threadIdx.x; pr < r * r; pr += blockDim.x) {
-        const int a = pr / r, b = pr - a * r;
-        double acc = 0.0;
-        for (int k = 0; k < K; ++k) acc += (double)Cs[k * r + a] * (double)Cs[k * r + b];
-        CtC[pr] = (float)acc;
+    // CtC = C^T C from the LDS copy of the new C on the fp64 MFMA (fp32 x fp32 products are exact in fp64): lane
+    // (rsub = l>>4, c16 = l&15) feeds C[4g + rsub][16nb + c16]; every wave takes every n_waves-th group of 4 rows;
+    // the per-wave accumulators (D layout: row = (l>>4) + 4 reg, col = l&15) are summed through LDS in fixed order.
+    {
+        typedef double f64x4 __attribute__((ext_vector_type(4)));
+        __shared__ double csm[16 * NBR][16 * NBR];
+        const int rsub = lane >> 4, c16 = lane & 15;
+        f64x4 acc[NBR][NBR];
+#pragma unroll
+        for (int a = 0; a < NBR; ++a)
+#pragma unroll
+            for (int b = 0; b < NBR; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+        const int n_groups = (K + 3) >> 2;
+        for (int gq = wave; gq < n_groups; gq += n_waves) {
+            const int row = 4 * gq + rsub;
+            double y[NBR];
+#pragma unroll
+            for (int nb = 0; nb < NBR; ++nb) {
+                const int col = 16 * nb + c16;
+                y[nb] = (row < K && col < r) ? (double)Cs[row * r + col] : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < NBR; ++a)
+#pragma unroll
+                for (int b = 0; b < NBR; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[a], y[b], acc[a][b], 0, 0, 0);
+        }
+        for (int wv = 0; wv < n_waves; ++wv) {  // fixed summation order
+            if (wave == wv) {
+#pragma unroll
+                for (int a = 0; a < NBR; ++a)
+#pragma unroll
+                    for (int b = 0; b < NBR; ++b)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            double &dst = csm[16 * a + rsub + 4 * v][16 * b + c16];
+                            dst = (wv == 0) ? acc[a][b][v] : dst + acc[a][b][v];
+                        }
+            }
+            __syncthreads();
+        }
+        for (int pr = threadIdx.x; pr < r * r; pr += blockDim.x) {
+            const int a = pr / r, b = pr - a * r;
+            CtC[pr] = (float)csm[a][b];
+        }
     }
     // fragment image of C for the X C kernels (see k_build_cfrag)
     const long total = (long)KC * 4 * NBc * 256;

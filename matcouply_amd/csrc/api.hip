@@ -224,12 +224,18 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     c->h_tile_slab.clear(), c->h_tile_row0.clear(), c->h_tile_nrows.clear();
     c->h_seg_slab.clear(), c->h_seg_row0.clear(), c->h_seg_nrows.clear();
     c->h_slab_seg_ptr.assign((size_t)I + 1, 0);
+    // segment = work unit of the two X passes: <= seg_rows rows of one slab.  256 rows (256 KB at K = 256) amortise the
+    // per-segment prologue on big problems; small problems (e.g. the per-rank shard of an 8-GPU run) get shorter
+    // segments so that there are still >= ~512 of them (measured optimum on a 64 K-row shard: 128 rows).
+    int64_t seg_rows = MCL_SEG_ROWS;
+    while (seg_rows > 32 && N / seg_rows < 512) seg_rows /= 2;
+    if (const char *e = getenv("MCL_SEG_ROWS")) seg_rows = std::max(16, atoi(e));
     for (int64_t i = 0; i < I; ++i) {
         c->h_slab_seg_ptr[(size_t)i] = (int)c->h_seg_slab.size();
-        for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; j += MCL_SEG_ROWS) {
+        for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; j += seg_rows) {
             c->h_seg_slab.push_back((int)i);
             c->h_seg_row0.push_back((int)j);
-            c->h_seg_nrows.push_back((int)std::min<int64_t>(MCL_SEG_ROWS, row_ptr[i + 1] - j));
+            c->h_seg_nrows.push_back((int)std::min<int64_t>(seg_rows, row_ptr[i + 1] - j));
         }
         for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; ++j) c->h_slab_of_row[(size_t)j] = (int)i;
         for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; j += 64) {
