@@ -359,7 +359,7 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict
                                                          float *__restrict__ rhoC, float *__restrict__ LinvC,
                                                          float *__restrict__ C, RegSet regs, int inner,
                                                          float *__restrict__ CtC, float *__restrict__ Cfrag, int KC,
-                                                         int NBc, double *__restrict__ diag_row) {
+                                                         int NBc, double *__restrict__ diag_row, int rows_per_wave) {
     extern __shared__ float smc[];
     __shared__ double dsm[16][DIAG_COLS];
     __shared__ float rho_s;
@@ -393,8 +393,9 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict
         }
     }
     __syncthreads();
-    const long row0 = 64L * wave;
-    const int nrows = min(64, K - 64 * wave);
+    // up to 16 waves, 16 / 32 / 64 rows each: short tiles keep the serial 5-iteration chain per wave short
+    const long row0 = (long)rows_per_wave * wave;
+    const int nrows = max(0, min(rows_per_wave, K - rows_per_wave * wave));
     double dg[DIAG_COLS];
     rows_fused_tile<NBR, NREG, VEC>(lane, row0, nrows, rho_s, Ls, nullptr, GR + (long)r * r, C, Cs, regs, r, inner, dg);
     if (lane == 0) {
@@ -981,7 +982,8 @@ static int launch_C_fused_t(mcl_context *c) {
                ((reinterpret_cast<uintptr_t>(c->C) & 15) == 0) && ((c->r * c->r) % 4 == 0);
     for (int k = 0; k < rs.n; ++k)
         vec = vec && ((reinterpret_cast<uintptr_t>(rs.aux[k]) & 15) == 0) && ((reinterpret_cast<uintptr_t>(rs.dual[k]) & 15) == 0);
-    const int n_waves = (int)((c->K + 63) / 64);
+    const int rpw = c->K <= 256 ? 16 : (c->K <= 512 ? 32 : 64);
+    const int n_waves = (int)((c->K + rpw - 1) / rpw);
     const size_t sm = sizeof(float) * (size_t)(c->r * c->r + c->K * c->r);
     int kct = 0;
     const int KC = mcl_xc_chunks(c, &kct);
@@ -993,7 +995,7 @@ static int launch_C_fused_t(mcl_context *c) {
         hipLaunchKernelGGL((k_C_finish_fused<NBR, NREG, VEC_>), dim3(1), dim3(64 * n_waves), sm, c->stream, c->GR,    \
                            (int)c->K, c->r, (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[2],     \
                            c->rhoC, c->LinvC, c->C, rs, c->opt.inner_n_iter_max, c->CtC, c->Cfrag, KC, c->NB,         \
-                           c->diagC_tile);                                                                            \
+                           c->diagC_tile, rpw);                                                                       \
     } while (0)
     if (vec) MCL_CF(true);
     else MCL_CF(false);
