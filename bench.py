@@ -263,7 +263,10 @@ def main():
         N_tot = int(t.item())
     S_X, S_B = 4.0 * N_loc * K, 4.0 * N_loc * r
     n_B = len(cfg["regs"][1])
-    alg_bytes = {0: S_X + S_B, 1: S_X + S_B, 2: (2 + 4 * n_B) * S_B}  # per launch: reads + writes of that kernel
+    # algorithmic bytes per launch (reads + writes): X^T pass reads X and B; the X C pass reads X, writes XC and - with the
+    # fused per-slab Gram epilogue - also reads B; the fused B rows read XC/aux/dual and write B/aux/dual
+    xc_fused = "GRAM=1" in eng.kernel_variant(0)
+    alg_bytes = {0: S_X + (2 if xc_fused else 1) * S_B, 1: S_X + S_B, 2: (2 + 4 * n_B) * S_B}
     for slot in range(3):
         tot_ms, n = eng.profile_read(slot)
         if n:
