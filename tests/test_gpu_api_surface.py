@@ -1,0 +1,135 @@
+"""-m gpu: the public API with the input kinds and corner shapes a drop-in user can throw at it."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.helpers import rel_err, split_rows
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _data(I=5, J=20, K=12, r=3, seed=0):
+    from oracle import aoadmm_oracle as orc
+
+    X, row_ptr = orc.synthetic_problem(I, J, K, r, seed=seed, dtype=np.float64)
+    return X, row_ptr, split_rows(X, row_ptr)
+
+
+def test_input_kinds_give_the_same_answer():
+    import torch
+    from matcouply_amd import decomposition as dec
+
+    X, row_ptr, mats = _data()
+    kw = dict(non_negative=True, n_iter_max=5, tol=None, absolute_tol=None, random_state=3)
+    ref = dec.cmf_aoadmm(mats, 3, **kw)
+    assert isinstance(ref[1][0], np.ndarray) and ref[1][0].dtype == np.float64
+    # float32 NumPy input -> float32 output
+    out32 = dec.cmf_aoadmm([m.astype(np.float32) for m in mats], 3, **kw)
+    assert out32[1][0].dtype == np.float32 and rel_err(out32[1][0], ref[1][0]) < 1e-5
+    # 3-D array (equal shapes) iterates like a list of matrices
+    out3d = dec.cmf_aoadmm(np.stack(mats), 3, **kw)
+    assert rel_err(out3d[1][2], ref[1][2]) < 1e-6
+    # torch CPU tensors -> torch CPU tensors; torch CUDA tensors -> CUDA tensors
+    out_t = dec.cmf_aoadmm([torch.as_tensor(m) for m in mats], 3, **kw)
+    assert isinstance(out_t[1][0], torch.Tensor) and not out_t[1][0].is_cuda and out_t[1][0].dtype == torch.float64
+    assert rel_err(out_t[1][0].numpy(), ref[1][0]) < 1e-6
+    out_c = dec.cmf_aoadmm([torch.as_tensor(m, dtype=torch.float32).cuda() for m in mats], 3, **kw)
+    assert out_c[1][0].is_cuda and rel_err(out_c[1][0].cpu().numpy(), ref[1][0]) < 1e-5
+    # data already packed in HBM
+    packed = dec.PackedMatrices(torch.as_tensor(X, dtype=torch.float32).cuda(), row_ptr)
+    assert len(packed) == 5 and packed[1].shape == (20, 12)
+    out_p = dec.cmf_aoadmm(packed, 3, **kw)
+    assert out_p[1][0].is_cuda and rel_err(out_p[1][0].cpu().numpy(), ref[1][0]) < 1e-5
+    # weights of an explicit init are folded into A (decomposition.py:22-28)
+    rs = np.random.RandomState(1)
+    A0, B0, C0 = rs.uniform(size=(5, 3)), [rs.uniform(size=(20, 3)) for _ in range(5)], rs.uniform(size=(12, 3))
+    w = np.array([2.0, 0.5, 1.5])
+    a = dec.cmf_aoadmm(mats, 3, init=(w, (A0, B0, C0)), n_iter_max=2, tol=None, absolute_tol=None)
+    b = dec.cmf_aoadmm(mats, 3, init=(None, (A0 * w, B0, C0)), n_iter_max=2, tol=None, absolute_tol=None)
+    assert rel_err(a[1][0], b[1][0]) < 1e-7 and a[0] is None
+
+
+@pytest.mark.parametrize("shape", [dict(I=1, J=9, K=5, r=2), dict(I=3, J=1, K=1, r=1), dict(I=2, J=70, K=3, r=3),
+                                   dict(I=4, J=5, K=260, r=2), dict(I=2, J=3, K=7, r=6)])
+def test_corner_shapes_against_oracle(shape):
+    from oracle import aoadmm_oracle as orc
+    from tests.test_gpu_end_to_end import _compare, _run_both
+
+    X, row_ptr = orc.synthetic_problem(shape["I"], shape["J"], shape["K"], shape["r"], seed=1, dtype=np.float64)
+    X = X.astype(np.float32).astype(np.float64)
+    nn = {"kind": "nn"}
+    st = orc.random_state_for(X, row_ptr, shape["r"], [[nn], [nn, {"kind": "l2ball", "norm_bound": 2.0}], [nn]], seed=2)
+    cmf, admm, diag, res = _run_both(st, 3)
+    _compare(cmf, admm, diag, st, res, 1e-5)
+
+
+def test_svd_initialisations_run():
+    from matcouply_amd import decomposition as dec
+
+    _, _, mats = _data(I=4, J=15, K=10, r=3, seed=5)
+    for init in ("svd", "threshold_svd"):
+        cmf, diag = dec.cmf_aoadmm(mats, 3, init=init, non_negative=(init == "threshold_svd"), n_iter_max=30,
+                                   tol=None, absolute_tol=None, return_errors=True)
+        assert diag.rec_errors[-1] < 0.2 and np.isfinite(diag.regularized_loss).all()
+    with pytest.raises(NotImplementedError):
+        dec.cmf_aoadmm(mats, 3, init="parafac2_als", n_iter_max=1)
+
+
+SHARDED = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["REPO"])
+import numpy as np, torch, torch.distributed as dist
+from matcouply_amd import decomposition as dec, penalties as pen
+from oracle import aoadmm_oracle as orc
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+J = np.array([40, 25, 64, 33, 90, 17])
+X, row_ptr = orc.synthetic_problem(6, J, 24, 4, seed=0, dtype=np.float64)
+mats = [X[row_ptr[i]:row_ptr[i+1]] for i in range(6)]
+rs = np.random.RandomState(5)
+A0, B0, C0 = rs.uniform(size=(6, 4)), [rs.uniform(size=(j, 4)) for j in J], rs.uniform(size=(24, 4))
+mk = lambda shp: rs.uniform(size=shp)
+auxA, dualA, auxC, dualC = mk((6, 4)), mk((6, 4)), mk((24, 4)), mk((24, 4))
+P0 = [np.eye(j, 4) for j in J]; D0 = mk((4, 4)); dualP = [mk((j, 4)) for j in J]
+auxL, dualL = [mk((j, 4)) for j in J], [mk((j, 4)) for j in J]
+def run(lo, hi, group):
+    regs = [[pen.NonNegativity(aux_init=auxA[lo:hi].copy(), dual_init=dualA[lo:hi].copy())],
+            [pen.Parafac2(aux_init=([p.copy() for p in P0[lo:hi]], D0.copy()), dual_init=[d.copy() for d in dualP[lo:hi]]),
+             pen.L2Ball(1.0, aux_init=[a.copy() for a in auxL[lo:hi]], dual_init=[d.copy() for d in dualL[lo:hi]])],
+            [pen.L1Penalty(0.05, non_negativity=True, aux_init=auxC.copy(), dual_init=dualC.copy())]]
+    return dec.cmf_aoadmm(mats[lo:hi], 4, init=(None, (A0[lo:hi].copy(), [b.copy() for b in B0[lo:hi]], C0.copy())), regs=regs,
+                          n_iter_max=5, tol=None, absolute_tol=None, return_errors=True, constant_feasibility_penalty=True,
+                          group=group)
+bounds = [0, 2, 6]
+cmf, diag = run(bounds[rank], bounds[rank + 1], dist.group.WORLD)
+if rank == 0:
+    ref_cmf, ref_diag = run(0, 6, None)
+    err = dict(A=float(np.linalg.norm(cmf[1][0] - ref_cmf[1][0][:2]) / np.linalg.norm(ref_cmf[1][0][:2])),
+               C=float(np.linalg.norm(cmf[1][2] - ref_cmf[1][2]) / np.linalg.norm(ref_cmf[1][2])),
+               rec=float(max(abs(a - b) / b for a, b in zip(diag.rec_errors, ref_diag.rec_errors))))
+    print("SHARDED_RESULT " + json.dumps(err), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_sharing_the_gpu_equal_single_process(tmp_path):
+    """cmf_aoadmm(group=) with the REAL engine: 2 processes share cuda:0, collectives over gloo (RCCL refuses two ranks on one
+    device); PARAFAC2 + constant feasibility penalty exercise every reduction of the step path."""
+    script = tmp_path / "sharded.py"
+    script.write_text(SHARDED)
+    env = dict(os.environ, REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    line = [l for l in out.stdout.splitlines() if l.startswith("SHARDED_RESULT")]
+    assert line, out.stdout[-2000:] + out.stderr[-3000:]
+    import json
+
+    err = json.loads(line[0].split(" ", 1)[1])
+    assert max(err.values()) < 2e-5, err
