@@ -254,7 +254,7 @@ def main():
 
     # live roofline of the dominant kernel (HIP events inside the library, same stream as the kernels)
     prof = []
-    names = {0: "X C pass", 1: "X^T (B o a) pass", 2: "fused B-phase rows"}
+    names = {0: "X C pass", 1: "X^T (B o a) pass", 2: "fused B-phase rows", 3: "one-pass sweep (X C -> B-phase -> X^T B)"}
     N_loc, K, r = X.shape[0], cfg["K"], cfg["r"]
     N_tot = N_loc
     if world > 1:
@@ -266,8 +266,9 @@ def main():
     # algorithmic bytes per launch (reads + writes): X^T pass reads X and B; the X C pass reads X, writes XC and - with the
     # fused per-slab Gram epilogue - also reads B; the fused B rows read XC/aux/dual and write B/aux/dual
     xc_fused = "GRAM=1" in eng.kernel_variant(0)
-    alg_bytes = {0: S_X + (2 if xc_fused else 1) * S_B, 1: S_X + S_B, 2: (2 + 4 * n_B) * S_B}
-    for slot in range(3):
+    # the one-pass sweep reads X once, reads aux/dual and writes B/aux/dual (X C never reaches memory)
+    alg_bytes = {0: S_X + (2 if xc_fused else 1) * S_B, 1: S_X + S_B, 2: (2 + 4 * n_B) * S_B, 3: S_X + (1 + 4 * n_B) * S_B}
+    for slot in range(4):
         tot_ms, n = eng.profile_read(slot)
         if n:
             prof.append((tot_ms / n, slot, n))
@@ -301,7 +302,8 @@ def main():
     if rank == 0:
         its = args.steps / elapsed
         S_X_tot, S_B_tot = 4.0 * N_tot * K, 4.0 * N_tot * r
-        bytes_iter = 2 * S_X_tot + (5 + 4 * n_B) * S_B_tot
+        swept = any(slot == 3 for _, slot, _ in prof)
+        bytes_iter = (S_X_tot + (1 + 4 * n_B) * S_B_tot) if swept else (2 * S_X_tot + (5 + 4 * n_B) * S_B_tot)
         out = {
             "metric": "AO-ADMM outer-iters/sec", "value": round(its, 2), "unit": "outer-iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),

@@ -134,7 +134,8 @@ int mcl_C_end(mcl_context *ctx);             /* invalidates everything derived f
 /* device pointers to internal by-products: 0 rhses [I, r], 1 cross_products [I, r, r], 2 X C [sum J_i, r],
  * 3 rho_B [I], 4 rho_A [I], 5 rho_C [1] */
 float *mcl_internal_buffer(mcl_context *ctx, int32_t which, int64_t *count);
-/* name of the kernel variant chosen for the current problem: which = 0 X C pass, 1 X^T B pass, 2 fused B-phase rows */
+/* name of the kernel variant chosen for the current problem: which = 0 X C pass, 1 X^T B pass, 2 fused B-phase rows,
+ * 3 one-pass sweep (B-phase + X^T B in a single pass over X; empty when the problem is not eligible) */
 const char *mcl_kernel_variant(mcl_context *ctx, int32_t which);
 /* HIP-event timing of the named kernels on the context's stream (for bench.py's roofline block).
  * mcl_profile_enable(ctx, capacity): record up to `capacity` launches per kernel slot (0 disables and frees);

@@ -302,7 +302,7 @@ class HipEngine:
         self._check(self.lib.mcl_profile_enable(self._h, int(capacity)))
 
     def profile_read(self, which):
-        """(total_ms, launches) of kernel slot `which` (0: X C pass, 1: X^T B pass, 2: fused B rows); synchronises."""
+        """(total_ms, launches) of kernel slot `which` (0: X C pass, 1: X^T B pass, 2: fused B rows, 3: one-pass sweep); synchronises."""
         tot, n = ctypes.c_double(), ctypes.c_int32()
         self._check(self.lib.mcl_profile_read(self._h, which, ctypes.byref(tot), ctypes.byref(n)))
         return tot.value, n.value

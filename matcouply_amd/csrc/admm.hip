@@ -13,12 +13,6 @@
 // ---------------------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------------------
-static __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
 // Gauss-Jordan inverse of an SPD r x r matrix held ONE COLUMN PER LANE in registers (fp64): lane c (< r) owns
 // col[i] = M[i][c]; lanes >= r and rows >= r hold identity padding.  Pivot column entries are fetched with
 // v_readlane (compile-time lane index), so there is no LDS traffic and no barrier.  SPD => no pivoting.
@@ -49,20 +43,6 @@ static __device__ __forceinline__ void gj_inverse_reg(double (&col)[RP], int r, 
             }
             col[p] = myp;
         }
-    }
-}
-
-static __device__ __forceinline__ float prox_elem(int kind, int nonneg, float p0, float p1, float thr, float y) {
-    switch (kind) {
-        case MCL_PEN_NN:
-            return fmaxf(y, 0.f);
-        case MCL_PEN_BOX:
-            return fminf(fmaxf(y, p0), p1);
-        case MCL_PEN_L1:
-            if (nonneg) return fmaxf(y - thr, 0.f);
-            return copysignf(fmaxf(fabsf(y) - thr, 0.f), y);
-        default:
-            return y;
     }
 }
 
@@ -1047,8 +1027,9 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
                   (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[0], c->opt.constant_A, c->rho_max,
                   c->rhoA, c->LinvA, c->A, c->regs[0], c->opt.inner_n_iter_max, fused_inner ? 1 : 0, c->e1,
                   c->diagA_row, next_B, (float)c->opt.l2_penalty[1], c->regs[1].n, c->rhoB, c->LinvB,
-                  (const int *)c->slab_seg_ptr, (const float *)(seg ? c->seg_rhs : nullptr),
-                  (const float *)(seg ? c->seg_btb : nullptr), c->rhsA);
+                  (const int *)(c->seg_from_sweep ? c->slab_bseg_ptr : c->slab_seg_ptr),
+                  (const float *)(seg ? c->seg_rhs : nullptr),
+                  (const float *)(seg ? (c->seg_from_sweep ? c->part_btb : c->seg_btb) : nullptr), c->rhsA);
     MCL_CHECK_HIP(c, hipGetLastError());
     c->b_systems_valid = (next_B != 0);
     return 0;

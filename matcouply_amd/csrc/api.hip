@@ -52,6 +52,18 @@ int64_t plan(mcl_context *c, char *base) {
     tm(c->tilesC, c->h_ctile_slab.size());
     tm(c->tilesA, c->h_atile_slab.size());
     tm(c->segs, c->h_seg_slab.size());
+    c->sweep_planned = mcl_sweep_shape_ok(c);
+    if (c->sweep_planned) {
+        tm(c->bsegs, c->h_bseg_slab.size());
+        c->slab_bseg_ptr = b.take<int>(I + 1);
+        c->Mpart = b.take<float>((int64_t)c->bsegs.n_tiles * K * 16 * c->NB);
+        c->part_btb = b.take<float>((int64_t)c->bsegs.n_tiles * r * r);
+        c->GRpart = b.take<float>((int64_t)c->bsegs.n_tiles * (K * 16 * c->NB + 256 * c->NB * c->NB));
+        c->sweep_cycles = b.take<long long>((int64_t)2048 * 6);
+    } else {
+        c->bsegs = TileMap{};
+        c->slab_bseg_ptr = nullptr, c->Mpart = nullptr, c->part_btb = nullptr, c->GRpart = nullptr;
+    }
     c->ext_A = b.take<int>(2);
     c->ext_C = b.take<int>(2);
     c->XC = b.take<float>(N * r);
@@ -64,7 +76,7 @@ int64_t plan(mcl_context *c, char *base) {
     c->GR = b.take<float>(E);
     c->rhoC = b.take<float>(1);
     c->LinvC = b.take<float>(r * r);
-    c->seg_rhs = b.take<float>((int64_t)c->segs.n_tiles * r);
+    c->seg_rhs = b.take<float>((int64_t)std::max(c->segs.n_tiles, c->bsegs.n_tiles) * r);
     c->seg_btb = b.take<float>((int64_t)c->segs.n_tiles * r * r);
     c->slab_seg_ptr = b.take<int>(I + 1);
     c->rhsA = b.take<float>(I * r);
@@ -199,8 +211,8 @@ int mcl_create(mcl_context **out, int device, void *hip_stream) {
 
 void mcl_destroy(mcl_context *ctx) {
     if (!ctx) return;
-    for (int s = 0; s < 3; ++s)
-        for (hipEvent_t e : ctx->prof_ev[s]) hipEventDestroy(e);
+    for (int s = 0; s < 4; ++s)
+        for (hipEvent_t e : ctx->prof_ev[s]) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -245,6 +257,22 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
         }
     }
     c->h_slab_seg_ptr[(size_t)I] = (int)c->h_seg_slab.size();
+    // bsegs of the one-pass sweep: <= 512 rows of one slab per WAVE, shorter on small problems so that there are still
+    // >= ~1024 of them (one per SIMD)
+    int64_t bseg_rows = 512;
+    while (bseg_rows > 64 && N / bseg_rows < 1024) bseg_rows /= 2;
+    if (const char *e = getenv("MCL_BSEG_ROWS")) bseg_rows = std::max(64, (atoi(e) / 64) * 64);
+    c->h_bseg_slab.clear(), c->h_bseg_row0.clear(), c->h_bseg_nrows.clear();
+    c->h_slab_bseg_ptr.assign((size_t)I + 1, 0);
+    for (int64_t i = 0; i < I; ++i) {
+        c->h_slab_bseg_ptr[(size_t)i] = (int)c->h_bseg_slab.size();
+        for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; j += bseg_rows) {
+            c->h_bseg_slab.push_back((int)i);
+            c->h_bseg_row0.push_back((int)j);
+            c->h_bseg_nrows.push_back((int)std::min<int64_t>(bseg_rows, row_ptr[i + 1] - j));
+        }
+    }
+    c->h_slab_bseg_ptr[(size_t)I] = (int)c->h_bseg_slab.size();
     auto single = [](int64_t rows, std::vector<int> &s, std::vector<int> &r0, std::vector<int> &nr) {
         s.clear(), r0.clear(), nr.clear();
         for (int64_t j = 0; j < rows; j += 64) {
@@ -258,6 +286,7 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     c->has_problem = true;
     c->has_workspace = false;
     c->xc_valid = c->ctc_valid = c->e1_valid = c->xsq_valid = false;
+    c->mseg_valid = c->grpart_valid = false;
     c->diag_valid[0] = c->diag_valid[1] = c->diag_valid[2] = false;
     return 0;
 }
@@ -279,6 +308,7 @@ int mcl_set_factors(mcl_context *c, float *A, float *B, float *C) {
     c->b_systems_valid = false;
     c->cfrag_valid = false;
     c->xc_valid = c->ctc_valid = c->e1_valid = false;
+    c->mseg_valid = c->grpart_valid = false;
     c->diag_valid[0] = c->diag_valid[1] = c->diag_valid[2] = false;
     return 0;
 }
@@ -350,12 +380,19 @@ int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
     MCL_CHECK_HIP(c, up(c->segs.row0, c->h_seg_row0));
     MCL_CHECK_HIP(c, up(c->segs.nrows, c->h_seg_nrows));
     MCL_CHECK_HIP(c, up(c->slab_seg_ptr, c->h_slab_seg_ptr));
+    if (c->sweep_planned) {
+        MCL_CHECK_HIP(c, up(c->bsegs.slab, c->h_bseg_slab));
+        MCL_CHECK_HIP(c, up(c->bsegs.row0, c->h_bseg_row0));
+        MCL_CHECK_HIP(c, up(c->bsegs.nrows, c->h_bseg_nrows));
+        MCL_CHECK_HIP(c, up(c->slab_bseg_ptr, c->h_slab_bseg_ptr));
+    }
     c->h_ext = {0, (int)c->I, 0, (int)c->K};
     MCL_CHECK_HIP(c, hipMemcpyAsync(c->ext_A, c->h_ext.data(), 2 * sizeof(int), hipMemcpyHostToDevice, s));
     MCL_CHECK_HIP(c, hipMemcpyAsync(c->ext_C, c->h_ext.data() + 2, 2 * sizeof(int), hipMemcpyHostToDevice, s));
     // the host vectors must outlive the async copies: they are members of the context
     c->has_workspace = true;
     c->cfrag_valid = false;
+    c->mseg_valid = c->grpart_valid = false;
     c->xc_valid = c->ctc_valid = c->e1_valid = c->xsq_valid = false;
     c->diag_valid[0] = c->diag_valid[1] = c->diag_valid[2] = false;
     return 0;
@@ -385,6 +422,7 @@ int mcl_B_factor(mcl_context *c) {
 int mcl_B_solve(mcl_context *c) {
     if (int rc = ready(c)) return rc;
     c->e1_valid = false;
+    c->mseg_valid = c->grpart_valid = false;
     c->diag_valid[1] = false;
     return mcl_launch_rows_solve(c, 1);
 }
@@ -411,10 +449,33 @@ int mcl_B_prox_finish(mcl_context *c, int32_t k) {
 }
 
 int mcl_update_B(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    if (mcl_sweep_eligible(c)) {
+        // one pass over X: B-phase fused with the per-bseg X^T B / B^T B that the C- and A-phases need (sweep.hip)
+        if (int rc = ensure_ctc(c)) return rc;
+        if (!c->cfrag_valid) {
+            if (int rc = mcl_launch_build_cfrag(c)) return rc;
+            c->cfrag_valid = true;
+        }
+        if (c->opt.constant_B)
+            if (int rc = mcl_launch_B_rho(c)) return rc;
+        if (int rc = mcl_B_factor(c)) return rc;
+        c->e1_valid = false;
+        const int rc = mcl_launch_sweep(c);
+        if (rc > 0) return rc;
+        if (rc == 0) {
+            c->mseg_valid = true;
+            c->grpart_valid = true;
+            c->diag_valid[1] = true;
+            return 0;
+        }
+        c->sweep_planned = false;  // the device refused the kernel's LDS size: two-pass path from now on
+    }
     if (int rc = mcl_B_begin(c)) return rc;
     if (int rc = mcl_B_factor(c)) return rc;
     c->e1_valid = false;
     if (c->opt.inner_n_iter_max <= 0) return 0;
+    c->mseg_valid = c->grpart_valid = false;
     if (mcl_mode_is_row_separable(c, 1)) {
         const int rc = mcl_launch_rows_fused(c, 1);
         if (rc == 0) {
@@ -429,6 +490,7 @@ int mcl_update_B(mcl_context *c) {
 // ---- C-phase -------------------------------------------------------------------------------------------
 int mcl_update_C_local(mcl_context *c) {
     if (int rc = ready(c)) return rc;
+    if (c->mseg_valid && c->grpart_valid) return mcl_launch_reduce_weighted(c);
     if (int rc = mcl_launch_contract_xt(c)) return rc;
     return mcl_launch_reduce_partials(c);
 }
@@ -480,6 +542,19 @@ int mcl_A_begin(mcl_context *c) {
     // When X C has to be recomputed anyway (C changed), the per-slab reductions ride in its epilogue; the
     // constant-rho pre-pass (k_A_rho) needs the assembled per-slab Gram, so it keeps the separate kernel.
     c->use_seg_gram = false;
+    c->seg_from_sweep = false;
+    if (c->mseg_valid && !c->opt.constant_A && mcl_mode_is_row_separable(c, 0)) {
+        // the sweep left M_i = X_i^T B_i per bseg: rhs_i = coldot(M_i, C), no pass over X
+        if (!c->cfrag_valid) {
+            if (int rc = mcl_launch_build_cfrag(c)) return rc;
+            c->cfrag_valid = true;
+        }
+        if (int rc = mcl_launch_A_rhs_from_M(c)) return rc;
+        c->use_seg_gram = true;
+        c->seg_from_sweep = true;
+        c->e1_valid = false;
+        return 0;
+    }
     if (!c->xc_valid && !c->opt.constant_A && mcl_mode_is_row_separable(c, 0) && !getenv("MCL_NO_FUSED_GRAM")) {
         c->xc_with_gram = true;
         const int rc = ensure_xc(c);
@@ -502,6 +577,7 @@ float *mcl_A_rho_max(mcl_context *c) { return c ? c->rho_max + 1 : nullptr; }
 int mcl_A_finish(mcl_context *c) {
     if (int rc = ready(c)) return rc;
     if (c->opt.inner_n_iter_max <= 0) return 0;
+    c->grpart_valid = false;  // the sweep's [G | R] partials were weighted with the previous a_i
     if (mcl_mode_is_row_separable(c, 0)) {
         if (int rc = mcl_launch_A_finish(c, true)) return rc;
     } else {
@@ -535,6 +611,7 @@ int mcl_A_factor(mcl_context *c) {
 
 int mcl_A_solve(mcl_context *c) {
     if (int rc = ready(c)) return rc;
+    c->grpart_valid = false;
     c->e1_valid = false;
     c->diag_valid[0] = false;
     c->b_systems_valid = false;
@@ -634,6 +711,7 @@ float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {
         case 7: p = c->LinvB, n = c->I * c->r * c->r; break;
         case 9: p = reinterpret_cast<float *>(c->pf2_acc), n = c->pf2_acc ? 2 * c->I * ((int64_t)c->r * c->r + 1) : 0; break;
         case 10: p = reinterpret_cast<float *>(c->pf2_S), n = c->pf2_S ? 2 * c->I * (int64_t)c->r * c->r : 0; break;
+        case 11: p = reinterpret_cast<float *>(c->sweep_cycles), n = c->sweep_cycles ? (int64_t)2048 * 6 * 2 : 0; break;
         case 8: p = reinterpret_cast<float *>(c->pf2_status), n = c->pf2_status ? c->I : 0; break;  // int32 bits
         default: break;
     }
@@ -643,14 +721,14 @@ float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {
 
 int mcl_profile_enable(mcl_context *c, int32_t capacity) {
     if (!c) return 1;
-    for (int s = 0; s < 3; ++s) {
-        for (hipEvent_t e : c->prof_ev[s]) hipEventDestroy(e);
+    for (int s = 0; s < 4; ++s) {
+        for (hipEvent_t e : c->prof_ev[s]) (void)hipEventDestroy(e);
         c->prof_ev[s].clear();
         c->prof_used[s] = 0;
     }
     c->prof_capacity = 0;
     if (capacity <= 0) return 0;
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < 4; ++s) {
         c->prof_ev[s].resize((size_t)2 * capacity);
         for (auto &e : c->prof_ev[s]) MCL_CHECK_HIP(c, hipEventCreate(&e));
     }
@@ -659,7 +737,7 @@ int mcl_profile_enable(mcl_context *c, int32_t capacity) {
 }
 
 int mcl_profile_read(mcl_context *c, int32_t which, double *total_ms, int32_t *count) {
-    if (!c || which < 0 || which > 2 || !total_ms || !count) return 1;
+    if (!c || which < 0 || which > 3 || !total_ms || !count) return 1;
     double tot = 0.0;
     const int n = c->prof_used[which];
     for (int i = 0; i < n; ++i) {

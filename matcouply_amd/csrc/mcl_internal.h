@@ -62,6 +62,7 @@ struct mcl_context {
     std::vector<int> h_ctile_slab, h_ctile_row0, h_ctile_nrows;  // C-mode: one slab of K rows
     std::vector<int> h_atile_slab, h_atile_row0, h_atile_nrows;  // A-mode: one slab of I rows
     std::vector<int> h_seg_slab, h_seg_row0, h_seg_nrows;
+    std::vector<int> h_bseg_slab, h_bseg_row0, h_bseg_nrows, h_slab_bseg_ptr;  // work units of the one-pass sweep
 
     // workspace carve-up (device pointers)
     char *ws = nullptr;
@@ -70,6 +71,17 @@ struct mcl_context {
     int *row_ptr_dev = nullptr;  // int32[I+1]
     TileMap tilesB, tilesC, tilesA;
     TileMap segs;  // <= MCL_SEG_ROWS-row segments of one slab each: work units of the X^T (B o a) pass
+    TileMap bsegs;  // block segments (<= 1024 rows of one slab) of k_sweep (sweep.hip)
+    int *slab_bseg_ptr = nullptr;  // int32[I+1] first bseg of every slab
+    float *Mpart = nullptr;        // [n_bsegs, K * 16 NB]  per-bseg X^T B in C-fragment order
+    float *part_btb = nullptr;     // [n_bsegs, r, r]       per-bseg B^T B
+    float *GRpart = nullptr;       // [n_bsegs, K * 16 NB + (16 NB)^2]  per-bseg a-weighted partial of [G | R]
+    int n_grpart = 0;
+    long long *sweep_cycles = nullptr;  // [n_blocks, 4 waves, 6] per-section cycle counts (MCL_SWEEP_DBG & 32)
+    bool grpart_valid = false;     // GRpart was weighted with the current A (and mseg_valid)
+    bool sweep_planned = false;    // the workspace holds the sweep buffers
+    bool mseg_valid = false;       // Mpart / part_btb correspond to the current B
+    bool seg_from_sweep = false;   // k_A_finish sums seg_rhs / part_btb over bsegs instead of segments
     float *XC = nullptr;        // [N, r]   X C  (cached between the A-phase and the next B-phase)
     float *Cfrag = nullptr;     // C in MFMA-fragment order for the X C kernel
     float *CtC = nullptr;       // [r, r]
@@ -126,10 +138,10 @@ struct mcl_context {
 
     std::string variant[4];
 
-    // optional HIP-event timing of kernel slots (0: X C pass, 1: X^T B pass, 2: fused B rows)
+    // optional HIP-event timing of kernel slots (0: X C pass, 1: X^T B pass, 2: fused B rows, 3: one-pass sweep)
     int prof_capacity = 0;
-    std::vector<hipEvent_t> prof_ev[3];
-    int prof_used[3] = {0, 0, 0};
+    std::vector<hipEvent_t> prof_ev[4];
+    int prof_used[4] = {0, 0, 0, 0};
 };
 
 // RAII helper: records start/stop events around a launch when profiling is enabled
@@ -173,6 +185,14 @@ int mcl_launch_contract_xt(mcl_context *c);                      // partials of 
 int mcl_launch_reduce_partials(mcl_context *c);                  // GR = sum of partials
 int mcl_launch_slab_gram(mcl_context *c);                        // rhsA, BtB from B and XC
 int mcl_contract_n_partials(const mcl_context *c);
+
+// ---- launchers implemented in sweep.hip --------------------------------------------------------------
+bool mcl_sweep_shape_ok(const mcl_context *c);   // shape has a k_sweep instantiation (decides the workspace plan)
+bool mcl_sweep_eligible(const mcl_context *c);   // ... and the current penalties / options / pointers allow it
+void mcl_sweep_geometry(const mcl_context *c, int *bsegs_per_wave, int *n_waves);
+int mcl_launch_sweep(mcl_context *c);            // B-phase + per-bseg X^T B, B^T B in one pass over X
+int mcl_launch_reduce_weighted(mcl_context *c);  // GR = sum of the sweep blocks' a-weighted partials
+int mcl_launch_A_rhs_from_M(mcl_context *c);     // seg_rhs[bseg] = coldot(M_bseg, C)
 
 // ---- launchers implemented in admm.hip ---------------------------------------------------------------
 int mcl_launch_ctc(mcl_context *c);

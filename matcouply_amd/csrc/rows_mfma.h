@@ -11,10 +11,33 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "../../include/matcouply_hip.h"
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef MFMA16
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #endif
+
+static __device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// elementwise prox of the row-separable penalties (penalties.py:503-586)
+static __device__ __forceinline__ float prox_elem(int kind, int nonneg, float p0, float p1, float thr, float y) {
+    switch (kind) {
+        case MCL_PEN_NN:
+            return fmaxf(y, 0.f);
+        case MCL_PEN_BOX:
+            return fminf(fmaxf(y, p0), p1);
+        case MCL_PEN_L1:
+            if (nonneg) return fmaxf(y - thr, 0.f);
+            return copysignf(fmaxf(fabsf(y) - thr, 0.f), y);
+        default:
+            return y;
+    }
+}
 
 template <int NBR>
 struct RowMat {

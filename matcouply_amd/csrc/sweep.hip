@@ -1,0 +1,652 @@
+// ONE pass over X per outer AO-ADMM iteration (gfx950), for row-separable penalties on the B_i.
+//
+// The reference touches X three times per iteration: X_i C for the B right-hand sides (decomposition.py:242),
+// X_i^T (B_i o a_i) for the C right-hand side (:312-315) and diag(B_i^T X_i C) for the A right-hand sides (:147-152).
+// With M_i = X_i^T B_i (K x r, per slab) two of them are algebra on a small matrix:
+//     C-phase:  sum_i X_i^T (B_i o a_i)   = sum_i M_i diag(a_i)                       (k_reduce_weighted)
+//     A-phase:  diag(B_i^T X_i C)[c]      = sum_k M_i[k][c] C[k][c]                   (k_A_rhs_from_M)
+// and M_i needs the NEW B_i rows, which (row-separable prox) depend only on the same rows of X C.  So k_sweep,
+// for every 16-row block of X staged ONCE in LDS:
+//     X C rows (MFMA, C fragments)  ->  B-phase inner ADMM loop in registers (decomposition.py:259-285)
+//     ->  B / aux / dual rows stored  ->  M_i += X_blk^T B_blk,  B_i^T B_i += B_blk^T B_blk  (MFMA)
+// X C is never written to memory.  HBM traffic per iteration: S_X + S_B (1 + 4 n_reg) instead of
+// 2 S_X + S_B (5 + 4 n_reg) for the two-pass path (k_contract_xc_row + k_rows_fused + k_contract_xt).
+//
+// Work unit = BSEG: <= bseg_rows consecutive rows of ONE slab, owned by ONE wave: the waves of a block only share the
+// LDS image of C and never synchronise inside the loop.  Per bseg the wave writes, straight from its accumulators and in
+// the SAME fragment order as the C image used by the X C product (k_build_cfrag, so both consumers stream them with
+// 16-byte coalesced loads): M_bseg (for the A-phase), its a-weighted copy with the weighted Gram (summed over bsegs
+// by k_reduce_frag for the C-phase) and B^T B.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "mcl_internal.h"
+#include "rows_mfma.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// lane naming: (q = l>>4, i16 = l&15).  Two register layouts of a 16 x 16 block of rows x columns occur:
+//   ROW layout (inner loop, memory): lane (row = i16, g = q) holds columns 4g..4g+3 of its row       (f32x4)
+//   COL layout (MFMA reduction over rows): lane (col = i16, q) reg v holds row 4q + v of its column
+// MFMA16(a, b, acc): D[i][j] += sum_kk A[i][kk] B[kk][j]; lane l feeds A[l&15][l>>4] and B[l>>4][l&15]; D lane l,
+// reg w = D[4(l>>4) + w][l&15].
+//
+// (1) X C, transposed:  A = C fragment (i <-> column c), B = X fragment (j <-> row)   -> D in ROW layout.
+//     both fragments index k = 64kc + 16kq + 4q + m (kq: which float4 of the lane, m: its component)
+// (2) inner loop in ROW layout (rows_mfma.h k-permutation: no cross-lane movement)
+// (3) B_new ROW -> COL layout through a 16 x 20-float wave-private LDS patch (conflict-free both ways)
+// (4) M += X_blk^T B_blk:  A = X[row 4q+v][4 s(i16) + m] with slot s(i) = 16kb + 4(i&3) + (i>>2),
+//     B = B_new COL reg v  ->  D lane (q,i16) reg w = M[64kb + 16w + 4q + m][i16]: exactly element
+//     (kc = kb, kq = w, lane, m) of the C-fragment order.
+// ---------------------------------------------------------------------------------------------------------
+// wave-uniform 64-bit element offset (SGPR pair): `base + uniform_off(..) + lane offset` compiles to the scalar-base +
+// 32-bit lane offset form of global_load, so per-row addresses cost no vector registers.  (The offset, not the pointer,
+// goes through readfirstlane: an integer -> pointer cast would lose the global address space and emit FLAT loads, which
+// also count on lgkmcnt and would serialise against every LDS wait.)
+static __device__ __forceinline__ long uniform_off(long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long)(((unsigned long long)hi << 32) | lo);
+}
+
+template <int KS, int NB, int NREG, int DEPTH, int NW>
+__global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, const float *__restrict__ Cfrag,
+                                               const float *__restrict__ A, const float *__restrict__ rhoB,
+                                               const float *__restrict__ LinvB, float *__restrict__ Bout, RegSet regs,
+                                               const int *__restrict__ bs_slab, const int *__restrict__ bs_row0,
+                                               const int *__restrict__ bs_nrows, int n_bsegs, int bsegs_per_wave,
+                                               int r, int inner, float *__restrict__ Mpart,
+                                               float *__restrict__ part_btb, float *__restrict__ GRpart,
+                                               double *__restrict__ diag_block, int dbg,
+                                               long long *__restrict__ cyc_out) {
+    constexpr int KW = 256 * KS;   // floats per tile row (= K)
+    constexpr int KC = 4 * KS;     // 64-column chunks
+    constexpr int W = 16 * NB;
+    constexpr int MS = KW * W;     // floats per M partial
+    constexpr int NR = NREG > 0 ? NREG : 1;
+    extern __shared__ float lds_dyn[];  // [4 wave tiles: 16 x K each][C fragments: K x 16 NB]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: row addresses stay in SGPRs
+    const int q = lane >> 4, i16 = lane & 15;
+    float *L = lds_dyn + wave * (16 * KW);
+    constexpr int NT = 64 * NW;    // threads per block
+    float *Cs = lds_dyn + NW * 16 * KW;  // C in fragment order: LDS reads count on lgkmcnt, so they never force the
+                                        // in-flight X prefetch (vmcnt, in-order) to drain the way global loads would
+    const int K = KW;
+
+    // LDS addressing: the XOR swizzle only touches the low 4 bits of the 16-byte slot index, so every access is one of
+    // a few per-lane bases plus a COMPILE-TIME offset (ds_read/ds_write immediate) - no per-access address registers.
+    int rd1[4], rd4[4];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) rd1[kq] = i16 * KW + (((4 * kq + q) ^ i16) << 2);  // (1): row i16, slot 16kc + 4kq + q
+    {
+        const int sl = 4 * (i16 & 3) + (i16 >> 2);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) rd4[v] = (4 * q + v) * KW + ((sl ^ (4 * q + v)) << 2);  // (4): row 4q+v, slot 16kb + sl
+    }
+    float bsel[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) bsel[v] = (i16 == 4 * q + v) ? 1.f : 0.f;
+    const int wr_lo = (lane & 15) << 2, wr_hi = (lane >> 4) << 6;  // tile write: row t, slot 64sc + lane -> (lane ^ t)
+
+    for (int e = threadIdx.x * 4; e < MS; e += 4 * NT)
+        *reinterpret_cast<f32x4 *>(Cs + e) = *reinterpret_cast<const f32x4 *>(Cfrag + e);
+    __syncthreads();
+
+    long long cyc[6] = {0, 0, 0, 0, 0, 0};  // (dbg & 32): cycles per section, per wave; [5] = 100 MHz wall ticks
+    const long long wall0 = (dbg & 32) ? (long long)wall_clock64() : 0;
+    auto tick = [&](int sec, long long &t0) {
+        if (dbg & 32) {
+            const long long t1 = __builtin_readcyclecounter();
+            cyc[sec] += t1 - t0;
+            t0 = t1;
+        }
+    };
+
+    const int wg = blockIdx.x * NW + wave;  // global wave index
+    const int bs0 = min(wg * bsegs_per_wave, n_bsegs);
+    const int bs1 = min(bs0 + bsegs_per_wave, n_bsegs);
+
+    double nf = 0.0, na = 0.0, gap[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) gap[k] = 0.0;
+
+    for (int bs = bs0; bs < bs1; ++bs) {
+        const int slab = __builtin_amdgcn_readfirstlane(bs_slab[bs]);
+        const long row0 = __builtin_amdgcn_readfirstlane(bs_row0[bs]);
+        const int nrows = __builtin_amdgcn_readfirstlane(bs_nrows[bs]);
+        const int wr0 = 0, wn = nrows;  // the wave owns the whole bseg
+        const int nblk = (wn + 15) >> 4;
+
+        f32x4 accM[KC][4][NB];
+        f32x4 accG[NB][NB];
+#pragma unroll
+        for (int kb = 0; kb < KC; ++kb)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) accM[kb][m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) accG[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if (nblk > 0) {
+            // per-slab operands of the inner loop (ROW layout: row = i16, g = q)
+            const float *Li = LinvB + (long)slab * r * r;
+            float LT[NB][NB][4];
+#pragma unroll
+            for (int hp = 0; hp < NB; ++hp)
+#pragma unroll
+                for (int h = 0; h < NB; ++h)
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq) {
+                        const int k = 16 * h + 4 * q + kq, c = 16 * hp + i16;
+                        LT[hp][h][kq] = (k < r && c < r) ? Li[k * r + c] : 0.f;
+                    }
+            float av[NB][4];
+#pragma unroll
+            for (int h = 0; h < NB; ++h)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int col = 16 * h + 4 * q + v;
+                    av[h][v] = (col < r) ? A[(long)slab * r + col] : 0.f;
+                }
+            const float rho = rhoB[slab];
+            // branch-free prox of the row-separable penalties (penalties.py:503-586), identical results to prox_elem:
+            //     prox(y) = clamp(y - clamp(y, pa, pb), plo, phi)          (clamp = v_med3_f32)
+            //   NN: (-inf, 0 | -inf, inf)   Box: (0, 0 | lo, hi)   L1: (-thr, thr | -inf, inf)   L1 + NN: (-inf, thr | ..)
+            float pa[NR], pb[NR], plo[NR], phi[NR];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const float thr = (k < NREG) ? regs.p0[k] / rho : 0.f;
+                const int kind = (k < NREG) ? regs.kind[k] : 0;
+                pa[k] = pb[k] = 0.f;
+                plo[k] = -INFINITY, phi[k] = INFINITY;
+                if (kind == MCL_PEN_NN) pa[k] = -INFINITY;
+                if (kind == MCL_PEN_BOX) plo[k] = regs.p0[k], phi[k] = regs.p1[k];
+                if (kind == MCL_PEN_L1) pa[k] = regs.nonneg[k] ? -INFINITY : -thr, pb[k] = thr;
+            }
+            int zcol[NB];
+            bool zok[NB];
+#pragma unroll
+            for (int h = 0; h < NB; ++h) {
+                zok[h] = (16 * h + 4 * q) < r;          // r % 4 == 0: a lane's 4 columns are all valid or all padding
+                zcol[h] = min(16 * h + 4 * q, r - 4);   // clamped: every load is unconditional
+            }
+
+            const long base = row0 + wr0;
+            const unsigned lane4 = 4u * (unsigned)lane;
+            f32x4 xr[DEPTH][KS][16];
+            f32x4 zs[DEPTH][NR][NB], us[DEPTH][NR][NB];  // aux / dual rows of the slot's block, updated IN PLACE
+            // Stage block `blk` of this wave into ring slot d.  Every load is unconditional (rows clamped into the
+            // wave's range, scalar arithmetic): a branch around loads makes the compiler's counted s_waitcnt vmcnt(N)
+            // collapse to the pessimistic merge of both paths and drains the prefetch at every block.
+            auto issue_x = [&](auto dc, int blk) {  // 16 rows x K columns, one 1 KB row segment per wave load
+                constexpr int d = decltype(dc)::value;
+#pragma unroll
+                for (int sc = 0; sc < KS; ++sc)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const long j = base + min(16 * blk + t, wn - 1);
+                        xr[d][sc][t] = *reinterpret_cast<const f32x4 *>(X + uniform_off(j * K + 256 * sc) + lane4);
+                    }
+            };
+            // aux / dual rows go straight into the registers the inner loop works on.  They are issued AFTER the slot's
+            // previous block has stored its rows, so the registers are never live across the load and the compiler
+            // needs no loop-carried copies (a copy of a loaded register is an early wait on the in-order queue: with
+            // ~36 KB per wave outstanding the queueing latency is several microseconds).  Padding columns (>= r) hold
+            // clamped real data: finite, multiplied by zero rows of L^-1, never stored.
+            auto issue_zu = [&](auto dc, int blk) {
+                constexpr int d = decltype(dc)::value;
+                const long jr = base + min(16 * blk + i16, wn - 1);
+#pragma unroll
+                for (int k = 0; k < NREG; ++k)
+#pragma unroll
+                    for (int h = 0; h < NB; ++h) {
+                        zs[d][k][h] = *reinterpret_cast<const f32x4 *>(regs.aux[k] + jr * r + zcol[h]);
+                        us[d][k][h] = *reinterpret_cast<const f32x4 *>(regs.dual[k] + jr * r + zcol[h]);
+                    }
+            };
+            // the scheduling barriers pin the queue order slot 0 | slot 1: the loop-head s_waitcnt vmcnt(N) is ONE
+            // instruction shared by the entry and the back edge, and a reordered prologue would shrink its N to ~0
+            issue_x(std::integral_constant<int, 0>{}, 0);
+            issue_zu(std::integral_constant<int, 0>{}, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (DEPTH == 2) {
+                issue_x(std::integral_constant<int, DEPTH - 1>{}, 1);
+                issue_zu(std::integral_constant<int, DEPTH - 1>{}, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+
+            auto body = [&](auto dc, int blk) {
+                constexpr int d = decltype(dc)::value;
+                long long t0 = (dbg & 32) ? (long long)__builtin_readcyclecounter() : 0;
+                // ---- registers -> LDS tile (row t, 16-B slot 64 sc + lane, physical slot XORed with the row)
+#pragma unroll
+                for (int sc = 0; sc < KS; ++sc)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        *reinterpret_cast<f32x4 *>(L + t * KW + 256 * sc + wr_hi + (wr_lo ^ (t << 2))) = xr[d][sc][t];
+                f32x4(&z)[NR][NB] = zs[d];
+                f32x4(&u)[NR][NB] = us[d];
+                // the X slot is free again: its next block goes out now and stays in flight for DEPTH block times
+                issue_x(dc, blk + DEPTH);
+                tick(0, t0);
+
+                // ---- (1) rhs^T = (X C)^T for the 16 rows, ROW layout
+                f32x4 acc[NB], acc2[NB];  // two chains: consecutive MFMAs never wait on each other
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = acc2[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // C and X fragments of the next 64-column chunk are fetched from LDS while the current chunk multiplies
+                // (double buffer by hand); the scheduling barriers keep the compiler from hoisting every LDS read of the
+                // block to the top (register pressure: the M accumulators and the staging registers take half the file)
+                {
+                    f32x4 cf[2][4][NB], fr[2][4];
+                    auto ld1 = [&](int sl, int kc) {
+#pragma unroll
+                        for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                cf[sl][kq][nb] =
+                                    *reinterpret_cast<const f32x4 *>(Cs + ((kc * 4 + kq) * NB + nb) * 256 + lane4);
+                            fr[sl][kq] = *reinterpret_cast<const f32x4 *>(L + rd1[kq] + 64 * kc);
+                        }
+                    };
+                    ld1(0, 0);
+                    if (!(dbg & 1))
+#pragma unroll
+                    for (int kc = 0; kc < KC; ++kc) {
+                        if (kc + 1 < KC) ld1((kc + 1) & 1, kc + 1);
+#pragma unroll
+                        for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                                for (int nb = 0; nb < NB; ++nb) {
+                                    if (m & 1) acc2[nb] = MFMA16(cf[kc & 1][kq][nb][m], fr[kc & 1][kq][m], acc2[nb]);
+                                    else acc[nb] = MFMA16(cf[kc & 1][kq][nb][m], fr[kc & 1][kq][m], acc[nb]);
+                                }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] += acc2[nb];
+
+                tick(1, t0);
+                // ---- (2) inner ADMM loop (decomposition.py:259-285), same arithmetic as rows_fused_tile
+                f32x4 rhs[NB], f[NB];
+#pragma unroll
+                for (int h = 0; h < NB; ++h) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) rhs[h][v] = acc[h][v] * av[h][v];
+                    f[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const int n_it = (dbg & 2) ? 0 : ((NREG == 0 && inner > 1) ? 1 : inner);
+                for (int it = 0; it < n_it; ++it) {
+                    f32x4 t[NB];
+#pragma unroll
+                    for (int h = 0; h < NB; ++h)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            float s = 0.f;
+#pragma unroll
+                            for (int k = 0; k < NREG; ++k) s += z[k][h][v] - u[k][h][v];
+                            t[h][v] = (NREG > 0) ? fmaf(rho, s, rhs[h][v]) : rhs[h][v];
+                        }
+#pragma unroll
+                    for (int hp = 0; hp < NB; ++hp) {
+                        f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int h = 0; h < NB; ++h)
+#pragma unroll
+                            for (int kq = 0; kq < 4; ++kq) a4 = MFMA16(LT[hp][h][kq], t[h][kq], a4);
+                        f[hp] = a4;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NREG; ++k)
+#pragma unroll
+                        for (int h = 0; h < NB; ++h)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const float y = f[h][v] + u[k][h][v];
+                                const float znew = __builtin_amdgcn_fmed3f(y - __builtin_amdgcn_fmed3f(y, pa[k], pb[k]), plo[k], phi[k]);
+                                u[k][h][v] = f[h][v] - (znew - u[k][h][v]);
+                                z[k][h][v] = znew;
+                            }
+                }
+
+                tick(2, t0);
+                // ---- store the rows, diagnostics, ROW -> COL transposition of B_new
+                const bool ok = 16 * blk + i16 < wn;
+                const long j = base + 16 * blk + i16;
+#pragma unroll
+                for (int h = 0; h < NB; ++h) {
+                    const bool live = ok && zok[h];
+                    const int col = 16 * h + 4 * q;
+                    if (live && !(dbg & 8)) {
+                        *reinterpret_cast<f32x4 *>(Bout + j * r + col) = f[h];
+#pragma unroll
+                        for (int k = 0; k < NREG; ++k) {
+                            *reinterpret_cast<f32x4 *>(regs.aux[k] + j * r + col) = z[k][h];
+                            *reinterpret_cast<f32x4 *>(regs.dual[k] + j * r + col) = u[k][h];
+                        }
+                        // 4-term partial sums in fp32, accumulated across blocks in fp64
+                        float s_nf = 0.f, s_na = 0.f, s_gap[NR];
+#pragma unroll
+                        for (int k = 0; k < NR; ++k) s_gap[k] = 0.f;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            s_nf = fmaf(f[h][v], f[h][v], s_nf);
+                            s_na += fabsf(f[h][v]);
+#pragma unroll
+                            for (int k = 0; k < NREG; ++k) {
+                                const float dlt = z[k][h][v] - f[h][v];
+                                s_gap[k] = fmaf(dlt, dlt, s_gap[k]);
+                            }
+                        }
+                        nf += (double)s_nf;
+                        na += (double)s_na;
+#pragma unroll
+                        for (int k = 0; k < NREG; ++k) gap[k] += (double)s_gap[k];
+                    }
+                    if (!live) f[h] = f32x4{0.f, 0.f, 0.f, 0.f};  // padding rows / columns must not reach M
+                }
+                issue_zu(dc, blk + DEPTH);  // rows of this slot's next block, into the registers just stored
+                // ROW -> COL layout on the matrix core: with A = f[nb][v] (A[row][kk] = B_new[row][4kk + v]) and the constant
+                // selector B_v[kk][j] = (j == 4kk + v), sum_v A_v B_v = B_new, and the MFMA result layout IS the COL
+                // layout (lane (q, i16) reg w = B_new[4q + w][i16]).  Exact: products with 1 and sums with 0.
+                float bt[NB][4];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f32x4 tr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) tr = MFMA16(f[nb][v], bsel[v], tr);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) bt[nb][w] = tr[w];
+                }
+
+                tick(3, t0);
+                // ---- (4) M += X_blk^T B_blk ; B^T B += B_blk^T B_blk
+                {
+                    f32x4 xa[2][4];
+                    auto ld4x = [&](int sl, int kb) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) xa[sl][v] = *reinterpret_cast<const f32x4 *>(L + rd4[v] + 64 * kb);
+                    };
+                    ld4x(0, 0);
+                    if (!(dbg & 4))
+#pragma unroll
+                    for (int kb = 0; kb < KC; ++kb) {
+                        if (kb + 1 < KC) ld4x((kb + 1) & 1, kb + 1);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                                for (int nb = 0; nb < NB; ++nb)
+                                    accM[kb][m][nb] = MFMA16(xa[kb & 1][v][m], bt[nb][v], accM[kb][m][nb]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int a = 0; a < NB; ++a)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) accG[a][b] = MFMA16(bt[a][v], bt[b][v], accG[a][b]);
+                tick(4, t0);
+            };
+            // branch-free ring: with DEPTH == 2 an odd tail runs one dummy block (all rows invalid: nothing stored,
+            // zero contribution to M)
+            for (int blk = 0; blk < nblk; blk += DEPTH) {
+                body(std::integral_constant<int, 0>{}, blk);
+                if (DEPTH == 2) body(std::integral_constant<int, DEPTH - 1>{}, blk + 1);
+            }
+        }
+
+        // ---- flush this bseg straight from the accumulators (fragment order: 1 KB per store instruction)
+        {
+            float *mp = Mpart + (long)bs * MS;
+            float *gp = GRpart + (long)bs * (MS + W * W);
+            const float *arow = A + (long)slab * r;
+            float a_c[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a_c[nb] = (16 * nb + i16 < r) ? arow[16 * nb + i16] : 0.f;
+#pragma unroll
+            for (int kb = 0; kb < KC; ++kb)
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const f32x4 val = {accM[kb][0][nb][w], accM[kb][1][nb][w], accM[kb][2][nb][w], accM[kb][3][nb][w]};
+                        const int e = ((((kb * 4 + w) * NB + nb) * 64 + lane) << 2);
+                        *reinterpret_cast<f32x4 *>(mp + e) = val;
+                        *reinterpret_cast<f32x4 *>(gp + e) = val * a_c[nb];  // column 16 nb + i16 of M diag(a)
+                    }
+#pragma unroll
+            for (int a = 0; a < NB; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int ra = 16 * a + 4 * q + w, cb = 16 * b + i16;
+                        if (ra < r && cb < r) {
+                            part_btb[((long)bs * r + ra) * r + cb] = accG[a][b][w];
+                            gp[MS + ra * W + cb] = arow[ra] * arow[cb] * accG[a][b][w];
+                        } else {
+                            gp[MS + ra * W + cb] = 0.f;
+                        }
+                    }
+        }
+    }
+
+    if (dbg & 32) cyc[5] = (long long)wall_clock64() - wall0;
+    if ((dbg & 32) && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cyc_out[((long)blockIdx.x * NW + wave) * 6 + i] = cyc[i];
+    }
+    // one diagnostics row per block
+    nf = wave_sum(nf);
+    na = wave_sum(na);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) gap[k] = wave_sum(gap[k]);
+    __syncthreads();  // every wave is done with its tile: the area is free
+    double(*dsm)[DIAG_COLS] = reinterpret_cast<double(*)[DIAG_COLS]>(lds_dyn);
+    if (lane == 0) {
+        dsm[wave][0] = nf;
+        dsm[wave][1] = na;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) dsm[wave][2 + k] = gap[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 + NREG)
+    {
+        double t = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) t += dsm[wv][threadIdx.x];  // fixed order
+        diag_block[(long)blockIdx.x * DIAG_COLS + threadIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// [G | R] = sum over the sweep's per-bseg a-weighted partials (decomposition.py:312-318).  Thread e walks the partials in fragment
+// order (coalesced) and scatters its sum to the row-major [G | R] image.  Fixed summation order (16 interleaved groups
+// of partials, 4 chains each, then the groups in order): deterministic, identical on every rank for identical input.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_reduce_frag(const float *__restrict__ GRpart, int n_part, int K, int r, int NB,
+                                                      int MS, float *__restrict__ GR) {
+    __shared__ float sm[16][64];
+    const int el = threadIdx.x & 63, pc = threadIdx.x >> 6;  // 64 elements x 16 interleaved groups of partials
+    const int e = blockIdx.x * 64 + el;
+    const int W = 16 * NB, PS = MS + W * W;
+    int out = -1;
+    if (e < MS) {
+        const int m = e & 3, ln = (e >> 2) & 63;
+        int t = e >> 8;
+        const int nb = t % NB;
+        t /= NB;
+        const int kq = t & 3, kc = t >> 2;
+        const int k = 64 * kc + 16 * kq + 4 * (ln >> 4) + m, c = 16 * nb + (ln & 15);
+        if (k < K && c < r) out = r * r + k * r + c;
+    } else if (e < PS) {
+        const int g = e - MS, a = g / W, b = g - a * W;
+        if (a < r && b < r) out = a * r + b;
+    }
+    float s = 0.f;
+    if (out >= 0) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int p = pc;
+        for (; p + 48 < n_part; p += 64) {
+            s0 += GRpart[(long)p * PS + e];
+            s1 += GRpart[(long)(p + 16) * PS + e];
+            s2 += GRpart[(long)(p + 32) * PS + e];
+            s3 += GRpart[(long)(p + 48) * PS + e];
+        }
+        for (; p < n_part; p += 16) s0 += GRpart[(long)p * PS + e];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    sm[pc][el] = s;
+    __syncthreads();
+    if (pc == 0 && out >= 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += sm[g][el];  // fixed order
+        GR[out] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rhs of the A-phase per bseg: seg_rhs[bseg][c] = sum_k M_bseg[k][c] C[k][c] with both operands in fragment order
+// (decomposition.py:147-152: diag(B_i^T X_i C)).  One block per bseg; thread t owns column 16 nb + (t & 15) of
+// wave-row (t >> 6) = nb (mod NB); fixed-order LDS tree.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_A_rhs_from_M(const float *__restrict__ Mpart, const float *__restrict__ Cfrag,
+                                                      int MS, int NB, int r, float *__restrict__ seg_rhs) {
+    __shared__ float sm[256];
+    const int bs = blockIdx.x;
+    const float *mp = Mpart + (long)bs * MS;
+    float s0 = 0.f, s1 = 0.f;
+    int e = threadIdx.x * 4;
+    for (; e + 1024 < MS; e += 2048) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(mp + e), b = *reinterpret_cast<const f32x4 *>(Cfrag + e);
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(mp + e + 1024), d = *reinterpret_cast<const f32x4 *>(Cfrag + e + 1024);
+        s0 += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+        s1 += (c[0] * d[0] + c[1] * d[1]) + (c[2] * d[2] + c[3] * d[3]);
+    }
+    for (; e < MS; e += 1024) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(mp + e), b = *reinterpret_cast<const f32x4 *>(Cfrag + e);
+        s0 += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+    }
+    sm[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    // threads with the same column: lane quarters q = 0..3 of every wave w with w % NB == nb
+    if ((int)threadIdx.x < 16 * NB) {
+        const int nb = threadIdx.x >> 4, c16 = threadIdx.x & 15;
+        float t = 0.f;
+        for (int w = nb; w < 4; w += NB)
+            for (int qq = 0; qq < 4; ++qq) t += sm[w * 64 + qq * 16 + c16];
+        const int col = 16 * nb + c16;
+        if (col < r) seg_rhs[(long)bs * r + col] = t;
+    }
+}
+
+// =========================================================================================================
+// host side
+// =========================================================================================================
+// Shapes the sweep kernel is instantiated for: K in {256, 512} (tile = K floats per row, LDS), K * NB <= 512
+// (accumulator registers), r % 4 == 0 (16-byte row accesses), 16-byte aligned operands.
+bool mcl_sweep_shape_ok(const mcl_context *c) {
+    if (getenv("MCL_NO_SWEEP")) return false;
+    if (c->K != 256 && c->K != 512) return false;
+    if (c->NB > 2 || c->K * c->NB > 512) return false;
+    if (c->r % 4 != 0) return false;
+    if (c->N == 0 || c->I == 0) return false;
+    if (c->N / c->I < 64) return false;  // tiny slabs: the per-bseg flush would dominate
+    return true;
+}
+
+bool mcl_sweep_eligible(const mcl_context *c) {
+    if (!c->sweep_planned || !mcl_sweep_shape_ok(c)) return false;
+    if (c->regs[1].n > 2 || !mcl_mode_is_row_separable(c, 1)) return false;
+    if (c->opt.inner_n_iter_max <= 0) return false;
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!al(c->X) || !al(c->B)) return false;
+    for (int k = 0; k < c->regs[1].n; ++k)
+        if (!al(c->regs[1].aux[k]) || !al(c->regs[1].dual[k])) return false;
+    return true;
+}
+
+static inline int sweep_MS(const mcl_context *c) { return (int)c->K * 16 * c->NB; }
+
+// waves of the sweep: `bsegs_per_wave` consecutive bsegs each; 1024 waves = one per SIMD (the register file and the LDS
+// tiles allow one or two).  n_waves is rounded up to whole blocks by the launcher (idle waves have an empty range).
+void mcl_sweep_geometry(const mcl_context *c, int *bsegs_per_wave, int *n_waves) {
+    const int n = std::max(c->bsegs.n_tiles, 1);
+    int target_waves = 1024;
+    if (const char *e = getenv("MCL_SWEEP_WAVES")) target_waves = std::max(1, atoi(e));
+    const int spw = (n + target_waves - 1) / target_waves;
+    *bsegs_per_wave = spw;
+    *n_waves = (n + spw - 1) / spw;
+}
+
+template <int KS, int NB, int NREG>
+static int launch_sweep_t(mcl_context *c) {
+    // 4 waves per block, one per SIMD (register file); K = 256, r <= 16 has room for a second staging slot
+    constexpr int NW = 4;
+    constexpr int DEPTH = (KS * NB == 1) ? 2 : 1;
+    const int n = c->bsegs.n_tiles;
+    int bpb, n_waves;
+    mcl_sweep_geometry(c, &bpb, &n_waves);
+    const int grid = (n_waves + NW - 1) / NW;
+    const size_t sm = sizeof(float) * (size_t)(NW * 16 * 256 * KS + 256 * KS * 16 * NB);  // up to the full 160 KB
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<KS, NB, NREG, DEPTH, NW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;  // caller falls back to the two-pass path
+    }
+    hipLaunchKernelGGL((k_sweep<KS, NB, NREG, DEPTH, NW>), dim3(grid), dim3(64 * NW), sm, c->stream, c->X, c->Cfrag, c->A,
+                       c->rhoB, c->LinvB, c->B, c->regs[1], c->bsegs.slab, c->bsegs.row0, c->bsegs.nrows, n, bpb, c->r,
+                       c->opt.inner_n_iter_max, c->Mpart, c->part_btb, c->GRpart, c->diagB_tile,
+                       getenv("MCL_SWEEP_DBG") ? atoi(getenv("MCL_SWEEP_DBG")) : 0, c->sweep_cycles);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    c->diag_rows[1] = grid;
+    c->n_grpart = n;  // one a-weighted partial per bseg
+    char buf[96];
+    snprintf(buf, sizeof buf, "k_sweep<KS=%d,NB=%d,NREG=%d,DEPTH=%d,NW=%d>", KS, NB, NREG, DEPTH, NW);
+    c->variant[3] = buf;
+    return 0;
+}
+
+int mcl_launch_sweep(mcl_context *c) {
+    ProfScope prof(c, 3);
+    const int ks = (int)(c->K / 256), n = c->regs[1].n;
+#define MCL_SW(KS_, NB_)                                  \
+    switch (n) {                                          \
+        case 0: return launch_sweep_t<KS_, NB_, 0>(c);    \
+        case 1: return launch_sweep_t<KS_, NB_, 1>(c);    \
+        default: return launch_sweep_t<KS_, NB_, 2>(c);   \
+    }
+    if (c->NB == 1) {
+        if (ks == 1) { MCL_SW(1, 1) }
+        MCL_SW(2, 1)
+    }
+    MCL_SW(1, 2)
+#undef MCL_SW
+}
+
+int mcl_launch_reduce_weighted(mcl_context *c) {
+    const int MS = sweep_MS(c), W = 16 * c->NB;
+    const int blocks = (MS + W * W + 63) / 64;
+    hipLaunchKernelGGL(k_reduce_frag, dim3(blocks), dim3(1024), 0, c->stream, c->GRpart, c->n_grpart, (int)c->K, c->r,
+                       c->NB, MS, c->GR);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int mcl_launch_A_rhs_from_M(mcl_context *c) {
+    hipLaunchKernelGGL(k_A_rhs_from_M, dim3(c->bsegs.n_tiles), dim3(256), 0, c->stream, c->Mpart, c->Cfrag, sweep_MS(c),
+                       c->NB, c->r, c->seg_rhs);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
