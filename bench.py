@@ -49,6 +49,8 @@ CONFIGS["c5s"] = dict(I=1024, J=512, K=256, r=32,
                       desc="c5 penalty stack (NN + L1 + L2Ball + Unimodal + PARAFAC2) at I=1024 J_i=512 K=256 rank=32 "
                            "(config 5 itself is I=8192 J=2048 K=1024: 68.7 GB of X)")
 CONFIGS["c3_8th"] = dict(CONFIGS["c3"], I=128, desc="one eighth of config 3 (the per-rank shard of an 8-GPU run): I=128 J_i=512 K=256 rank=16")
+CONFIGS["k512"] = dict(CONFIGS["c3"], I=512, J=512, K=512, desc="K=512 variant of config 3 (same bytes of X): I=512 J_i=512 K=512 rank=16")
+CONFIGS["r32"] = dict(CONFIGS["c3"], r=32, desc="rank-32 variant of config 3: I=1024 J_i=512 K=256 rank=32")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 

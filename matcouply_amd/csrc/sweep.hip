@@ -222,12 +222,19 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
             auto body = [&](auto dc, int blk) {
                 constexpr int d = decltype(dc)::value;
                 long long t0 = (dbg & 32) ? (long long)__builtin_readcyclecounter() : 0;
+                // opaque copies of the per-lane LDS bases: the compiler must form every LDS address as base + immediate
+                // inside the block instead of hoisting one precomputed address register per access out of the loop
+                // (that costs ~50 registers, i.e. spills to scratch, whose reloads also sit in the vmcnt queue)
+                int wl = wr_lo;
+                unsigned l4 = lane4;
+                asm volatile("" : "+v"(wl), "+v"(l4));
+                const float *csl = Cs + l4;
                 // ---- registers -> LDS tile (row t, 16-B slot 64 sc + lane, physical slot XORed with the row)
 #pragma unroll
                 for (int sc = 0; sc < KS; ++sc)
 #pragma unroll
                     for (int t = 0; t < 16; ++t)
-                        *reinterpret_cast<f32x4 *>(L + t * KW + 256 * sc + wr_hi + (wr_lo ^ (t << 2))) = xr[d][sc][t];
+                        *reinterpret_cast<f32x4 *>(L + t * KW + 256 * sc + wr_hi + (wl ^ (t << 2))) = xr[d][sc][t];
                 f32x4(&z)[NR][NB] = zs[d];
                 f32x4(&u)[NR][NB] = us[d];
                 // the X slot is free again: its next block goes out now and stays in flight for DEPTH block times
@@ -242,30 +249,33 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                 // (double buffer by hand); the scheduling barriers keep the compiler from hoisting every LDS read of the
                 // block to the top (register pressure: the M accumulators and the staging registers take half the file)
                 {
-                    f32x4 cf[2][4][NB], fr[2][4];
+                    constexpr int DB = (KS * NB == 1) ? 2 : 1;  // bigger variants have no registers left for a second buffer
+                    f32x4 cf[DB][4][NB], fr[DB][4];
                     auto ld1 = [&](int sl, int kc) {
 #pragma unroll
                         for (int kq = 0; kq < 4; ++kq) {
 #pragma unroll
                             for (int nb = 0; nb < NB; ++nb)
-                                cf[sl][kq][nb] =
-                                    *reinterpret_cast<const f32x4 *>(Cs + ((kc * 4 + kq) * NB + nb) * 256 + lane4);
+                                cf[sl][kq][nb] = *reinterpret_cast<const f32x4 *>(csl + ((kc * 4 + kq) * NB + nb) * 256);
                             fr[sl][kq] = *reinterpret_cast<const f32x4 *>(L + rd1[kq] + 64 * kc);
                         }
                     };
-                    ld1(0, 0);
+                    if (DB == 2) ld1(0, 0);
                     if (!(dbg & 1))
 #pragma unroll
                     for (int kc = 0; kc < KC; ++kc) {
-                        if (kc + 1 < KC) ld1((kc + 1) & 1, kc + 1);
+                        if (DB == 1) ld1(0, kc);
+                        else if (kc + 1 < KC) ld1((kc + 1) & 1, kc + 1);
 #pragma unroll
                         for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
                             for (int m = 0; m < 4; ++m)
 #pragma unroll
                                 for (int nb = 0; nb < NB; ++nb) {
-                                    if (m & 1) acc2[nb] = MFMA16(cf[kc & 1][kq][nb][m], fr[kc & 1][kq][m], acc2[nb]);
-                                    else acc[nb] = MFMA16(cf[kc & 1][kq][nb][m], fr[kc & 1][kq][m], acc[nb]);
+                                    constexpr int sb = 0;
+                                    const int sl = (DB == 2) ? (kc & 1) : sb;
+                                    if (m & 1) acc2[nb] = MFMA16(cf[sl][kq][nb][m], fr[sl][kq][m], acc2[nb]);
+                                    else acc[nb] = MFMA16(cf[sl][kq][nb][m], fr[sl][kq][m], acc[nb]);
                                 }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -369,23 +379,25 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                 tick(3, t0);
                 // ---- (4) M += X_blk^T B_blk ; B^T B += B_blk^T B_blk
                 {
-                    f32x4 xa[2][4];
+                    constexpr int DB = (KS * NB == 1) ? 2 : 1;
+                    f32x4 xa[DB][4];
                     auto ld4x = [&](int sl, int kb) {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) xa[sl][v] = *reinterpret_cast<const f32x4 *>(L + rd4[v] + 64 * kb);
                     };
-                    ld4x(0, 0);
+                    if (DB == 2) ld4x(0, 0);
                     if (!(dbg & 4))
 #pragma unroll
                     for (int kb = 0; kb < KC; ++kb) {
-                        if (kb + 1 < KC) ld4x((kb + 1) & 1, kb + 1);
+                        if (DB == 1) ld4x(0, kb);
+                        else if (kb + 1 < KC) ld4x((kb + 1) & 1, kb + 1);
 #pragma unroll
                         for (int v = 0; v < 4; ++v)
 #pragma unroll
                             for (int m = 0; m < 4; ++m)
 #pragma unroll
                                 for (int nb = 0; nb < NB; ++nb)
-                                    accM[kb][m][nb] = MFMA16(xa[kb & 1][v][m], bt[nb][v], accM[kb][m][nb]);
+                                    accM[kb][m][nb] = MFMA16(xa[(DB == 2) ? (kb & 1) : 0][v][m], bt[nb][v], accM[kb][m][nb]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
