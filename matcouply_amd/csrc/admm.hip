@@ -347,16 +347,24 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     constexpr int RP = 16 * NBR;
     if (wave == 0) {
+        // all loads of the system in flight at once (clamped indices, masked at use); the trace is summed in the same
+        // order as a serial loop (lane 0 reads the diagonal entries through v_readlane)
+        const bool act = lane < r;
+        const int cl = act ? lane : 0;
+        float g[RP];
+#pragma unroll
+        for (int d = 0; d < RP; ++d) g[d] = GR[(d < r ? d : r - 1) * r + cl];
         double tr = 0.0;
-        for (int c = 0; c < r; ++c) tr += (double)GR[c * r + c];
+#pragma unroll
+        for (int d = 0; d < RP; ++d)
+            if (d < r) tr += (double)readlane_f32(g[d], d);  // G[d][d], wave-uniform
         const float rho = (float)(0.5 * tr * scale);
         const double shift = (double)rho * NREG + (double)l2;
-        const bool act = lane < r;
         double col[RP];
 #pragma unroll
         for (int d = 0; d < RP; ++d) {
             double v = (d == lane) ? 1.0 : 0.0;
-            if (act && d < r) v = (double)GR[d * r + lane] + (d == lane ? shift : 0.0);
+            if (act && d < r) v = (double)g[d] + (d == lane ? shift : 0.0);
             col[d] = v;
         }
         gj_inverse_reg<RP>(col, r, lane);
@@ -414,19 +422,34 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict
 #pragma unroll
                 for (int b = 0; b < NBR; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[a], y[b], acc[a][b], 0, 0, 0);
         }
-        for (int wv = 0; wv < n_waves; ++wv) {  // fixed summation order
-            if (wave == wv) {
+        if (NBR == 1) {
+            // every wave parks its accumulators in its own LDS slot (behind the C image), then one pass sums the slots
+            // in wave order: 2 barriers instead of n_waves
+            double *slots = reinterpret_cast<double *>(smc + ((r * r + K * r + 1) & ~1));
 #pragma unroll
-                for (int a = 0; a < NBR; ++a)
-#pragma unroll
-                    for (int b = 0; b < NBR; ++b)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            double &dst = csm[16 * a + rsub + 4 * v][16 * b + c16];
-                            dst = (wv == 0) ? acc[a][b][v] : dst + acc[a][b][v];
-                        }
+            for (int v = 0; v < 4; ++v) slots[wave * 256 + (rsub + 4 * v) * 16 + c16] = acc[0][0][v];
+            __syncthreads();
+            for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+                double t = 0.0;
+                for (int wv = 0; wv < n_waves; ++wv) t += slots[wv * 256 + e];  // fixed order
+                csm[e >> 4][e & 15] = t;
             }
             __syncthreads();
+        } else {
+            for (int wv = 0; wv < n_waves; ++wv) {  // fixed summation order
+                if (wave == wv) {
+#pragma unroll
+                    for (int a = 0; a < NBR; ++a)
+#pragma unroll
+                        for (int b = 0; b < NBR; ++b)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                double &dst = csm[16 * a + rsub + 4 * v][16 * b + c16];
+                                dst = (wv == 0) ? acc[a][b][v] : dst + acc[a][b][v];
+                            }
+                }
+                __syncthreads();
+            }
         }
         for (int pr = threadIdx.x; pr < r * r; pr += blockDim.x) {
             const int a = pr / r, b = pr - a * r;
@@ -478,18 +501,42 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
         sg0 = slab_seg_ptr[i];
         sg1 = slab_seg_ptr[i + 1];
     }
+    // Every global load of the kernel is issued up front, unconditionally (clamped column, masked at use): the loads
+    // of one stage are all in flight together instead of one dependent L2 round trip per matrix row.
+    float ctc[RP], btbv[RP];
+#pragma unroll
+    for (int d = 0; d < RP; ++d) {
+        const int dd = d < r ? d : r - 1;
+        ctc[d] = CtC[dd * r + c];
+        btbv[d] = (seg_btb != nullptr) ? 0.f : BtB[((long)i * r + dd) * r + c];
+    }
+    float rhs_pre = (seg_rhs != nullptr) ? 0.f : rhsA[(long)i * r + c];
+    float z_pre[MCL_MAX_REGS], u_pre[MCL_MAX_REGS];
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k) {
+        z_pre[k] = u_pre[k] = 0.f;
+        if (k < regs.n) {
+            z_pre[k] = regs.aux[k][(long)i * r + c];
+            u_pre[k] = regs.dual[k][(long)i * r + c];
+        }
+    }
+    const float a_pre = A[(long)i * r + c];
+    if (seg_btb != nullptr) {  // sum the per-segment partial Grams / right-hand sides of this slab (fixed order)
+        for (int sg = sg0; sg < sg1; ++sg) {
+            float v[RP];
+#pragma unroll
+            for (int d = 0; d < RP; ++d) v[d] = seg_btb[((long)sg * r + (d < r ? d : r - 1)) * r + c];
+            const float rv = seg_rhs[(long)sg * r + c];
+#pragma unroll
+            for (int d = 0; d < RP; ++d) btbv[d] += v[d];
+            rhs_pre += rv;
+        }
+    }
 #pragma unroll
     for (int d = 0; d < RP; ++d) {
         float q = 0.f;
         if (act && d < r) {
-            float btb;
-            if (seg_btb != nullptr) {  // sum the per-segment partial Grams of this slab (fixed order)
-                btb = 0.f;
-                for (int sg = sg0; sg < sg1; ++sg) btb += seg_btb[((long)sg * r + d) * r + c];
-            } else {
-                btb = BtB[((long)i * r + d) * r + c];
-            }
-            q = (float)((double)btb * (double)CtC[d * r + c]);
+            q = (float)((double)btbv[d] * (double)ctc[d]);
             BtB[((long)i * r + d) * r + c] = q;
         }
         qcol[d] = q;
@@ -514,26 +561,19 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
             if (act && d < r) LinvA[((long)i * r + d) * r + c] = (float)col[d];
         return;
     }
-    float rhs = 0.f;
-    if (act) {
-        if (seg_rhs != nullptr) {
-            for (int sg = sg0; sg < sg1; ++sg) rhs += seg_rhs[(long)sg * r + c];
-            rhsA_out[(long)i * r + c] = rhs;  // keep the `rhses` by-product available
-        } else {
-            rhs = rhsA[(long)i * r + c];
-        }
-    }
+    const float rhs = act ? rhs_pre : 0.f;
+    if (act && seg_rhs != nullptr) rhsA_out[(long)i * r + c] = rhs;  // keep the `rhses` by-product available
     float z[MCL_MAX_REGS], u[MCL_MAX_REGS], thr[MCL_MAX_REGS];
 #pragma unroll
     for (int k = 0; k < MCL_MAX_REGS; ++k) {
         z[k] = u[k] = thr[k] = 0.f;
         if (k < n && act) {
-            z[k] = regs.aux[k][(long)i * r + c];
-            u[k] = regs.dual[k][(long)i * r + c];
+            z[k] = z_pre[k];
+            u[k] = u_pre[k];
         }
         if (k < n) thr[k] = regs.p0[k] / rho;
     }
-    float a = act ? A[(long)i * r + c] : 0.f;
+    float a = act ? a_pre : 0.f;
     const int n_it = (n == 0 && inner > 1) ? 1 : inner;
     for (int it = 0; it < n_it; ++it) {
         float s = 0.f;
@@ -606,7 +646,7 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
         for (int d = 0; d < RP; ++d) {
             const float ad = (d < r) ? readlane_f32(a, d) : 0.f;
             double v = (d == lane) ? 1.0 : 0.0;
-            if (act && d < r) v = (double)CtC[d * r + c] * (double)ad * (double)a;
+            if (act && d < r) v = (double)ctc[d] * (double)ad * (double)a;
             if (d == lane && act) trb = v;
             col[d] = v;
         }
@@ -964,7 +1004,8 @@ static int launch_C_fused_t(mcl_context *c) {
         vec = vec && ((reinterpret_cast<uintptr_t>(rs.aux[k]) & 15) == 0) && ((reinterpret_cast<uintptr_t>(rs.dual[k]) & 15) == 0);
     const int rpw = c->K <= 256 ? 16 : (c->K <= 512 ? 32 : 64);
     const int n_waves = (int)((c->K + rpw - 1) / rpw);
-    const size_t sm = sizeof(float) * (size_t)(c->r * c->r + c->K * c->r);
+    size_t sm = sizeof(float) * (size_t)(c->r * c->r + c->K * c->r);
+    if (NBR == 1) sm = ((sm + 7) & ~size_t(7)) + sizeof(double) * 256 * (size_t)n_waves;  // per-wave CtC slots
     int kct = 0;
     const int KC = mcl_xc_chunks(c, &kct);
 #define MCL_CF(VEC_)                                                                                                  \

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                 // (double buffer by hand); the scheduling barriers keep the compiler from hoisting every LDS read of the
                 // block to the top (register pressure: the M accumulators and the staging registers take half the file)
                 {
-                    constexpr int DB = (KS * NB == 1) ? 2 : 1;  // bigger variants have no registers left for a second buffer
+                    constexpr int DB = (KS * NB == 1 && NW == 4) ? 2 : 1;  // no registers left for a second buffer otherwise
                     f32x4 cf[DB][4][NB], fr[DB][4];
                     auto ld1 = [&](int sl, int kc) {
 #pragma unroll
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                 tick(3, t0);
                 // ---- (4) M += X_blk^T B_blk ; B^T B += B_blk^T B_blk
                 {
-                    constexpr int DB = (KS * NB == 1) ? 2 : 1;
+                    constexpr int DB = (KS * NB == 1 && NW == 4) ? 2 : 1;
                     f32x4 xa[DB][4];
                     auto ld4x = [&](int sl, int kb) {
 #pragma unroll
@@ -602,11 +602,8 @@ void mcl_sweep_geometry(const mcl_context *c, int *bsegs_per_wave, int *n_waves)
     *n_waves = (n + spw - 1) / spw;
 }
 
-template <int KS, int NB, int NREG>
-static int launch_sweep_t(mcl_context *c) {
-    // 4 waves per block, one per SIMD (register file); K = 256, r <= 16 has room for a second staging slot
-    constexpr int NW = 4;
-    constexpr int DEPTH = (KS * NB == 1) ? 2 : 1;
+template <int KS, int NB, int NREG, int NW, int DEPTH>
+static int launch_sweep_w(mcl_context *c) {
     const int n = c->bsegs.n_tiles;
     int bpb, n_waves;
     mcl_sweep_geometry(c, &bpb, &n_waves);
@@ -628,6 +625,14 @@ static int launch_sweep_t(mcl_context *c) {
     snprintf(buf, sizeof buf, "k_sweep<KS=%d,NB=%d,NREG=%d,DEPTH=%d,NW=%d>", KS, NB, NREG, DEPTH, NW);
     c->variant[3] = buf;
     return 0;
+}
+
+template <int KS, int NB, int NREG>
+static int launch_sweep_t(mcl_context *c) {
+    // 4 waves per block = one per SIMD (the kernel needs > 256 registers); K = 256, r <= 16 has room for a second
+    // staging slot.  (Measured: 8 leaner waves per block = two per SIMD run no faster - fp32 MFMA and VALU work of two
+    // waves do not co-execute (SQ_VALU_MFMA_COEXEC_CYCLES = 0) - and double the per-bseg partial traffic.)
+    return launch_sweep_w<KS, NB, NREG, 4, (KS * NB == 1) ? 2 : 1>(c);
 }
 
 int mcl_launch_sweep(mcl_context *c) {
