@@ -56,18 +56,20 @@ int64_t plan(mcl_context *c, char *base) {
     if (c->sweep_planned) {
         tm(c->bsegs, c->h_bseg_slab.size());
         c->slab_bseg_ptr = b.take<int>(I + 1);
-        c->Mpart = b.take<float>((int64_t)c->bsegs.n_tiles * K * 16 * c->NB);
+        c->Mpart = b.take<float>((int64_t)c->bsegs.n_tiles * mcl_sweep_KS(c) * 256 * 16 * c->NB);
         c->part_btb = b.take<float>((int64_t)c->bsegs.n_tiles * r * r);
-        c->GRpart = b.take<float>((int64_t)c->bsegs.n_tiles * (K * 16 * c->NB + 256 * c->NB * c->NB));
+        c->GRpart = b.take<float>((int64_t)c->bsegs.n_tiles * (mcl_sweep_KS(c) * 256 * 16 * c->NB + 256 * c->NB * c->NB));
+        c->CfragS = (K % 256 == 0) ? nullptr : b.take<float>((int64_t)mcl_sweep_KS(c) * 256 * 16 * c->NB);
         c->sweep_cycles = b.take<long long>((int64_t)2048 * 6);
     } else {
         c->bsegs = TileMap{};
-        c->slab_bseg_ptr = nullptr, c->Mpart = nullptr, c->part_btb = nullptr, c->GRpart = nullptr;
+        c->slab_bseg_ptr = nullptr, c->Mpart = nullptr, c->part_btb = nullptr, c->GRpart = nullptr, c->CfragS = nullptr;
     }
     c->ext_A = b.take<int>(2);
     c->ext_C = b.take<int>(2);
     c->XC = b.take<float>(N * r);
     c->Cfrag = b.take<float>((int64_t)xc_chunks(c) * 4 * c->NB * 256);
+    if (c->sweep_planned && K % 256 == 0) c->CfragS = c->Cfrag;  // same chunk count: one image serves both
     c->CtC = b.take<float>(r * r);
     c->rhoB = b.take<float>(I);
     c->LinvB = b.take<float>(I * r * r);
@@ -142,6 +144,20 @@ int ensure_xc(mcl_context *c) {
         }
         if (int rc = mcl_launch_contract_xc(c)) return rc;
         c->xc_valid = true;
+    }
+    return 0;
+}
+
+// fragment image of the current C for the sweep kernels
+int ensure_cfrag_sweep(mcl_context *c) {
+    if (c->CfragS == c->Cfrag) {
+        if (!c->cfrag_valid) {
+            if (int rc = mcl_launch_build_cfrag(c)) return rc;
+            c->cfrag_valid = true;
+        }
+    } else if (!c->cfrags_valid) {
+        if (int rc = mcl_launch_build_cfrag_sweep(c)) return rc;
+        c->cfrags_valid = true;
     }
     return 0;
 }
@@ -306,7 +322,7 @@ int mcl_set_factors(mcl_context *c, float *A, float *B, float *C) {
     c->A = A, c->B = B, c->C = C;
     c->has_factors = true;
     c->b_systems_valid = false;
-    c->cfrag_valid = false;
+    c->cfrag_valid = c->cfrags_valid = false;
     c->xc_valid = c->ctc_valid = c->e1_valid = false;
     c->mseg_valid = c->grpart_valid = false;
     c->diag_valid[0] = c->diag_valid[1] = c->diag_valid[2] = false;
@@ -391,7 +407,7 @@ int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
     MCL_CHECK_HIP(c, hipMemcpyAsync(c->ext_C, c->h_ext.data() + 2, 2 * sizeof(int), hipMemcpyHostToDevice, s));
     // the host vectors must outlive the async copies: they are members of the context
     c->has_workspace = true;
-    c->cfrag_valid = false;
+    c->cfrag_valid = c->cfrags_valid = false;
     c->mseg_valid = c->grpart_valid = false;
     c->xc_valid = c->ctc_valid = c->e1_valid = c->xsq_valid = false;
     c->diag_valid[0] = c->diag_valid[1] = c->diag_valid[2] = false;
@@ -453,10 +469,7 @@ int mcl_update_B(mcl_context *c) {
     if (mcl_sweep_eligible(c)) {
         // one pass over X: B-phase fused with the per-bseg X^T B / B^T B that the C- and A-phases need (sweep.hip)
         if (int rc = ensure_ctc(c)) return rc;
-        if (!c->cfrag_valid) {
-            if (int rc = mcl_launch_build_cfrag(c)) return rc;
-            c->cfrag_valid = true;
-        }
+        if (int rc = ensure_cfrag_sweep(c)) return rc;
         if (c->opt.constant_B)
             if (int rc = mcl_launch_B_rho(c)) return rc;
         if (int rc = mcl_B_factor(c)) return rc;
@@ -514,6 +527,7 @@ int mcl_update_C_finish(mcl_context *c) {
             c->b_systems_valid = false;
             c->ctc_valid = true;
             c->cfrag_valid = true;
+            c->cfrags_valid = false;
             c->diag_valid[2] = true;
             return 0;
         }
@@ -522,7 +536,7 @@ int mcl_update_C_finish(mcl_context *c) {
     if (int rc = mcl_launch_C_prepare(c)) return rc;
     if (c->opt.inner_n_iter_max <= 0) return 0;
     c->xc_valid = c->ctc_valid = c->e1_valid = false;
-    c->cfrag_valid = false;
+    c->cfrag_valid = c->cfrags_valid = false;
     c->b_systems_valid = false;
     if (mcl_mode_is_row_separable(c, 2)) {
         const int rc = mcl_launch_rows_fused(c, 2);
@@ -545,10 +559,7 @@ int mcl_A_begin(mcl_context *c) {
     c->seg_from_sweep = false;
     if (c->mseg_valid && !c->opt.constant_A && mcl_mode_is_row_separable(c, 0)) {
         // the sweep left M_i = X_i^T B_i per bseg: rhs_i = coldot(M_i, C), no pass over X
-        if (!c->cfrag_valid) {
-            if (int rc = mcl_launch_build_cfrag(c)) return rc;
-            c->cfrag_valid = true;
-        }
+        if (int rc = ensure_cfrag_sweep(c)) return rc;
         if (int rc = mcl_launch_A_rhs_from_M(c)) return rc;
         c->use_seg_gram = true;
         c->seg_from_sweep = true;
@@ -635,7 +646,7 @@ int mcl_C_begin(mcl_context *c) {
 int mcl_C_solve(mcl_context *c) {
     if (int rc = ready(c)) return rc;
     c->xc_valid = c->ctc_valid = c->e1_valid = false;
-    c->cfrag_valid = false;
+    c->cfrag_valid = c->cfrags_valid = false;
     c->b_systems_valid = false;
     c->diag_valid[2] = false;
     return mcl_launch_rows_solve(c, 2);
@@ -644,7 +655,7 @@ int mcl_C_solve(mcl_context *c) {
 int mcl_C_end(mcl_context *c) {
     if (int rc = ready(c)) return rc;
     c->xc_valid = c->ctc_valid = c->e1_valid = false;
-    c->cfrag_valid = false;
+    c->cfrag_valid = c->cfrags_valid = false;
     c->b_systems_valid = false;
     c->diag_valid[2] = false;
     return 0;

@@ -55,11 +55,11 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                                                const float *__restrict__ LinvB, float *__restrict__ Bout, RegSet regs,
                                                const int *__restrict__ bs_slab, const int *__restrict__ bs_row0,
                                                const int *__restrict__ bs_nrows, int n_bsegs, int bsegs_per_wave,
-                                               int r, int inner, float *__restrict__ Mpart,
+                                               int K, int r, int inner, float *__restrict__ Mpart,
                                                float *__restrict__ part_btb, float *__restrict__ GRpart,
                                                double *__restrict__ diag_block, int dbg,
                                                long long *__restrict__ cyc_out) {
-    constexpr int KW = 256 * KS;   // floats per tile row (= K)
+    constexpr int KW = 256 * KS;   // floats per tile row: K rounded up to 256 (K % 4 == 0, K <= KW)
     constexpr int KC = 4 * KS;     // 64-column chunks
     constexpr int W = 16 * NB;
     constexpr int MS = KW * W;     // floats per M partial
@@ -72,7 +72,6 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
     constexpr int NT = 64 * NW;    // threads per block
     float *Cs = lds_dyn + NW * 16 * KW;  // C in fragment order: LDS reads count on lgkmcnt, so they never force the
                                         // in-flight X prefetch (vmcnt, in-order) to drain the way global loads would
-    const int K = KW;
 
     // LDS addressing: the XOR swizzle only touches the low 4 bits of the 16-byte slot index, so every access is one of
     // a few per-lane bases plus a COMPILE-TIME offset (ds_read/ds_write immediate) - no per-access address registers.
@@ -177,6 +176,12 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
 
             const long base = row0 + wr0;
             const unsigned lane4 = 4u * (unsigned)lane;
+            // column offset of this lane in super-chunk sc, clamped into the row when K is not a multiple of 256: the
+            // padding columns then hold copies of real (finite) data that only ever meet zero C fragments, and the rows
+            // of M they produce (k >= K) are never read
+            unsigned xcol[KS];
+#pragma unroll
+            for (int sc = 0; sc < KS; ++sc) xcol[sc] = (unsigned)min(256 * sc + 4 * lane, K - 4);
             f32x4 xr[DEPTH][KS][16];
             f32x4 zs[DEPTH][NR][NB], us[DEPTH][NR][NB];  // aux / dual rows of the slot's block, updated IN PLACE
             // Stage block `blk` of this wave into ring slot d.  Every load is unconditional (rows clamped into the
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {
                         const long j = base + min(16 * blk + t, wn - 1);
-                        xr[d][sc][t] = *reinterpret_cast<const f32x4 *>(X + uniform_off(j * K + 256 * sc) + lane4);
+                        xr[d][sc][t] = *reinterpret_cast<const f32x4 *>(X + uniform_off(j * K) + xcol[sc]);
                     }
             };
             // aux / dual rows go straight into the registers the inner loop works on.  They are issued AFTER the slot's
@@ -566,12 +571,14 @@ __global__ __launch_bounds__(256) void k_A_rhs_from_M(const float *__restrict__ 
 // =========================================================================================================
 // host side
 // =========================================================================================================
-// Shapes the sweep kernel is instantiated for: K in {256, 512} (tile = K floats per row, LDS), K * NB <= 512
-// (accumulator registers), r % 4 == 0 (16-byte row accesses), 16-byte aligned operands.
+// Shapes the sweep kernel is instantiated for: K <= 512 and K % 4 == 0 (tile rows of 256 or 512 floats in LDS, 16-byte
+// row accesses; other K are zero-padded through the C fragments), Kpad * NB <= 512 (accumulator registers), r % 4 == 0.
+int mcl_sweep_KS(const mcl_context *c) { return (int)((c->K + 255) / 256); }
+
 bool mcl_sweep_shape_ok(const mcl_context *c) {
     if (getenv("MCL_NO_SWEEP")) return false;
-    if (c->K != 256 && c->K != 512) return false;
-    if (c->NB > 2 || c->K * c->NB > 512) return false;
+    if (c->K < 4 || c->K > 512 || c->K % 4 != 0) return false;
+    if (c->NB > 2 || mcl_sweep_KS(c) * c->NB > 2) return false;
     if (c->r % 4 != 0) return false;
     if (c->N == 0 || c->I == 0) return false;
     if (c->N / c->I < 64) return false;  // tiny slabs: the per-bseg flush would dominate
@@ -589,7 +596,7 @@ bool mcl_sweep_eligible(const mcl_context *c) {
     return true;
 }
 
-static inline int sweep_MS(const mcl_context *c) { return (int)c->K * 16 * c->NB; }
+static inline int sweep_MS(const mcl_context *c) { return mcl_sweep_KS(c) * 256 * 16 * c->NB; }
 
 // waves of the sweep: `bsegs_per_wave` consecutive bsegs each; 1024 waves = one per SIMD (the register file and the LDS
 // tiles allow one or two).  n_waves is rounded up to whole blocks by the launcher (idle waves have an empty range).
@@ -614,8 +621,9 @@ static int launch_sweep_w(mcl_context *c) {
         (void)hipGetLastError();
         return -1;  // caller falls back to the two-pass path
     }
-    hipLaunchKernelGGL((k_sweep<KS, NB, NREG, DEPTH, NW>), dim3(grid), dim3(64 * NW), sm, c->stream, c->X, c->Cfrag, c->A,
-                       c->rhoB, c->LinvB, c->B, c->regs[1], c->bsegs.slab, c->bsegs.row0, c->bsegs.nrows, n, bpb, c->r,
+    hipLaunchKernelGGL((k_sweep<KS, NB, NREG, DEPTH, NW>), dim3(grid), dim3(64 * NW), sm, c->stream, c->X, c->CfragS, c->A,
+                       c->rhoB, c->LinvB, c->B, c->regs[1], c->bsegs.slab, c->bsegs.row0, c->bsegs.nrows, n, bpb, (int)c->K,
+                       c->r,
                        c->opt.inner_n_iter_max, c->Mpart, c->part_btb, c->GRpart, c->diagB_tile,
                        getenv("MCL_SWEEP_DBG") ? atoi(getenv("MCL_SWEEP_DBG")) : 0, c->sweep_cycles);
     MCL_CHECK_HIP(c, hipGetLastError());
@@ -637,7 +645,7 @@ static int launch_sweep_t(mcl_context *c) {
 
 int mcl_launch_sweep(mcl_context *c) {
     ProfScope prof(c, 3);
-    const int ks = (int)(c->K / 256), n = c->regs[1].n;
+    const int ks = mcl_sweep_KS(c), n = c->regs[1].n;
 #define MCL_SW(KS_, NB_)                                  \
     switch (n) {                                          \
         case 0: return launch_sweep_t<KS_, NB_, 0>(c);    \
@@ -652,6 +660,30 @@ int mcl_launch_sweep(mcl_context *c) {
 #undef MCL_SW
 }
 
+// C in fragment order with 4 * KS chunks (the image k_sweep copies into LDS and k_A_rhs_from_M multiplies with).  For
+// K % 256 == 0 it IS the image of the X C kernels (CfragS aliases Cfrag, kept current by k_C_finish_fused).
+__global__ void k_build_cfrag_sweep(const float *__restrict__ C, int K, int r, int KC, int NB, float *__restrict__ Cfrag) {
+    const long total = (long)KC * 4 * NB * 256;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int m = idx & 3, lane = (idx >> 2) & 63;
+    long t = idx >> 8;
+    const int nb = t % NB;
+    t /= NB;
+    const int kq = t & 3, kc = t >> 2;
+    const int k = 64 * kc + 16 * kq + 4 * (lane >> 4) + m, col = 16 * nb + (lane & 15);
+    Cfrag[idx] = (k < K && col < r) ? C[(long)k * r + col] : 0.f;
+}
+
+int mcl_launch_build_cfrag_sweep(mcl_context *c) {
+    const int KC = 4 * mcl_sweep_KS(c);
+    const long total = (long)KC * 4 * c->NB * 256;
+    hipLaunchKernelGGL(k_build_cfrag_sweep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->C, (int)c->K,
+                       c->r, KC, c->NB, c->CfragS);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
 int mcl_launch_reduce_weighted(mcl_context *c) {
     const int MS = sweep_MS(c), W = 16 * c->NB;
     const int blocks = (MS + W * W + 63) / 64;
@@ -662,7 +694,7 @@ int mcl_launch_reduce_weighted(mcl_context *c) {
 }
 
 int mcl_launch_A_rhs_from_M(mcl_context *c) {
-    hipLaunchKernelGGL(k_A_rhs_from_M, dim3(c->bsegs.n_tiles), dim3(256), 0, c->stream, c->Mpart, c->Cfrag, sweep_MS(c),
+    hipLaunchKernelGGL(k_A_rhs_from_M, dim3(c->bsegs.n_tiles), dim3(256), 0, c->stream, c->Mpart, c->CfragS, sweep_MS(c),
                        c->NB, c->r, c->seg_rhs);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;

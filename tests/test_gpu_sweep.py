@@ -24,6 +24,12 @@ CASES = {
                       [[NN], [{"kind": "l1", "reg_strength": 0.05, "non_negativity": True}], [NN]], (False, False)),
     "k256_r8_constant": ([2100, 1024, 64], 256, 8, [[NN], [NN], [NN]], (True, True)),
     "k256_r16_constant_B": ([260, 100, 99, 515], 256, 16, [[NN], [NN], [NN]], (False, True)),
+    # K that is not a multiple of 256: tile rows padded through zero C fragments
+    "k128_r8_nn": ([256, 256, 100, 77], 128, 8, [[NN], [NN], [NN]], (False, False)),
+    "k200_r16_box": ([150, 400, 260, 96], 200, 16, [[NN], [{"kind": "box", "min_val": 0.0, "max_val": 1.5}], [NN]], (False, False)),
+    "k300_r12_nn": ([150, 400, 260, 96], 300, 12, [[NN], [NN], [NN]], (False, False)),
+    "k36_r4_none": ([90, 200, 64], 36, 4, [[NN], [], [NN]], (False, False)),
+    "k508_r16_nn": ([130, 222, 97], 508, 16, [[NN], [NN], [NN]], (False, False)),
     # bsegs shorter than one 16-row block, ragged tails, a slab of exactly one block
     "k256_ragged_tails": ([70, 130, 33, 257, 64, 16, 401, 15, 17, 300], 256, 16, [[NN], [NN], [NN]], (False, False)),
 }
@@ -81,12 +87,16 @@ def test_one_iteration_phase_by_phase(name):
         rec = np.sqrt(max(0.0, d[E.DIAG_X_SQ] - 2 * d[E.DIAG_INNER] + d[E.DIAG_MODEL_SQ]) / d[E.DIAG_X_SQ])
         errs["rec"] = abs(rec - ref.rec_error_from_A_byproducts()) / ref.rec_error_from_A_byproducts()
         errs["normB"] = abs(d[E.DIAG_NORM_SQ + 1] - np.sum(ref.B ** 2)) / np.sum(ref.B ** 2)
-        bad = {k: v for k, v in errs.items() if not (v < 1e-5)}
+        # a mode without penalties has un-shifted, possibly ill-conditioned normal equations that amplify every fp32
+        # rounding (see test_gpu_end_to_end.test_scale_parity_vs_oracle): 1e-4 there, 1e-5 everywhere else
+        tol = 1e-4 if any(len(m) == 0 for m in st.regs) else 1e-5
+        bad = {k: v for k, v in errs.items() if not (v < tol)}
         assert not bad, (name, it, bad)
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["k256_r16_nn", "k512_r12_l1_box", "k256_ragged_tails", "k256_r8_constant"])
+@pytest.mark.parametrize("name", ["k256_r16_nn", "k512_r12_l1_box", "k256_ragged_tails", "k256_r8_constant", "k128_r8_nn",
+                                  "k300_r12_nn"])
 def test_trajectory_vs_oracle(name):
     from tests.test_gpu_end_to_end import _compare, _run_both
 
@@ -160,7 +170,8 @@ def test_by_products_are_not_reused_out_of_order():
 def test_shapes_without_a_sweep_instantiation_keep_the_two_pass_path():
     from oracle import aoadmm_oracle as orc
 
-    for J, K, r in (([300, 200], 128, 8), ([300, 200], 1024, 16), ([300, 200], 256, 6), ([20, 30, 10, 25], 256, 16)):
+    for J, K, r in (([300, 200], 130, 8), ([300, 200], 1024, 16), ([300, 200], 256, 6), ([20, 30, 10, 25], 256, 16),
+                    ([300, 200], 516, 16), ([300, 200], 512, 32)):
         X, row_ptr = orc.synthetic_problem(len(J), np.array(J), K, r, seed=0, dtype=np.float64)
         st = orc.random_state_for(X, row_ptr, r, [[NN], [NN], [NN]], seed=1)
         eng = engine_from_oracle_state(st)
