@@ -35,13 +35,68 @@ static __device__ __forceinline__ void gj_inverse_reg(double (&col)[RP], int r, 
             double cp[RP];
 #pragma unroll
             for (int i = 0; i < RP; ++i) cp[i] = readlane_f64(col[i], p);  // M[i][p]
-            const double piv = 1.0 / cp[p];
+            // 1 / pivot by v_rcp_f64 + two Newton steps (full double precision for the positive pivots of an SPD
+            // system; the IEEE division sequence is a third of the step's latency)
+            double piv = __builtin_amdgcn_rcp(cp[p]);
+            piv = fma(fma(-cp[p], piv, 1.0), piv, piv);
+            piv = fma(fma(-cp[p], piv, 1.0), piv, piv);
             const double myp = (lane == p) ? piv : col[p] * piv;  // scaled pivot-row entry of this column
 #pragma unroll
             for (int i = 0; i < RP; ++i) {
                 if (i != p) col[i] = (lane == p) ? -cp[i] * piv : col[i] - cp[i] * myp;
             }
             col[p] = myp;
+        }
+    }
+}
+
+// The same Gauss-Jordan with the ROWS of every column split over G = 64 / RP lane groups (RP = 16: 4 groups x 4 rows),
+// so that all 64 lanes work instead of RP: lane l = g * RP + c holds col[j] = M[g * RL + j][c], j < RL = RP / G.
+// Per pivot p the step needs M[i][p] for the lane's own rows (from lane g * RP + p: ds_bpermute, no LDS memory), the
+// pivot-row entry M[p][c] (from lane pg * RP + c) and the pivot itself (v_readlane, uniform): 2 (RL + 1) permutes and
+// RL updates instead of 2 RP readlanes and RP updates - about 4x shorter for RP = 16.
+template <int RP>
+struct GJRows {
+    static constexpr int G = (64 / RP < RP) ? 64 / RP : RP;  // lane groups
+    static constexpr int RL = RP / G;                        // rows per lane
+    static constexpr int LANES = RP * G;
+};
+
+static __device__ __forceinline__ double bperm_f64(int src_lane, double v) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+static __device__ __forceinline__ float bperm_f32(int src_lane, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+
+template <int RP>
+static __device__ __forceinline__ void gj_inverse_rows(double (&col)[GJRows<RP>::RL], int r, int lane) {
+    constexpr int RL = GJRows<RP>::RL;
+    const int c = lane % RP, g = lane / RP;
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+        if (p < r) {  // wave-uniform
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int pg = p / RL, pj = p % RL;
+            const double pivot = readlane_f64(col[pj], pg * RP + p);
+            double cp[RL];
+#pragma unroll
+            for (int j = 0; j < RL; ++j) cp[j] = bperm_f64(g * RP + p, col[j]);  // M[g RL + j][p]
+            const double prow = bperm_f64(pg * RP + c, col[pj]);                  // M[p][c]
+            double piv = __builtin_amdgcn_rcp(pivot);
+            piv = fma(fma(-pivot, piv, 1.0), piv, piv);
+            piv = fma(fma(-pivot, piv, 1.0), piv, piv);
+            const double myp = (c == p) ? piv : prow * piv;
+#pragma unroll
+            for (int j = 0; j < RL; ++j) {
+                const bool is_p = (g == pg) && (j == pj);
+                const double upd = (c == p) ? -cp[j] * piv : col[j] - cp[j] * myp;
+                col[j] = is_p ? myp : upd;
+            }
         }
     }
 }
@@ -347,32 +402,40 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     constexpr int RP = 16 * NBR;
     if (wave == 0) {
-        // all loads of the system in flight at once (clamped indices, masked at use); the trace is summed in the same
-        // order as a serial loop (lane 0 reads the diagonal entries through v_readlane)
-        const bool act = lane < r;
-        const int cl = act ? lane : 0;
-        float g[RP];
-#pragma unroll
-        for (int d = 0; d < RP; ++d) g[d] = GR[(d < r ? d : r - 1) * r + cl];
+        // system in the row-split layout of GJRows<RP> (lane = g * RP + c holds rows g * RL + j of column c): all loads in
+        // flight at once (clamped indices, masked at use), all 64 lanes busy in the Gauss-Jordan
+        constexpr int RL = GJRows<RP>::RL;
+        const int cc = lane % RP, g = lane / RP;
+        const bool act = cc < r;
+        const int cl = act ? cc : 0;
+        float gv[RL];
         double tr = 0.0;
 #pragma unroll
-        for (int d = 0; d < RP; ++d)
-            if (d < r) tr += (double)readlane_f32(g[d], d);  // G[d][d], wave-uniform
+        for (int j = 0; j < RL; ++j) {
+            const int d = g * RL + j;
+            gv[j] = GR[(d < r ? d : r - 1) * r + cl];
+        }
+#pragma unroll
+        for (int j = 0; j < RL; ++j)
+            if (act && g * RL + j == cc) tr = (double)gv[j];
+        tr = wave_sum(tr);
         const float rho = (float)(0.5 * tr * scale);
         const double shift = (double)rho * NREG + (double)l2;
-        double col[RP];
+        double col[RL];
 #pragma unroll
-        for (int d = 0; d < RP; ++d) {
-            double v = (d == lane) ? 1.0 : 0.0;
-            if (act && d < r) v = (double)g[d] + (d == lane ? shift : 0.0);
-            col[d] = v;
+        for (int j = 0; j < RL; ++j) {
+            const int d = g * RL + j;
+            double v = (d == cc) ? 1.0 : 0.0;
+            if (act && d < r) v = (double)gv[j] + (d == cc ? shift : 0.0);
+            col[j] = v;
         }
-        gj_inverse_reg<RP>(col, r, lane);
+        gj_inverse_rows<RP>(col, r, lane);
 #pragma unroll
-        for (int d = 0; d < RP; ++d) {
+        for (int j = 0; j < RL; ++j) {
+            const int d = g * RL + j;
             if (act && d < r) {
-                Ls[d * r + lane] = (float)col[d];
-                LinvC[d * r + lane] = (float)col[d];
+                Ls[d * r + cc] = (float)col[j];
+                LinvC[d * r + cc] = (float)col[j];
             }
         }
         if (lane == 0) {
@@ -662,6 +725,209 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
 #pragma unroll
         for (int d = 0; d < RP; ++d)
             if (act && d < r) LinvB[((long)i * r + d) * r + c] = (float)col[d];
+        if (lane == 0) rhoB[i] = rb;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_A_finish with the rows of every system split over the lane groups of GJRows<RP> (all 64 lanes busy; the Gauss-Jordan
+// sweeps, the matrix-vector products of the inner loop and of the error terms are ~4x shorter for rank 9..16).
+// Lane l = g * RP + c: column c, rows d = g * RL + j.  Per-column quantities (rhs, a, aux, dual) are replicated in
+// every group; group 0 stores them.  Same arithmetic as k_A_finish up to the association of the fp64 sums over d.
+// ---------------------------------------------------------------------------------------------------------
+template <int RP>
+__global__ __launch_bounds__(256) void k_A_finish_rows(const float *__restrict__ rhsA, float *__restrict__ BtB,
+                                                       const float *__restrict__ CtC, int I, int r, float scale,
+                                                       float l2, int constant, const float *__restrict__ rho_max,
+                                                       float *__restrict__ rhoA, float *__restrict__ LinvA,
+                                                       float *__restrict__ A, RegSet regs, int inner, int fused_inner,
+                                                       double *__restrict__ e1, double *__restrict__ diag_row,
+                                                       int next_B, float l2_B, int n_regs_B, float *__restrict__ rhoB,
+                                                       float *__restrict__ LinvB, const int *__restrict__ slab_seg_ptr,
+                                                       const float *__restrict__ seg_rhs,
+                                                       const float *__restrict__ seg_btb, float *__restrict__ rhsA_out) {
+    constexpr int RL = GJRows<RP>::RL, G = GJRows<RP>::G;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= I) return;
+    const int cc = lane % RP, g = lane / RP;
+    const bool in_range = lane < GJRows<RP>::LANES;  // RP = 4 uses 16 lanes only
+    const bool act = in_range && cc < r;
+    const bool lead = act && g == 0;                 // the lanes that own the per-column results
+    const int c = act ? cc : 0;
+    int drow[RL];
+    bool dok[RL];
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {
+        const int d = (in_range ? g : 0) * RL + j;
+        dok[j] = act && d < r;
+        drow[j] = d < r ? d : r - 1;  // clamped: every load is unconditional
+    }
+    int sg0 = 0, sg1 = 0;
+    if (seg_btb != nullptr) {
+        sg0 = slab_seg_ptr[i];
+        sg1 = slab_seg_ptr[i + 1];
+    }
+    // all global loads up front
+    float ctc[RL], btbv[RL];
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {
+        ctc[j] = CtC[drow[j] * r + c];
+        btbv[j] = (seg_btb != nullptr) ? 0.f : BtB[((long)i * r + drow[j]) * r + c];
+    }
+    float rhs_pre = (seg_rhs != nullptr) ? 0.f : rhsA[(long)i * r + c];
+    float z[MCL_MAX_REGS], u[MCL_MAX_REGS], thr[MCL_MAX_REGS];
+    const int n = regs.n;
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k) {
+        z[k] = u[k] = 0.f;
+        if (k < n) {
+            z[k] = regs.aux[k][(long)i * r + c];
+            u[k] = regs.dual[k][(long)i * r + c];
+        }
+    }
+    float a = A[(long)i * r + c];
+    if (seg_btb != nullptr) {  // per-segment partial Grams / right-hand sides of this slab, fixed order
+        for (int sg = sg0; sg < sg1; ++sg) {
+            float v[RL];
+#pragma unroll
+            for (int j = 0; j < RL; ++j) v[j] = seg_btb[((long)sg * r + drow[j]) * r + c];
+            const float rv = seg_rhs[(long)sg * r + c];
+#pragma unroll
+            for (int j = 0; j < RL; ++j) btbv[j] += v[j];
+            rhs_pre += rv;
+        }
+    }
+    float qf[RL];
+    double tr = 0.0;
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {
+        float q = 0.f;
+        if (dok[j]) {
+            q = (float)((double)btbv[j] * (double)ctc[j]);
+            BtB[((long)i * r + drow[j]) * r + c] = q;
+            if (drow[j] == c) tr = (double)q;
+        }
+        qf[j] = q;
+    }
+    tr = wave_sum(tr);
+    float rho = (float)(0.5 * tr * scale);
+    if (constant) rho = rho_max[1];
+    const double shift = (double)rho * n + (double)l2;
+    double col[RL];
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {
+        const int d = g * RL + j;
+        double v = (d == cc) ? 1.0 : 0.0;  // identity padding (also for the idle lanes of RP = 4)
+        if (dok[j]) v = (double)qf[j] + (d == cc ? shift : 0.0);
+        col[j] = v;
+    }
+    gj_inverse_rows<RP>(col, r, in_range ? lane : cc);
+    if (lane == 0) rhoA[i] = rho;
+    if (!fused_inner) {
+#pragma unroll
+        for (int j = 0; j < RL; ++j)
+            if (dok[j]) LinvA[((long)i * r + drow[j]) * r + c] = (float)col[j];
+        return;
+    }
+    const float rhs = act ? rhs_pre : 0.f;
+    if (lead && seg_rhs != nullptr) rhsA_out[(long)i * r + c] = rhs;
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k) {
+        if (!(k < n && act)) z[k] = u[k] = 0.f;
+        thr[k] = (k < n) ? regs.p0[k] / rho : 0.f;
+    }
+    if (!act) a = 0.f;
+    // sum over the G row groups of one column: lanes c, RP + c, ... (fixed association)
+    auto group_sum = [&](double v) -> double {
+#pragma unroll
+        for (int o = RP; o < 64 && o < RP * G; o <<= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    const int n_it = (n == 0 && inner > 1) ? 1 : inner;
+    for (int it = 0; it < n_it; ++it) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k)
+            if (k < n) sacc += z[k] - u[k];
+        const float t = (n > 0) ? fmaf(rho, sacc, rhs) : rhs;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {
+            const float td = bperm_f32(g * RP + g * RL + j, t);  // t_d, d = g RL + j (column d of my own group)
+            if (g * RL + j < r) acc += (double)td * col[j];
+        }
+        a = (float)group_sum(acc);
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) {
+            if (k < n) {
+                const float y = a + u[k];
+                const float zn = prox_elem(regs.kind[k], regs.nonneg[k], regs.p0[k], regs.p1[k], thr[k], y);
+                u[k] = a - (zn - u[k]);
+                z[k] = zn;
+            }
+        }
+    }
+    if (!act) a = 0.f;
+    if (lead) {
+        A[(long)i * r + c] = a;
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) {
+            if (k < n) {
+                regs.aux[k][(long)i * r + c] = z[k];
+                regs.dual[k][(long)i * r + c] = u[k];
+            }
+        }
+    }
+    // <X_i, M_i> = rhs_i . a_i ;  ||M_i||^2 = a_i^T Q_i a_i
+    float ad[RL];
+    double qa = 0.0;
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {
+        ad[j] = bperm_f32(g * RP + g * RL + j, a);  // a_d
+        if (g * RL + j < r) qa += (double)qf[j] * (double)ad[j];
+    }
+    qa = group_sum(qa);
+    const double inner_i = wave_sum(lead ? (double)rhs * (double)a : 0.0);
+    const double model_i = wave_sum(lead ? (double)a * qa : 0.0);
+    const double nf = wave_sum(lead ? (double)a * (double)a : 0.0);
+    const double na = wave_sum(lead ? fabs((double)a) : 0.0);
+    double gap[MCL_MAX_REGS];
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k) {
+        const double dlt = (lead && k < n) ? (double)z[k] - (double)a : 0.0;
+        gap[k] = wave_sum(dlt * dlt);
+    }
+    if (lane == 0) {
+        e1[2 * i] = inner_i;
+        e1[2 * i + 1] = model_i;
+        double *o = diag_row + (long)i * DIAG_COLS;
+        o[0] = nf;
+        o[1] = na;
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) o[2 + k] = gap[k];
+    }
+    if (next_B) {
+        // systems of the next B-phase: L_i = CtC o a_i a_i^T + (rho_i n_B + l2_B) I (decomposition.py:243-256)
+        double trb = 0.0;
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {
+            const int d = g * RL + j;
+            double v = (d == cc) ? 1.0 : 0.0;
+            if (dok[j]) v = (double)ctc[j] * (double)ad[j] * (double)a;
+            if (dok[j] && d == cc) trb = v;
+            col[j] = v;
+        }
+        trb = wave_sum(trb);
+        const float rb = (float)(0.5 * trb * scale);
+        const double shiftb = (double)rb * n_regs_B + (double)l2_B;
+#pragma unroll
+        for (int j = 0; j < RL; ++j)
+            if (dok[j] && g * RL + j == cc) col[j] += shiftb;
+        gj_inverse_rows<RP>(col, r, in_range ? lane : cc);
+#pragma unroll
+        for (int j = 0; j < RL; ++j)
+            if (dok[j]) LinvB[((long)i * r + drow[j]) * r + c] = (float)col[j];
         if (lane == 0) rhoB[i] = rb;
     }
 }
@@ -1064,13 +1330,24 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     const int next_B = (fused_inner && !c->opt.constant_B && !getenv("MCL_NO_NEXT_B")) ? 1 : 0;
     const bool seg = c->use_seg_gram;
     dim3 grid((unsigned)((c->I + 3) / 4)), block(256);
-    DISPATCH_RP_T(c, k_A_finish, grid, block, c->rhsA, c->BtB, c->CtC, (int)c->I, c->r,
-                  (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[0], c->opt.constant_A, c->rho_max,
-                  c->rhoA, c->LinvA, c->A, c->regs[0], c->opt.inner_n_iter_max, fused_inner ? 1 : 0, c->e1,
-                  c->diagA_row, next_B, (float)c->opt.l2_penalty[1], c->regs[1].n, c->rhoB, c->LinvB,
-                  (const int *)(c->seg_from_sweep ? c->slab_bseg_ptr : c->slab_seg_ptr),
-                  (const float *)(seg ? c->seg_rhs : nullptr),
-                  (const float *)(seg ? (c->seg_from_sweep ? c->part_btb : c->seg_btb) : nullptr), c->rhsA);
+#define MCL_AF_ARGS                                                                                                   \
+    c->rhsA, c->BtB, c->CtC, (int)c->I, c->r, (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[0],   \
+        c->opt.constant_A, c->rho_max, c->rhoA, c->LinvA, c->A, c->regs[0], c->opt.inner_n_iter_max,                  \
+        fused_inner ? 1 : 0, c->e1, c->diagA_row, next_B, (float)c->opt.l2_penalty[1], c->regs[1].n, c->rhoB, c->LinvB, \
+        (const int *)(c->seg_from_sweep ? c->slab_bseg_ptr : c->slab_seg_ptr),                                        \
+        (const float *)(seg ? c->seg_rhs : nullptr),                                                                  \
+        (const float *)(seg ? (c->seg_from_sweep ? c->part_btb : c->seg_btb) : nullptr), c->rhsA
+    // ranks 5..32: rows of every system split over the lane groups (all 64 lanes busy); 64 columns fill the wave anyway
+    if (c->RP == 64 || c->RP == 4 || getenv("MCL_A_FINISH_COLS")) {
+        DISPATCH_RP_T(c, k_A_finish, grid, block, MCL_AF_ARGS);
+    } else if (c->RP == 8) {
+        hipLaunchKernelGGL((k_A_finish_rows<8>), grid, block, 0, c->stream, MCL_AF_ARGS);
+    } else if (c->RP == 16) {
+        hipLaunchKernelGGL((k_A_finish_rows<16>), grid, block, 0, c->stream, MCL_AF_ARGS);
+    } else {
+        hipLaunchKernelGGL((k_A_finish_rows<32>), grid, block, 0, c->stream, MCL_AF_ARGS);
+    }
+#undef MCL_AF_ARGS
     MCL_CHECK_HIP(c, hipGetLastError());
     c->b_systems_valid = (next_B != 0);
     return 0;
