@@ -49,7 +49,7 @@ static __device__ __forceinline__ long uniform_off(long v) {
     return (long)(((unsigned long long)hi << 32) | lo);
 }
 
-template <int KS, int NB, int NREG, int DEPTH, int NW>
+template <int KS, int NB, int NREG, int DEPTH, int NW, bool VEC>
 __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, const float *__restrict__ Cfrag,
                                                const float *__restrict__ A, const float *__restrict__ rhoB,
                                                const float *__restrict__ LinvB, float *__restrict__ Bout, RegSet regs,
@@ -170,8 +170,10 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
             bool zok[NB];
 #pragma unroll
             for (int h = 0; h < NB; ++h) {
-                zok[h] = (16 * h + 4 * q) < r;          // r % 4 == 0: a lane's 4 columns are all valid or all padding
-                zcol[h] = min(16 * h + 4 * q, r - 4);   // clamped: every load is unconditional
+                // VEC (r % 4 == 0): a lane's 4 columns are all valid or all padding, one 16-byte access; otherwise 4 scalar
+                // accesses with per-element clamps / guards
+                zok[h] = (16 * h + 4 * q) < r;
+                zcol[h] = VEC ? min(16 * h + 4 * q, r - 4) : 16 * h + 4 * q;  // clamped: every load is unconditional
             }
 
             const long base = row0 + wr0;
@@ -209,8 +211,17 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                 for (int k = 0; k < NREG; ++k)
 #pragma unroll
                     for (int h = 0; h < NB; ++h) {
-                        zs[d][k][h] = *reinterpret_cast<const f32x4 *>(regs.aux[k] + jr * r + zcol[h]);
-                        us[d][k][h] = *reinterpret_cast<const f32x4 *>(regs.dual[k] + jr * r + zcol[h]);
+                        if (VEC) {
+                            zs[d][k][h] = *reinterpret_cast<const f32x4 *>(regs.aux[k] + jr * r + zcol[h]);
+                            us[d][k][h] = *reinterpret_cast<const f32x4 *>(regs.dual[k] + jr * r + zcol[h]);
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const int cv = min(zcol[h] + v, r - 1);
+                                zs[d][k][h][v] = regs.aux[k][jr * r + cv];
+                                us[d][k][h][v] = regs.dual[k][jr * r + cv];
+                            }
+                        }
                     }
             };
             // the scheduling barriers pin the queue order slot 0 | slot 1: the loop-head s_waitcnt vmcnt(N) is ONE
@@ -340,13 +351,26 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                     const bool live = ok && zok[h];
                     const int col = 16 * h + 4 * q;
                     if (live && !(dbg & 8)) {
-                        *reinterpret_cast<f32x4 *>(Bout + j * r + col) = f[h];
+                        if (VEC) {
+                            *reinterpret_cast<f32x4 *>(Bout + j * r + col) = f[h];
 #pragma unroll
-                        for (int k = 0; k < NREG; ++k) {
-                            *reinterpret_cast<f32x4 *>(regs.aux[k] + j * r + col) = z[k][h];
-                            *reinterpret_cast<f32x4 *>(regs.dual[k] + j * r + col) = u[k][h];
+                            for (int k = 0; k < NREG; ++k) {
+                                *reinterpret_cast<f32x4 *>(regs.aux[k] + j * r + col) = z[k][h];
+                                *reinterpret_cast<f32x4 *>(regs.dual[k] + j * r + col) = u[k][h];
+                            }
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                if (col + v < r) {
+                                    Bout[j * r + col + v] = f[h][v];
+#pragma unroll
+                                    for (int k = 0; k < NREG; ++k) {
+                                        regs.aux[k][j * r + col + v] = z[k][h][v];
+                                        regs.dual[k][j * r + col + v] = u[k][h][v];
+                                    }
+                                }
                         }
-                        // 4-term partial sums in fp32, accumulated across blocks in fp64
+                        // 4-term partial sums in fp32, accumulated across blocks in fp64 (f is exactly 0 in padding columns)
                         float s_nf = 0.f, s_na = 0.f, s_gap[NR];
 #pragma unroll
                         for (int k = 0; k < NR; ++k) s_gap[k] = 0.f;
@@ -356,7 +380,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                             s_na += fabsf(f[h][v]);
 #pragma unroll
                             for (int k = 0; k < NREG; ++k) {
-                                const float dlt = z[k][h][v] - f[h][v];
+                                const float dlt = (VEC || col + v < r) ? z[k][h][v] - f[h][v] : 0.f;
                                 s_gap[k] = fmaf(dlt, dlt, s_gap[k]);
                             }
                         }
@@ -572,14 +596,13 @@ __global__ __launch_bounds__(256) void k_A_rhs_from_M(const float *__restrict__ 
 // host side
 // =========================================================================================================
 // Shapes the sweep kernel is instantiated for: K <= 512 and K % 4 == 0 (tile rows of 256 or 512 floats in LDS, 16-byte
-// row accesses; other K are zero-padded through the C fragments), Kpad * NB <= 512 (accumulator registers), r % 4 == 0.
+// row accesses of X; other K are zero-padded through the C fragments), Kpad * NB <= 512 (accumulator registers).
 int mcl_sweep_KS(const mcl_context *c) { return (int)((c->K + 255) / 256); }
 
 bool mcl_sweep_shape_ok(const mcl_context *c) {
     if (getenv("MCL_NO_SWEEP")) return false;
     if (c->K < 4 || c->K > 512 || c->K % 4 != 0) return false;
     if (c->NB > 2 || mcl_sweep_KS(c) * c->NB > 2) return false;
-    if (c->r % 4 != 0) return false;
     if (c->N == 0 || c->I == 0) return false;
     if (c->N / c->I < 64) return false;  // tiny slabs: the per-bseg flush would dominate
     return true;
@@ -589,10 +612,7 @@ bool mcl_sweep_eligible(const mcl_context *c) {
     if (!c->sweep_planned || !mcl_sweep_shape_ok(c)) return false;
     if (c->regs[1].n > 2 || !mcl_mode_is_row_separable(c, 1)) return false;
     if (c->opt.inner_n_iter_max <= 0) return false;
-    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (!al(c->X) || !al(c->B)) return false;
-    for (int k = 0; k < c->regs[1].n; ++k)
-        if (!al(c->regs[1].aux[k]) || !al(c->regs[1].dual[k])) return false;
+    if (reinterpret_cast<uintptr_t>(c->X) & 15) return false;
     return true;
 }
 
@@ -609,19 +629,19 @@ void mcl_sweep_geometry(const mcl_context *c, int *bsegs_per_wave, int *n_waves)
     *n_waves = (n + spw - 1) / spw;
 }
 
-template <int KS, int NB, int NREG, int NW, int DEPTH>
-static int launch_sweep_w(mcl_context *c) {
+template <int KS, int NB, int NREG, int NW, int DEPTH, bool VEC>
+static int launch_sweep_v(mcl_context *c) {
     const int n = c->bsegs.n_tiles;
     int bpb, n_waves;
     mcl_sweep_geometry(c, &bpb, &n_waves);
     const int grid = (n_waves + NW - 1) / NW;
     const size_t sm = sizeof(float) * (size_t)(NW * 16 * 256 * KS + 256 * KS * 16 * NB);  // up to the full 160 KB
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<KS, NB, NREG, DEPTH, NW>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<KS, NB, NREG, DEPTH, NW, VEC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
         (void)hipGetLastError();
         return -1;  // caller falls back to the two-pass path
     }
-    hipLaunchKernelGGL((k_sweep<KS, NB, NREG, DEPTH, NW>), dim3(grid), dim3(64 * NW), sm, c->stream, c->X, c->CfragS, c->A,
+    hipLaunchKernelGGL((k_sweep<KS, NB, NREG, DEPTH, NW, VEC>), dim3(grid), dim3(64 * NW), sm, c->stream, c->X, c->CfragS, c->A,
                        c->rhoB, c->LinvB, c->B, c->regs[1], c->bsegs.slab, c->bsegs.row0, c->bsegs.nrows, n, bpb, (int)c->K,
                        c->r,
                        c->opt.inner_n_iter_max, c->Mpart, c->part_btb, c->GRpart, c->diagB_tile,
@@ -630,9 +650,19 @@ static int launch_sweep_w(mcl_context *c) {
     c->diag_rows[1] = grid;
     c->n_grpart = n;  // one a-weighted partial per bseg
     char buf[96];
-    snprintf(buf, sizeof buf, "k_sweep<KS=%d,NB=%d,NREG=%d,DEPTH=%d,NW=%d>", KS, NB, NREG, DEPTH, NW);
+    snprintf(buf, sizeof buf, "k_sweep<KS=%d,NB=%d,NREG=%d,DEPTH=%d,NW=%d,VEC=%d>", KS, NB, NREG, DEPTH, NW, VEC ? 4 : 1);
     c->variant[3] = buf;
     return 0;
+}
+
+template <int KS, int NB, int NREG, int NW, int DEPTH>
+static int launch_sweep_w(mcl_context *c) {
+    // 16-byte row accesses of B / aux / dual need r % 4 == 0 and 16-byte aligned bases
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    bool vec = (c->r % 4 == 0) && al(c->B);
+    for (int k = 0; k < c->regs[1].n; ++k) vec = vec && al(c->regs[1].aux[k]) && al(c->regs[1].dual[k]);
+    if (vec) return launch_sweep_v<KS, NB, NREG, NW, DEPTH, true>(c);
+    return launch_sweep_v<KS, NB, NREG, NW, DEPTH, false>(c);
 }
 
 template <int KS, int NB, int NREG>

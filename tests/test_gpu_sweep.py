@@ -30,6 +30,11 @@ CASES = {
     "k300_r12_nn": ([150, 400, 260, 96], 300, 12, [[NN], [NN], [NN]], (False, False)),
     "k36_r4_none": ([90, 200, 64], 36, 4, [[NN], [], [NN]], (False, False)),
     "k508_r16_nn": ([130, 222, 97], 508, 16, [[NN], [NN], [NN]], (False, False)),
+    # ranks that are not a multiple of 4: scalar row accesses of B / aux / dual
+    "k256_r5_nn": ([150, 400, 260, 96], 256, 5, [[NN], [NN], [NN]], (False, False)),
+    "k128_r3_l1": ([256, 100, 77, 300], 128, 3, [[NN], [{"kind": "l1", "reg_strength": 0.03}], [NN]], (False, False)),
+    "k512_r7_box": ([130, 222, 97], 512, 7, [[NN], [{"kind": "box", "min_val": 0.0, "max_val": 1.2}, NN], [NN]], (False, False)),
+    "k256_r21_nn": ([150, 400, 260], 256, 21, [[NN], [NN], [NN]], (False, False)),
     # bsegs shorter than one 16-row block, ragged tails, a slab of exactly one block
     "k256_ragged_tails": ([70, 130, 33, 257, 64, 16, 401, 15, 17, 300], 256, 16, [[NN], [NN], [NN]], (False, False)),
 }
@@ -96,7 +101,7 @@ def test_one_iteration_phase_by_phase(name):
 
 
 @pytest.mark.parametrize("name", ["k256_r16_nn", "k512_r12_l1_box", "k256_ragged_tails", "k256_r8_constant", "k128_r8_nn",
-                                  "k300_r12_nn"])
+                                  "k300_r12_nn", "k256_r5_nn", "k512_r7_box"])
 def test_trajectory_vs_oracle(name):
     from tests.test_gpu_end_to_end import _compare, _run_both
 
@@ -170,8 +175,8 @@ def test_by_products_are_not_reused_out_of_order():
 def test_shapes_without_a_sweep_instantiation_keep_the_two_pass_path():
     from oracle import aoadmm_oracle as orc
 
-    for J, K, r in (([300, 200], 130, 8), ([300, 200], 1024, 16), ([300, 200], 256, 6), ([20, 30, 10, 25], 256, 16),
-                    ([300, 200], 516, 16), ([300, 200], 512, 32)):
+    for J, K, r in (([300, 200], 130, 8), ([300, 200], 1024, 16), ([20, 30, 10, 25], 256, 16), ([300, 200], 516, 16),
+                    ([300, 200], 512, 32), ([300, 200], 256, 40)):
         X, row_ptr = orc.synthetic_problem(len(J), np.array(J), K, r, seed=0, dtype=np.float64)
         st = orc.random_state_for(X, row_ptr, r, [[NN], [NN], [NN]], seed=1)
         eng = engine_from_oracle_state(st)
