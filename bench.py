@@ -142,8 +142,10 @@ def cpu_baseline(cfg, budget_s=15.0):
     cores = os.cpu_count() or 1
     I, J, K, r = cfg["I"], cfg["J"], cfg["K"], cfg["r"]
 
+    J_all = np.random.RandomState(0).randint(128, 1025, I) if J == "ragged" else None  # config 4
+
     def timed(I_s, iters):
-        X, row_ptr = orc.synthetic_problem(I_s, J, K, r, seed=0, dtype=np.float64)
+        X, row_ptr = orc.synthetic_problem(I_s, J if J_all is None else J_all[:I_s], K, r, seed=0, dtype=np.float64)
         st = orc.random_state_for(X, row_ptr, r, cfg["regs"], seed=1)
         st.update_B(); st.update_C(); st.update_A()  # warm-up iteration (BLAS thread pool, page faults)
         t0 = time.perf_counter()

@@ -95,7 +95,7 @@ int64_t plan(mcl_context *c, char *base) {
     c->x_sq = b.take<double>(1);
     // generic (non row-separable) path scratch
     const int64_t maxrows = std::max<int64_t>(N, std::max<int64_t>(I, K));
-    c->colsq = b.take<double>(std::max<int64_t>(I, 1) * r);
+    c->colsq = b.take<double>(std::max<int64_t>(I, 1) * r * MCL_MAX_REGS);  // one table per penalty slot (fused stack)
     if (has_kind(c, MCL_PEN_UNIMODAL)) {
         c->uni_f64 = b.take<double>(8 * (maxrows + std::max<int64_t>(I, 1)) * r);
         c->uni_i32 = b.take<int>(2 * maxrows * r);
@@ -165,16 +165,25 @@ int ensure_cfrag_sweep(mcl_context *c) {
 // generic inner loop of mode m: solve, then per penalty prox (+ reduction) and dual update
 int generic_inner_loop(mcl_context *c, int mode) {
     const int n_it = (c->regs[mode].n == 0) ? std::min(1, (int)c->opt.inner_n_iter_max) : c->opt.inner_n_iter_max;
+    // single-process run of the whole stack: per-slab statistics first (Gram / polar factor / Delta, column norms),
+    // then ONE row pass for every prox + dual step (the step API used by multi-GPU hosts keeps one pass per penalty)
+    const bool fuse = mcl_stack_can_fuse(c, mode);
     for (int it = 0; it < n_it; ++it) {
         if (mode == 0) {
             if (int rc = mcl_launch_A_rows_solve(c)) return rc;
         } else {
             if (int rc = mcl_launch_rows_solve(c, mode)) return rc;
         }
-        for (int k = 0; k < c->regs[mode].n; ++k) {
-            if (int rc = mcl_launch_generic_prox_local(c, mode, k)) return rc;
-            if (int rc = mcl_launch_generic_prox_finish(c, mode, k)) return rc;
+        c->stack_fused = fuse;
+        int rc = 0;
+        for (int k = 0; k < c->regs[mode].n && rc == 0; ++k) {
+            rc = mcl_launch_generic_prox_local(c, mode, k);
+            if (rc == 0) rc = mcl_launch_generic_prox_finish(c, mode, k);
         }
+        c->stack_fused = false;
+        if (rc) return rc;
+        if (fuse)
+            if (int rc2 = mcl_launch_rows_finish_fused(c, mode)) return rc2;
     }
     c->diag_valid[mode] = false;
     return 0;

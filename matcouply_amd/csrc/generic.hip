@@ -965,6 +965,78 @@ __global__ __launch_bounds__(256) void k_rows_dual(ModeView mv, RegSet regs, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// ONE row pass for the prox + dual steps of a whole penalty stack made of row-separable kinds, L2 balls and PARAFAC2,
+// once the per-slab statistics are known (column norms -> colsq; polar factor T_i and the new Delta): F is read once,
+// P = (F + U) T_i stays in registers for its dual update.  Replaces k_pf2_apply + k_rows_pf2_dual + k_rows_l2ball
+// (+ k_rows_prox_rowsep), i.e. three to four passes over the B-sized arrays per inner iteration.
+// ---------------------------------------------------------------------------------------------------------
+template <int NBR, bool VEC>
+__global__ __launch_bounds__(256) void k_rows_finish_fused(ModeView mv, RegSet regs, int r, const float *__restrict__ T,
+                                                           const double *__restrict__ colsq) {
+    TILE_PROLOGUE();
+    const float rho = mv.rho[slab];
+    int kpf2 = -1;
+    for (int k = 0; k < regs.n; ++k)
+        if (regs.kind[k] == MCL_PEN_PARAFAC2) kpf2 = k;
+    RowMat<NBR> Ts, D;
+    if (kpf2 >= 0) {
+        Ts.load(T + (long)slab * r * r, r, lane);
+        D.load(regs.aux2[kpf2], r, lane);
+    }
+    FOR_ROW_BLOCKS() {
+        const bool ok = 16 * rb + row16 < nrows;
+        const long j = row0 + 16 * rb + (ok ? row16 : 0);
+        f32x4 f[NBR];
+#pragma unroll
+        for (int h = 0; h < NBR; ++h) f[h] = row_ld4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r);
+        for (int k = 0; k < regs.n; ++k) {
+            const int kind = regs.kind[k];
+            f32x4 u[NBR], z[NBR];
+#pragma unroll
+            for (int h = 0; h < NBR; ++h) u[h] = row_ld4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r);
+            if (kind == MCL_PEN_PARAFAC2) {
+                f32x4 y[NBR], pd[NBR];
+#pragma unroll
+                for (int h = 0; h < NBR; ++h) y[h] = f[h] + u[h];
+                Ts.apply(y, z);   // P = Y T_i      (the aux variable)
+                D.apply(z, pd);   // P Delta        (what the dual is measured against)
+#pragma unroll
+                for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) u[h][v] = f[h][v] - (pd[h][v] - u[h][v]);
+            } else if (kind == MCL_PEN_L2BALL) {
+                const float bound = regs.p0[k];
+#pragma unroll
+                for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int col = 16 * h + 4 * g + v;
+                        const float nrm = (col < r) ? (float)sqrt(colsq[((long)k * mv.n_slabs + slab) * r + col]) : 1.f;
+                        float y = f[h][v] + u[h][v];
+                        if (regs.nonneg[k]) y = fmaxf(y, 0.f);
+                        z[h][v] = y * (bound / fmaxf(nrm, bound));
+                        u[h][v] = f[h][v] - (z[h][v] - u[h][v]);
+                    }
+            } else {
+                const float thr = regs.p0[k] / rho;
+#pragma unroll
+                for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        z[h][v] = prox_elem_g(kind, regs.nonneg[k], regs.p0[k], regs.p1[k], thr, f[h][v] + u[h][v]);
+                        u[h][v] = f[h][v] - (z[h][v] - u[h][v]);
+                    }
+            }
+#pragma unroll
+            for (int h = 0; h < NBR; ++h) {
+                row_st4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r, z[h]);
+                row_st4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r, u[h]);
+            }
+        }
+    }
+}
+
 // =========================================================================================================
 // host launchers
 // =========================================================================================================
@@ -1032,9 +1104,15 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
         case MCL_PEN_NN:
         case MCL_PEN_BOX:
         case MCL_PEN_L1:
+            if (c->stack_fused) break;  // no statistics; the fused finish pass does the prox
             DISPATCH_ROWS(c, vec, k_rows_prox_rowsep, grid, block, mv, rs, k, c->r);
             break;
         case MCL_PEN_L2BALL:
+            if (c->stack_fused) {  // statistics only; slot k of the colsq table
+                hipLaunchKernelGGL(k_slab_colsq, dim3((unsigned)mv.n_slabs), dim3(256), 0, c->stream, mv.ext, mv.F,
+                                   rs.dual[k], rs.nonneg[k], c->r, c->RP, c->colsq + (long)k * mv.n_slabs * c->r);
+                break;
+            }
             hipLaunchKernelGGL(k_slab_colsq, dim3((unsigned)mv.n_slabs), dim3(256), 0, c->stream, mv.ext, mv.F,
                                rs.dual[k], rs.nonneg[k], c->r, c->RP, c->colsq);
             DISPATCH_ROWS(c, vec, k_rows_l2ball, grid, block, mv, rs, k, c->r, (const double *)c->colsq);
@@ -1081,7 +1159,8 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
             }
             hipLaunchKernelGGL(k_pf2_algebra, dim3((unsigned)c->I), dim3(64), sm, c->stream, c->pf2_S, rs.aux2[k],
                                c->rhoB, r, c->pf2_T, c->pf2_acc, status);
-            DISPATCH_ROWS(c, vec, k_pf2_apply, grid, block, mv, (const float *)rs.dual[k], (const float *)c->pf2_T, rs.aux[k], r);
+            if (!c->stack_fused)  // the fused finish pass applies T_i itself
+                DISPATCH_ROWS(c, vec, k_pf2_apply, grid, block, mv, (const float *)rs.dual[k], (const float *)c->pf2_T, rs.aux[k], r);
             hipLaunchKernelGGL(k_pf2_sum, dim3((unsigned)(n2 + 1)), dim3(256), 0, c->stream, c->pf2_acc, (int)c->I, n2 + 1,
                                c->pf2_red);
             break;
@@ -1102,9 +1181,38 @@ int mcl_launch_generic_prox_finish(mcl_context *c, int mode, int k) {
     const int n2 = c->r * c->r;
     hipLaunchKernelGGL(k_pf2_delta, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->pf2_red, c->r,
                        rs.aux2[k]);
+    if (c->stack_fused) {  // the dual update rides in the fused finish pass
+        MCL_CHECK_HIP(c, hipGetLastError());
+        return 0;
+    }
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
     const bool vec = rows_vec_ok(c, mv, rs, nullptr);
     DISPATCH_ROWS(c, vec, k_rows_pf2_dual, grid, block, mv, rs, k, c->r);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+// A penalty stack of row-separable kinds, L2 balls and PARAFAC2 (at least one of the latter two, no host-evaluated or
+// unimodal member) can take ONE row pass for all prox + dual steps after the per-slab statistics.
+bool mcl_stack_can_fuse(const mcl_context *c, int mode) {
+    if (getenv("MCL_NO_STACK_FUSION")) return false;
+    const RegSet &rs = c->regs[mode];
+    bool slabwise = false;
+    for (int k = 0; k < rs.n; ++k) {
+        const int kind = rs.kind[k];
+        if (kind == MCL_PEN_L2BALL || kind == MCL_PEN_PARAFAC2) slabwise = true;
+        else if (kind != MCL_PEN_NN && kind != MCL_PEN_BOX && kind != MCL_PEN_L1) return false;
+    }
+    return slabwise && mode != 0;
+}
+
+int mcl_launch_rows_finish_fused(mcl_context *c, int mode) {
+    ModeView mv = view_of(c, mode);
+    if (mv.n_tiles == 0) return 0;
+    const RegSet &rs = c->regs[mode];
+    dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
+    const bool vec = rows_vec_ok(c, mv, rs, nullptr);
+    DISPATCH_ROWS(c, vec, k_rows_finish_fused, grid, block, mv, rs, c->r, (const float *)c->pf2_T, (const double *)c->colsq);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

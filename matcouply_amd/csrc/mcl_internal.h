@@ -137,6 +137,7 @@ struct mcl_context {
     bool b_systems_valid = false;  // rhoB/LinvB already hold the systems of the coming B-phase (built by A-finish)
     int diag_rows[3] = {0, 0, 0};  // rows currently valid in diagA_row / diagB_tile / diagC_tile
     bool b_begun = false;
+    bool stack_fused = false;  // generic inner loop: statistics kernels only, then one fused prox + dual row pass
 
     std::string variant[4];
 
@@ -216,3 +217,5 @@ int mcl_launch_rows_diag(mcl_context *c, int mode);
 int mcl_launch_diag_final(mcl_context *c, double *out, int include_replicated, bool a_from_rows);
 int mcl_launch_x_sq(mcl_context *c);
 bool mcl_mode_is_row_separable(const mcl_context *c, int mode);
+bool mcl_stack_can_fuse(const mcl_context *c, int mode);          // generic.hip
+int mcl_launch_rows_finish_fused(mcl_context *c, int mode);       // generic.hip
