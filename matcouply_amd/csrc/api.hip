@@ -103,6 +103,10 @@ int64_t plan(mcl_context *c, char *base) {
         c->uni_f64 = nullptr;
         c->uni_i32 = nullptr;
     }
+    // per-tile statistics of the B solve pass (fused generic stacks)
+    c->slab_tile_ptr = b.take<int>(I + 1);
+    c->stat_gram = has_kind(c, MCL_PEN_PARAFAC2) ? b.take<double>((int64_t)c->tilesB.n_tiles * 256 * c->NB * c->NB) : nullptr;
+    c->stat_colsq = has_kind(c, MCL_PEN_L2BALL) ? b.take<double>((int64_t)c->tilesB.n_tiles * MCL_MAX_REGS * r) : nullptr;
     if (has_kind(c, MCL_PEN_PARAFAC2)) {
         c->pf2_S = b.take<double>(I * r * r);
         c->pf2_T = b.take<float>(I * r * r);
@@ -168,19 +172,23 @@ int generic_inner_loop(mcl_context *c, int mode) {
     // single-process run of the whole stack: per-slab statistics first (Gram / polar factor / Delta, column norms),
     // then ONE row pass for every prox + dual step (the step API used by multi-GPU hosts keeps one pass per penalty)
     const bool fuse = mcl_stack_can_fuse(c, mode);
+    const bool stats = fuse && mcl_stats_can_ride_in_solve(c, mode);
     for (int it = 0; it < n_it; ++it) {
         if (mode == 0) {
             if (int rc = mcl_launch_A_rows_solve(c)) return rc;
+        } else if (stats) {
+            if (int rc = mcl_launch_rows_solve_stats(c)) return rc;
         } else {
             if (int rc = mcl_launch_rows_solve(c, mode)) return rc;
         }
         c->stack_fused = fuse;
+        c->stats_in_solve = stats;
         int rc = 0;
         for (int k = 0; k < c->regs[mode].n && rc == 0; ++k) {
             rc = mcl_launch_generic_prox_local(c, mode, k);
             if (rc == 0) rc = mcl_launch_generic_prox_finish(c, mode, k);
         }
-        c->stack_fused = false;
+        c->stack_fused = c->stats_in_solve = false;
         if (rc) return rc;
         if (fuse)
             if (int rc2 = mcl_launch_rows_finish_fused(c, mode)) return rc2;
@@ -261,6 +269,7 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     c->h_tile_slab.clear(), c->h_tile_row0.clear(), c->h_tile_nrows.clear();
     c->h_seg_slab.clear(), c->h_seg_row0.clear(), c->h_seg_nrows.clear();
     c->h_slab_seg_ptr.assign((size_t)I + 1, 0);
+    c->h_slab_tile_ptr.assign((size_t)I + 1, 0);
     // segment = work unit of the two X passes: <= seg_rows rows of one slab.  256 rows (256 KB at K = 256) amortise the
     // per-segment prologue on big problems; small problems (e.g. the per-rank shard of an 8-GPU run) get shorter
     // segments so that there are still >= ~512 of them (measured optimum on a 64 K-row shard: 128 rows).
@@ -269,6 +278,7 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     if (const char *e = getenv("MCL_SEG_ROWS")) seg_rows = std::max(16, atoi(e));
     for (int64_t i = 0; i < I; ++i) {
         c->h_slab_seg_ptr[(size_t)i] = (int)c->h_seg_slab.size();
+        c->h_slab_tile_ptr[(size_t)i] = (int)c->h_tile_slab.size();
         for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; j += seg_rows) {
             c->h_seg_slab.push_back((int)i);
             c->h_seg_row0.push_back((int)j);
@@ -282,6 +292,7 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
         }
     }
     c->h_slab_seg_ptr[(size_t)I] = (int)c->h_seg_slab.size();
+    c->h_slab_tile_ptr[(size_t)I] = (int)c->h_tile_slab.size();
     // bsegs of the one-pass sweep: <= 512 rows of one slab per WAVE, shorter on small problems so that there are still
     // >= ~1024 of them (one per SIMD)
     int64_t bseg_rows = 512;
@@ -405,6 +416,7 @@ int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
     MCL_CHECK_HIP(c, up(c->segs.row0, c->h_seg_row0));
     MCL_CHECK_HIP(c, up(c->segs.nrows, c->h_seg_nrows));
     MCL_CHECK_HIP(c, up(c->slab_seg_ptr, c->h_slab_seg_ptr));
+    MCL_CHECK_HIP(c, up(c->slab_tile_ptr, c->h_slab_tile_ptr));
     if (c->sweep_planned) {
         MCL_CHECK_HIP(c, up(c->bsegs.slab, c->h_bseg_slab));
         MCL_CHECK_HIP(c, up(c->bsegs.row0, c->h_bseg_row0));

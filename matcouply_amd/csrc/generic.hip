@@ -122,6 +122,181 @@ __global__ __launch_bounds__(256) void k_rows_solve(ModeView mv, const float *__
     }
 }
 
+// The same solve with the per-slab statistics of the slab-wise penalties riding in its epilogue (mode 1, fused stacks):
+//   PARAFAC2:  per-tile Gram Y^T Y, Y = F + U   - B_new rows go ROW -> COL layout through 4 selector MFMAs (exact), then
+//              the fp64 MFMA accumulates exact fp32 x fp32 products exactly like k_pf2_gram
+//   L2 ball :  per-tile column sums of squares of (F + U) (optionally clamped at 0), fp64
+// k_stats_reduce sums the tiles of every slab in fixed order.  Saves the two extra reads of F and the duals that
+// k_pf2_gram and k_slab_colsq need.
+template <int NBR, bool VEC>
+__global__ __launch_bounds__(256) void k_rows_solve_stats(ModeView mv, const float *__restrict__ rhs_src,
+                                                          const float *__restrict__ Arows, const float *__restrict__ Linv,
+                                                          RegSet regs, int r, double *__restrict__ stat_gram,
+                                                          double *__restrict__ stat_colsq) {
+    typedef double f64x4s __attribute__((ext_vector_type(4)));
+    TILE_PROLOGUE();
+    const float rho = mv.rho[slab];
+    RowMat<NBR> L, D;
+    L.load(Linv + (long)slab * r * r, r, lane);
+    int kpf2 = -1;
+    for (int k = 0; k < regs.n; ++k)
+        if (regs.kind[k] == MCL_PEN_PARAFAC2) kpf2 = k;
+    if (kpf2 >= 0) D.load(regs.aux2[kpf2], r, lane);
+    float av[NBR][4];
+#pragma unroll
+    for (int h = 0; h < NBR; ++h)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int col = 16 * h + 4 * g + v;
+            av[h][v] = (Arows != nullptr && col < r) ? Arows[(long)slab * r + col] : 1.f;
+        }
+    float bsel[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) bsel[v] = (row16 == 4 * g + v) ? 1.f : 0.f;
+    f64x4s accS[NBR][NBR];
+#pragma unroll
+    for (int a = 0; a < NBR; ++a)
+#pragma unroll
+        for (int b = 0; b < NBR; ++b) accS[a][b] = f64x4s{0.0, 0.0, 0.0, 0.0};
+    double csq[MCL_MAX_REGS][NBR][4];
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k)
+#pragma unroll
+        for (int h = 0; h < NBR; ++h)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) csq[k][h][v] = 0.0;
+    FOR_ROW_BLOCKS() {
+        const bool ok = 16 * rb + row16 < nrows;
+        const long j = row0 + 16 * rb + (ok ? row16 : 0);
+        f32x4 t[NBR], f[NBR], ukeep[MCL_MAX_REGS][NBR];
+#pragma unroll
+        for (int h = 0; h < NBR; ++h) {
+            t[h] = row_ld4<VEC>(rhs_src, j, 16 * h + 4 * g, ok, r);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) t[h][v] *= av[h][v];
+        }
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) {
+            if (k < regs.n) {
+                f32x4 z[NBR];
+#pragma unroll
+                for (int h = 0; h < NBR; ++h) z[h] = row_ld4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r);
+                if (k == kpf2) {
+                    f32x4 pz[NBR];
+                    D.apply(z, pz);
+#pragma unroll
+                    for (int h = 0; h < NBR; ++h) z[h] = pz[h];
+                }
+#pragma unroll
+                for (int h = 0; h < NBR; ++h) {
+                    ukeep[k][h] = row_ld4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) t[h][v] = fmaf(rho, z[h][v] - ukeep[k][h][v], t[h][v]);
+                }
+            }
+        }
+        L.apply(t, f);
+#pragma unroll
+        for (int h = 0; h < NBR; ++h) row_st4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r, f[h]);
+        // ---- statistics of the new rows (padding rows / columns contribute zeros: row_ld4 returned zeros for them and
+        //      L.apply leaves padding columns at zero)
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) {
+            if (k < regs.n) {
+                if (regs.kind[k] == MCL_PEN_L2BALL) {
+#pragma unroll
+                    for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            float y = f[h][v] + ukeep[k][h][v];
+                            if (regs.nonneg[k]) y = fmaxf(y, 0.f);
+                            if (ok) csq[k][h][v] += (double)y * (double)y;
+                        }
+                } else if (k == kpf2) {
+                    double yt[NBR][4];
+#pragma unroll
+                    for (int nb = 0; nb < NBR; ++nb) {
+                        f32x4 tr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const float y = ok ? f[nb][v] + ukeep[k][nb][v] : 0.f;
+                            tr = MFMA16(y, bsel[v], tr);  // COL layout: lane (q, i16) reg w = Y[4q + w][16nb + i16]
+                        }
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) yt[nb][w] = (double)tr[w];
+                    }
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+#pragma unroll
+                        for (int a = 0; a < NBR; ++a)
+#pragma unroll
+                            for (int b = 0; b < NBR; ++b)
+                                accS[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(yt[a][w], yt[b][w], accS[a][b], 0, 0, 0);
+                }
+            }
+        }
+    }
+    constexpr int W = 16 * NBR;
+    if (kpf2 >= 0) {  // D layout of the f64 MFMA: col = l & 15, row = (l >> 4) + 4 reg
+        double *out = stat_gram + (long)tile * W * W;
+#pragma unroll
+        for (int a = 0; a < NBR; ++a)
+#pragma unroll
+            for (int b = 0; b < NBR; ++b)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) out[(16 * a + g + 4 * v) * W + 16 * b + row16] = accS[a][b][v];
+    }
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k) {
+        if (k < regs.n && regs.kind[k] == MCL_PEN_L2BALL) {
+#pragma unroll
+            for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    double sq = csq[k][h][v];
+                    sq += __shfl_xor(sq, 1);
+                    sq += __shfl_xor(sq, 2);
+                    sq += __shfl_xor(sq, 4);
+                    sq += __shfl_xor(sq, 8);
+                    const int col = 16 * h + 4 * g + v;
+                    if (row16 == 0 && col < r) stat_colsq[((long)tile * MCL_MAX_REGS + k) * r + col] = sq;
+                }
+        }
+    }
+}
+
+// per-slab sums of the per-tile statistics, fixed order: S[slab] (natural r x r layout) and colsq[k][slab]
+__global__ __launch_bounds__(256) void k_stats_reduce(const int *__restrict__ slab_tile_ptr, const double *__restrict__ stat_gram,
+                                                      const double *__restrict__ stat_colsq, RegSet regs, int r, int W,
+                                                      int n_slabs, double *__restrict__ S, double *__restrict__ colsq) {
+    const int slab = blockIdx.x;
+    const int t0 = slab_tile_ptr[slab], t1 = slab_tile_ptr[slab + 1];
+    int kpf2 = -1;
+    for (int k = 0; k < regs.n; ++k)
+        if (regs.kind[k] == MCL_PEN_PARAFAC2) kpf2 = k;
+    if (kpf2 >= 0) {
+        for (int e = threadIdx.x; e < r * r; e += 256) {
+            const int a = e / r, b = e - a * r;
+            double s0 = 0.0, s1 = 0.0;
+            int t = t0;
+            for (; t + 1 < t1; t += 2) {
+                s0 += stat_gram[(long)t * W * W + a * W + b];
+                s1 += stat_gram[(long)(t + 1) * W * W + a * W + b];
+            }
+            if (t < t1) s0 += stat_gram[(long)t * W * W + a * W + b];
+            S[((long)slab * r + a) * r + b] = s0 + s1;
+        }
+    }
+    for (int k = 0; k < regs.n; ++k) {
+        if (regs.kind[k] != MCL_PEN_L2BALL) continue;
+        for (int col = threadIdx.x; col < r; col += 256) {
+            double s = 0.0;
+            for (int t = t0; t < t1; ++t) s += stat_colsq[((long)t * MCL_MAX_REGS + k) * r + col];
+            colsq[((long)k * n_slabs + slab) * r + col] = s;
+        }
+    }
+}
+
 // mode 0: every row has its own system (decomposition.py:184-195); one wave per row
 __global__ __launch_bounds__(64) void k_A_rows_solve(const float *__restrict__ rhsA, const float *__restrict__ rhoA,
                                                      const float *__restrict__ LinvA, float *__restrict__ A,
@@ -1109,6 +1284,7 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
             break;
         case MCL_PEN_L2BALL:
             if (c->stack_fused) {  // statistics only; slot k of the colsq table
+                if (c->stats_in_solve) break;  // already produced by k_rows_solve_stats + k_stats_reduce
                 hipLaunchKernelGGL(k_slab_colsq, dim3((unsigned)mv.n_slabs), dim3(256), 0, c->stream, mv.ext, mv.F,
                                    rs.dual[k], rs.nonneg[k], c->r, c->RP, c->colsq + (long)k * mv.n_slabs * c->r);
                 break;
@@ -1136,7 +1312,9 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                 return 1;
             }
             const int r = c->r, n2 = r * r;
-            if (c->NB == 1)
+            if (c->stats_in_solve) {
+                // S_i already produced by k_rows_solve_stats + k_stats_reduce
+            } else if (c->NB == 1)
                 hipLaunchKernelGGL(k_pf2_gram<1>, dim3((unsigned)c->I), dim3(256), 0, c->stream, mv.ext, mv.F, rs.dual[k], r, c->pf2_S);
             else if (c->NB == 2)
                 hipLaunchKernelGGL(k_pf2_gram<2>, dim3((unsigned)c->I), dim3(256), 0, c->stream, mv.ext, mv.F, rs.dual[k], r, c->pf2_S);
@@ -1213,6 +1391,37 @@ int mcl_launch_rows_finish_fused(mcl_context *c, int mode) {
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
     const bool vec = rows_vec_ok(c, mv, rs, nullptr);
     DISPATCH_ROWS(c, vec, k_rows_finish_fused, grid, block, mv, rs, c->r, (const float *)c->pf2_T, (const double *)c->colsq);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+// mode 1 only (that is where the passes are big); needs the per-tile tables of the plan
+bool mcl_stats_can_ride_in_solve(const mcl_context *c, int mode) {
+    if (mode != 1 || getenv("MCL_NO_SOLVE_STATS")) return false;
+    const RegSet &rs = c->regs[1];
+    for (int k = 0; k < rs.n; ++k) {
+        if (rs.kind[k] == MCL_PEN_PARAFAC2 && !c->stat_gram) return false;
+        if (rs.kind[k] == MCL_PEN_L2BALL && !c->stat_colsq) return false;
+    }
+    return c->NB <= 2;  // fp64 accumulators: (16 NB)^2 / 64 doubles per lane
+}
+
+int mcl_launch_rows_solve_stats(mcl_context *c) {
+    ModeView mv = view_of(c, 1);
+    if (mv.n_tiles == 0) return 0;
+    const float *rhs = c->XC;
+    dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
+    const bool vec = rows_vec_ok(c, mv, c->regs[1], rhs);
+    if (c->NB == 1) {
+        if (vec) hipLaunchKernelGGL((k_rows_solve_stats<1, true>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, (const float *)c->LinvB, c->regs[1], c->r, c->stat_gram, c->stat_colsq);
+        else hipLaunchKernelGGL((k_rows_solve_stats<1, false>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, (const float *)c->LinvB, c->regs[1], c->r, c->stat_gram, c->stat_colsq);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_rows_solve_stats<2, true>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, (const float *)c->LinvB, c->regs[1], c->r, c->stat_gram, c->stat_colsq);
+        else hipLaunchKernelGGL((k_rows_solve_stats<2, false>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, (const float *)c->LinvB, c->regs[1], c->r, c->stat_gram, c->stat_colsq);
+    }
+    hipLaunchKernelGGL(k_stats_reduce, dim3((unsigned)c->I), dim3(256), 0, c->stream, (const int *)c->slab_tile_ptr,
+                       (const double *)c->stat_gram, (const double *)c->stat_colsq, c->regs[1], c->r, 16 * c->NB, (int)c->I,
+                       c->pf2_S, c->colsq);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

@@ -138,6 +138,12 @@ struct mcl_context {
     int diag_rows[3] = {0, 0, 0};  // rows currently valid in diagA_row / diagB_tile / diagC_tile
     bool b_begun = false;
     bool stack_fused = false;  // generic inner loop: statistics kernels only, then one fused prox + dual row pass
+    bool stats_in_solve = false;   // ... and the B-mode statistics (PARAFAC2 Gram, L2-ball column norms) already came out of
+                                   // the solve pass (k_rows_solve_stats + k_stats_reduce)
+    std::vector<int> h_slab_tile_ptr;  // first B tile of every slab
+    int *slab_tile_ptr = nullptr;      // int32[I+1]
+    double *stat_gram = nullptr;       // [tilesB, (16 NB)^2]  per-tile Y^T Y, Y = B + U_pf2 (fp64 MFMA result order)
+    double *stat_colsq = nullptr;      // [tilesB, MCL_MAX_REGS, r]  per-tile column sums of squares of (B + U_k)
 
     std::string variant[4];
 
@@ -219,3 +225,5 @@ int mcl_launch_x_sq(mcl_context *c);
 bool mcl_mode_is_row_separable(const mcl_context *c, int mode);
 bool mcl_stack_can_fuse(const mcl_context *c, int mode);          // generic.hip
 int mcl_launch_rows_finish_fused(mcl_context *c, int mode);       // generic.hip
+bool mcl_stats_can_ride_in_solve(const mcl_context *c, int mode);  // generic.hip
+int mcl_launch_rows_solve_stats(mcl_context *c);                  // generic.hip: B solve + per-tile statistics + reduce
