@@ -191,9 +191,9 @@ int generic_inner_loop(mcl_context *c, int mode) {
         c->stack_fused = c->stats_in_solve = false;
         if (rc) return rc;
         if (fuse)
-            if (int rc2 = mcl_launch_rows_finish_fused(c, mode)) return rc2;
+            if (int rc2 = mcl_launch_rows_finish_fused(c, mode, it == n_it - 1)) return rc2;  // diagnostics: last pass only
     }
-    c->diag_valid[mode] = false;
+    c->diag_valid[mode] = fuse && n_it > 0;  // the fused finish pass leaves the mode's diagnostics table current
     return 0;
 }
 

@@ -1148,8 +1148,12 @@ __global__ __launch_bounds__(256) void k_rows_dual(ModeView mv, RegSet regs, int
 // ---------------------------------------------------------------------------------------------------------
 template <int NBR, bool VEC>
 __global__ __launch_bounds__(256) void k_rows_finish_fused(ModeView mv, RegSet regs, int r, const float *__restrict__ T,
-                                                           const double *__restrict__ colsq) {
+                                                           const double *__restrict__ colsq,
+                                                           double *__restrict__ diag_tile, int want_diag) {
     TILE_PROLOGUE();
+    double nf = 0.0, na = 0.0, gap[MCL_MAX_REGS];  // per-tile diagnostics (same sums as k_rows_diag)
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k) gap[k] = 0.0;
     const float rho = mv.rho[slab];
     int kpf2 = -1;
     for (int k = 0; k < regs.n; ++k)
@@ -1164,10 +1168,21 @@ __global__ __launch_bounds__(256) void k_rows_finish_fused(ModeView mv, RegSet r
         const long j = row0 + 16 * rb + (ok ? row16 : 0);
         f32x4 f[NBR];
 #pragma unroll
-        for (int h = 0; h < NBR; ++h) f[h] = row_ld4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r);
-        for (int k = 0; k < regs.n; ++k) {
+        for (int h = 0; h < NBR; ++h) {
+            f[h] = row_ld4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r);  // zeros for padding rows / columns
+            if (want_diag) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    nf += (double)f[h][v] * (double)f[h][v];
+                    na += fabs((double)f[h][v]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) {
+            if (k >= regs.n) continue;
             const int kind = regs.kind[k];
-            f32x4 u[NBR], z[NBR];
+            f32x4 u[NBR], z[NBR], zg[NBR];  // zg: what the feasibility gap is measured against (P Delta for PARAFAC2)
 #pragma unroll
             for (int h = 0; h < NBR; ++h) u[h] = row_ld4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r);
             if (kind == MCL_PEN_PARAFAC2) {
@@ -1177,9 +1192,11 @@ __global__ __launch_bounds__(256) void k_rows_finish_fused(ModeView mv, RegSet r
                 Ts.apply(y, z);   // P = Y T_i      (the aux variable)
                 D.apply(z, pd);   // P Delta        (what the dual is measured against)
 #pragma unroll
-                for (int h = 0; h < NBR; ++h)
+                for (int h = 0; h < NBR; ++h) {
+                    zg[h] = pd[h];
 #pragma unroll
                     for (int v = 0; v < 4; ++v) u[h][v] = f[h][v] - (pd[h][v] - u[h][v]);
+                }
             } else if (kind == MCL_PEN_L2BALL) {
                 const float bound = regs.p0[k];
 #pragma unroll
@@ -1207,8 +1224,28 @@ __global__ __launch_bounds__(256) void k_rows_finish_fused(ModeView mv, RegSet r
             for (int h = 0; h < NBR; ++h) {
                 row_st4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r, z[h]);
                 row_st4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r, u[h]);
+                if (kind != MCL_PEN_PARAFAC2) zg[h] = z[h];
+                if (want_diag)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const bool valid = ok && (16 * h + 4 * g + v < r);
+                    const double dlt = valid ? (double)zg[h][v] - (double)f[h][v] : 0.0;
+                    gap[k] += dlt * dlt;
+                }
             }
         }
+    }
+    if (!want_diag) return;
+    nf = wave_sum_d(nf);
+    na = wave_sum_d(na);
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k) gap[k] = wave_sum_d(gap[k]);
+    if (lane == 0) {
+        double *o = diag_tile + (long)tile * DIAG_COLS;
+        o[0] = nf;
+        o[1] = na;
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) o[2 + k] = gap[k];
     }
 }
 
@@ -1384,14 +1421,17 @@ bool mcl_stack_can_fuse(const mcl_context *c, int mode) {
     return slabwise && mode != 0;
 }
 
-int mcl_launch_rows_finish_fused(mcl_context *c, int mode) {
+int mcl_launch_rows_finish_fused(mcl_context *c, int mode, bool want_diag) {
     ModeView mv = view_of(c, mode);
     if (mv.n_tiles == 0) return 0;
     const RegSet &rs = c->regs[mode];
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
     const bool vec = rows_vec_ok(c, mv, rs, nullptr);
-    DISPATCH_ROWS(c, vec, k_rows_finish_fused, grid, block, mv, rs, c->r, (const float *)c->pf2_T, (const double *)c->colsq);
+    double *diag = (mode == 1) ? c->diagB_tile : c->diagC_tile;
+    DISPATCH_ROWS(c, vec, k_rows_finish_fused, grid, block, mv, rs, c->r, (const float *)c->pf2_T, (const double *)c->colsq,
+                  diag, want_diag ? 1 : 0);
     MCL_CHECK_HIP(c, hipGetLastError());
+    if (want_diag) c->diag_rows[mode] = mv.n_tiles;  // one row per tile, as k_rows_diag writes them
     return 0;
 }
 

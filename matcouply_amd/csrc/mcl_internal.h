@@ -224,6 +224,6 @@ int mcl_launch_diag_final(mcl_context *c, double *out, int include_replicated, b
 int mcl_launch_x_sq(mcl_context *c);
 bool mcl_mode_is_row_separable(const mcl_context *c, int mode);
 bool mcl_stack_can_fuse(const mcl_context *c, int mode);          // generic.hip
-int mcl_launch_rows_finish_fused(mcl_context *c, int mode);       // generic.hip
+int mcl_launch_rows_finish_fused(mcl_context *c, int mode, bool want_diag);  // generic.hip
 bool mcl_stats_can_ride_in_solve(const mcl_context *c, int mode);  // generic.hip
 int mcl_launch_rows_solve_stats(mcl_context *c);                  // generic.hip: B solve + per-tile statistics + reduce
