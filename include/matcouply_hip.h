@@ -115,6 +115,10 @@ int mcl_B_solve(mcl_context *ctx);           /* one normal-equation solve (decom
 int mcl_B_prox_local(mcl_context *ctx, int32_t k);  /* prox of penalty k; PARAFAC2: bases + local Delta sums */
 float *mcl_B_prox_reduce_buffer(mcl_context *ctx, int32_t k, int64_t *count); /* PARAFAC2: [sum rho P^T Y | sum rho] */
 int mcl_B_prox_finish(mcl_context *ctx, int32_t k); /* PARAFAC2: Delta; all: dual update (decomposition.py:282-285) */
+/* Contract of one inner iteration: mcl_B_solve, then for EVERY penalty k in order: mcl_B_prox_local(k) [all-reduce of
+ * mcl_B_prox_reduce_buffer(k) for PARAFAC2] mcl_B_prox_finish(k).  For stacks of row-separable kinds, L2 balls and
+ * PARAFAC2 the library defers the aux / dual row updates of all penalties to ONE pass issued by the last
+ * mcl_B_prox_finish of the round, so the rows are only final once the whole stack has been stepped. */
 int mcl_A_begin(mcl_context *ctx);           /* X C, rhs_i, Q_i, rho_i (decomposition.py:136-162) */
 float *mcl_A_rho_max(mcl_context *ctx);
 int mcl_A_finish(mcl_context *ctx);          /* systems, inner ADMM loop, by-products (decomposition.py:163-219) */

@@ -461,13 +461,22 @@ int mcl_B_solve(mcl_context *c) {
     c->e1_valid = false;
     c->mseg_valid = c->grpart_valid = false;
     c->diag_valid[1] = false;
+    // fusable stacks (see generic_inner_loop): statistics out of the solve pass, ONE prox + dual row pass once the
+    // last penalty of the stack has been finished - the per-penalty calls below then only run the per-slab algebra
+    c->step_fuse = mcl_stack_can_fuse(c, 1);
+    c->step_stats = c->step_fuse && mcl_stats_can_ride_in_solve(c, 1);
+    c->step_done_mask = 0;
+    if (c->step_stats) return mcl_launch_rows_solve_stats(c);
     return mcl_launch_rows_solve(c, 1);
 }
 
 int mcl_B_prox_local(mcl_context *c, int32_t k) {
     if (int rc = ready(c)) return rc;
     if (k < 0 || k >= c->regs[1].n) return fail(c, "mcl_B_prox_local: penalty index out of range");
-    return mcl_launch_generic_prox_local(c, 1, k);
+    c->stack_fused = c->step_fuse, c->stats_in_solve = c->step_stats;
+    const int rc = mcl_launch_generic_prox_local(c, 1, k);
+    c->stack_fused = c->stats_in_solve = false;
+    return rc;
 }
 
 float *mcl_B_prox_reduce_buffer(mcl_context *c, int32_t k, int64_t *count) {
@@ -482,7 +491,17 @@ float *mcl_B_prox_reduce_buffer(mcl_context *c, int32_t k, int64_t *count) {
 int mcl_B_prox_finish(mcl_context *c, int32_t k) {
     if (int rc = ready(c)) return rc;
     if (k < 0 || k >= c->regs[1].n) return fail(c, "mcl_B_prox_finish: penalty index out of range");
-    return mcl_launch_generic_prox_finish(c, 1, k);
+    c->stack_fused = c->step_fuse, c->stats_in_solve = c->step_stats;
+    int rc = mcl_launch_generic_prox_finish(c, 1, k);
+    c->stack_fused = c->stats_in_solve = false;
+    if (rc == 0 && c->step_fuse) {
+        c->step_done_mask |= 1u << k;
+        if (c->step_done_mask == (1u << c->regs[1].n) - 1u) {  // whole stack stepped: the fused row pass
+            rc = mcl_launch_rows_finish_fused(c, 1, false);
+            c->step_fuse = c->step_stats = false;
+        }
+    }
+    return rc;
 }
 
 int mcl_update_B(mcl_context *c) {

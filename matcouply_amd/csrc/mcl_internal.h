@@ -138,6 +138,8 @@ struct mcl_context {
     int diag_rows[3] = {0, 0, 0};  // rows currently valid in diagA_row / diagB_tile / diagC_tile
     bool b_begun = false;
     bool stack_fused = false;  // generic inner loop: statistics kernels only, then one fused prox + dual row pass
+    bool step_fuse = false, step_stats = false;  // the same two decisions for the current mcl_B_solve .. mcl_B_prox_* round
+    unsigned step_done_mask = 0;                 // penalties finished in this round
     bool stats_in_solve = false;   // ... and the B-mode statistics (PARAFAC2 Gram, L2-ball column norms) already came out of
                                    // the solve pass (k_rows_solve_stats + k_stats_reduce)
     std::vector<int> h_slab_tile_ptr;  // first B tile of every slab
