@@ -156,6 +156,9 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
             //     prox(y) = clamp(y - clamp(y, pa, pb), plo, phi)          (clamp = v_med3_f32)
             //   NN: (-inf, 0 | -inf, inf)   Box: (0, 0 | lo, hi)   L1: (-thr, thr | -inf, inf)   L1 + NN: (-inf, thr | ..)
             float pa[NR], pb[NR], plo[NR], phi[NR];
+            bool all_nn = NREG > 0;
+#pragma unroll
+            for (int k = 0; k < NREG; ++k) all_nn = all_nn && regs.kind[k] == MCL_PEN_NN;
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
                 const float thr = (k < NREG) ? regs.p0[k] / rho : 0.f;
@@ -309,15 +312,17 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                     f[h] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 const int n_it = (dbg & 2) ? 0 : ((NREG == 0 && inner > 1) ? 1 : inner);
-                for (int it = 0; it < n_it; ++it) {
+                // one inner iteration; NNONLY: every penalty is a plain non-negativity constraint, whose prox is one v_max
+                auto inner_iter = [&](auto nn_only) {
+                    constexpr bool NNONLY = decltype(nn_only)::value;
                     f32x4 t[NB];
 #pragma unroll
                     for (int h = 0; h < NB; ++h)
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
-                            float s = 0.f;
+                            float s = (NREG > 0) ? z[0][h][v] - u[0][h][v] : 0.f;
 #pragma unroll
-                            for (int k = 0; k < NREG; ++k) s += z[k][h][v] - u[k][h][v];
+                            for (int k = 1; k < NREG; ++k) s += z[k][h][v] - u[k][h][v];
                             t[h][v] = (NREG > 0) ? fmaf(rho, s, rhs[h][v]) : rhs[h][v];
                         }
 #pragma unroll
@@ -336,10 +341,17 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
                                 const float y = f[h][v] + u[k][h][v];
-                                const float znew = __builtin_amdgcn_fmed3f(y - __builtin_amdgcn_fmed3f(y, pa[k], pb[k]), plo[k], phi[k]);
+                                const float znew =
+                                    NNONLY ? fmaxf(y, 0.f)
+                                           : __builtin_amdgcn_fmed3f(y - __builtin_amdgcn_fmed3f(y, pa[k], pb[k]), plo[k], phi[k]);
                                 u[k][h][v] = f[h][v] - (znew - u[k][h][v]);
                                 z[k][h][v] = znew;
                             }
+                };
+                if (all_nn) {
+                    for (int it = 0; it < n_it; ++it) inner_iter(std::true_type{});
+                } else {
+                    for (int it = 0; it < n_it; ++it) inner_iter(std::false_type{});
                 }
 
                 tick(2, t0);
