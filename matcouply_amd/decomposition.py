@@ -202,8 +202,8 @@ def _parse_mode_penalties(non_negative, lower_bound, upper_bound, l2_norm_bound,
     if unimodal:
         regs.append(penalties.Unimodality(non_negativity=non_negative, aux_init=aux_init, dual_init=dual_init))
         skip_non_negative = True
-    if generalized_l2_penalty is not None and generalized_l2_penalty is not False:
-        raise NotImplementedError("generalized_l2_penalty is out of scope of this engine (SURVEY.md 2.1)")
+    if generalized_l2_penalty is not None and generalized_l2_penalty is not False:  # None, False or the norm matrix
+        regs.append(penalties.GeneralizedL2Penalty(generalized_l2_penalty, aux_init=aux_init, dual_init=dual_init, svd=svd))
     if l2_norm_bound:
         regs.append(penalties.L2Ball(l2_norm_bound, non_negativity=non_negative, aux_init=aux_init, dual_init=dual_init))
         skip_non_negative = True
@@ -394,7 +394,7 @@ def cmf_aoadmm(
     ``matrices`` is a list of I arrays (NumPy or torch, J_i x K) or a :class:`PackedMatrices` already in HBM.  The
     arithmetic runs in fp32 on the device (rank x rank systems and all reductions in fp64); results are returned in the
     array type and dtype of the input.  Not supported (out of scope, raise ``NotImplementedError``): ``tv_penalty``,
-    ``generalized_l2_penalty``, TensorLy-ALS initialisations, ``inner_tol``.  Penalties without a native kernel (user
+    TensorLy-ALS initialisations, ``inner_tol``.  Penalties without a native kernel (user
     subclasses of ``matcouply_amd.penalties.ADMMPenalty``) are evaluated through their own Python methods on device
     tensors between the native solve and dual-update steps.
 

@@ -11,8 +11,10 @@ proximal steps run in native HIP kernels (the object hands the engine a descript
 the `factor_matrix*_update` / `subtract_from_aux*` methods below are the user-facing restatement of the same
 operators on NumPy arrays or torch tensors, so that code written against the reference (direct prox calls,
 the reusable test kit, custom subclasses) keeps working.  A penalty WITHOUT a native descriptor (a user
-subclass) is driven through the engine's step calls with its Python prox evaluated on device tensors.
-`GeneralizedL2Penalty`, `TotalVariationPenalty` and `UnitSimplex` of the reference are out of scope.
+subclass) is driven through the engine's step calls with its Python prox evaluated on device tensors; that is also how
+`GeneralizedL2Penalty` (:595-747) and `UnitSimplex` (:928-980) run: their prox is a pair of matrix products / a sort +
+cumulative sum, written below for NumPy arrays and torch (device) tensors alike.  `TotalVariationPenalty` of the
+reference needs the GPL `condat_tv` package and is out of scope.
 """
 from abc import ABC, abstractmethod
 
@@ -288,6 +290,83 @@ class L2Ball(HardConstraintMixin, MatrixPenalty):
 
     def _native_descriptor(self):
         return (_engine.PEN_L2BALL, bool(self.non_negativity), float(self.norm_bound), 0.0)
+
+
+class GeneralizedL2Penalty(MatrixPenalty):
+    r"""Penalty x^T M x on every column, M symmetric positive semidefinite (penalties.py:595-747), e.g. a graph Laplacian.
+
+    prox: (M + rho/2 I)^-1 (rho/2) x = U (S + rho/2 I)^-1 U^T (rho/2) x with M = U S U^T computed once.  No native kernel:
+    the solver evaluates it on device tensors as two matrix products per call."""
+
+    def __init__(self, norm_matrix, svd="truncated_svd", aux_init="random_uniform", dual_init="random_uniform",
+                 validate=True):
+        super().__init__(aux_init, dual_init)
+        self.norm_matrix = norm_matrix
+        self.svd = svd
+        self.validate = validate
+        M = norm_matrix.detach().cpu().numpy() if is_torch(norm_matrix) else np.asarray(norm_matrix)
+        if validate and not np.all(M.T == M):
+            raise ValueError("The norm matrix should be symmetric positive semidefinite")
+        if validate and np.any(np.linalg.eigvals(M) < -1e-14):
+            raise ValueError("The norm matrix should be symmetric positive semidefinite")
+        self._U, self._s, _ = get_svd(svd)(np.asarray(M, dtype=np.float64))  # Vh ignored: the norm matrix is symmetric
+        self._device_cache = {}
+
+    @property
+    def svd_fun(self):
+        return get_svd(self.svd)
+
+    def _factors_like(self, x):
+        """(U, s, M) as arrays of the same kind / dtype / device as x"""
+        if not is_torch(x):
+            return self._U, self._s, np.asarray(self.norm_matrix.detach().cpu().numpy() if is_torch(self.norm_matrix)
+                                                else self.norm_matrix)
+        key = (x.device, x.dtype)
+        if key not in self._device_cache:
+            M = self.norm_matrix.detach().cpu().numpy() if is_torch(self.norm_matrix) else np.asarray(self.norm_matrix)
+            self._device_cache[key] = tuple(torch.as_tensor(np.ascontiguousarray(a), dtype=x.dtype, device=x.device)
+                                            for a in (self._U, self._s, M))
+        return self._device_cache[key]
+
+    def factor_matrix_update(self, factor_matrix, feasibility_penalty, aux):
+        U, s, _ = self._factors_like(factor_matrix)
+        s_aug = s + 0.5 * feasibility_penalty
+        tmp = U.T @ (0.5 * feasibility_penalty * factor_matrix)
+        return (U * (1 / s_aug)) @ tmp
+
+    def _penalty(self, x):
+        _, _, M = self._factors_like(x)
+        return (x.T @ M @ x).trace() if is_torch(x) else np.trace(x.T @ M @ x)
+
+    def penalty(self, x):
+        if is_tensor(x):
+            return self._penalty(x)
+        return sum(self._penalty(xi) for xi in x)
+
+
+class UnitSimplex(HardConstraintMixin, MatrixPenalty):
+    """Component vectors non-negative and summing to one (penalties.py:928-980).
+
+    The reference finds the Lagrange multiplier mu of sum(max(y - mu, 0)) = 1 per column by bisection; the sorted
+    cumulative-sum formula used here is the exact root of the same equation and runs on the device for torch tensors."""
+
+    def factor_matrix_update(self, factor_matrix, feasibility_penalty, aux):
+        y = factor_matrix
+        n = y.shape[0]
+        if is_torch(y):
+            u, _ = torch.sort(y, dim=0, descending=True)
+            css = torch.cumsum(u, dim=0) - 1.0
+            idx = torch.arange(1, n + 1, dtype=y.dtype, device=y.device).unsqueeze(1)
+            k = (u - css / idx > 0).to(torch.int64).cumsum(dim=0).argmax(dim=0)  # last index where the condition holds
+            mu = css.gather(0, k.unsqueeze(0)).squeeze(0) / (k.to(y.dtype) + 1.0)
+            return torch.clamp(y - mu.unsqueeze(0), min=0)
+        y = np.asarray(y)
+        u = -np.sort(-y, axis=0)
+        css = np.cumsum(u, axis=0) - 1.0
+        cond = u - css / np.arange(1, n + 1)[:, None] > 0
+        k = n - 1 - np.argmax(cond[::-1], axis=0)
+        mu = css[k, np.arange(y.shape[1])] / (k + 1.0)
+        return np.clip(y - mu[None, :], 0, None)
 
 
 def _prefix_isotonic(y, non_negativity):

@@ -16,6 +16,9 @@ Fixture families:
                           + one seeded `init="random"` run pinning the RNG draw order
   G3  prox.npz            each penalty's prox on standard-normal inputs; unimodal regression vectors
   G4  stopping.json       stopping-message / n_iter / list-length matrix (decomposition.py:990-1100)
+  G5  more_penalties.npz  GeneralizedL2Penalty / UnitSimplex: prox vectors and a 10-iteration
+                          trajectory with a graph-Laplacian penalty on the B_i and the unit simplex on C
+                          (`python oracle/tools/gen_golden.py --only more` regenerates just this family)
 
 Penalties are described by neutral JSON descriptors ({"kind": "l1", "reg_strength": 0.1, ...}) so
 that the fixtures do not depend on any class of the reference or of the product.
@@ -63,6 +66,10 @@ def make_ref_penalty(desc, aux_init="random_uniform", dual_init="random_uniform"
         return ref_pen.Unimodality(non_negativity=desc.get("non_negativity", False), **kw)
     if kind == "parafac2":
         return ref_pen.Parafac2(**kw)
+    if kind == "gl2":
+        return ref_pen.GeneralizedL2Penalty(np.asarray(desc["norm_matrix"], dtype=float), **kw)
+    if kind == "simplex":
+        return ref_pen.UnitSimplex(**kw)
     raise ValueError(kind)
 
 
@@ -422,11 +429,80 @@ def gen_stopping():
         print("stopping:", res.get("message"), res.get("n_iter"))
 
 
+# ----------------------------------------------------------------------------------------------
+# G5: GeneralizedL2Penalty / UnitSimplex
+# ----------------------------------------------------------------------------------------------
+def chain_laplacian(n, weight=1.0):
+    M = 2 * np.eye(n) - np.eye(n, k=1) - np.eye(n, k=-1)
+    M[0, 0] = M[-1, -1] = 1
+    return weight * M
+
+
+def gen_more_penalties():
+    rng = np.random.RandomState(11)
+    n_mats, J, r = 4, 10, 3
+    row_ptr = np.arange(n_mats + 1, dtype=np.int64) * J
+    Y = rng.standard_normal((n_mats * J, r))
+    rhos = rng.uniform(2, 3, size=n_mats)
+    G = rng.standard_normal((J, J))
+    arrays = dict(Y=Y, row_ptr=row_ptr, rhos=rhos, M_chain=chain_laplacian(J), M_dense=G @ G.T / J)
+    descs = [{"kind": "gl2", "norm_matrix": "M_chain"}, {"kind": "gl2", "norm_matrix": "M_dense"}, {"kind": "simplex"}]
+    for ci, d in enumerate(descs):
+        dd = dict(d)
+        if d["kind"] == "gl2":
+            dd["norm_matrix"] = arrays[d["norm_matrix"]]
+        pen = make_ref_penalty(dd)
+        arrays[f"p{ci}_single_rho10"] = np.asarray(pen.factor_matrix_update(Y[:J].copy(), 10.0, None))
+        arrays[f"p{ci}_list"] = pack_rows(pen.factor_matrices_update(split_rows(Y, row_ptr), list(rhos), [None] * n_mats))
+        arrays[f"p{ci}_penalty"] = np.array(float(pen.penalty(Y[:J])))
+        arrays[f"p{ci}_penalty_list"] = np.array(float(pen.penalty(split_rows(Y, row_ptr))))
+    arrays["manifest"] = np.array(json.dumps(descs))
+
+    # trajectory on config-1 data: graph Laplacian (smoothness along the rows of every B_i) + NN on A + simplex on C
+    matrices, _ = get_simple_simulated_data(noise_level=0.2, random_state=1)
+    I, (Jd, K), rk = len(matrices), matrices[0].shape, 3
+    rp = np.arange(I + 1, dtype=np.int64) * Jd
+    A0, B0, C0 = rng.uniform(size=(I, rk)), rng.uniform(size=(I * Jd, rk)), rng.uniform(size=(K, rk))
+    M_traj = chain_laplacian(Jd, 0.5)
+    spec = [[NN], [{"kind": "gl2", "norm_matrix": "M_traj"}], [{"kind": "simplex"}]]
+    shapes = {0: (I, rk), 1: (I * Jd, rk), 2: (K, rk)}
+    regs = [[], [], []]
+    arrays.update(t_A0=A0, t_B0=B0, t_C0=C0, M_traj=M_traj)
+    for mode in range(3):
+        for sidx, d in enumerate(spec[mode]):
+            aux, dual = rng.uniform(size=shapes[mode]), rng.uniform(size=shapes[mode])
+            arrays[f"t_aux_in_m{mode}_{sidx}"], arrays[f"t_dual_in_m{mode}_{sidx}"] = aux, dual
+            dd = dict(d)
+            if d["kind"] == "gl2":
+                dd["norm_matrix"] = M_traj
+            regs[mode].append(make_ref_penalty(
+                dd, aux_init=split_rows(aux, rp) if mode == 1 else aux.copy(),
+                dual_init=split_rows(dual, rp) if mode == 1 else dual.copy()))
+    cmf, admm_vars, diag = ref_dec.cmf_aoadmm(
+        matrices, rk, init=(None, (A0.copy(), split_rows(B0, rp), C0.copy())), regs=regs, n_iter_max=10, tol=None,
+        absolute_tol=None, return_errors=True, return_admm_vars=True)
+    arrays.update(t_A=cmf[1][0], t_B=pack_rows(cmf[1][1]), t_C=cmf[1][2], t_rec_errors=np.array(diag.rec_errors),
+                  t_regularized_loss=np.array(diag.regularized_loss))
+    for mode in range(3):
+        for sidx in range(len(spec[mode])):
+            aux, dual = admm_vars.auxes[mode][sidx], admm_vars.duals[mode][sidx]
+            arrays[f"t_aux_m{mode}_{sidx}"] = pack_rows(aux) if mode == 1 else np.asarray(aux)
+            arrays[f"t_dual_m{mode}_{sidx}"] = pack_rows(dual) if mode == 1 else np.asarray(dual)
+    arrays["t_spec"] = np.array(json.dumps(dict(regs=spec, rank=rk, n_iter_max=10)))
+    np.savez_compressed(os.path.join(OUT, "more_penalties.npz"), **arrays)
+    print(f"more_penalties: rec {diag.rec_errors[0]:.6f} -> {diag.rec_errors[-1]:.6f}; "
+          f"column sums of C {np.sum(cmf[1][2], axis=0)}")
+
+
 if __name__ == "__main__":
     print("reference version", matcouply.__version__)
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "more":
+        gen_more_penalties()
+        sys.exit(0)
     gen_phase()
     gen_traj()
     gen_prox()
     gen_stopping()
+    gen_more_penalties()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"total fixture bytes: {total}")

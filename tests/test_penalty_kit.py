@@ -150,3 +150,41 @@ class TestParafac2(BaseTestFactorMatricesPenalty):
 
     test_given_init = test_rank_and_mode_validation = test_validating_given_init = test_input_validation_for_init = \
         lambda self, *a, **k: pytest.skip("PARAFAC2-specific initialisation is covered in tests/test_host_api.py")
+
+
+class TestUnitSimplex(MixinTestHardConstraint, BaseTestFactorMatrixPenalty):
+    PenaltyType = pen.UnitSimplex
+    min_rows = 2
+
+    def get_invariant_matrix(self, rng, shape):
+        M = rng.uniform(0.1, 1.0, size=shape)
+        return M / M.sum(axis=0, keepdims=True)
+
+    def get_non_invariant_matrix(self, rng, shape):
+        return rng.uniform(0.6, 1.0, size=shape) + 1.0  # every column sums to more than one
+
+    def test_result_is_on_the_simplex(self, rng):
+        x = self.PenaltyType().factor_matrix_update(rng.standard_normal((9, 4)) * 3, 1.0, None)
+        assert x.min() >= 0 and np.allclose(x.sum(axis=0), 1.0)
+
+
+_CHAIN = 2 * np.eye(6) - np.eye(6, k=1) - np.eye(6, k=-1)
+_CHAIN[0, 0] = _CHAIN[-1, -1] = 1
+
+
+class TestGeneralizedL2Penalty(BaseTestFactorMatrixPenalty):
+    PenaltyType = pen.GeneralizedL2Penalty
+    penalty_default_kwargs = {"norm_matrix": _CHAIN}
+    min_rows = max_rows = 6  # the norm matrix fixes the number of rows
+
+    def get_invariant_matrix(self, rng, shape):
+        return np.ones(shape) * rng.uniform(-1, 1, size=(1, shape[1]))  # null space of the chain Laplacian
+
+    def get_non_invariant_matrix(self, rng, shape):
+        return rng.standard_normal(shape) + np.arange(shape[0])[:, None]
+
+    def test_penalty(self, rng):
+        x = rng.standard_normal((6, 3))
+        p = self.PenaltyType(_CHAIN)
+        assert p.penalty(x) == pytest.approx(np.sum(np.diff(x, axis=0) ** 2))  # the quadratic form of the chain graph
+        assert p.penalty([x, 2 * x]) == pytest.approx(5 * p.penalty(x))
