@@ -384,6 +384,7 @@ def cmf_aoadmm(
     verbose=False,
     *,
     group=None,
+    _byproducts=None,
 ):
     r"""Fit a regularized coupled matrix factorization model with AO-ADMM on an MI355X.
 
@@ -756,11 +757,70 @@ def cmf_aoadmm(
             rec_errors=rec_errors, feasibility_gaps=feasibility_gaps, regularized_loss=losses,
             satisfied_stopping_condition=satisfied_stopping_condition,
             satisfied_feasibility_condition=feasibility_criterion, message=message, n_iter=it + 1))
+    if _byproducts is not None and update_A:
+        _byproducts["rhses"] = out(eng.rhses())
+        _byproducts["cross_products"] = out(eng.cross_products())
     if hasattr(eng, "close"):
         eng.close()
     if len(result) == 1:
         return result[0]
     return tuple(result)
+
+
+def _single_phase(mode, matrices, reg, cmf, aux_list, dual_list, l2_penalty, inner_n_iter_max, inner_tol,
+                  feasibility_penalty_scale, constant_feasibility_penalty):
+    """One call of one phase on the device, with the given ADMM variables as initial state."""
+    import copy
+
+    if len(reg) != len(aux_list) or len(reg) != len(dual_list):
+        raise ValueError("reg, aux and dual lists must have the same length")
+    stack = []
+    for r_k, aux, dual in zip(reg, aux_list, dual_list):
+        r_c = copy.copy(r_k)  # same penalty, initial state = the caller's variables
+        r_c.aux_init, r_c.dual_init = aux, dual
+        stack.append(r_c)
+    weights, (A, B_is, C) = cmf
+    regs = [[], [], []]
+    regs[mode] = stack
+    l2 = [0, 0, 0]
+    l2[mode] = l2_penalty if l2_penalty else 0
+    by = {}
+    new_cmf, admm = cmf_aoadmm(
+        matrices, A.shape[1], init=(None, (A, B_is, C)), regs=regs, l2_penalty=l2, n_iter_max=1, tol=None, absolute_tol=None,
+        feasibility_tol=None, inner_tol=inner_tol, inner_n_iter_max=inner_n_iter_max,
+        feasibility_penalty_scale=feasibility_penalty_scale,
+        constant_feasibility_penalty=({0: "A", 1: "B"}.get(mode, False) if constant_feasibility_penalty else False),
+        update_A=(mode == 0), update_B_is=(mode == 1), update_C=(mode == 2), return_admm_vars=True, _byproducts=by)
+    out_cmf = (None, [new_cmf[1][0], new_cmf[1][1], new_cmf[1][2]])
+    return out_cmf, list(admm.auxes[mode]), list(admm.duals[mode]), by
+
+
+def admm_update_A(matrices, reg, cmf, A_aux_list, A_dual_list, l2_penalty, inner_n_iter_max, inner_tol,
+                  feasibility_penalty_scale, constant_feasibility_penalty, svd_fun=None):
+    """One A-phase (reference: decomposition.py:120-219, same positional arguments and return value
+    ``(cmf, A_aux_list, A_dual_list, (rhses, cross_products))``) on the device.  `svd_fun` is accepted for compatibility:
+    the r x r systems are symmetric positive definite and solved by Gauss-Jordan elimination in fp64 registers."""
+    out_cmf, aux, dual, by = _single_phase(0, matrices, reg, cmf, A_aux_list, A_dual_list, l2_penalty, inner_n_iter_max,
+                                           inner_tol, feasibility_penalty_scale, constant_feasibility_penalty)
+    rhses, cross = by["rhses"], by["cross_products"]
+    return out_cmf, aux, dual, ([rhses[i] for i in range(len(rhses))], [cross[i] for i in range(len(cross))])
+
+
+def admm_update_B(matrices, reg, cmf, B_is_aux_list, B_is_dual_list, l2_penalty, inner_n_iter_max, inner_tol,
+                  feasibility_penalty_scale, constant_feasibility_penalty, svd_fun=None):
+    """One B-phase (reference: decomposition.py:222-292); returns ``(cmf, B_is_aux_list, B_is_dual_list)``."""
+    out_cmf, aux, dual, _ = _single_phase(1, matrices, reg, cmf, B_is_aux_list, B_is_dual_list, l2_penalty,
+                                          inner_n_iter_max, inner_tol, feasibility_penalty_scale,
+                                          constant_feasibility_penalty)
+    return out_cmf, aux, dual
+
+
+def admm_update_C(matrices, reg, cmf, C_aux_list, C_dual_list, l2_penalty, inner_n_iter_max, inner_tol,
+                  feasibility_penalty_scale, svd_fun=None):
+    """One C-phase (reference: decomposition.py:295-344); returns ``(cmf, C_aux_list, C_dual_list)``."""
+    out_cmf, aux, dual, _ = _single_phase(2, matrices, reg, cmf, C_aux_list, C_dual_list, l2_penalty, inner_n_iter_max,
+                                          inner_tol, feasibility_penalty_scale, False)
+    return out_cmf, aux, dual
 
 
 def parafac2_aoadmm(

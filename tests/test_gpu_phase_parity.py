@@ -61,3 +61,48 @@ def test_phase_C_goldens():
 
 def test_phase_A_goldens():
     print("worst rel err A:", _run_phase("A", 0))
+
+
+@pytest.mark.parametrize("name,mode", [("B", 1), ("C", 2), ("A", 0)])
+def test_public_admm_update_functions(name, mode):
+    """admm_update_A / admm_update_B / admm_update_C with the reference's positional signature against its own outputs"""
+    from matcouply_amd import decomposition as dec
+    from tests.helpers import split_rows
+    from tests.test_gpu_end_to_end import _regs_from_state
+
+    arrs = load_npz(f"phase_{name}.npz")
+    n_run = 0
+    for ci, case in enumerate(manifest_of(arrs)):
+        if case["inner"] <= 0 or (mode == 0 and case["constant"] is False and
+                                  any(d["kind"] in ("l2ball", "unimodal") for d in case["regs"])):
+            continue  # (matrix penalties on A need a constant feasibility penalty: the reference raises there too)
+        st = _phase_state(mode, case)
+        rp = st.row_ptr
+        mats = split_rows(st.X, rp)
+        cmf = (None, (st.A.copy(), split_rows(st.B, rp), st.C.copy()))
+        reg = _regs_from_state(st)[mode]
+        aux = [(split_rows(z[0], rp), z[1].copy()) if isinstance(z, tuple) else (split_rows(z, rp) if mode == 1 else z.copy())
+               for z in st.aux[mode]]
+        dual = [split_rows(u, rp) if mode == 1 else u.copy() for u in st.dual[mode]]
+        args = (mats, reg, cmf, aux, dual, case["l2"], case["inner"], None, case["scale"])
+        if mode == 1:
+            out_cmf, aux_o, dual_o = dec.admm_update_B(*args, case["constant"], None)
+            factor = np.concatenate(out_cmf[1][1])
+        elif mode == 2:
+            out_cmf, aux_o, dual_o = dec.admm_update_C(*args, None)
+            factor = out_cmf[1][2]
+        else:
+            out_cmf, aux_o, dual_o, (rhses, cross) = dec.admm_update_A(*args, case["constant"], None)
+            factor = out_cmf[1][0]
+            assert rel_err(np.stack(rhses), arrs[f"c{ci}_rhses"]) < TOL
+            assert rel_err(np.stack(cross), arrs[f"c{ci}_cross_products"]) < TOL
+        assert rel_err(factor, arrs[f"c{ci}_factor"]) < TOL, (name, ci, case)
+        for s, d in enumerate(case["regs"]):
+            if d["kind"] == "parafac2":
+                assert rel_err(np.concatenate(aux_o[s][0]), arrs[f"c{ci}_aux{s}_P"]) < TOL
+                assert rel_err(aux_o[s][1], arrs[f"c{ci}_aux{s}_Delta"]) < TOL
+            else:
+                got = np.concatenate(aux_o[s]) if mode == 1 else aux_o[s]
+                assert rel_err(got, arrs[f"c{ci}_aux{s}"]) < TOL, (name, ci, case)
+        n_run += 1
+    assert n_run >= 10
