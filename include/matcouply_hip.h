@@ -37,7 +37,9 @@ enum mcl_penalty_kind {
     MCL_PEN_L2BALL = 4,   /* L2Ball          penalties.py:844-925  */
     MCL_PEN_UNIMODAL = 5, /* Unimodality     penalties.py:983-1015 */
     MCL_PEN_PARAFAC2 = 6, /* Parafac2        penalties.py:1018-1324 (mode 1 only) */
-    MCL_PEN_EXTERNAL = 7  /* user prox evaluated by the host between mcl_*_solve and mcl_*_dual */
+    MCL_PEN_EXTERNAL = 7, /* user prox evaluated by the host between mcl_*_solve and mcl_*_dual */
+    MCL_PEN_TV = 8        /* TotalVariationPenalty  penalties.py:750-841: p0 = TV strength, p1 = L1 strength; the prox
+                             (condat_tv.tv_denoise_matrix in the reference) is L. Condat's direct 1-D TV algorithm */
 };
 
 typedef struct {

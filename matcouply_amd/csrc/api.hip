@@ -357,7 +357,9 @@ int mcl_set_penalties(mcl_context *c, int32_t mode, int32_t n, const mcl_penalty
     rs.n = n;
     for (int k = 0; k < n; ++k) {
         const mcl_penalty_desc &d = descs[k];
-        if (d.kind < MCL_PEN_NN || d.kind > MCL_PEN_EXTERNAL) return fail(c, "mcl_set_penalties: unknown penalty kind");
+        if (d.kind < MCL_PEN_NN || d.kind > MCL_PEN_TV) return fail(c, "mcl_set_penalties: unknown penalty kind");
+        if (d.kind == MCL_PEN_TV && (d.p0 <= 0 || d.p1 < 0))
+            return fail(c, "mcl_set_penalties: TV strength must be positive and its L1 strength non-negative");
         if (d.kind == MCL_PEN_PARAFAC2 && mode != 1)
             return fail(c, "mcl_set_penalties: PARAFAC2 constraint can only be imposed with mode=1");
         if (d.kind == MCL_PEN_PARAFAC2 && !d.aux2) return fail(c, "mcl_set_penalties: PARAFAC2 needs the coordinate matrix");

@@ -403,6 +403,91 @@ __global__ __launch_bounds__(256) void k_rows_l2ball(ModeView mv, RegSet regs, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Total variation (penalties.py:750-841): per column of a slab, aux = argmin 1/2 ||y - (F + U)||^2 + lam sum |y_n - y_{n-1}|
+// with lam = 2 alpha / rho, then the L1 soft threshold with l1 / rho.  The reference calls condat_tv (GPL); this is
+// L. Condat's direct algorithm (IEEE SPL 20(11), 2013) restated from the paper: one pass with occasional restarts at
+// the last position where a bound was active; fp64 like the unimodal regression (its decisions are discontinuous).
+// One lane per (slab, column): the r lanes of a slab read / write consecutive addresses.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_slab_tv(const int *__restrict__ ext, int n_slabs, const float *__restrict__ F,
+                                                const float *__restrict__ rho_arr, RegSet regs, int kreg, int r) {
+    const long t = (long)blockIdx.x * 64 + threadIdx.x;
+    if (t >= (long)n_slabs * r) return;
+    const int slab = (int)(t / r), col = (int)(t - (long)slab * r);
+    const long s = ext[slab];
+    const int n = ext[slab + 1] - ext[slab];
+    if (n <= 0) return;
+    const float *U = regs.dual[kreg];
+    float *Z = regs.aux[kreg];
+    const double rho = (double)rho_arr[slab];
+    const double lam = 2.0 * (double)regs.p0[kreg] / rho;
+    const float l1 = (float)((double)regs.p1[kreg] / rho);
+    auto in = [&](int k) -> double { return (double)(F[(s + k) * r + col] + U[(s + k) * r + col]); };
+    auto emit = [&](int a, int b, double v) {  // y[a..b] = v, then soft threshold
+        float z = (float)v;
+        if (l1 > 0.f) z = copysignf(fmaxf(fabsf(z) - l1, 0.f), z);
+        for (int k = a; k <= b; ++k) Z[(s + k) * r + col] = z;
+    };
+    int k = 0, k0 = 0, km = 0, kp = 0;
+    double x0 = in(0);
+    double vmin = x0 - lam, vmax = x0 + lam, umin = lam, umax = -lam;
+    for (;;) {
+        if (k == n - 1) {
+            if (umin < 0.0) {
+                emit(k0, km, vmin);
+                k0 = km + 1;
+                k = km = k0;
+                vmin = in(k);
+                umin = lam;
+                umax = vmin + lam - vmax;
+            } else if (umax > 0.0) {
+                emit(k0, kp, vmax);
+                k0 = kp + 1;
+                k = kp = k0;
+                vmax = in(k);
+                umax = -lam;
+                umin = vmax - lam - vmin;
+            } else {
+                vmin += umin / (double)(k - k0 + 1);
+                emit(k0, k, vmin);
+                return;
+            }
+        } else {
+            const double xn = in(k + 1);
+            umin += xn - vmin;
+            umax += xn - vmax;
+            if (umin < -lam) {
+                emit(k0, km, vmin);
+                k0 = km + 1;
+                k = km = kp = k0;
+                vmin = in(k);
+                vmax = vmin + 2.0 * lam;
+                umin = lam, umax = -lam;
+            } else if (umax > lam) {
+                emit(k0, kp, vmax);
+                k0 = kp + 1;
+                k = km = kp = k0;
+                vmax = in(k);
+                vmin = vmax - 2.0 * lam;
+                umin = lam, umax = -lam;
+            } else {
+                ++k;
+                if (umin >= lam) {
+                    km = k;
+                    vmin += (umin - lam) / (double)(km - k0 + 1);
+                    umin = lam;
+                }
+                if (umax <= -lam) {
+                    kp = k;
+                    vmax += (umax + lam) / (double)(kp - k0 + 1);
+                    umax = -lam;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Unimodality: one thread per (slab, column); prefix isotonic regression in both directions in fp64
 // (the projection is discontinuous in its split index, so the arithmetic is kept in double).
 // Scratch arrays are column-interleaved (index * r + col) so the r threads of a slab access them coalesced.
@@ -1341,6 +1426,13 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                                    mv.ext, mv.n_slabs, mv.F, rs, k, c->r, sc.eL, sc.sy, sc.sw, sc.sy2,
                                    getenv("MCL_UNI_DBG") ? atoi(getenv("MCL_UNI_DBG")) : 0);
             if (!getenv("MCL_UNIMODAL_V1")) DISPATCH_ROWS(c, vec, k_rows_dual, grid, block, mv, rs, k, c->r);
+            break;
+        }
+        case MCL_PEN_TV: {
+            const long nthreads = (long)mv.n_slabs * c->r;
+            hipLaunchKernelGGL(k_slab_tv, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, c->stream, mv.ext, mv.n_slabs,
+                               (const float *)mv.F, mv.rho, rs, k, c->r);
+            DISPATCH_ROWS(c, vec, k_rows_dual, grid, block, mv, rs, k, c->r);
             break;
         }
         case MCL_PEN_PARAFAC2: {

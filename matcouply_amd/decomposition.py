@@ -208,7 +208,8 @@ def _parse_mode_penalties(non_negative, lower_bound, upper_bound, l2_norm_bound,
         regs.append(penalties.L2Ball(l2_norm_bound, non_negativity=non_negative, aux_init=aux_init, dual_init=dual_init))
         skip_non_negative = True
     if tv_penalty:
-        raise NotImplementedError("tv_penalty needs the GPL condat_tv library in the reference and is out of scope here")
+        regs.append(penalties.TotalVariationPenalty(tv_penalty, l1_strength=l1_penalty, aux_init=aux_init, dual_init=dual_init))
+        l1_penalty = 0  # already included in the total variation penalty
     if l1_penalty:
         regs.append(penalties.L1Penalty(l1_penalty, non_negativity=non_negative, aux_init=aux_init, dual_init=dual_init))
         skip_non_negative = True
@@ -394,8 +395,8 @@ def cmf_aoadmm(
 
     ``matrices`` is a list of I arrays (NumPy or torch, J_i x K) or a :class:`PackedMatrices` already in HBM.  The
     arithmetic runs in fp32 on the device (rank x rank systems and all reductions in fp64); results are returned in the
-    array type and dtype of the input.  Not supported (out of scope, raise ``NotImplementedError``): ``tv_penalty``,
-    TensorLy-ALS initialisations, ``inner_tol``.  Penalties without a native kernel (user
+    array type and dtype of the input.  Not supported (out of scope, raise ``NotImplementedError``): TensorLy-ALS
+    initialisations, ``inner_tol``.  Penalties without a native kernel (user
     subclasses of ``matcouply_amd.penalties.ADMMPenalty``) are evaluated through their own Python methods on device
     tensors between the native solve and dual-update steps.
 
@@ -601,7 +602,7 @@ def cmf_aoadmm(
                 mode_gaps.append(np.sqrt(d[base]) / fnorm)
                 if isinstance(reg, penalties.L1Penalty):
                     reg_penalty += reg.reg_strength * d[base + 1]
-                elif native[mode][k].kind == _engine.PEN_EXTERNAL:
+                elif native[mode][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV):  # value computed on device tensors
                     factor = [eng.B[sl] for sl in row_slices] if mode == 1 else (eng.A if mode == 0 else eng.C)
                     reg_penalty += float(reg.penalty(factor))
             gaps.append(mode_gaps)
@@ -630,7 +631,11 @@ def cmf_aoadmm(
     feasibility_criterion = None
 
     it = -1  # Needed if n_iter_max <= 0
-    fast_path = (not (tol or absolute_tol)) and world == 1 and not verbose and n_iter_max > 0 and not any(has_ext)
+    host_value = any(r.kind == _engine.PEN_TV for m in range(3) for r in native[m])  # penalty value needs a host call
+    fast_path = ((not (tol or absolute_tol)) and world == 1 and not verbose and n_iter_max > 0 and not any(has_ext)
+                 and not host_value)
+    if host_value and world > 1:
+        raise NotImplementedError("TotalVariationPenalty is not supported with group= (its penalty value is summed on the host)")
     lazy_diag = (not (tol or absolute_tol)) and world > 1 and not verbose and n_iter_max > 0
     if lazy_diag:
         # sharded, fixed iteration count: nothing depends on the diagnostics inside the loop, so their partial sums stay

@@ -13,8 +13,10 @@ operators on NumPy arrays or torch tensors, so that code written against the ref
 the reusable test kit, custom subclasses) keeps working.  A penalty WITHOUT a native descriptor (a user
 subclass) is driven through the engine's step calls with its Python prox evaluated on device tensors; that is also how
 `GeneralizedL2Penalty` (:595-747) and `UnitSimplex` (:928-980) run: their prox is a pair of matrix products / a sort +
-cumulative sum, written below for NumPy arrays and torch (device) tensors alike.  `TotalVariationPenalty` of the
-reference needs the GPL `condat_tv` package and is out of scope.
+cumulative sum, written below for NumPy arrays and torch (device) tensors alike.  `TotalVariationPenalty` (:750-841)
+needs the GPL `condat_tv` package in the reference; here its prox is an own restatement of L. Condat's published direct
+1-D TV algorithm (native kernel k_slab_tv; host version below), verified against the optimality conditions of the
+problem since that package is not available to generate reference vectors.
 """
 from abc import ABC, abstractmethod
 
@@ -290,6 +292,99 @@ class L2Ball(HardConstraintMixin, MatrixPenalty):
 
     def _native_descriptor(self):
         return (_engine.PEN_L2BALL, bool(self.non_negativity), float(self.norm_bound), 0.0)
+
+
+def tv_denoise(x, lam):
+    """argmin_y 1/2 ||y - x||^2 + lam sum_n |y_n - y_{n-1}| for a vector (L. Condat, "A Direct Algorithm for 1-D Total
+    Variation Denoising", IEEE Signal Processing Letters 20(11), 2013), host NumPy version of the kernel k_slab_tv."""
+    x = np.asarray(x, dtype=float)
+    n = len(x)
+    y = np.empty(n)
+    if n == 0:
+        return y
+    if lam <= 0:
+        return x.copy()
+    k = k0 = km = kp = 0
+    vmin, vmax, umin, umax = x[0] - lam, x[0] + lam, lam, -lam
+    while True:
+        if k == n - 1:
+            if umin < 0.0:
+                y[k0:km + 1] = vmin
+                k0 = k = km = km + 1
+                vmin, umin = x[k], lam
+                umax = vmin + lam - vmax
+            elif umax > 0.0:
+                y[k0:kp + 1] = vmax
+                k0 = k = kp = kp + 1
+                vmax, umax = x[k], -lam
+                umin = vmax - lam - vmin
+            else:
+                y[k0:k + 1] = vmin + umin / (k - k0 + 1)
+                return y
+        else:
+            umin += x[k + 1] - vmin
+            umax += x[k + 1] - vmax
+            if umin < -lam:
+                y[k0:km + 1] = vmin
+                k0 = k = km = kp = km + 1
+                vmin = x[k]
+                vmax, umin, umax = vmin + 2.0 * lam, lam, -lam
+            elif umax > lam:
+                y[k0:kp + 1] = vmax
+                k0 = k = km = kp = kp + 1
+                vmax = x[k]
+                vmin, umin, umax = vmax - 2.0 * lam, lam, -lam
+            else:
+                k += 1
+                if umin >= lam:
+                    km = k
+                    vmin += (umin - lam) / (km - k0 + 1)
+                    umin = lam
+                if umax <= -lam:
+                    kp = k
+                    vmax += (umax + lam) / (kp - k0 + 1)
+                    umax = -lam
+
+
+class TotalVariationPenalty(MatrixPenalty):
+    r"""Piecewise constant components: alpha * sum_n |x_n - x_{n-1}| (+ beta * sum_n |x_n|) on every column
+    (penalties.py:750-841).  prox: TV denoising with 2 alpha / rho, then the L1 soft threshold with beta / rho."""
+
+    def __init__(self, reg_strength, l1_strength=0, aux_init="random_uniform", dual_init="random_uniform"):
+        if reg_strength <= 0:
+            raise ValueError("The TV regularization strength must be positive.")
+        if l1_strength < 0:
+            raise ValueError("The L1 regularization strength must be non-negative.")
+        super().__init__(aux_init, dual_init)
+        self.reg_strength = reg_strength
+        self.l1_strength = l1_strength
+
+    def factor_matrix_update(self, factor_matrix, feasibility_penalty, aux):
+        fm = factor_matrix.detach().cpu().numpy() if is_torch(factor_matrix) else np.asarray(factor_matrix)
+        lam = self.reg_strength * 2 / feasibility_penalty
+        X = np.stack([tv_denoise(fm[:, c], lam) for c in range(fm.shape[1])], axis=1)
+        if self.l1_strength:
+            X = np.sign(X) * np.clip(np.abs(X) - self.l1_strength / feasibility_penalty, 0, float("inf"))
+        if is_torch(factor_matrix):
+            return torch.as_tensor(X, dtype=factor_matrix.dtype, device=factor_matrix.device)
+        return X
+
+    def _penalty(self, x):
+        if is_torch(x):
+            value = self.reg_strength * torch.diff(x, dim=0).abs().sum()
+        else:
+            value = self.reg_strength * np.sum(np.abs(np.diff(x, axis=0)))
+        if self.l1_strength:
+            value = value + self.l1_strength * _sum(_abs(x))
+        return value
+
+    def penalty(self, x):
+        if is_tensor(x):
+            return self._penalty(x)
+        return sum(self._penalty(xi) for xi in x)
+
+    def _native_descriptor(self):
+        return (_engine.PEN_TV, False, float(self.reg_strength), float(self.l1_strength))
 
 
 class GeneralizedL2Penalty(MatrixPenalty):

@@ -27,7 +27,7 @@ def rel_err(a, b):
 
 
 # ---- GPU helpers (only used by -m gpu tests) ---------------------------------------------------------
-KIND = {"nn": 1, "box": 2, "l1": 3, "l2ball": 4, "unimodal": 5, "parafac2": 6}
+KIND = {"nn": 1, "box": 2, "l1": 3, "l2ball": 4, "unimodal": 5, "parafac2": 6, "tv": 8}
 
 
 def native_regs(descs, aux, dual, device):
@@ -49,6 +49,8 @@ def native_regs(descs, aux, dual, device):
             out.append(NativeReg(kind, t(z), t(u), non_negativity=d.get("non_negativity", False), p0=d["reg_strength"]))
         elif d["kind"] == "l2ball":
             out.append(NativeReg(kind, t(z), t(u), non_negativity=d.get("non_negativity", False), p0=d["norm_bound"]))
+        elif d["kind"] == "tv":
+            out.append(NativeReg(kind, t(z), t(u), p0=d["reg_strength"], p1=d.get("l1_strength", 0.0)))
         elif d["kind"] == "unimodal":
             out.append(NativeReg(kind, t(z), t(u), non_negativity=d.get("non_negativity", False)))
         else:

@@ -8,7 +8,7 @@ import torch
 from matcouply_amd import _engine
 from oracle import aoadmm_oracle as orc
 
-KIND_NAME = {1: "nn", 2: "box", 3: "l1", 4: "l2ball", 5: "unimodal", 6: "parafac2"}
+KIND_NAME = {1: "nn", 2: "box", 3: "l1", 4: "l2ball", 5: "unimodal", 6: "parafac2", 8: "tv"}
 
 
 def _desc(reg):
@@ -20,6 +20,8 @@ def _desc(reg):
         d["reg_strength"] = reg.p0
     elif name == "l2ball":
         d["norm_bound"] = reg.p0
+    elif name == "tv":
+        d.update(reg_strength=reg.p0, l1_strength=reg.p1)
     return d
 
 

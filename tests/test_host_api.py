@@ -37,6 +37,12 @@ def make_penalty(d, aux_init="random_uniform", dual_init="random_uniform"):
         return pen.Unimodality(non_negativity=d.get("non_negativity", False), **kw)
     if k == "parafac2":
         return pen.Parafac2(**kw)
+    if k == "tv":
+        return pen.TotalVariationPenalty(d["reg_strength"], l1_strength=d.get("l1_strength", 0.0), **kw)
+    if k == "gl2":
+        return pen.GeneralizedL2Penalty(d["norm_matrix"], **kw)
+    if k == "simplex":
+        return pen.UnitSimplex(**kw)
     raise ValueError(k)
 
 
@@ -282,8 +288,8 @@ def test_argument_errors(checker_engine):
         dec.cmf_aoadmm(X, 3, n_iter_max=1, regs=[[1], [], []])
     with pytest.raises(ValueError):
         dec.cmf_aoadmm(X, 3, n_iter_max=1, l2_penalty=[1, 2])
-    with pytest.raises(NotImplementedError):
-        dec.cmf_aoadmm(X, 3, n_iter_max=1, tv_penalty=1.0)
+    with pytest.raises(ValueError):
+        dec.cmf_aoadmm(X, 3, n_iter_max=1, tv_penalty=-1.0)  # negative TV strength (penalties.py:812-813)
     # update_X=False freezes that mode and drops its penalties (decomposition.py:896-901)
     rs = np.random.RandomState(3)
     init = (None, (rs.uniform(size=(15, 3)), [rs.uniform(size=(50, 3)) for _ in range(15)], rs.uniform(size=(20, 3))))

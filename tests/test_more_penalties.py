@@ -148,3 +148,112 @@ def test_generalized_l2_keyword():
     assert np.isfinite(diag.regularized_loss).all() and diag.rec_errors[-1] < diag.rec_errors[0]
     with pytest.raises(ValueError):
         pen.GeneralizedL2Penalty(np.ones((3, 4)))
+
+
+# ---- TotalVariationPenalty: the reference's prox lives in the absent GPL package condat_tv, so the anchor is the
+# ---- optimality system of the problem itself (plus a brute-force dual solver on small inputs)
+def _tv_kkt(x, y, lam, tol=1e-9):
+    u = np.cumsum(x - y)           # -u[:-1] is the dual variable of the differences
+    assert abs(u[-1]) < tol * max(1.0, np.abs(x).sum())
+    s, d = -u[:-1], np.diff(y)
+    assert np.all(np.abs(s) <= lam + tol)
+    assert np.all(np.abs(s[d > 1e-12] - lam) < 1e-7) and np.all(np.abs(s[d < -1e-12] + lam) < 1e-7)
+
+
+def _tv_brute(x, lam, iters=20000):
+    D = np.diff(np.eye(len(x)), axis=0)
+    s = np.zeros(len(x) - 1)
+    for _ in range(iters):
+        s = np.clip(s + 0.25 * (D @ (x - D.T @ s)), -lam, lam)
+    return x - D.T @ s
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_tv_denoise_is_optimal(impl):
+    from matcouply_amd import penalties as pen
+
+    f = orc.tv_denoise_1d if impl == "oracle" else pen.tv_denoise
+    rng = np.random.RandomState(0)
+    for n in (1, 2, 3, 5, 8, 13, 40, 100):
+        for lam in (0.01, 0.1, 0.5, 2.0, 50.0):
+            for rep in range(5):
+                x = rng.standard_normal(n) * rng.choice([0.1, 1, 5])
+                if rep == 0:
+                    x = np.round(x)  # ties
+                y = f(x, lam)
+                if n == 1:
+                    assert abs(y[0] - x[0]) < 1e-12
+                    continue
+                _tv_kkt(x, y, lam)
+                if n <= 8 and rep < 2:
+                    assert np.abs(y - _tv_brute(x, lam)).max() < 1e-9
+
+
+def test_tv_penalty_host_methods():
+    from matcouply_amd import penalties as pen
+
+    rng = np.random.RandomState(1)
+    Y = rng.standard_normal((30, 4))
+    d = {"kind": "tv", "reg_strength": 0.3, "l1_strength": 0.1}
+    p = pen.TotalVariationPenalty(0.3, l1_strength=0.1)
+    assert rel_err(p.factor_matrix_update(Y, 2.5, None), orc.prox_matrix(d, Y, 2.5)) < 1e-13
+    assert abs(float(p.penalty(Y)) - orc.penalty_value(d, Y)) < 1e-12
+    out = p.factor_matrix_update(Y, 1e-3, None)            # huge lam: every column collapses to its mean, then shrinks
+    assert np.allclose(out, out[0:1]) and np.all(np.abs(out) <= np.abs(Y.mean(axis=0)) + 1e-12)
+    with pytest.raises(ValueError):
+        pen.TotalVariationPenalty(0.0)
+    with pytest.raises(ValueError):
+        pen.TotalVariationPenalty(1.0, l1_strength=-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2, 0])
+def test_tv_phase_vs_oracle(mode):
+    """the native TV kernel (one lane per slab column) inside one phase against the oracle"""
+    import copy
+    import torch
+    from tests.helpers import engine_from_oracle_state, to_np
+
+    J = np.array([40, 7, 130, 1, 64, 33])
+    X, row_ptr = orc.synthetic_problem(len(J), J, 24, 4, seed=3, dtype=np.float64)
+    X = X.astype(np.float32).astype(np.float64)
+    tv = {"kind": "tv", "reg_strength": 0.05, "l1_strength": 0.02 if mode == 2 else 0.0}
+    regs = [[{"kind": "nn"}], [{"kind": "nn"}], [{"kind": "nn"}]]
+    regs[mode] = [tv, {"kind": "nn"}] if mode == 1 else [tv]
+    st = orc.random_state_for(X, row_ptr, 4, regs, seed=5)
+    st.constant_A = (mode == 0)
+    ref = copy.deepcopy(st)
+    eng = engine_from_oracle_state(st)
+    if mode == 1:
+        eng.update_B(); ref.update_B()
+        got, want = eng.B, ref.B
+    elif mode == 2:
+        eng.update_C_local(); eng.update_C_finish(); ref.update_C()
+        got, want = eng.C, ref.C
+    else:
+        eng.update_A(); ref.update_A()
+        got, want = eng.A, ref.A
+    torch.cuda.synchronize()
+    assert rel_err(to_np(got), want) < 1e-5
+    assert rel_err(to_np(eng.regs[mode][0].aux), ref.aux[mode][0]) < 1e-5
+    assert np.linalg.norm(to_np(eng.regs[mode][0].dual) - ref.dual[mode][0]) / max(np.linalg.norm(ref.dual[mode][0]),
+                                                                                 np.linalg.norm(want)) < 1e-5
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_tv_trajectory_and_keyword():
+    from matcouply_amd import decomposition as dec
+    from tests.test_gpu_end_to_end import _compare, _run_both
+
+    J = np.array([60, 25, 90, 41])
+    X, row_ptr = orc.synthetic_problem(len(J), J, 32, 3, seed=8, dtype=np.float64)
+    X = X.astype(np.float32).astype(np.float64)
+    regs = [[{"kind": "nn"}], [{"kind": "tv", "reg_strength": 0.02, "l1_strength": 0.0}, {"kind": "nn"}],
+            [{"kind": "tv", "reg_strength": 0.01, "l1_strength": 0.005}]]
+    st = orc.random_state_for(X, row_ptr, 3, regs, seed=2)
+    cmf, admm, diag, res = _run_both(st, 6)
+    _compare(cmf, admm, diag, st, res, 2e-5, tol_rec=2e-5)
+    cmf2, d2 = dec.cmf_aoadmm(split_rows(X, row_ptr), 3, tv_penalty={2: 0.01}, l1_penalty={2: 0.005}, non_negative={0: True},
+                              n_iter_max=4, tol=None, absolute_tol=None, return_errors=True, random_state=0)
+    assert np.isfinite(d2.regularized_loss).all() and d2.rec_errors[-1] < d2.rec_errors[0]

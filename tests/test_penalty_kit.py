@@ -188,3 +188,24 @@ class TestGeneralizedL2Penalty(BaseTestFactorMatrixPenalty):
         p = self.PenaltyType(_CHAIN)
         assert p.penalty(x) == pytest.approx(np.sum(np.diff(x, axis=0) ** 2))  # the quadratic form of the chain graph
         assert p.penalty([x, 2 * x]) == pytest.approx(5 * p.penalty(x))
+
+
+class TestTotalVariationPenalty(BaseTestFactorMatrixPenalty):
+    PenaltyType = pen.TotalVariationPenalty
+    penalty_default_kwargs = {"reg_strength": 1}
+    min_rows = 3
+
+    def get_invariant_matrix(self, rng, shape):
+        return np.ones(shape) * rng.uniform(-1, 1, size=(1, shape[1]))  # constant columns: zero total variation
+
+    def get_non_invariant_matrix(self, rng, shape):
+        M = np.ones(shape)
+        M[1::2] = -1.0
+        return M * (1 + np.arange(shape[0]))[:, None]
+
+    def test_penalty(self, rng):
+        x = rng.standard_normal((7, 3))
+        assert self.PenaltyType(0.5).penalty(x) == pytest.approx(0.5 * np.sum(np.abs(np.diff(x, axis=0))))
+        assert self.PenaltyType(0.5, l1_strength=2).penalty(x) == pytest.approx(
+            0.5 * np.sum(np.abs(np.diff(x, axis=0))) + 2 * np.sum(np.abs(x)))
+        assert self.PenaltyType(1).penalty([x, x]) == pytest.approx(2 * self.PenaltyType(1).penalty(x))
