@@ -396,7 +396,7 @@ def cmf_aoadmm(
     ``matrices`` is a list of I arrays (NumPy or torch, J_i x K) or a :class:`PackedMatrices` already in HBM.  The
     arithmetic runs in fp32 on the device (rank x rank systems and all reductions in fp64); results are returned in the
     array type and dtype of the input.  Not supported (out of scope, raise ``NotImplementedError``): TensorLy-ALS
-    initialisations, ``inner_tol``.  Penalties without a native kernel (user
+    initialisations.  ``inner_tol`` > 0 is supported on a slower step path (see below in the code).  Penalties without a native kernel (user
     subclasses of ``matcouply_amd.penalties.ADMMPenalty``) are evaluated through their own Python methods on device
     tensors between the native solve and dual-update steps.
 
@@ -422,9 +422,10 @@ def cmf_aoadmm(
         regs[1] = []
     if not update_C:
         regs[2] = []
-    if inner_tol:
-        raise NotImplementedError("inner_tol (early exit of the inner ADMM loops) is not supported by the fused kernels; "
-                                  "the default inner_tol=None runs inner_n_iter_max iterations as the reference does")
+    # inner_tol > 0 (early exit of the inner ADMM loops, decomposition.py:90-117) needs a convergence test after every
+    # inner iteration: the modes then run on the step path (native solves, every prox through the penalty objects' own
+    # methods on device tensors) instead of the fused kernels - functional, not fast; the default None is the fast path
+    check_inner = bool(inner_tol) and inner_tol > 0
     if isinstance(constant_feasibility_penalty, str) and constant_feasibility_penalty not in {"A", "B"}:
         raise ValueError(
             f"If `constant_feasibility_penalty` is a string, it must be 'A' or 'B', not {constant_feasibility_penalty}")
@@ -454,7 +455,7 @@ def cmf_aoadmm(
     ext_aux = {}
     for mode in range(3):
         for k, (reg, aux, dual) in enumerate(zip(regs[mode], aux_lists[mode], dual_lists[mode])):
-            desc = getattr(reg, "_native_descriptor", lambda: None)()
+            desc = None if check_inner else getattr(reg, "_native_descriptor", lambda: None)()
             dual_t = _pack_rows(dual, device) if mode == 1 else _to_dev(dual, device)
             if desc is None:
                 if mode == 1:
@@ -529,6 +530,17 @@ def cmf_aoadmm(
         nat.aux.copy_(reg.aux_as_matrix(obj).to(nat.aux.dtype))
         nat.dual.copy_(F - (nat.aux - nat.dual))
 
+    def inner_converged(F, F_old, mode):
+        """decomposition.py:90-117 on device tensors: relative change and every feasibility gap of the mode below inner_tol"""
+        if not check_inner:
+            return False
+        nrm = torch.linalg.norm(F.double())
+        if float(torch.linalg.norm(F.double() - F_old.double())) > inner_tol * float(nrm):
+            return False
+        if not native[mode]:
+            return True
+        return max(float(torch.linalg.norm(F.double() - nat.aux.double()) / nrm) for nat in native[mode]) < inner_tol
+
     def do_update_B():
         if not needs_B_steps:
             eng.update_B()
@@ -539,6 +551,7 @@ def cmf_aoadmm(
         eng.B_factor()
         n_it = inner_n_iter_max if native[1] else min(1, inner_n_iter_max)
         for _ in range(n_it):
+            B_old = eng.B.clone() if check_inner else None
             eng.B_solve()
             for k, reg in enumerate(native[1]):
                 if reg.kind == _engine.PEN_EXTERNAL:
@@ -550,6 +563,8 @@ def cmf_aoadmm(
                 if reg.kind == _engine.PEN_PARAFAC2:
                     all_reduce(eng.B_prox_reduce_buffer(k))
                 eng.B_prox_finish(k)
+            if inner_converged(eng.B, B_old, 1):
+                break
 
     def do_update_C():
         gr = eng.update_C_local()
@@ -560,10 +575,13 @@ def cmf_aoadmm(
         eng.C_begin()
         n_it = inner_n_iter_max if native[2] else min(1, inner_n_iter_max)
         for _ in range(n_it):
+            C_old = eng.C.clone() if check_inner else None
             eng.C_solve()
             rho_c = eng.rho(2).cpu().numpy()
             for k in range(len(native[2])):
                 host_prox_matrix(2, k, eng.C, rho_c, True)
+            if inner_converged(eng.C, C_old, 2):
+                break
         eng.C_end()
 
     def do_update_A():
@@ -575,9 +593,12 @@ def cmf_aoadmm(
             rho_a = eng.rho(0).cpu().numpy()
             n_it = inner_n_iter_max if native[0] else min(1, inner_n_iter_max)
             for _ in range(n_it):
+                A_old = eng.A.clone() if check_inner else None
                 eng.A_solve()
                 for k in range(len(native[0])):
                     host_prox_matrix(0, k, eng.A, rho_a, constant_A)
+                if inner_converged(eng.A, A_old, 0):
+                    break
             eng.A_end()
             return
         if not needs_A_steps:

@@ -489,6 +489,28 @@ def gen_more_penalties():
             arrays[f"t_aux_m{mode}_{sidx}"] = pack_rows(aux) if mode == 1 else np.asarray(aux)
             arrays[f"t_dual_m{mode}_{sidx}"] = pack_rows(dual) if mode == 1 else np.asarray(dual)
     arrays["t_spec"] = np.array(json.dumps(dict(regs=spec, rank=rk, n_iter_max=10)))
+
+    # early exit of the inner loops (inner_tol, decomposition.py:90-117): 8 outer iterations, up to 25 inner ones
+    spec_it = [[NN], [NN, BALL1NN], [L1NN]]
+    regs = [[], [], []]
+    for mode in range(3):
+        for sidx, d in enumerate(spec_it[mode]):
+            aux, dual = rng.uniform(size=shapes[mode]), rng.uniform(size=shapes[mode])
+            arrays[f"it_aux_in_m{mode}_{sidx}"], arrays[f"it_dual_in_m{mode}_{sidx}"] = aux, dual
+            regs[mode].append(make_ref_penalty(
+                d, aux_init=split_rows(aux, rp) if mode == 1 else aux.copy(),
+                dual_init=split_rows(dual, rp) if mode == 1 else dual.copy()))
+    cmf, admm_vars, diag = ref_dec.cmf_aoadmm(
+        matrices, rk, init=(None, (A0.copy(), split_rows(B0, rp), C0.copy())), regs=regs, n_iter_max=8, tol=None,
+        absolute_tol=None, inner_tol=1e-2, inner_n_iter_max=25, return_errors=True, return_admm_vars=True)
+    arrays.update(it_A=cmf[1][0], it_B=pack_rows(cmf[1][1]), it_C=cmf[1][2], it_rec_errors=np.array(diag.rec_errors),
+                  it_regularized_loss=np.array(diag.regularized_loss))
+    for mode in range(3):
+        for sidx in range(len(spec_it[mode])):
+            aux, dual = admm_vars.auxes[mode][sidx], admm_vars.duals[mode][sidx]
+            arrays[f"it_aux_m{mode}_{sidx}"] = pack_rows(aux) if mode == 1 else np.asarray(aux)
+            arrays[f"it_dual_m{mode}_{sidx}"] = pack_rows(dual) if mode == 1 else np.asarray(dual)
+    arrays["it_spec"] = np.array(json.dumps(dict(regs=spec_it, rank=rk, n_iter_max=8, inner_tol=1e-2, inner_n_iter_max=25)))
     np.savez_compressed(os.path.join(OUT, "more_penalties.npz"), **arrays)
     print(f"more_penalties: rec {diag.rec_errors[0]:.6f} -> {diag.rec_errors[-1]:.6f}; "
           f"column sums of C {np.sum(cmf[1][2], axis=0)}")

@@ -257,3 +257,52 @@ def test_tv_trajectory_and_keyword():
     cmf2, d2 = dec.cmf_aoadmm(split_rows(X, row_ptr), 3, tv_penalty={2: 0.01}, l1_penalty={2: 0.005}, non_negative={0: True},
                               n_iter_max=4, tol=None, absolute_tol=None, return_errors=True, random_state=0)
     assert np.isfinite(d2.regularized_loss).all() and d2.rec_errors[-1] < d2.rec_errors[0]
+
+
+# ---- inner_tol: early exit of the inner ADMM loops (decomposition.py:90-117)
+def _inner_tol_state(arrs):
+    spec = json.loads(str(arrs["it_spec"]))
+    c1 = load_npz("c1_data.npz")
+    regs = spec["regs"]
+    aux = [[arrs[f"it_aux_in_m{m}_{s}"] for s in range(len(regs[m]))] for m in range(3)]
+    dual = [[arrs[f"it_dual_in_m{m}_{s}"] for s in range(len(regs[m]))] for m in range(3)]
+    st = orc.OracleState(c1["X"], c1["row_ptr"], arrs["t_A0"], arrs["t_B0"], arrs["t_C0"], regs, aux, dual,
+                         inner_n_iter_max=spec["inner_n_iter_max"])
+    st.inner_tol = spec["inner_tol"]
+    return st, spec
+
+
+def test_oracle_inner_tol_matches_reference():
+    arrs = load_npz("more_penalties.npz")
+    st, spec = _inner_tol_state(arrs)
+    res = orc.run(st, spec["n_iter_max"], tol=None, absolute_tol=None)
+    assert max(st.inner_iters) < spec["inner_n_iter_max"]  # the early exit is actually taken
+    assert rel_err(st.A, arrs["it_A"]) < 1e-10 and rel_err(st.B, arrs["it_B"]) < 1e-10 and rel_err(st.C, arrs["it_C"]) < 1e-10
+    np.testing.assert_allclose(res["rec_errors"], arrs["it_rec_errors"], rtol=1e-10)
+    np.testing.assert_allclose(res["losses"], arrs["it_regularized_loss"], rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_solver_inner_tol_matches_reference():
+    """inner_tol > 0 through cmf_aoadmm (step path: native solves, prox of every penalty on device tensors, convergence test
+    after every inner iteration) vs the reference's trajectory.  The exit decisions compare quantities far from their
+    thresholds on this problem, so fp32 takes the same exits."""
+    from matcouply_amd import decomposition as dec
+    from tests.test_host_api import make_penalty
+
+    arrs = load_npz("more_penalties.npz")
+    spec = json.loads(str(arrs["it_spec"]))
+    c1 = load_npz("c1_data.npz")
+    X, rp = c1["X"], c1["row_ptr"]
+    regs = [[make_penalty(d, aux_init=(split_rows(arrs[f"it_aux_in_m{m}_{s}"], rp) if m == 1 else arrs[f"it_aux_in_m{m}_{s}"].copy()),
+                          dual_init=(split_rows(arrs[f"it_dual_in_m{m}_{s}"], rp) if m == 1 else arrs[f"it_dual_in_m{m}_{s}"].copy()))
+             for s, d in enumerate(spec["regs"][m])] for m in range(3)]
+    cmf, admm, diag = dec.cmf_aoadmm(
+        split_rows(X, rp), spec["rank"], init=(None, (arrs["t_A0"].copy(), split_rows(arrs["t_B0"], rp), arrs["t_C0"].copy())),
+        regs=regs, n_iter_max=spec["n_iter_max"], tol=None, absolute_tol=None, inner_tol=spec["inner_tol"],
+        inner_n_iter_max=spec["inner_n_iter_max"], return_errors=True, return_admm_vars=True)
+    tol = 5e-5
+    assert rel_err(cmf[1][0], arrs["it_A"]) < tol and rel_err(cmf[1][2], arrs["it_C"]) < tol
+    assert rel_err(np.concatenate(cmf[1][1]), arrs["it_B"]) < tol
+    np.testing.assert_allclose(diag.rec_errors, arrs["it_rec_errors"], rtol=5e-5)
+    np.testing.assert_allclose(diag.regularized_loss, arrs["it_regularized_loss"], rtol=1e-4)
