@@ -17,6 +17,41 @@ class CoupledMatrixFactorization:
         self.weights = weights
         self.factors = factors
 
+    @classmethod
+    def from_CPTensor(cls, cp_tensor, shapes=None):
+        """(weights, (A, B, C)) of a third-order CP tensor -> coupled matrix factorization with B_i = B, or the first J_i
+        rows of B when `shapes` = [(J_i, K), ...] is given (coupled_matrices.py:101-151)."""
+        weights, factors = cp_tensor
+        if len(factors) != 3:
+            raise ValueError("Must be a third order CP tensor to convert into a coupled matrix factorization")
+        A, B, C = factors
+        copy = lambda x: None if x is None else (x.clone() if hasattr(x, "clone") else np.array(x))
+        if shapes is not None:
+            if len(shapes) != A.shape[0]:
+                raise ValueError(f"The first mode has length {A.shape[0]}, which is different "
+                                 f"than the length indicated by the shapes argument ({len(shapes)})")
+            B_is = []
+            for J_i, K in shapes:
+                if K != C.shape[0]:
+                    raise ValueError(f"The third mode has length {C.shape[0]}, which is different "
+                                     f"than the length indicated by the shapes argument ({K})")
+                if J_i > B.shape[0]:
+                    raise ValueError(f"The second mode of the CP tensor mode has length {B.shape[0]}, which "
+                                     f"is smaller than the length indicated by the shape ({J_i}) of matrix")
+                B_is.append(copy(B)[:J_i, :])
+        else:
+            B_is = [copy(B) for _ in range(A.shape[0])]
+        return cls((copy(weights), [copy(A), B_is, copy(C)]))
+
+    @classmethod
+    def from_Parafac2Tensor(cls, parafac2_tensor):
+        """(weights, (A, B, C), projections) of a PARAFAC2 tensor -> coupled matrix factorization with B_i = P_i B
+        (coupled_matrices.py:153-172)."""
+        weights, factors, projection_matrices = parafac2_tensor
+        A, B, C = factors
+        copy = lambda x: None if x is None else (x.clone() if hasattr(x, "clone") else np.array(x))
+        return cls((copy(weights), [copy(A), [P_i @ B for P_i in projection_matrices], copy(C)]))
+
     def __getitem__(self, item):
         if item == 0:
             return self.weights

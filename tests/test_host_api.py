@@ -297,3 +297,24 @@ def test_argument_errors(checker_engine):
                                absolute_tol=None, return_admm_vars=True)
     np.testing.assert_array_equal(cmf[1][2], init[1][2])
     assert admm.auxes[2] == [] and len(admm.auxes[0]) == 1
+
+
+def test_cmf_from_cp_and_parafac2_tensors():
+    """CoupledMatrixFactorization.from_CPTensor / from_Parafac2Tensor (coupled_matrices.py:101-172) on plain tuples"""
+    from matcouply_amd.coupled_matrices import CoupledMatrixFactorization as CMF
+
+    rs = np.random.RandomState(0)
+    A, B, C = rs.uniform(size=(4, 3)), rs.uniform(size=(6, 3)), rs.uniform(size=(5, 3))
+    T = np.einsum("ir,jr,kr->ijk", A, B, C)
+    assert np.allclose(CMF.from_CPTensor((None, (A, B, C))).to_tensor(), T)
+    c2 = CMF.from_CPTensor((np.ones(3), (A, B, C)), shapes=[(6, 5), (4, 5), (2, 5), (6, 5)])
+    assert [m.shape for m in c2.to_matrices()] == [(6, 5), (4, 5), (2, 5), (6, 5)]
+    assert np.allclose(c2.to_matrices()[1], T[1, :4])
+    Ps = [np.linalg.qr(rs.standard_normal((7, 6)))[0] for _ in range(4)]
+    c3 = CMF.from_Parafac2Tensor((None, (A, B, C), Ps))
+    assert np.allclose(c3.to_matrices()[2], Ps[2] @ B @ np.diag(A[2]) @ C.T)
+    for bad in (lambda: CMF.from_CPTensor((None, (A, B))), lambda: CMF.from_CPTensor((None, (A, B, C)), shapes=[(6, 5)]),
+                lambda: CMF.from_CPTensor((None, (A, B, C)), shapes=[(6, 4)] * 4),
+                lambda: CMF.from_CPTensor((None, (A, B, C)), shapes=[(9, 5)] * 4)):
+        with pytest.raises(ValueError):
+            bad()
