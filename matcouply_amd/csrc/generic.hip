@@ -774,6 +774,206 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v2(const int *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Unimodality, third version (default): the v2 algorithm with a cheaper pooling step -
+//   * the block right below the one being built (the only one a step compares against) is cached in REGISTERS with its
+//     q; the common step (compare, no merge, push) touches LDS with stores only, a merge reads LDS once per popped block;
+//   * ring entries are (sum, count) only - q of a block is recomputed when it becomes the cached top;
+//   * all global / scratch addresses advance by pointer increments instead of 64-bit index products.
+// Same arithmetic, same decisions (fp64 comparisons of the same quantities) as v2 / the reference.
+// ---------------------------------------------------------------------------------------------------------
+#define RC3 16
+struct UniRing3 {
+    double *sy, *sw;  // LDS [RC3][64]
+    int h, cnt;       // ring index of its top entry, number of entries in the ring
+    long mem_n;       // entries spilled to global memory
+};
+
+static __device__ __forceinline__ void ur3_push(UniRing3 &st, int lane, double sy, double sw, double *__restrict__ gsy,
+                                                double *__restrict__ gsw, long base, int r, int col) {
+    if (st.cnt == RC3) {  // spill the bottom entry of the ring
+        const int b = ((st.h - RC3 + 1) & (RC3 - 1)) * 64 + lane;
+        const long idx = (base + st.mem_n) * r + col;
+        gsy[idx] = st.sy[b];
+        gsw[idx] = st.sw[b];
+        st.mem_n += 1;
+        st.cnt = RC3 - 1;
+    }
+    st.h = (st.h + 1) & (RC3 - 1);
+    const int t = st.h * 64 + lane;
+    st.sy[t] = sy;
+    st.sw[t] = sw;
+    st.cnt += 1;
+}
+
+// pops the top entry of the ring (refilling it from the spill area when it runs dry); false if nothing is left
+static __device__ __forceinline__ bool ur3_pop(UniRing3 &st, int lane, double &sy, double &sw, const double *__restrict__ gsy,
+                                               const double *__restrict__ gsw, long base, int r, int col) {
+    if (st.cnt == 0) {
+        if (st.mem_n == 0) return false;
+        const int nref = st.mem_n >= 8 ? 8 : (int)st.mem_n;  // refill (independent loads, one latency)
+        for (int i = 0; i < nref; ++i) {
+            const long idx = (base + st.mem_n - 1 - i) * r + col;
+            const int t = ((st.h - i) & (RC3 - 1)) * 64 + lane;
+            st.sy[t] = gsy[idx];
+            st.sw[t] = gsw[idx];
+        }
+        st.mem_n -= nref;
+        st.cnt = nref;
+    }
+    const int tp = st.h * 64 + lane;
+    sy = st.sy[tp];
+    sw = st.sw[tp];
+    st.h = (st.h - 1) & (RC3 - 1);
+    st.cnt -= 1;
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_slab_unimodal_v3(const int *__restrict__ ext, int n_slabs, float *__restrict__ F,
+                                                         RegSet regs, int k, int r, double *__restrict__ errL,
+                                                         double *__restrict__ ssy, double *__restrict__ ssw) {
+    __shared__ double ring[2][RC3 * 64];
+    const int lane = threadIdx.x;
+    const long t = (long)blockIdx.x * 64 + threadIdx.x;
+    if (t >= (long)n_slabs * r) return;
+    const int slab = (int)(t / r), col = (int)(t - (long)slab * r);
+    const int s = ext[slab], e = ext[slab + 1], n = e - s;
+    if (n <= 0) return;
+    const int nonneg = regs.nonneg[k];
+    float *__restrict__ Z = regs.aux[k];
+    const float *__restrict__ U = regs.dual[k];
+    const long eb = (long)s + slab;  // n + 1 error entries per slab
+
+    UniRing3 st;
+    st.sy = ring[0], st.sw = ring[1];
+    double csy, csw, cq, cum2, Qb;      // block being built (q = cq), sum of y^2, sum of q over the blocks below it
+    double tsy, tsw, tq;                // cached top of the stack below the current block
+    bool has_top;
+    auto qof = [&](double sy, double sw) -> double { return (nonneg && sy < 0.0) ? 0.0 : sy * sy / sw; };
+    auto step = [&](double v, bool first) {
+        if (!first) {  // the finished block becomes the cached top; the previous top moves into the ring
+            if (has_top) ur3_push(st, lane, tsy, tsw, ssy, ssw, s, r, col);
+            tsy = csy, tsw = csw, tq = cq;
+            has_top = true;
+            Qb += cq;
+        }
+        csy = v;
+        csw = 1.0;
+        while (has_top && csy * tsw <= tsy * csw) {  // mean(cur) <= mean(top): pool
+            Qb -= tq;
+            csy += tsy;
+            csw += tsw;
+            has_top = ur3_pop(st, lane, tsy, tsw, ssy, ssw, s, r, col);
+            if (has_top) tq = qof(tsy, tsw);
+        }
+        cq = qof(csy, csw);
+    };
+    auto reset = [&]() {
+        st.h = 0, st.cnt = 0, st.mem_n = 0;
+        cum2 = 0.0, Qb = 0.0, csy = 0.0, csw = 1.0, cq = 0.0;
+        tsy = 0.0, tsw = 1.0, tq = 0.0;
+        has_top = false;
+    };
+
+    constexpr int UB = 8;  // y loads are issued UB elements ahead (one memory latency per batch)
+    const long rs = r;
+    // pass 1: prefix errors, left to right
+    reset();
+    {
+        const float *fp = F + (long)s * rs + col, *up = U + (long)s * rs + col;
+        double *ep = errL + eb * rs + col;
+        *ep = 0.0;
+        for (int i0 = 0; i0 < n; i0 += UB) {
+            double vb[UB];
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                const long o = (long)min(i0 + j, n - 1) * rs;
+                vb[j] = (double)(fp[o] + up[o]);
+            }
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                const int i = i0 + j;
+                if (i < n) {
+                    const double v = vb[j];
+                    cum2 += v * v;
+                    step(v, i == 0);
+                    ep += rs;
+                    *ep = (nonneg && csy < 0.0) ? cum2 : cum2 - (Qb + cq);
+                }
+            }
+        }
+    }
+    // pass 2: suffix errors right to left + best split (smallest t among the minima)
+    reset();
+    double best = errL[(eb + n) * rs + col];
+    int split = n;
+    {
+        const float *fp = F + ((long)e - 1) * rs + col, *up = U + ((long)e - 1) * rs + col;
+        const double *ep = errL + (eb + n - 1) * rs + col;
+        for (int i0 = 0; i0 < n; i0 += UB) {
+            double vb[UB], eb_l[UB];
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                const long o = (long)min(i0 + j, n - 1) * rs;
+                vb[j] = (double)(fp[-o] + up[-o]);
+                eb_l[j] = ep[-o];
+            }
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                const int i = i0 + j;
+                if (i < n) {
+                    const double v = vb[j];
+                    cum2 += v * v;
+                    step(v, i == 0);
+                    const double er = (nonneg && csy < 0.0) ? cum2 : cum2 - (Qb + cq);
+                    const double tot = eb_l[j] + er;
+                    if (tot <= best) {
+                        best = tot;
+                        split = n - 1 - i;
+                    }
+                }
+            }
+        }
+    }
+    // passes 3 / 4: the two fits, expanded store-only into aux (the dual update follows in k_rows_dual)
+    for (int side = 0; side < 2; ++side) {
+        const int len = side == 0 ? split : n - split;
+        if (len == 0) continue;
+        reset();
+        const long dir = side == 0 ? rs : -rs;
+        const long p0 = (side == 0 ? (long)s : (long)e - 1) * rs + col;
+        {
+            const float *fp = F + p0, *up = U + p0;
+            for (int i0 = 0; i0 < len; i0 += UB) {
+                double vb[UB];
+#pragma unroll
+                for (int j = 0; j < UB; ++j) {
+                    const long o = (long)min(i0 + j, len - 1) * dir;
+                    vb[j] = (double)(fp[o] + up[o]);
+                }
+#pragma unroll
+                for (int j = 0; j < UB; ++j)
+                    if (i0 + j < len) step(vb[j], i0 + j == 0);
+            }
+        }
+        float *zp = Z + p0;
+        auto emit_block = [&](double sy, double sw) {
+            double lev = sy / sw;
+            if (nonneg && lev < 0.0) lev = 0.0;
+            const float z = (float)lev;
+            const long cnt = (long)sw;
+            for (long c = 0; c < cnt; ++c, zp += dir) *zp = z;
+        };
+        for (long m = 0; m < st.mem_n; ++m) emit_block(ssy[((long)s + m) * rs + col], ssw[((long)s + m) * rs + col]);
+        for (int i = st.cnt - 1; i >= 0; --i) {  // ring entries, bottom first
+            const int tp = ((st.h - i) & (RC3 - 1)) * 64 + lane;
+            emit_block(st.sy[tp], st.sw[tp]);
+        }
+        if (has_top) emit_block(tsy, tsw);
+        emit_block(csy, csw);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // PARAFAC2 prox (mode 1):  Y_i = B_i + U_i,  P_i = polar(Y_i Delta^T),  Delta <- sum rho_i P_i^T Y_i / sum rho_i
 // Gram route in fp64:  S_i = Y_i^T Y_i,  G_i = Delta S_i Delta^T = V L V^T,  W_i = V L^-1/2 V^T,
 //                      T_i = Delta^T W_i,  P_i = Y_i T_i,  P_i^T Y_i = T_i^T S_i.
@@ -1418,6 +1618,12 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
         case MCL_PEN_UNIMODAL: {
             const long nthreads = (long)mv.n_slabs * c->r;
             UniScratch sc = uni_scratch(c);
+            if (!getenv("MCL_UNIMODAL_V1") && !getenv("MCL_UNIMODAL_V2")) {
+                hipLaunchKernelGGL(k_slab_unimodal_v3, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, c->stream,
+                                   mv.ext, mv.n_slabs, mv.F, rs, k, c->r, sc.eL, sc.sy, sc.sw);
+                DISPATCH_ROWS(c, vec, k_rows_dual, grid, block, mv, rs, k, c->r);
+                break;
+            }
             if (getenv("MCL_UNIMODAL_V1"))
                 hipLaunchKernelGGL(k_slab_unimodal, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, c->stream, mv.ext,
                                    mv.n_slabs, mv.F, rs, k, c->r, sc);
