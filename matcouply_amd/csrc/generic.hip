@@ -1482,6 +1482,13 @@ __global__ __launch_bounds__(256) void k_rows_finish_fused(ModeView mv, RegSet r
 #pragma unroll
                     for (int v = 0; v < 4; ++v) u[h][v] = f[h][v] - (pd[h][v] - u[h][v]);
                 }
+            } else if (kind == MCL_PEN_UNIMODAL) {  // aux rows already written by the column regressions
+#pragma unroll
+                for (int h = 0; h < NBR; ++h) {
+                    z[h] = row_ld4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) u[h][v] = f[h][v] - (z[h][v] - u[h][v]);
+                }
             } else if (kind == MCL_PEN_L2BALL) {
                 const float bound = regs.p0[k];
 #pragma unroll
@@ -1507,7 +1514,7 @@ __global__ __launch_bounds__(256) void k_rows_finish_fused(ModeView mv, RegSet r
             }
 #pragma unroll
             for (int h = 0; h < NBR; ++h) {
-                row_st4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r, z[h]);
+                if (kind != MCL_PEN_UNIMODAL) row_st4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r, z[h]);
                 row_st4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r, u[h]);
                 if (kind != MCL_PEN_PARAFAC2) zg[h] = z[h];
                 if (want_diag)
@@ -1621,7 +1628,8 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
             if (!getenv("MCL_UNIMODAL_V1") && !getenv("MCL_UNIMODAL_V2")) {
                 hipLaunchKernelGGL(k_slab_unimodal_v3, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, c->stream,
                                    mv.ext, mv.n_slabs, mv.F, rs, k, c->r, sc.eL, sc.sy, sc.sw);
-                DISPATCH_ROWS(c, vec, k_rows_dual, grid, block, mv, rs, k, c->r);
+                if (!c->stack_fused)  // the fused finish pass updates the dual
+                    DISPATCH_ROWS(c, vec, k_rows_dual, grid, block, mv, rs, k, c->r);
                 break;
             }
             if (getenv("MCL_UNIMODAL_V1"))
@@ -1705,15 +1713,17 @@ int mcl_launch_generic_prox_finish(mcl_context *c, int mode, int k) {
     return 0;
 }
 
-// A penalty stack of row-separable kinds, L2 balls and PARAFAC2 (at least one of the latter two, no host-evaluated or
-// unimodal member) can take ONE row pass for all prox + dual steps after the per-slab statistics.
+// A penalty stack of row-separable kinds, L2 balls, unimodality and PARAFAC2 (at least one of the latter three, no
+// host-evaluated member) can take ONE row pass for all prox + dual steps after the per-slab work (statistics; for
+// unimodality the column regressions themselves, which write the aux rows - the pass then only updates their dual).
 bool mcl_stack_can_fuse(const mcl_context *c, int mode) {
     if (getenv("MCL_NO_STACK_FUSION")) return false;
     const RegSet &rs = c->regs[mode];
     bool slabwise = false;
     for (int k = 0; k < rs.n; ++k) {
         const int kind = rs.kind[k];
-        if (kind == MCL_PEN_L2BALL || kind == MCL_PEN_PARAFAC2) slabwise = true;
+        if (kind == MCL_PEN_UNIMODAL && (getenv("MCL_UNIMODAL_V1") || getenv("MCL_UNIMODAL_V2"))) return false;
+        if (kind == MCL_PEN_L2BALL || kind == MCL_PEN_PARAFAC2 || kind == MCL_PEN_UNIMODAL) slabwise = true;
         else if (kind != MCL_PEN_NN && kind != MCL_PEN_BOX && kind != MCL_PEN_L1) return false;
     }
     return slabwise && mode != 0;
