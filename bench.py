@@ -49,6 +49,8 @@ CONFIGS["c5s"] = dict(I=1024, J=512, K=256, r=32,
                       desc="c5 penalty stack (NN + L1 + L2Ball + Unimodal + PARAFAC2) at I=1024 J_i=512 K=256 rank=32 "
                            "(config 5 itself is I=8192 J=2048 K=1024: 68.7 GB of X)")
 CONFIGS["c3_8th"] = dict(CONFIGS["c3"], I=128, desc="one eighth of config 3 (the per-rank shard of an 8-GPU run): I=128 J_i=512 K=256 rank=16")
+CONFIGS["c3_half"] = dict(CONFIGS["c3"], I=512, desc="one half of config 3 (the per-rank shard of a 2-GPU run): I=512 J_i=512 K=256 rank=16")
+CONFIGS["c3_4th"] = dict(CONFIGS["c3"], I=256, desc="one quarter of config 3 (the per-rank shard of a 4-GPU run): I=256 J_i=512 K=256 rank=16")
 CONFIGS["k512"] = dict(CONFIGS["c3"], I=512, J=512, K=512, desc="K=512 variant of config 3 (same bytes of X): I=512 J_i=512 K=512 rank=16")
 CONFIGS["r32"] = dict(CONFIGS["c3"], r=32, desc="rank-32 variant of config 3: I=1024 J_i=512 K=256 rank=32")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
@@ -242,7 +244,11 @@ def main():
     for it in range(args.warmup):
         step(it)
     sync()
-    eng.profile_enable(args.steps)
+    # HIP events inside the library around every `stride`-th launch of the timed region: an event pair opens ~5 us
+    # dispatch gaps before and after the kernel (11 us per step when every launch is bracketed - measured), so the
+    # timed loop samples ~10 launches instead of taxing all of them
+    prof_stride = max(1, args.steps // 10)
+    eng.profile_enable(args.steps, stride=prof_stride)
     sync()
     t0 = time.perf_counter()
     for it in range(args.steps):
@@ -298,7 +304,8 @@ def main():
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(eng.kernel_variant(slot)),
                         traffic_source="profiles/r1_%s_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % args.config,
                         kernel=eng.kernel_variant(slot),
-                        kernel_role=names[slot], avg_us=round(avg_ms * 1e3, 2), launches=n,
+                        kernel_role=names[slot], avg_us=round(avg_ms * 1e3, 2), launches_timed=n,
+                        launches_in_timed_region=args.steps, event_stride=prof_stride,
                         algorithmic_bytes_per_launch=int(alg_bytes[slot]),
                         all_kernels_avg_us={names[s]: round(a * 1e3, 2) for a, s, _ in prof})
 

@@ -147,6 +147,9 @@ const char *mcl_kernel_variant(mcl_context *ctx, int32_t which);
  * mcl_profile_enable(ctx, capacity): record up to `capacity` launches per kernel slot (0 disables and frees);
  * mcl_profile_read(ctx, which, &total_ms, &count): synchronises the recorded events of slot `which` and resets it. */
 int mcl_profile_enable(mcl_context *ctx, int32_t capacity);
+/* record only every `stride`-th launch of a slot (default 1): an event pair opens ~5 us dispatch gaps on either side of
+ * the kernel, so a timed loop samples its launches instead of bracketing all of them */
+int mcl_profile_set_stride(mcl_context *ctx, int32_t stride);
 int mcl_profile_read(mcl_context *ctx, int32_t which, double *total_ms, int32_t *count);
 
 #ifdef __cplusplus

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "mcl_iterate", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
     "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
-    "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_read",
+    "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_set_stride", "mcl_profile_read",
 ]
 
 
@@ -94,6 +94,7 @@ def load_library():
         "mcl_internal_buffer": (P, [P, I32, ctypes.POINTER(I64)]),
         "mcl_kernel_variant": (ctypes.c_char_p, [P, I32]),
         "mcl_profile_enable": (ctypes.c_int, [P, I32]),
+        "mcl_profile_set_stride": (ctypes.c_int, [P, I32]),
         "mcl_profile_read": (ctypes.c_int, [P, I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I32)]),
     }
     for name, (res, args) in sig.items():
@@ -298,8 +299,10 @@ class HipEngine:
     def cross_products(self):
         return self.internal(1).view(self.I, self.r, self.r)
 
-    def profile_enable(self, capacity):
+    def profile_enable(self, capacity, stride=1):
+        """HIP-event pairs around up to `capacity` launches per kernel slot, every `stride`-th launch only."""
         self._check(self.lib.mcl_profile_enable(self._h, int(capacity)))
+        self._check(self.lib.mcl_profile_set_stride(self._h, int(stride)))
 
     def profile_read(self, which):
         """(total_ms, launches) of kernel slot `which` (0: X C pass, 1: X^T B pass, 2: fused B rows, 3: one-pass sweep); synchronises."""

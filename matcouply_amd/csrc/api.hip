@@ -778,6 +778,7 @@ int mcl_profile_enable(mcl_context *c, int32_t capacity) {
         for (hipEvent_t e : c->prof_ev[s]) (void)hipEventDestroy(e);
         c->prof_ev[s].clear();
         c->prof_used[s] = 0;
+        c->prof_seen[s] = 0;
     }
     c->prof_capacity = 0;
     if (capacity <= 0) return 0;
@@ -786,6 +787,13 @@ int mcl_profile_enable(mcl_context *c, int32_t capacity) {
         for (auto &e : c->prof_ev[s]) MCL_CHECK_HIP(c, hipEventCreate(&e));
     }
     c->prof_capacity = capacity;
+    return 0;
+}
+
+int mcl_profile_set_stride(mcl_context *c, int32_t stride) {
+    if (!c || stride < 1) return 1;
+    c->prof_stride = stride;
+    for (int s = 0; s < 4; ++s) c->prof_seen[s] = 0;
     return 0;
 }
 

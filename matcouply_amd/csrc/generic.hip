@@ -974,6 +974,259 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v3(const int *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Unimodality, fourth version (default).  Same projection and the same decision rules as v3 / the reference
+// (_unimodal_regression.py:27-104), organised so that a column costs TWO pooling sweeps instead of three and a
+// pooling (merge) iteration - the divergent inner loop that bounds the kernel - carries no division:
+//   * a stack entry is (sum, count, Q) with Q = sum of q over the stack up to and including the entry, so the prefix
+//     error after a merge is read off the newly exposed top (v3 recomputed q = sum^2 / count of every popped block);
+//     one reciprocal of the (integer) count per element gives both the level and q of the block being built;
+//   * each sweep records, per position, (level, length) of the block that ENDS there at that time.  The stack at time
+//     t is the chain  block ending at t-1 -> block ending at (its start - 1) -> ...: a block below the top is never
+//     touched again, so its record from the time it was the top is still its state.  The two fits are therefore
+//     emitted from the records by walking the chain from the split outwards (no third pooling sweep);
+//   * the emit loops walk POSITIONS in lockstep over the wave (loads and stores of the r lanes of a slab coalesce),
+//     records are fetched in unconditional 8-element batches;
+//   * ring entries are 20 bytes and the ring holds 8: 10 KB of LDS per wave, 16 waves per CU.
+// The records of the right-to-left sweep are stored at the position they belong to, so both emit loops index rows.
+// ---------------------------------------------------------------------------------------------------------
+#define RC4 8
+struct UniRing4 {
+    double *sy, *q;  // LDS [RC4][64]
+    int *cw;         // LDS [RC4][64]
+    int h, cnt;      // ring index of its top entry, number of entries in the ring
+    long mem_n;      // entries spilled to global memory
+};
+struct UniRec {
+    float lev;
+    int len;
+};
+
+static __device__ __forceinline__ void ur4_push(UniRing4 &st, int lane, double sy, int cw, double q, double *__restrict__ gsy,
+                                                double *__restrict__ gq, int *__restrict__ gcw, long base, long rs, int col) {
+    if (st.cnt == RC4) {  // spill the bottom entry of the ring
+        const int b = ((st.h - RC4 + 1) & (RC4 - 1)) * 64 + lane;
+        const long idx = (base + st.mem_n) * rs + col;
+        gsy[idx] = st.sy[b];
+        gq[idx] = st.q[b];
+        gcw[idx] = st.cw[b];
+        st.mem_n += 1;
+        st.cnt = RC4 - 1;
+    }
+    st.h = (st.h + 1) & (RC4 - 1);
+    const int t = st.h * 64 + lane;
+    st.sy[t] = sy;
+    st.q[t] = q;
+    st.cw[t] = cw;
+    st.cnt += 1;
+}
+
+static __device__ __forceinline__ bool ur4_pop(UniRing4 &st, int lane, double &sy, int &cw, double &q, const double *__restrict__ gsy,
+                                               const double *__restrict__ gq, const int *__restrict__ gcw, long base, long rs,
+                                               int col) {
+    if (st.cnt == 0) {
+        if (st.mem_n == 0) return false;
+        const int nref = st.mem_n >= RC4 / 2 ? RC4 / 2 : (int)st.mem_n;  // refill (independent loads, one latency)
+        for (int i = 0; i < nref; ++i) {
+            const long idx = (base + st.mem_n - 1 - i) * rs + col;
+            const int t = ((st.h - i) & (RC4 - 1)) * 64 + lane;
+            st.sy[t] = gsy[idx];
+            st.q[t] = gq[idx];
+            st.cw[t] = gcw[idx];
+        }
+        st.mem_n -= nref;
+        st.cnt = nref;
+    }
+    const int tp = st.h * 64 + lane;
+    sy = st.sy[tp];
+    q = st.q[tp];
+    cw = st.cw[tp];
+    st.h = (st.h - 1) & (RC4 - 1);
+    st.cnt -= 1;
+    return true;
+}
+
+// 1 / w for a positive integer-valued w: hardware estimate + two Newton steps (<= 1 ulp)
+static __device__ __forceinline__ double rcp_count(double w) {
+    double x = __builtin_amdgcn_rcp(w);
+    x = __builtin_fma(__builtin_fma(-w, x, 1.0), x, x);
+    x = __builtin_fma(__builtin_fma(-w, x, 1.0), x, x);
+    return x;
+}
+
+static __device__ __forceinline__ int wave_max_i(int v) {
+    for (int o = 32; o; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+static __device__ __forceinline__ int wave_min_i(int v) {
+    for (int o = 32; o; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__ ext, int n_slabs, float *__restrict__ F,
+                                                         RegSet regs, int k, int r, UniScratch sc) {
+    __shared__ double ring_d[2][RC4 * 64];
+    __shared__ int ring_i[RC4 * 64];
+    const int lane = threadIdx.x;
+    const long t = (long)blockIdx.x * 64 + threadIdx.x;
+    const bool live = t < (long)n_slabs * r;  // no early exit: the emit loops use wave-wide reductions
+    const int slab = live ? (int)(t / r) : 0, col = live ? (int)(t - (long)slab * r) : 0;
+    const int s = ext[slab], e = ext[slab + 1];
+    const int n = live ? max(e - s, 0) : 0;
+    const int nonneg = regs.nonneg[k];
+    float *__restrict__ Z = regs.aux[k];
+    const float *__restrict__ U = regs.dual[k];
+    double *__restrict__ errL = sc.eL;
+    double *__restrict__ gsy = sc.sy, *__restrict__ gq = sc.sy2;
+    int *__restrict__ gcw = sc.stL;
+    UniRec *__restrict__ recL = reinterpret_cast<UniRec *>(sc.lvL), *__restrict__ recR = reinterpret_cast<UniRec *>(sc.lvR);
+    const long rs = r;
+    const long eb = (long)s + slab;  // n + 1 error entries per slab
+
+    UniRing4 st;
+    st.sy = ring_d[0], st.q = ring_d[1], st.cw = ring_i;
+    double csy, ccw, curQ, cum2;  // block being built (count kept as a double), Q including it, sum of y^2
+    double tsy, tcw, tQ;          // cached top of the stack below it
+    bool has_top, neg;
+    float levf;
+    auto reset = [&]() {
+        st.h = 0, st.cnt = 0, st.mem_n = 0;
+        cum2 = 0.0, csy = 0.0, ccw = 1.0, curQ = 0.0;
+        tsy = 0.0, tcw = 1.0, tQ = 0.0;
+        has_top = false, neg = false, levf = 0.f;
+    };
+    // one element: returns the prefix error; leaves (levf, ccw) = record of the block ending at this element
+    auto step = [&](double v, bool first) -> double {
+        cum2 += v * v;
+        if (!first) {  // the finished block becomes the cached top; the previous top moves into the ring
+            if (has_top) ur4_push(st, lane, tsy, (int)tcw, tQ, gsy, gq, gcw, s, rs, col);
+            tsy = csy, tcw = ccw, tQ = curQ;
+            has_top = true;
+        }
+        csy = v;
+        ccw = 1.0;
+        while (has_top && csy * tcw <= tsy * ccw) {  // mean(cur) <= mean(top): pool
+            csy += tsy;
+            ccw += tcw;
+            int icw;
+            has_top = ur4_pop(st, lane, tsy, icw, tQ, gsy, gq, gcw, s, rs, col);
+            tcw = (double)icw;
+        }
+        const double lev = csy * rcp_count(ccw);
+        neg = nonneg && csy < 0.0;
+        curQ = (has_top ? tQ : 0.0) + (neg ? 0.0 : csy * lev);
+        levf = neg ? 0.f : (float)lev;
+        return neg ? cum2 : cum2 - curQ;
+    };
+
+    constexpr int UB = 8;  // loads are issued UB elements ahead (one memory latency per batch)
+    // sweep 1: prefix errors and block records, left to right
+    reset();
+    if (n > 0) {
+        const float *fp = F + (long)s * rs + col, *up = U + (long)s * rs + col;
+        double *ep = errL + eb * rs + col;
+        UniRec *rp = recL + (long)s * rs + col;
+        *ep = 0.0;
+        for (int i0 = 0; i0 < n; i0 += UB) {
+            double vb[UB];
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                const long o = (long)min(i0 + j, n - 1) * rs;
+                vb[j] = (double)(fp[o] + up[o]);
+            }
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                if (i0 + j < n) {
+                    const double er = step(vb[j], i0 + j == 0);
+                    ep += rs;
+                    *ep = er;
+                    UniRec rc;
+                    rc.lev = levf, rc.len = (int)ccw;
+                    *rp = rc;
+                    rp += rs;
+                }
+            }
+        }
+    }
+    // sweep 2: suffix errors right to left + best split (smallest t among the minima); records stored by position
+    reset();
+    int split = n;
+    if (n > 0) {
+        double best = errL[(eb + n) * rs + col];
+        const float *fp = F + ((long)e - 1) * rs + col, *up = U + ((long)e - 1) * rs + col;
+        const double *ep = errL + (eb + n - 1) * rs + col;
+        UniRec *rp = recR + ((long)e - 1) * rs + col;
+        for (int i0 = 0; i0 < n; i0 += UB) {
+            double vb[UB], eb_l[UB];
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                const long o = (long)min(i0 + j, n - 1) * rs;
+                vb[j] = (double)(fp[-o] + up[-o]);
+                eb_l[j] = ep[-o];
+            }
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                const int i = i0 + j;
+                if (i < n) {
+                    const double tot = eb_l[j] + step(vb[j], i == 0);
+                    UniRec rc;
+                    rc.lev = levf, rc.len = (int)ccw;
+                    *rp = rc;
+                    rp -= rs;
+                    if (tot <= best) {
+                        best = tot;
+                        split = n - 1 - i;
+                    }
+                }
+            }
+        }
+    }
+    // emit, positions in lockstep over the wave.  Left fit: chain from position split-1 downwards.
+    const int nm1 = max(n - 1, 0);
+    {
+        const UniRec *rp = recL + (long)s * rs + col;
+        float *zp = Z + (long)s * rs + col;
+        int rem = 0;
+        float z = 0.f;
+        for (int j0 = wave_max_i(split) - 1; j0 >= 0; j0 -= UB) {
+            UniRec rb[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) rb[u] = rp[(long)min(max(j0 - u, 0), nm1) * rs];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int j = j0 - u;
+                if (j >= 0 && j < split) {
+                    if (rem == 0) z = rb[u].lev, rem = rb[u].len;
+                    zp[(long)j * rs] = z;
+                    rem -= 1;
+                }
+            }
+        }
+    }
+    // Right fit: chain from position split upwards (records of sweep 2 extend to the right of their position).
+    {
+        const UniRec *rp = recR + (long)s * rs + col;
+        float *zp = Z + (long)s * rs + col;
+        int rem = 0;
+        float z = 0.f;
+        const int jend = wave_max_i(n);
+        for (int j0 = wave_min_i(live && n > 0 ? split : 0x7fffffff); j0 < jend; j0 += UB) {
+            UniRec rb[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) rb[u] = rp[(long)min(j0 + u, nm1) * rs];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int j = j0 + u;
+                if (j >= split && j < n) {
+                    if (rem == 0) z = rb[u].lev, rem = rb[u].len;
+                    zp[(long)j * rs] = z;
+                    rem -= 1;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // PARAFAC2 prox (mode 1):  Y_i = B_i + U_i,  P_i = polar(Y_i Delta^T),  Delta <- sum rho_i P_i^T Y_i / sum rho_i
 // Gram route in fp64:  S_i = Y_i^T Y_i,  G_i = Delta S_i Delta^T = V L V^T,  W_i = V L^-1/2 V^T,
 //                      T_i = Delta^T W_i,  P_i = Y_i T_i,  P_i^T Y_i = T_i^T S_i.
@@ -1625,7 +1878,14 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
         case MCL_PEN_UNIMODAL: {
             const long nthreads = (long)mv.n_slabs * c->r;
             UniScratch sc = uni_scratch(c);
-            if (!getenv("MCL_UNIMODAL_V1") && !getenv("MCL_UNIMODAL_V2")) {
+            if (!getenv("MCL_UNIMODAL_V1") && !getenv("MCL_UNIMODAL_V2") && !getenv("MCL_UNIMODAL_V3")) {
+                hipLaunchKernelGGL(k_slab_unimodal_v4, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, c->stream,
+                                   mv.ext, mv.n_slabs, mv.F, rs, k, c->r, sc);
+                if (!c->stack_fused)  // the fused finish pass updates the dual
+                    DISPATCH_ROWS(c, vec, k_rows_dual, grid, block, mv, rs, k, c->r);
+                break;
+            }
+            if (getenv("MCL_UNIMODAL_V3")) {
                 hipLaunchKernelGGL(k_slab_unimodal_v3, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, c->stream,
                                    mv.ext, mv.n_slabs, mv.F, rs, k, c->r, sc.eL, sc.sy, sc.sw);
                 if (!c->stack_fused)  // the fused finish pass updates the dual

@@ -153,6 +153,8 @@ struct mcl_context {
     int prof_capacity = 0;
     std::vector<hipEvent_t> prof_ev[4];
     int prof_used[4] = {0, 0, 0, 0};
+    int prof_stride = 1;               // record every prof_stride-th launch of a slot (an event pair costs ~10 us of
+    int prof_seen[4] = {0, 0, 0, 0};   // dispatch gaps around the kernel, so timed loops sample instead)
 };
 
 // RAII helper: records start/stop events around a launch when profiling is enabled
@@ -161,7 +163,8 @@ struct ProfScope {
     int slot;
     bool on;
     ProfScope(mcl_context *ctx, int s) : c(ctx), slot(s), on(false) {
-        if (c->prof_capacity > 0 && c->prof_used[slot] < c->prof_capacity) {
+        if (c->prof_capacity > 0 && c->prof_used[slot] < c->prof_capacity &&
+            (c->prof_seen[slot]++ % c->prof_stride) == 0) {
             on = true;
             (void)hipEventRecord(c->prof_ev[slot][2 * c->prof_used[slot]], c->stream);
         }
