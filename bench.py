@@ -48,6 +48,7 @@ CONFIGS["c5s"] = dict(I=1024, J=512, K=256, r=32,
                             [{"kind": "l1", "reg_strength": 0.1, "non_negativity": True}]],
                       desc="c5 penalty stack (NN + L1 + L2Ball + Unimodal + PARAFAC2) at I=1024 J_i=512 K=256 rank=32 "
                            "(config 5 itself is I=8192 J=2048 K=1024: 68.7 GB of X)")
+CONFIGS["c5_32nd"] = dict(CONFIGS["c5s"], I=256, J=2048, K=1024, desc="1/32 of config 5: I=256 J_i=2048 K=1024 rank=32, full penalty stack")
 CONFIGS["c3_8th"] = dict(CONFIGS["c3"], I=128, desc="one eighth of config 3 (the per-rank shard of an 8-GPU run): I=128 J_i=512 K=256 rank=16")
 CONFIGS["c3_half"] = dict(CONFIGS["c3"], I=512, desc="one half of config 3 (the per-rank shard of a 2-GPU run): I=512 J_i=512 K=256 rank=16")
 CONFIGS["c3_4th"] = dict(CONFIGS["c3"], I=256, desc="one quarter of config 3 (the per-rank shard of a 4-GPU run): I=256 J_i=512 K=256 rank=16")

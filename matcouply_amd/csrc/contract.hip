@@ -402,6 +402,7 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
     if (s0 >= s1) return;
 
     constexpr int CR = CREG ? 4 : 1;
+    constexpr bool CPRE = !CREG && NB <= 2;  // 64 NB registers of C fragments per super-chunk
     f32x4 creg[CR][4][NB];
     if (CREG) {
 #pragma unroll
@@ -470,6 +471,21 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
                     for (int v = 0; v < 4; ++v) bcur[nb][v] = bnx[nb][v];
             }
             for (int sc = 0; sc < SC; ++sc) {
+                // K > 256: the C fragments of this super-chunk are loaded BEFORE the X prefetch is issued, so the wait
+                // on them leaves the prefetch in flight (memory returns in order: fragment loads issued after it
+                // would drain it in every kc step - the K = 1024 pass ran at 2.4 TB/s that way)
+                f32x4 cpre[CPRE ? 4 : 1][4][NB];
+                if (CPRE) {
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+                        for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                cpre[kc][kq][nb] = *reinterpret_cast<const f32x4 *>(
+                                    Cfrag + ((((long)(4 * sc + kc) * 4 + kq) * NB + nb) * 64 + lane) * 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 // registers -> LDS: row t, logical 16-B slot = lane, physical slot = lane ^ t
 #pragma unroll
                 for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4 *>(L + t * 256 + ((lane ^ t) << 2)) = xr[t];
@@ -477,6 +493,7 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
                 if (sc + 1 < SC) issue(row0, nrows, blk, sc + 1);
                 else if (blk + 1 < nblk) issue(row0, nrows, blk + 1, 0);
                 else issue(nrow0, nnrows, 0, 0);
+                if (CPRE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kc = 0; kc < 4; ++kc) {
                     f32x4 fr[4];
@@ -489,6 +506,7 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
                             if (CREG) cf[kq][nb] = creg[kc][kq][nb];
+                            else if (CPRE) cf[kq][nb] = cpre[kc][kq][nb];
                             else
                                 cf[kq][nb] = *reinterpret_cast<const f32x4 *>(
                                     Cfrag + ((((long)(4 * sc + kc) * 4 + kq) * NB + nb) * 64 + lane) * 4);

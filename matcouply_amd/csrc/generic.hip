@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__
         return neg ? cum2 : cum2 - curQ;
     };
 
-    constexpr int UB = 8;  // loads are issued UB elements ahead (one memory latency per batch)
+    constexpr int UB = 8;  // elements per load batch; the NEXT batch is in flight while the current one is pooled
     // sweep 1: prefix errors and block records, left to right
     reset();
     if (n > 0) {
@@ -1126,12 +1126,20 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__
         double *ep = errL + eb * rs + col;
         UniRec *rp = recL + (long)s * rs + col;
         *ep = 0.0;
+        float fb[UB], ub[UB];
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+            const long o = (long)min(j, n - 1) * rs;
+            fb[j] = fp[o], ub[j] = up[o];
+        }
         for (int i0 = 0; i0 < n; i0 += UB) {
             double vb[UB];
 #pragma unroll
-            for (int j = 0; j < UB; ++j) {
-                const long o = (long)min(i0 + j, n - 1) * rs;
-                vb[j] = (double)(fp[o] + up[o]);
+            for (int j = 0; j < UB; ++j) vb[j] = (double)(fb[j] + ub[j]);
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {  // unconditional clamped loads of the next batch
+                const long o = (long)min(i0 + UB + j, n - 1) * rs;
+                fb[j] = fp[o], ub[j] = up[o];
             }
 #pragma unroll
             for (int j = 0; j < UB; ++j) {
@@ -1155,13 +1163,21 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__
         const float *fp = F + ((long)e - 1) * rs + col, *up = U + ((long)e - 1) * rs + col;
         const double *ep = errL + (eb + n - 1) * rs + col;
         UniRec *rp = recR + ((long)e - 1) * rs + col;
+        float fb[UB], ub[UB];
+        double eb_n[UB];
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+            const long o = (long)min(j, n - 1) * rs;
+            fb[j] = fp[-o], ub[j] = up[-o], eb_n[j] = ep[-o];
+        }
         for (int i0 = 0; i0 < n; i0 += UB) {
             double vb[UB], eb_l[UB];
 #pragma unroll
+            for (int j = 0; j < UB; ++j) vb[j] = (double)(fb[j] + ub[j]), eb_l[j] = eb_n[j];
+#pragma unroll
             for (int j = 0; j < UB; ++j) {
-                const long o = (long)min(i0 + j, n - 1) * rs;
-                vb[j] = (double)(fp[-o] + up[-o]);
-                eb_l[j] = ep[-o];
+                const long o = (long)min(i0 + UB + j, n - 1) * rs;
+                fb[j] = fp[-o], ub[j] = up[-o], eb_n[j] = ep[-o];
             }
 #pragma unroll
             for (int j = 0; j < UB; ++j) {
@@ -1180,19 +1196,27 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__
             }
         }
     }
-    // emit, positions in lockstep over the wave.  Left fit: chain from position split-1 downwards.
+    // emit, positions in lockstep over the wave (EB records per batch, the next batch in flight).
+    // Left fit: chain from position split-1 downwards.
+    constexpr int EB = 16;
     const int nm1 = max(n - 1, 0);
     {
         const UniRec *rp = recL + (long)s * rs + col;
         float *zp = Z + (long)s * rs + col;
         int rem = 0;
         float z = 0.f;
-        for (int j0 = wave_max_i(split) - 1; j0 >= 0; j0 -= UB) {
-            UniRec rb[UB];
+        const int jtop = wave_max_i(split) - 1;
+        UniRec rn[EB];
 #pragma unroll
-            for (int u = 0; u < UB; ++u) rb[u] = rp[(long)min(max(j0 - u, 0), nm1) * rs];
+        for (int u = 0; u < EB; ++u) rn[u] = rp[(long)min(max(jtop - u, 0), nm1) * rs];
+        for (int j0 = jtop; j0 >= 0; j0 -= EB) {
+            UniRec rb[EB];
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
+            for (int u = 0; u < EB; ++u) rb[u] = rn[u];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) rn[u] = rp[(long)min(max(j0 - EB - u, 0), nm1) * rs];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
                 const int j = j0 - u;
                 if (j >= 0 && j < split) {
                     if (rem == 0) z = rb[u].lev, rem = rb[u].len;
@@ -1209,12 +1233,20 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__
         int rem = 0;
         float z = 0.f;
         const int jend = wave_max_i(n);
-        for (int j0 = wave_min_i(live && n > 0 ? split : 0x7fffffff); j0 < jend; j0 += UB) {
-            UniRec rb[UB];
+        const int jbot = wave_min_i(live && n > 0 ? split : 0x7fffffff);
+        UniRec rn[EB];
+        if (jbot < jend) {
 #pragma unroll
-            for (int u = 0; u < UB; ++u) rb[u] = rp[(long)min(j0 + u, nm1) * rs];
+            for (int u = 0; u < EB; ++u) rn[u] = rp[(long)min(jbot + u, nm1) * rs];
+        }
+        for (int j0 = jbot; j0 < jend; j0 += EB) {
+            UniRec rb[EB];
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
+            for (int u = 0; u < EB; ++u) rb[u] = rn[u];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) rn[u] = rp[(long)min(j0 + EB + u, nm1) * rs];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
                 const int j = j0 + u;
                 if (j >= split && j < n) {
                     if (rem == 0) z = rb[u].lev, rem = rb[u].len;
