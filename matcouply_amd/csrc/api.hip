@@ -173,11 +173,14 @@ int generic_inner_loop(mcl_context *c, int mode) {
     // then ONE row pass for every prox + dual step (the step API used by multi-GPU hosts keeps one pass per penalty)
     const bool fuse = mcl_stack_can_fuse(c, mode);
     const bool stats = fuse && mcl_stats_can_ride_in_solve(c, mode);
+    // ... and with the statistics riding in the solve, the finish pass of iteration t also does the solve of t + 1
+    const bool chain = stats && !getenv("MCL_NO_PASS_CHAIN");
     for (int it = 0; it < n_it; ++it) {
         if (mode == 0) {
             if (int rc = mcl_launch_A_rows_solve(c)) return rc;
         } else if (stats) {
-            if (int rc = mcl_launch_rows_solve_stats(c)) return rc;
+            if (!chain || it == 0)
+                if (int rc = mcl_launch_rows_solve_stats(c)) return rc;
         } else {
             if (int rc = mcl_launch_rows_solve(c, mode)) return rc;
         }
@@ -190,8 +193,13 @@ int generic_inner_loop(mcl_context *c, int mode) {
         }
         c->stack_fused = c->stats_in_solve = false;
         if (rc) return rc;
-        if (fuse)
-            if (int rc2 = mcl_launch_rows_finish_fused(c, mode, it == n_it - 1)) return rc2;  // diagnostics: last pass only
+        if (fuse) {
+            if (chain && it + 1 < n_it) {
+                if (int rc2 = mcl_launch_rows_finish_solve_stats(c)) return rc2;
+            } else if (int rc2 = mcl_launch_rows_finish_fused(c, mode, it == n_it - 1)) {  // diagnostics: last pass only
+                return rc2;
+            }
+        }
     }
     c->diag_valid[mode] = fuse && n_it > 0;  // the fused finish pass leaves the mode's diagnostics table current
     return 0;

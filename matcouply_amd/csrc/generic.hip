@@ -1826,6 +1826,200 @@ __global__ __launch_bounds__(256) void k_rows_finish_fused(ModeView mv, RegSet r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Inner iteration t -> t+1 of a fused stack in ONE row pass (mode 1, single process): the prox + dual steps of
+// iteration t (k_rows_finish_fused) followed, on the same registers, by the solve of iteration t+1 and the statistics
+// of its new rows (k_rows_solve_stats).  Z_k - U_k of every penalty stays in registers, so between two inner iterations
+// the pass reads F, the duals, rhs (+ the aux rows the column regressions wrote) and writes F and the duals:
+// (2 + 2n + 1) S_B instead of (2 + 2n) + (1 + 4n) S_B for the two separate passes.  The aux rows are not written here -
+// no later step of the inner loop reads them (PARAFAC2's Delta and T_i carry its state); the LAST inner iteration ends
+// with the plain k_rows_finish_fused, which writes them and the diagnostics.
+// ---------------------------------------------------------------------------------------------------------
+template <int NBR, bool VEC>
+__global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, const float *__restrict__ rhs_src,
+                                                                 const float *__restrict__ Arows,
+                                                                 const float *__restrict__ Linv, RegSet regs, int r,
+                                                                 const float *__restrict__ T,
+                                                                 const double *__restrict__ colsq,
+                                                                 double *__restrict__ stat_gram,
+                                                                 double *__restrict__ stat_colsq) {
+    typedef double f64x4s __attribute__((ext_vector_type(4)));
+    TILE_PROLOGUE();
+    const float rho = mv.rho[slab];
+    int kpf2 = -1;
+    for (int k = 0; k < regs.n; ++k)
+        if (regs.kind[k] == MCL_PEN_PARAFAC2) kpf2 = k;
+    RowMat<NBR> L, Ts, D;
+    L.load(Linv + (long)slab * r * r, r, lane);
+    if (kpf2 >= 0) {
+        Ts.load(T + (long)slab * r * r, r, lane);
+        D.load(regs.aux2[kpf2], r, lane);
+    }
+    float av[NBR][4];
+#pragma unroll
+    for (int h = 0; h < NBR; ++h)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int col = 16 * h + 4 * g + v;
+            av[h][v] = (Arows != nullptr && col < r) ? Arows[(long)slab * r + col] : 1.f;
+        }
+    // L2-ball scale factors of iteration t (from the per-slab column norms)
+    float l2s[MCL_MAX_REGS][NBR][4];
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k)
+#pragma unroll
+        for (int h = 0; h < NBR; ++h)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                l2s[k][h][v] = 1.f;
+                if (k < regs.n && regs.kind[k] == MCL_PEN_L2BALL) {
+                    const int col = 16 * h + 4 * g + v;
+                    const float bound = regs.p0[k];
+                    const float nrm = (col < r) ? (float)sqrt(colsq[((long)k * mv.n_slabs + slab) * r + col]) : 1.f;
+                    l2s[k][h][v] = bound / fmaxf(nrm, bound);
+                }
+            }
+    float bsel[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) bsel[v] = (row16 == 4 * g + v) ? 1.f : 0.f;
+    f64x4s accS[NBR][NBR];
+#pragma unroll
+    for (int a = 0; a < NBR; ++a)
+#pragma unroll
+        for (int b = 0; b < NBR; ++b) accS[a][b] = f64x4s{0.0, 0.0, 0.0, 0.0};
+    double csq[MCL_MAX_REGS][NBR][4];
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k)
+#pragma unroll
+        for (int h = 0; h < NBR; ++h)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) csq[k][h][v] = 0.0;
+    FOR_ROW_BLOCKS() {
+        const bool ok = 16 * rb + row16 < nrows;
+        const long j = row0 + 16 * rb + (ok ? row16 : 0);
+        f32x4 f[NBR], t[NBR], ukeep[MCL_MAX_REGS][NBR];
+#pragma unroll
+        for (int h = 0; h < NBR; ++h) {
+            f[h] = row_ld4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r);  // zeros for padding rows / columns
+            t[h] = row_ld4<VEC>(rhs_src, j, 16 * h + 4 * g, ok, r);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) t[h][v] *= av[h][v];
+        }
+        // ---- iteration t: prox + dual of every penalty (same arithmetic as k_rows_finish_fused)
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) {
+            if (k >= regs.n) continue;
+            const int kind = regs.kind[k];
+            f32x4 u[NBR], zg[NBR];
+#pragma unroll
+            for (int h = 0; h < NBR; ++h) u[h] = row_ld4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r);
+            if (kind == MCL_PEN_PARAFAC2) {
+                f32x4 y[NBR], pz[NBR];
+#pragma unroll
+                for (int h = 0; h < NBR; ++h) y[h] = f[h] + u[h];
+                Ts.apply(y, pz);   // P = Y T_i
+                D.apply(pz, zg);   // P Delta
+            } else if (kind == MCL_PEN_UNIMODAL) {  // aux rows written by the column regressions
+#pragma unroll
+                for (int h = 0; h < NBR; ++h) zg[h] = row_ld4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r);
+            } else if (kind == MCL_PEN_L2BALL) {
+#pragma unroll
+                for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        float y = f[h][v] + u[h][v];
+                        if (regs.nonneg[k]) y = fmaxf(y, 0.f);
+                        zg[h][v] = y * l2s[k][h][v];
+                    }
+            } else {
+                const float thr = regs.p0[k] / rho;
+#pragma unroll
+                for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        zg[h][v] = prox_elem_g(kind, regs.nonneg[k], regs.p0[k], regs.p1[k], thr, f[h][v] + u[h][v]);
+            }
+#pragma unroll
+            for (int h = 0; h < NBR; ++h) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    u[h][v] = f[h][v] - (zg[h][v] - u[h][v]);
+                    t[h][v] = fmaf(rho, zg[h][v] - u[h][v], t[h][v]);
+                }
+                row_st4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r, u[h]);
+                ukeep[k][h] = u[h];
+            }
+        }
+        // ---- iteration t + 1: solve, store, statistics of the new rows (same arithmetic as k_rows_solve_stats)
+        f32x4 fn[NBR];
+        L.apply(t, fn);
+#pragma unroll
+        for (int h = 0; h < NBR; ++h) row_st4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r, fn[h]);
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) {
+            if (k < regs.n) {
+                if (regs.kind[k] == MCL_PEN_L2BALL) {
+#pragma unroll
+                    for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            float y = fn[h][v] + ukeep[k][h][v];
+                            if (regs.nonneg[k]) y = fmaxf(y, 0.f);
+                            if (ok) csq[k][h][v] += (double)y * (double)y;
+                        }
+                } else if (k == kpf2) {
+                    double yt[NBR][4];
+#pragma unroll
+                    for (int nb = 0; nb < NBR; ++nb) {
+                        f32x4 tr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const float y = ok ? fn[nb][v] + ukeep[k][nb][v] : 0.f;
+                            tr = MFMA16(y, bsel[v], tr);  // COL layout: lane (q, i16) reg w = Y[4q + w][16nb + i16]
+                        }
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) yt[nb][w] = (double)tr[w];
+                    }
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+#pragma unroll
+                        for (int a = 0; a < NBR; ++a)
+#pragma unroll
+                            for (int b = 0; b < NBR; ++b)
+                                accS[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(yt[a][w], yt[b][w], accS[a][b], 0, 0, 0);
+                }
+            }
+        }
+    }
+    constexpr int W = 16 * NBR;
+    if (kpf2 >= 0) {  // D layout of the f64 MFMA: col = l & 15, row = (l >> 4) + 4 reg
+        double *out = stat_gram + (long)tile * W * W;
+#pragma unroll
+        for (int a = 0; a < NBR; ++a)
+#pragma unroll
+            for (int b = 0; b < NBR; ++b)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) out[(16 * a + g + 4 * v) * W + 16 * b + row16] = accS[a][b][v];
+    }
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k) {
+        if (k < regs.n && regs.kind[k] == MCL_PEN_L2BALL) {
+#pragma unroll
+            for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    double sq = csq[k][h][v];
+                    sq += __shfl_xor(sq, 1);
+                    sq += __shfl_xor(sq, 2);
+                    sq += __shfl_xor(sq, 4);
+                    sq += __shfl_xor(sq, 8);
+                    const int col = 16 * h + 4 * g + v;
+                    if (row16 == 0 && col < r) stat_colsq[((long)tile * MCL_MAX_REGS + k) * r + col] = sq;
+                }
+        }
+    }
+}
+
 // =========================================================================================================
 // host launchers
 // =========================================================================================================
@@ -2044,6 +2238,32 @@ bool mcl_stats_can_ride_in_solve(const mcl_context *c, int mode) {
         if (rs.kind[k] == MCL_PEN_L2BALL && !c->stat_colsq) return false;
     }
     return c->NB <= 2;  // fp64 accumulators: (16 NB)^2 / 64 doubles per lane
+}
+
+// finish of inner iteration t + solve / statistics of iteration t + 1 in one pass (see k_rows_finish_solve_stats)
+int mcl_launch_rows_finish_solve_stats(mcl_context *c) {
+    ModeView mv = view_of(c, 1);
+    if (mv.n_tiles == 0) return 0;
+    const float *rhs = c->XC;
+    dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
+    const bool vec = rows_vec_ok(c, mv, c->regs[1], rhs);
+#define MCL_FSS(NBR_, VEC_)                                                                                          \
+    hipLaunchKernelGGL((k_rows_finish_solve_stats<NBR_, VEC_>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, \
+                       (const float *)c->LinvB, c->regs[1], c->r, (const float *)c->pf2_T, (const double *)c->colsq,   \
+                       c->stat_gram, c->stat_colsq)
+    if (c->NB == 1) {
+        if (vec) MCL_FSS(1, true);
+        else MCL_FSS(1, false);
+    } else {
+        if (vec) MCL_FSS(2, true);
+        else MCL_FSS(2, false);
+    }
+#undef MCL_FSS
+    hipLaunchKernelGGL(k_stats_reduce, dim3((unsigned)c->I), dim3(256), 0, c->stream, (const int *)c->slab_tile_ptr,
+                       (const double *)c->stat_gram, (const double *)c->stat_colsq, c->regs[1], c->r, 16 * c->NB, (int)c->I,
+                       c->pf2_S, c->colsq);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
 }
 
 int mcl_launch_rows_solve_stats(mcl_context *c) {

@@ -231,4 +231,5 @@ bool mcl_mode_is_row_separable(const mcl_context *c, int mode);
 bool mcl_stack_can_fuse(const mcl_context *c, int mode);          // generic.hip
 int mcl_launch_rows_finish_fused(mcl_context *c, int mode, bool want_diag);  // generic.hip
 bool mcl_stats_can_ride_in_solve(const mcl_context *c, int mode);  // generic.hip
+int mcl_launch_rows_finish_solve_stats(mcl_context *c);           // generic.hip: finish of iteration t + solve / stats of t + 1
 int mcl_launch_rows_solve_stats(mcl_context *c);                  // generic.hip: B solve + per-tile statistics + reduce
