@@ -174,7 +174,9 @@ int generic_inner_loop(mcl_context *c, int mode) {
     const bool fuse = mcl_stack_can_fuse(c, mode);
     const bool stats = fuse && mcl_stats_can_ride_in_solve(c, mode);
     // ... and with the statistics riding in the solve, the finish pass of iteration t also does the solve of t + 1
-    const bool chain = stats && !getenv("MCL_NO_PASS_CHAIN");
+    int n_l2 = 0;
+    for (int k = 0; k < c->regs[mode].n; ++k) n_l2 += c->regs[mode].kind[k] == MCL_PEN_L2BALL;
+    const bool chain = stats && n_l2 <= 1 && !getenv("MCL_NO_PASS_CHAIN");  // the chained kernel carries one L2-ball slot
     for (int it = 0; it < n_it; ++it) {
         if (mode == 0) {
             if (int rc = mcl_launch_A_rows_solve(c)) return rc;

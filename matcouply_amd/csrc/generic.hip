@@ -1863,22 +1863,24 @@ __global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, co
             const int col = 16 * h + 4 * g + v;
             av[h][v] = (Arows != nullptr && col < r) ? Arows[(long)slab * r + col] : 1.f;
         }
-    // L2-ball scale factors of iteration t (from the per-slab column norms)
-    float l2s[MCL_MAX_REGS][NBR][4];
+    // L2-ball scale factors of iteration t (from the per-slab column norms); the host chains stacks with at most ONE
+    // L2 ball (register budget: two waves per SIMD at rank 32)
+    int kl2 = -1;
+    for (int k = 0; k < regs.n; ++k)
+        if (regs.kind[k] == MCL_PEN_L2BALL) kl2 = k;
+    float l2s[NBR][4];
 #pragma unroll
-    for (int k = 0; k < MCL_MAX_REGS; ++k)
+    for (int h = 0; h < NBR; ++h)
 #pragma unroll
-        for (int h = 0; h < NBR; ++h)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                l2s[k][h][v] = 1.f;
-                if (k < regs.n && regs.kind[k] == MCL_PEN_L2BALL) {
-                    const int col = 16 * h + 4 * g + v;
-                    const float bound = regs.p0[k];
-                    const float nrm = (col < r) ? (float)sqrt(colsq[((long)k * mv.n_slabs + slab) * r + col]) : 1.f;
-                    l2s[k][h][v] = bound / fmaxf(nrm, bound);
-                }
+        for (int v = 0; v < 4; ++v) {
+            l2s[h][v] = 1.f;
+            if (kl2 >= 0) {
+                const int col = 16 * h + 4 * g + v;
+                const float bound = regs.p0[kl2];
+                const float nrm = (col < r) ? (float)sqrt(colsq[((long)kl2 * mv.n_slabs + slab) * r + col]) : 1.f;
+                l2s[h][v] = bound / fmaxf(nrm, bound);
             }
+        }
     float bsel[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) bsel[v] = (row16 == 4 * g + v) ? 1.f : 0.f;
@@ -1887,17 +1889,15 @@ __global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, co
     for (int a = 0; a < NBR; ++a)
 #pragma unroll
         for (int b = 0; b < NBR; ++b) accS[a][b] = f64x4s{0.0, 0.0, 0.0, 0.0};
-    double csq[MCL_MAX_REGS][NBR][4];
+    double csq[NBR][4];
 #pragma unroll
-    for (int k = 0; k < MCL_MAX_REGS; ++k)
+    for (int h = 0; h < NBR; ++h)
 #pragma unroll
-        for (int h = 0; h < NBR; ++h)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) csq[k][h][v] = 0.0;
+        for (int v = 0; v < 4; ++v) csq[h][v] = 0.0;
     FOR_ROW_BLOCKS() {
         const bool ok = 16 * rb + row16 < nrows;
         const long j = row0 + 16 * rb + (ok ? row16 : 0);
-        f32x4 f[NBR], t[NBR], ukeep[MCL_MAX_REGS][NBR];
+        f32x4 f[NBR], t[NBR], upf[NBR], ul2[NBR];  // new duals of the PARAFAC2 / L2-ball penalty (statistics below)
 #pragma unroll
         for (int h = 0; h < NBR; ++h) {
             f[h] = row_ld4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r);  // zeros for padding rows / columns
@@ -1929,7 +1929,7 @@ __global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, co
                     for (int v = 0; v < 4; ++v) {
                         float y = f[h][v] + u[h][v];
                         if (regs.nonneg[k]) y = fmaxf(y, 0.f);
-                        zg[h][v] = y * l2s[k][h][v];
+                        zg[h][v] = y * l2s[h][v];
                     }
             } else {
                 const float thr = regs.p0[k] / rho;
@@ -1947,7 +1947,8 @@ __global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, co
                     t[h][v] = fmaf(rho, zg[h][v] - u[h][v], t[h][v]);
                 }
                 row_st4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r, u[h]);
-                ukeep[k][h] = u[h];
+                if (k == kpf2) upf[h] = u[h];
+                if (k == kl2) ul2[h] = u[h];
             }
         }
         // ---- iteration t + 1: solve, store, statistics of the new rows (same arithmetic as k_rows_solve_stats)
@@ -1955,40 +1956,36 @@ __global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, co
         L.apply(t, fn);
 #pragma unroll
         for (int h = 0; h < NBR; ++h) row_st4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r, fn[h]);
+        if (kl2 >= 0) {
 #pragma unroll
-        for (int k = 0; k < MCL_MAX_REGS; ++k) {
-            if (k < regs.n) {
-                if (regs.kind[k] == MCL_PEN_L2BALL) {
+            for (int h = 0; h < NBR; ++h)
 #pragma unroll
-                    for (int h = 0; h < NBR; ++h)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            float y = fn[h][v] + ukeep[k][h][v];
-                            if (regs.nonneg[k]) y = fmaxf(y, 0.f);
-                            if (ok) csq[k][h][v] += (double)y * (double)y;
-                        }
-                } else if (k == kpf2) {
-                    double yt[NBR][4];
-#pragma unroll
-                    for (int nb = 0; nb < NBR; ++nb) {
-                        f32x4 tr = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const float y = ok ? fn[nb][v] + ukeep[k][nb][v] : 0.f;
-                            tr = MFMA16(y, bsel[v], tr);  // COL layout: lane (q, i16) reg w = Y[4q + w][16nb + i16]
-                        }
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) yt[nb][w] = (double)tr[w];
-                    }
-#pragma unroll
-                    for (int w = 0; w < 4; ++w)
-#pragma unroll
-                        for (int a = 0; a < NBR; ++a)
-#pragma unroll
-                            for (int b = 0; b < NBR; ++b)
-                                accS[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(yt[a][w], yt[b][w], accS[a][b], 0, 0, 0);
+                for (int v = 0; v < 4; ++v) {
+                    float y = fn[h][v] + ul2[h][v];
+                    if (regs.nonneg[kl2]) y = fmaxf(y, 0.f);
+                    if (ok) csq[h][v] += (double)y * (double)y;
                 }
+        }
+        if (kpf2 >= 0) {
+            double yt[NBR][4];
+#pragma unroll
+            for (int nb = 0; nb < NBR; ++nb) {
+                f32x4 tr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float y = ok ? fn[nb][v] + upf[nb][v] : 0.f;
+                    tr = MFMA16(y, bsel[v], tr);  // COL layout: lane (q, i16) reg w = Y[4q + w][16nb + i16]
+                }
+#pragma unroll
+                for (int w = 0; w < 4; ++w) yt[nb][w] = (double)tr[w];
             }
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int a = 0; a < NBR; ++a)
+#pragma unroll
+                    for (int b = 0; b < NBR; ++b)
+                        accS[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(yt[a][w], yt[b][w], accS[a][b], 0, 0, 0);
         }
     }
     constexpr int W = 16 * NBR;
@@ -2001,22 +1998,19 @@ __global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, co
 #pragma unroll
                 for (int v = 0; v < 4; ++v) out[(16 * a + g + 4 * v) * W + 16 * b + row16] = accS[a][b][v];
     }
+    if (kl2 >= 0) {
 #pragma unroll
-    for (int k = 0; k < MCL_MAX_REGS; ++k) {
-        if (k < regs.n && regs.kind[k] == MCL_PEN_L2BALL) {
+        for (int h = 0; h < NBR; ++h)
 #pragma unroll
-            for (int h = 0; h < NBR; ++h)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    double sq = csq[k][h][v];
-                    sq += __shfl_xor(sq, 1);
-                    sq += __shfl_xor(sq, 2);
-                    sq += __shfl_xor(sq, 4);
-                    sq += __shfl_xor(sq, 8);
-                    const int col = 16 * h + 4 * g + v;
-                    if (row16 == 0 && col < r) stat_colsq[((long)tile * MCL_MAX_REGS + k) * r + col] = sq;
-                }
-        }
+            for (int v = 0; v < 4; ++v) {
+                double sq = csq[h][v];
+                sq += __shfl_xor(sq, 1);
+                sq += __shfl_xor(sq, 2);
+                sq += __shfl_xor(sq, 4);
+                sq += __shfl_xor(sq, 8);
+                const int col = 16 * h + 4 * g + v;
+                if (row16 == 0 && col < r) stat_colsq[((long)tile * MCL_MAX_REGS + kl2) * r + col] = sq;
+            }
     }
 }
 
