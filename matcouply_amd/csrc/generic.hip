@@ -1062,12 +1062,19 @@ static __device__ __forceinline__ int wave_min_i(int v) {
     return v;
 }
 
+// MODE 0: everything in one lane per column (throughput: fewest bytes, used when the columns fill the device).
+// MODE 1 + MODE 2: few columns (less than about one wave per SIMD) - the two sweeps run concurrently in different waves
+// (direction = block parity; the right-to-left one stores its errors instead of searching the split), then a second
+// launch searches the split with the same comparisons in the same order and emits.  Halves the serial chain.
+template <int MODE>
 __global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__ ext, int n_slabs, float *__restrict__ F,
                                                          RegSet regs, int k, int r, UniScratch sc) {
-    __shared__ double ring_d[2][RC4 * 64];
-    __shared__ int ring_i[RC4 * 64];
+    __shared__ double ring_d[2][MODE == 2 ? 1 : RC4 * 64];
+    __shared__ int ring_i[MODE == 2 ? 1 : RC4 * 64];
     const int lane = threadIdx.x;
-    const long t = (long)blockIdx.x * 64 + threadIdx.x;
+    const bool do_L = MODE == 0 || (MODE == 1 && (blockIdx.x & 1) == 0);
+    const bool do_R = MODE == 0 || (MODE == 1 && (blockIdx.x & 1) == 1);
+    const long t = (long)(MODE == 1 ? blockIdx.x >> 1 : blockIdx.x) * 64 + threadIdx.x;
     const bool live = t < (long)n_slabs * r;  // no early exit: the emit loops use wave-wide reductions
     const int slab = live ? (int)(t / r) : 0, col = live ? (int)(t - (long)slab * r) : 0;
     const int s = ext[slab], e = ext[slab + 1];
@@ -1075,9 +1082,10 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__
     const int nonneg = regs.nonneg[k];
     float *__restrict__ Z = regs.aux[k];
     const float *__restrict__ U = regs.dual[k];
-    double *__restrict__ errL = sc.eL;
-    double *__restrict__ gsy = sc.sy, *__restrict__ gq = sc.sy2;
-    int *__restrict__ gcw = sc.stL;
+    double *__restrict__ errL = sc.eL, *__restrict__ errR = sc.eR;
+    // spill areas of the block stack: the concurrent right-to-left sweep of MODE 1 has its own
+    double *__restrict__ gsy = (MODE == 1 && do_R) ? sc.sw : sc.sy, *__restrict__ gq = (MODE == 1 && do_R) ? sc.cum2 : sc.sy2;
+    int *__restrict__ gcw = (MODE == 1 && do_R) ? sc.stR : sc.stL;
     UniRec *__restrict__ recL = reinterpret_cast<UniRec *>(sc.lvL), *__restrict__ recR = reinterpret_cast<UniRec *>(sc.lvR);
     const long rs = r;
     const long eb = (long)s + slab;  // n + 1 error entries per slab
@@ -1121,7 +1129,7 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__
     constexpr int UB = 8;  // elements per load batch; the NEXT batch is in flight while the current one is pooled
     // sweep 1: prefix errors and block records, left to right
     reset();
-    if (n > 0) {
+    if (do_L && n > 0) {
         const float *fp = F + (long)s * rs + col, *up = U + (long)s * rs + col;
         double *ep = errL + eb * rs + col;
         UniRec *rp = recL + (long)s * rs + col;
@@ -1158,17 +1166,19 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__
     // sweep 2: suffix errors right to left + best split (smallest t among the minima); records stored by position
     reset();
     int split = n;
-    if (n > 0) {
-        double best = errL[(eb + n) * rs + col];
+    if (do_R && n > 0) {
+        double best = (MODE == 0) ? errL[(eb + n) * rs + col] : 0.0;
         const float *fp = F + ((long)e - 1) * rs + col, *up = U + ((long)e - 1) * rs + col;
         const double *ep = errL + (eb + n - 1) * rs + col;
+        double *erp = errR + (eb + 1) * rs + col;  // MODE 1: errR[i + 1] = error of the suffix of length i + 1
         UniRec *rp = recR + ((long)e - 1) * rs + col;
         float fb[UB], ub[UB];
         double eb_n[UB];
 #pragma unroll
         for (int j = 0; j < UB; ++j) {
             const long o = (long)min(j, n - 1) * rs;
-            fb[j] = fp[-o], ub[j] = up[-o], eb_n[j] = ep[-o];
+            fb[j] = fp[-o], ub[j] = up[-o];
+            eb_n[j] = (MODE == 0) ? ep[-o] : 0.0;
         }
         for (int i0 = 0; i0 < n; i0 += UB) {
             double vb[UB], eb_l[UB];
@@ -1177,17 +1187,58 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__
 #pragma unroll
             for (int j = 0; j < UB; ++j) {
                 const long o = (long)min(i0 + UB + j, n - 1) * rs;
-                fb[j] = fp[-o], ub[j] = up[-o], eb_n[j] = ep[-o];
+                fb[j] = fp[-o], ub[j] = up[-o];
+                if (MODE == 0) eb_n[j] = ep[-o];
             }
 #pragma unroll
             for (int j = 0; j < UB; ++j) {
                 const int i = i0 + j;
                 if (i < n) {
-                    const double tot = eb_l[j] + step(vb[j], i == 0);
+                    const double er = step(vb[j], i == 0);
                     UniRec rc;
                     rc.lev = levf, rc.len = (int)ccw;
                     *rp = rc;
                     rp -= rs;
+                    if (MODE == 0) {
+                        const double tot = eb_l[j] + er;
+                        if (tot <= best) {
+                            best = tot;
+                            split = n - 1 - i;
+                        }
+                    } else {
+                        *erp = er;
+                        erp += rs;
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 1) return;
+    if (MODE == 2 && n > 0) {  // the split search of sweep 2, from the stored errors (same sums, same order)
+        double best = errL[(eb + n) * rs + col];
+        const double *epl = errL + (eb + n - 1) * rs + col;
+        const double *epr = errR + (eb + 1) * rs + col;
+        constexpr int SB = 16;
+        double ln[SB], rn_[SB];
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+            const long o = (long)min(j, n - 1) * rs;
+            ln[j] = epl[-o], rn_[j] = epr[o];
+        }
+        for (int i0 = 0; i0 < n; i0 += SB) {
+            double lb[SB], rb[SB];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) lb[j] = ln[j], rb[j] = rn_[j];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const long o = (long)min(i0 + SB + j, n - 1) * rs;
+                ln[j] = epl[-o], rn_[j] = epr[o];
+            }
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const int i = i0 + j;
+                if (i < n) {
+                    const double tot = lb[j] + rb[j];
                     if (tot <= best) {
                         best = tot;
                         split = n - 1 - i;
@@ -2099,8 +2150,19 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
             const long nthreads = (long)mv.n_slabs * c->r;
             UniScratch sc = uni_scratch(c);
             if (!getenv("MCL_UNIMODAL_V1") && !getenv("MCL_UNIMODAL_V2") && !getenv("MCL_UNIMODAL_V3")) {
-                hipLaunchKernelGGL(k_slab_unimodal_v4, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, c->stream,
-                                   mv.ext, mv.n_slabs, mv.F, rs, k, c->r, sc);
+                const unsigned nwav = (unsigned)((nthreads + 63) / 64);
+                // fewer columns than about one wave per SIMD: the two sweeps run concurrently in different waves
+                int wave_split = nwav <= 1024;
+                if (const char *ev = getenv("MCL_UNI_SPLIT")) wave_split = atoi(ev);
+                if (wave_split) {
+                    hipLaunchKernelGGL(k_slab_unimodal_v4<1>, dim3(2 * nwav), dim3(64), 0, c->stream, mv.ext, mv.n_slabs,
+                                       mv.F, rs, k, c->r, sc);
+                    hipLaunchKernelGGL(k_slab_unimodal_v4<2>, dim3(nwav), dim3(64), 0, c->stream, mv.ext, mv.n_slabs, mv.F,
+                                       rs, k, c->r, sc);
+                } else {
+                    hipLaunchKernelGGL(k_slab_unimodal_v4<0>, dim3(nwav), dim3(64), 0, c->stream, mv.ext, mv.n_slabs, mv.F,
+                                       rs, k, c->r, sc);
+                }
                 if (!c->stack_fused)  // the fused finish pass updates the dual
                     DISPATCH_ROWS(c, vec, k_rows_dual, grid, block, mv, rs, k, c->r);
                 break;

@@ -1,0 +1,85 @@
+"""-m gpu: the unimodal-regression prox (matcouply/_unimodal_regression.py:27-141, penalties.py:1014-1015) through every
+organisation of the native kernel - one lane per column (throughput form), the two sweeps split over waves + split
+search / emit launch (latency form, picked automatically for few columns), and the previous kernel generation - against
+the oracle's regression on the same fp32 inputs.  The fits are fp32 roundings of fp64 block means: equal up to one
+unit in the last place unless a split decision differed, which would show as an O(1) difference."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import aoadmm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    # name: (J_i, rank)  - ragged slabs, ranks that do not divide the wave, a slab longer than any ring / batch size
+    "ragged_r5": ([37, 1, 260, 64, 9, 130], 5),
+    "long_r16": ([3000, 17, 512], 16),
+    "r32": ([200, 333, 64, 48], 32),
+    "r3_many": ([50] * 40, 3),
+}
+
+
+def _problem(J, r, nonneg, data, seed):
+    import torch
+
+    from matcouply_amd._engine import PEN_UNIMODAL, HipEngine, NativeReg
+
+    rng = np.random.RandomState(seed)
+    J = np.asarray(J)
+    row_ptr = np.concatenate([[0], np.cumsum(J)]).astype(np.int64)
+    N, I, K = int(row_ptr[-1]), len(J), 8
+    if data == "noise":
+        B = rng.standard_normal((N, r))
+    elif data == "monotone":  # deep block stacks: every element its own block in one direction
+        B = np.concatenate([np.linspace(-1, 2, j)[:, None] * (1 + np.arange(r)[None, :]) for j in J]) + 1e-3 * rng.standard_normal((N, r))
+    else:  # peaks
+        B = np.concatenate([np.exp(-0.5 * ((np.arange(j)[:, None] - rng.rand(1, r) * j) / (0.1 * j + 1)) ** 2) for j in J])
+        B = B + 0.05 * rng.standard_normal((N, r))
+    U = 0.1 * rng.standard_normal((N, r))
+    dev = torch.device("cuda", 0)
+    f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+    aux = torch.zeros((N, r), dtype=torch.float32, device=dev)
+    eng = HipEngine(f32(rng.rand(N, K)), row_ptr, r, f32(rng.rand(I, r) + 0.1), f32(B), f32(rng.rand(K, r)),
+                    [[], [NativeReg(PEN_UNIMODAL, aux, f32(U), non_negativity=nonneg)], []])
+    return eng, aux, row_ptr
+
+
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+@pytest.mark.parametrize("nonneg", [False, True])
+@pytest.mark.parametrize("data", ["noise", "monotone", "peaks"])
+def test_unimodal_kernel_forms_agree_with_oracle(shape, nonneg, data):
+    import torch
+
+    J, r = SHAPES[shape]
+    eng, aux, row_ptr = _problem(J, r, nonneg, data, seed=len(shape) + 7 * nonneg)
+    eng.B_begin()
+    eng.B_factor()
+    B0, U0 = eng.B.clone(), eng.regs[1][0].dual.clone()
+    Y = (B0 + U0).cpu().numpy().astype(np.float64)  # the fp32 sum the kernels form, as exact doubles
+    want = np.concatenate([orc.unimodal_columns(Y[row_ptr[i]: row_ptr[i + 1]], nonneg) for i in range(len(J))])
+    saved = {k: os.environ.get(k) for k in ("MCL_UNI_SPLIT", "MCL_UNIMODAL_V3")}
+    try:
+        for env in ({"MCL_UNI_SPLIT": "0"}, {"MCL_UNI_SPLIT": "1"}, {"MCL_UNIMODAL_V3": "1"}):
+            for k in saved:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            eng.B.copy_(B0)
+            eng.regs[1][0].dual.copy_(U0)
+            aux.zero_()
+            eng.B_prox_local(0)
+            torch.cuda.synchronize()
+            got = aux.cpu().numpy().astype(np.float64)
+            scale = max(1.0, float(np.abs(want).max()))
+            assert np.abs(got - want).max() <= 2.4e-7 * scale, (env, shape, nonneg, data, float(np.abs(got - want).max()))
+            # the dual step of the penalty: U <- B - (Z - U)   (decomposition.py:282-285)
+            Unew = eng.regs[1][0].dual.cpu().numpy().astype(np.float64)
+            ref = B0.cpu().numpy().astype(np.float64) - (got - U0.cpu().numpy().astype(np.float64))
+            assert np.abs(Unew - ref).max() <= 1e-6 * scale, (env, "dual")
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+        eng.close()
