@@ -188,12 +188,13 @@ int generic_inner_loop(mcl_context *c, int mode) {
         }
         c->stack_fused = fuse;
         c->stats_in_solve = stats;
+        c->pf2_delta_fused = !getenv("MCL_NO_PF2_DELTA_FUSION");
         int rc = 0;
         for (int k = 0; k < c->regs[mode].n && rc == 0; ++k) {
             rc = mcl_launch_generic_prox_local(c, mode, k);
             if (rc == 0) rc = mcl_launch_generic_prox_finish(c, mode, k);
         }
-        c->stack_fused = c->stats_in_solve = false;
+        c->stack_fused = c->stats_in_solve = c->pf2_delta_fused = false;
         if (rc) return rc;
         if (fuse) {
             if (chain && it + 1 < n_it) {

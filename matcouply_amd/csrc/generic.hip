@@ -1510,16 +1510,54 @@ static __device__ __forceinline__ void mm_t(const SymTiles<NB> &A, const SymTile
         }
 }
 
-template <int NB>
-__global__ __launch_bounds__(64) void k_pf2_algebra_ns(const double *__restrict__ S, const float *__restrict__ Delta,
+// TILES: the per-tile statistics of the solve pass (k_rows_solve_stats / k_rows_finish_solve_stats) are summed HERE, in
+// k_stats_reduce's order - S_i goes to LDS (and to S for the Jacobi fallback), the L2-ball column sums to colsq - which
+// saves the separate reduction launch in front of this kernel in every inner iteration.
+struct TileStats {
+    const int *slab_tile_ptr;
+    const double *stat_gram, *stat_colsq;
+    double *colsq;
+    int W, n_slabs;
+};
+template <int NB, bool TILES>
+__global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, const float *__restrict__ Delta,
                                                        const float *__restrict__ rho, const int *__restrict__ ext, int r,
                                                        float *__restrict__ T, double *__restrict__ acc_out,
-                                                       int *__restrict__ status) {
+                                                       int *__restrict__ status, TileStats ts, RegSet regs) {
+    __shared__ double Ssm[TILES ? 256 * NB * NB : 1];
     const int slab = blockIdx.x, lane = threadIdx.x;
     const int q = lane >> 4, c16 = lane & 15;
     const int n2 = r * r;
     const double *Ss = S + (long)slab * n2;
-    auto Sat = [&](int i, int j) -> double { return (i < r && j < r) ? Ss[i * r + j] : 0.0; };
+    if (TILES) {
+        const int t0 = ts.slab_tile_ptr[slab], t1 = ts.slab_tile_ptr[slab + 1];
+        const long WW = (long)ts.W * ts.W;
+        for (int e = lane; e < n2; e += 64) {
+            const int a = e / r, b = e - a * r;
+            double s0 = 0.0, s1 = 0.0;
+            int t = t0;
+            for (; t + 1 < t1; t += 2) {
+                s0 += ts.stat_gram[t * WW + a * ts.W + b];
+                s1 += ts.stat_gram[(t + 1) * WW + a * ts.W + b];
+            }
+            if (t < t1) s0 += ts.stat_gram[t * WW + a * ts.W + b];
+            Ssm[e] = s0 + s1;
+            S[(long)slab * n2 + e] = s0 + s1;
+        }
+        for (int k = 0; k < regs.n; ++k) {
+            if (regs.kind[k] != MCL_PEN_L2BALL) continue;
+            for (int col = lane; col < r; col += 64) {
+                double sq = 0.0;
+                for (int t = t0; t < t1; ++t) sq += ts.stat_colsq[((long)t * MCL_MAX_REGS + k) * r + col];
+                ts.colsq[((long)k * ts.n_slabs + slab) * r + col] = sq;
+            }
+        }
+        __syncthreads();
+    }
+    auto Sat = [&](int i, int j) -> double {
+        if (TILES) return (i < r && j < r) ? Ssm[i * r + j] : 0.0;
+        return (i < r && j < r) ? Ss[i * r + j] : 0.0;
+    };
     auto Dat = [&](int i, int j) -> double { return (i < r && j < r) ? (double)Delta[i * r + j] : 0.0; };
     if (ext[slab + 1] - ext[slab] < r) {  // fewer rows than columns: rank-deficient by construction
         if (lane == 0) status[slab] = 1;
@@ -1711,6 +1749,29 @@ __global__ __launch_bounds__(256) void k_pf2_sum(const double *__restrict__ acc,
     if (threadIdx.x == 0) red[e] = (float)((sm[0] + sm[1]) + (sm[2] + sm[3]));
 }
 
+// k_pf2_sum + k_pf2_delta in one launch (single-process runs: no all-reduce between them).  Workgroup e sums element e
+// and the weight total with the same order and roundings as the two kernels.
+__global__ __launch_bounds__(256) void k_pf2_sum_delta(const double *__restrict__ acc, int n_slabs, int n2,
+                                                       float *__restrict__ red, float *__restrict__ Delta) {
+    __shared__ double sm[2][4];
+    const int e = blockIdx.x, n_el = n2 + 1;
+    double s = 0.0, w = 0.0;
+    for (int i = threadIdx.x; i < n_slabs; i += 256) {
+        s += acc[(long)i * n_el + e];
+        w += acc[(long)i * n_el + n2];
+    }
+    s = wave_sum_d(s);
+    w = wave_sum_d(w);
+    if ((threadIdx.x & 63) == 0) sm[0][threadIdx.x >> 6] = s, sm[1][threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float re = (float)((sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]));
+        const float rw = (float)((sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]));
+        red[e] = re;
+        if (e == 0) red[n2] = rw;
+        Delta[e] = re / rw;
+    }
+}
 __global__ void k_pf2_delta(const float *__restrict__ red, int r, float *__restrict__ Delta) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < r * r) Delta[e] = red[e] / red[r * r];
@@ -2122,6 +2183,16 @@ static UniScratch uni_scratch(mcl_context *c) {
     return s;
 }
 
+// The per-slab sums of the solve pass's tile statistics are taken by the PARAFAC2 Newton-Schulz kernel itself when
+// the B stack has a PARAFAC2 member handled by that kernel (otherwise k_stats_reduce runs after the solve pass).
+bool mcl_stats_reduce_in_algebra(const mcl_context *c) {
+    if (getenv("MCL_STATS_REDUCE") || getenv("MCL_PF2_JACOBI") || c->NB > 2) return false;
+    const RegSet &rs = c->regs[1];
+    for (int k = 0; k < rs.n; ++k)
+        if (rs.kind[k] == MCL_PEN_PARAFAC2) return true;
+    return false;
+}
+
 int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
     ModeView mv = view_of(c, mode);
     if (mv.n_tiles == 0) return 0;
@@ -2213,19 +2284,30 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
             const int *status = nullptr;
             if (c->NB <= 2 && !getenv("MCL_PF2_JACOBI")) {
                 status = c->pf2_status;
-                if (c->NB == 1)
-                    hipLaunchKernelGGL(k_pf2_algebra_ns<1>, dim3((unsigned)c->I), dim3(64), 0, c->stream, c->pf2_S, rs.aux2[k],
-                                       c->rhoB, mv.ext, r, c->pf2_T, c->pf2_acc, c->pf2_status);
-                else
-                    hipLaunchKernelGGL(k_pf2_algebra_ns<2>, dim3((unsigned)c->I), dim3(64), 0, c->stream, c->pf2_S, rs.aux2[k],
-                                       c->rhoB, mv.ext, r, c->pf2_T, c->pf2_acc, c->pf2_status);
+                TileStats ts{c->slab_tile_ptr, c->stat_gram, c->stat_colsq, c->colsq, 16 * c->NB, (int)c->I};
+                const bool tiles = c->stats_in_solve && mcl_stats_reduce_in_algebra(c);
+#define MCL_NS(NB_, TILES_)                                                                                          \
+    hipLaunchKernelGGL((k_pf2_algebra_ns<NB_, TILES_>), dim3((unsigned)c->I), dim3(64), 0, c->stream, c->pf2_S,       \
+                       rs.aux2[k], c->rhoB, mv.ext, r, c->pf2_T, c->pf2_acc, c->pf2_status, ts, rs)
+                if (c->NB == 1) {
+                    if (tiles) MCL_NS(1, true);
+                    else MCL_NS(1, false);
+                } else {
+                    if (tiles) MCL_NS(2, true);
+                    else MCL_NS(2, false);
+                }
+#undef MCL_NS
             }
             hipLaunchKernelGGL(k_pf2_algebra, dim3((unsigned)c->I), dim3(64), sm, c->stream, c->pf2_S, rs.aux2[k],
                                c->rhoB, r, c->pf2_T, c->pf2_acc, status);
             if (!c->stack_fused)  // the fused finish pass applies T_i itself
                 DISPATCH_ROWS(c, vec, k_pf2_apply, grid, block, mv, (const float *)rs.dual[k], (const float *)c->pf2_T, rs.aux[k], r);
-            hipLaunchKernelGGL(k_pf2_sum, dim3((unsigned)(n2 + 1)), dim3(256), 0, c->stream, c->pf2_acc, (int)c->I, n2 + 1,
-                               c->pf2_red);
+            if (c->pf2_delta_fused)  // single-process inner loop: Delta follows at once, no all-reduce in between
+                hipLaunchKernelGGL(k_pf2_sum_delta, dim3((unsigned)n2), dim3(256), 0, c->stream, c->pf2_acc, (int)c->I, n2,
+                                   c->pf2_red, rs.aux2[k]);
+            else
+                hipLaunchKernelGGL(k_pf2_sum, dim3((unsigned)(n2 + 1)), dim3(256), 0, c->stream, c->pf2_acc, (int)c->I,
+                                   n2 + 1, c->pf2_red);
             break;
         }
         default:
@@ -2242,8 +2324,9 @@ int mcl_launch_generic_prox_finish(mcl_context *c, int mode, int k) {
     ModeView mv = view_of(c, mode);
     if (mv.n_tiles == 0) return 0;
     const int n2 = c->r * c->r;
-    hipLaunchKernelGGL(k_pf2_delta, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->pf2_red, c->r,
-                       rs.aux2[k]);
+    if (!c->pf2_delta_fused)
+        hipLaunchKernelGGL(k_pf2_delta, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->pf2_red, c->r,
+                           rs.aux2[k]);
     if (c->stack_fused) {  // the dual update rides in the fused finish pass
         MCL_CHECK_HIP(c, hipGetLastError());
         return 0;
@@ -2315,9 +2398,10 @@ int mcl_launch_rows_finish_solve_stats(mcl_context *c) {
         else MCL_FSS(2, false);
     }
 #undef MCL_FSS
-    hipLaunchKernelGGL(k_stats_reduce, dim3((unsigned)c->I), dim3(256), 0, c->stream, (const int *)c->slab_tile_ptr,
-                       (const double *)c->stat_gram, (const double *)c->stat_colsq, c->regs[1], c->r, 16 * c->NB, (int)c->I,
-                       c->pf2_S, c->colsq);
+    if (!mcl_stats_reduce_in_algebra(c))
+        hipLaunchKernelGGL(k_stats_reduce, dim3((unsigned)c->I), dim3(256), 0, c->stream, (const int *)c->slab_tile_ptr,
+                           (const double *)c->stat_gram, (const double *)c->stat_colsq, c->regs[1], c->r, 16 * c->NB,
+                           (int)c->I, c->pf2_S, c->colsq);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
@@ -2335,9 +2419,10 @@ int mcl_launch_rows_solve_stats(mcl_context *c) {
         if (vec) hipLaunchKernelGGL((k_rows_solve_stats<2, true>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, (const float *)c->LinvB, c->regs[1], c->r, c->stat_gram, c->stat_colsq);
         else hipLaunchKernelGGL((k_rows_solve_stats<2, false>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, (const float *)c->LinvB, c->regs[1], c->r, c->stat_gram, c->stat_colsq);
     }
-    hipLaunchKernelGGL(k_stats_reduce, dim3((unsigned)c->I), dim3(256), 0, c->stream, (const int *)c->slab_tile_ptr,
-                       (const double *)c->stat_gram, (const double *)c->stat_colsq, c->regs[1], c->r, 16 * c->NB, (int)c->I,
-                       c->pf2_S, c->colsq);
+    if (!mcl_stats_reduce_in_algebra(c))
+        hipLaunchKernelGGL(k_stats_reduce, dim3((unsigned)c->I), dim3(256), 0, c->stream, (const int *)c->slab_tile_ptr,
+                           (const double *)c->stat_gram, (const double *)c->stat_colsq, c->regs[1], c->r, 16 * c->NB,
+                           (int)c->I, c->pf2_S, c->colsq);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

@@ -140,6 +140,7 @@ struct mcl_context {
     bool stack_fused = false;  // generic inner loop: statistics kernels only, then one fused prox + dual row pass
     bool step_fuse = false, step_stats = false;  // the same two decisions for the current mcl_B_solve .. mcl_B_prox_* round
     unsigned step_done_mask = 0;                 // penalties finished in this round
+    bool pf2_delta_fused = false;  // single-process inner loop: k_pf2_sum_delta instead of k_pf2_sum / (all-reduce) / k_pf2_delta
     bool stats_in_solve = false;   // ... and the B-mode statistics (PARAFAC2 Gram, L2-ball column norms) already came out of
                                    // the solve pass (k_rows_solve_stats + k_stats_reduce)
     std::vector<int> h_slab_tile_ptr;  // first B tile of every slab
@@ -231,5 +232,6 @@ bool mcl_mode_is_row_separable(const mcl_context *c, int mode);
 bool mcl_stack_can_fuse(const mcl_context *c, int mode);          // generic.hip
 int mcl_launch_rows_finish_fused(mcl_context *c, int mode, bool want_diag);  // generic.hip
 bool mcl_stats_can_ride_in_solve(const mcl_context *c, int mode);  // generic.hip
+bool mcl_stats_reduce_in_algebra(const mcl_context *c);            // generic.hip
 int mcl_launch_rows_finish_solve_stats(mcl_context *c);           // generic.hip: finish of iteration t + solve / stats of t + 1
 int mcl_launch_rows_solve_stats(mcl_context *c);                  // generic.hip: B solve + per-tile statistics + reduce
