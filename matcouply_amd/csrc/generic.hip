@@ -1532,17 +1532,41 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
     if (TILES) {
         const int t0 = ts.slab_tile_ptr[slab], t1 = ts.slab_tile_ptr[slab + 1];
         const long WW = (long)ts.W * ts.W;
-        for (int e = lane; e < n2; e += 64) {
+        // the order of k_stats_reduce (even tile offsets -> s0, odd -> s1, ascending), tiles fetched TB at a time with
+        // independent clamped loads (one memory latency per batch instead of one per tile)
+        constexpr int EPL = 4 * NB * NB, TB = NB == 1 ? 8 : 2;  // elements per lane (n2 <= 256 NB^2); register budget
+        double s0[EPL], s1[EPL];
+        long off[EPL];
+#pragma unroll
+        for (int m = 0; m < EPL; ++m) {
+            const int e = min(lane + 64 * m, n2 - 1);
             const int a = e / r, b = e - a * r;
-            double s0 = 0.0, s1 = 0.0;
-            int t = t0;
-            for (; t + 1 < t1; t += 2) {
-                s0 += ts.stat_gram[t * WW + a * ts.W + b];
-                s1 += ts.stat_gram[(t + 1) * WW + a * ts.W + b];
+            off[m] = (long)a * ts.W + b;
+            s0[m] = 0.0, s1[m] = 0.0;
+        }
+        for (int tb = t0; tb < t1; tb += TB) {
+            double v[TB][EPL];
+#pragma unroll
+            for (int u = 0; u < TB; ++u)
+#pragma unroll
+                for (int m = 0; m < EPL; ++m) v[u][m] = ts.stat_gram[min(tb + u, t1 - 1) * WW + off[m]];
+#pragma unroll
+            for (int u = 0; u < TB; ++u)
+                if (tb + u < t1) {
+#pragma unroll
+                    for (int m = 0; m < EPL; ++m) {
+                        if (((tb + u - t0) & 1) == 0) s0[m] += v[u][m];
+                        else s1[m] += v[u][m];
+                    }
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < EPL; ++m) {
+            const int e = lane + 64 * m;
+            if (e < n2) {
+                Ssm[e] = s0[m] + s1[m];
+                S[(long)slab * n2 + e] = s0[m] + s1[m];
             }
-            if (t < t1) s0 += ts.stat_gram[t * WW + a * ts.W + b];
-            Ssm[e] = s0 + s1;
-            S[(long)slab * n2 + e] = s0 + s1;
         }
         for (int k = 0; k < regs.n; ++k) {
             if (regs.kind[k] != MCL_PEN_L2BALL) continue;
