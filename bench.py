@@ -138,11 +138,38 @@ def make_engine(cfg, X, row_ptr, I_loc, rank, device, seed=1):
     return HipEngine(X, row_ptr, r, A, B, C, regs)
 
 
+def usable_cores():
+    """Host cores this process may use: the affinity mask capped by the cgroup CPU quota (cpu.max), if any."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(cfg, budget_s=15.0):
     """Oracle (NumPy, fp64 like the reference) on the host cores, bounded sample: a subset of the slabs, >= 1 iteration."""
     from oracle import aoadmm_oracle as orc
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
+    try:  # BLAS threads = the cores this process may actually use (a 256-thread pool on a 16-CPU quota thrashes)
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(limits=cores)
+    except Exception:
+        pass
     I, J, K, r = cfg["I"], cfg["J"], cfg["K"], cfg["r"]
 
     J_all = np.random.RandomState(0).randint(128, 1025, I) if J == "ragged" else None  # config 4 (SURVEY.md 8d)
@@ -166,7 +193,8 @@ def cpu_baseline(cfg, budget_s=15.0):
     value = 1.0 / (t_iter * I / I_s)
     return dict(value=value, unit="outer-iters/s", cores=cores, kind="port",
                 sample=f"{iters} outer iterations (after 1 warm-up) of the NumPy fp64 oracle on the first {I_s} of {I} slabs "
-                       f"of the same synthetic workload, BLAS threads = {cores}; value scaled by {I_s}/{I}")
+                       f"of the same synthetic workload, BLAS threads = {cores} (affinity mask capped by the cgroup CPU quota; "
+                       f"os.cpu_count() = {os.cpu_count()}); value scaled by {I_s}/{I}")
 
 
 def main():
