@@ -19,6 +19,9 @@ Fixture families:
   G5  more_penalties.npz  GeneralizedL2Penalty / UnitSimplex: prox vectors and a 10-iteration
                           trajectory with a graph-Laplacian penalty on the B_i and the unit simplex on C
                           (`python oracle/tools/gen_golden.py --only more` regenerates just this family)
+  G6  readme_example.npz   the call of the reference's README (README.rst:66-91: non_negative, L1 on C, L2 balls on
+                          A and B_i, PARAFAC2, unimodality, constant feasibility penalty, random_state=0), 10 iterations
+                          (`--only readme`)
 
 Penalties are described by neutral JSON descriptors ({"kind": "l1", "reg_strength": 0.1, ...}) so
 that the fixtures do not depend on any class of the reference or of the product.
@@ -516,15 +519,45 @@ def gen_more_penalties():
           f"column sums of C {np.sum(cmf[1][2], axis=0)}")
 
 
+# ----------------------------------------------------------------------------------------------
+# G6: the call of the reference's README (README.rst:66-91) as a 10-iteration trajectory
+# ----------------------------------------------------------------------------------------------
+def gen_readme():
+    matrices, _ = get_simple_simulated_data(noise_level=0.2, random_state=1)
+    r = 3
+    kwargs = dict(non_negative=True, l1_penalty={2: 0.1}, l2_norm_bound=[1, 1, 0], parafac2=True, unimodal={1: True},
+                  constant_feasibility_penalty=True, random_state=0)
+    cmf, admm_vars, diag = ref_dec.cmf_aoadmm(matrices, r, n_iter_max=10, tol=None, absolute_tol=None, return_errors=True,
+                                              return_admm_vars=True, **kwargs)
+    arrays = dict(A=cmf[1][0], B=pack_rows(cmf[1][1]), C=cmf[1][2], rec_errors=np.array(diag.rec_errors),
+                  regularized_loss=np.array(diag.regularized_loss))
+    for mode in range(3):
+        gaps = np.array([[float(g) for g in it_gaps[mode]] for it_gaps in diag.feasibility_gaps])
+        arrays[f"gaps_m{mode}"] = gaps.reshape(len(diag.feasibility_gaps), -1)
+    arrays["aux_A0"] = np.asarray(admm_vars.auxes[0][0])
+    arrays["dual_A0"] = np.asarray(admm_vars.duals[0][0])
+    arrays["aux_B0_Delta"] = np.asarray(admm_vars.auxes[1][0][1])
+    arrays["n_regs"] = np.array([len(admm_vars.auxes[m]) for m in range(3)])
+    arrays["spec"] = np.array(json.dumps(dict(
+        kwargs=dict(non_negative=True, l1_penalty={"2": 0.1}, l2_norm_bound=[1, 1, 0], parafac2=True, unimodal={"1": True},
+                    constant_feasibility_penalty=True, random_state=0, n_iter_max=10), rank=r)))
+    np.savez_compressed(os.path.join(OUT, "readme_example.npz"), **arrays)
+    print(f"readme_example: rec {diag.rec_errors[0]:.6f} -> {diag.rec_errors[-1]:.6f}; regs per mode {arrays['n_regs']}")
+
+
 if __name__ == "__main__":
     print("reference version", matcouply.__version__)
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "more":
         gen_more_penalties()
+        sys.exit(0)
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "readme":
+        gen_readme()
         sys.exit(0)
     gen_phase()
     gen_traj()
     gen_prox()
     gen_stopping()
     gen_more_penalties()
+    gen_readme()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"total fixture bytes: {total}")

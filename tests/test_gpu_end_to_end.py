@@ -113,6 +113,23 @@ def test_seeded_keyword_run_on_gpu():
     assert rel_err(cmf[1][0], arrs["A"]) < 1e-4 and rel_err(np.concatenate(cmf[1][1]), arrs["B"]) < 1e-4
 
 
+def test_readme_example_of_the_reference_on_gpu():
+    """README.rst:66-91 of the reference through the public API on the device: L2 ball on A with a constant feasibility
+    penalty, PARAFAC2 + unimodality + L2 ball on the B_i, L1 on C, seeded random initialisation."""
+    from matcouply_amd import decomposition as dec
+
+    arrs = load_npz("readme_example.npz")
+    c1 = load_npz("c1_data.npz")
+    cmf, diag = dec.cmf_aoadmm(split_rows(c1["X"], c1["row_ptr"]), 3, non_negative=True, l1_penalty={2: 0.1},
+                               l2_norm_bound=[1, 1, 0], parafac2=True, unimodal={1: True}, constant_feasibility_penalty=True,
+                               n_iter_max=10, tol=None, absolute_tol=None, return_errors=True, random_state=0)
+    np.testing.assert_allclose(diag.rec_errors, arrs["rec_errors"], rtol=2e-5)
+    np.testing.assert_allclose(diag.regularized_loss, arrs["regularized_loss"], rtol=5e-5)
+    e = {"A": rel_err(cmf[1][0], arrs["A"]), "B": rel_err(np.concatenate(cmf[1][1]), arrs["B"]), "C": rel_err(cmf[1][2], arrs["C"])}
+    print("README example, 10 it vs reference:", {k: f"{v:.1e}" for k, v in e.items()})
+    assert max(e.values()) < 1e-4, e
+
+
 def test_config1_converges_like_the_reference():
     from matcouply_amd import decomposition as dec
     from matcouply_amd.data import get_simple_simulated_data

@@ -230,6 +230,29 @@ def test_seeded_keyword_run_pins_rng_order(checker_engine):
     assert rel_err(np.concatenate(admm_vars.duals[1][1]), arrs["dual_B1"]) < 1e-6
 
 
+README_KW = dict(non_negative=True, l1_penalty={2: 0.1}, l2_norm_bound=[1, 1, 0], parafac2=True, unimodal={1: True},
+                 constant_feasibility_penalty=True, random_state=0)
+
+
+def test_readme_example_of_the_reference(checker_engine):
+    """The call of the reference's README (README.rst:66-91): L2 ball on A under a constant feasibility penalty, the full
+    B stack (PARAFAC2, unimodality, L2 ball), L1 on C - 10 iterations against the reference's own trajectory."""
+    arrs = load_npz("readme_example.npz")
+    c1 = load_npz("c1_data.npz")
+    cmf, admm_vars, diag = dec.cmf_aoadmm(split_rows(c1["X"], c1["row_ptr"]), 3, n_iter_max=10, tol=None, absolute_tol=None,
+                                          return_errors=True, return_admm_vars=True, **README_KW)
+    assert [len(a) for a in admm_vars.auxes] == list(arrs["n_regs"])
+    np.testing.assert_allclose(diag.rec_errors, arrs["rec_errors"], rtol=1e-7)
+    np.testing.assert_allclose(diag.regularized_loss, arrs["regularized_loss"], rtol=1e-7)
+    for m in range(3):
+        got = np.array([[float(g) for g in it[m]] for it in diag.feasibility_gaps]).reshape(len(diag.feasibility_gaps), -1)
+        np.testing.assert_allclose(got, arrs[f"gaps_m{m}"], rtol=1e-6, atol=1e-12)
+    assert rel_err(cmf[1][0], arrs["A"]) < 1e-7 and rel_err(np.concatenate(cmf[1][1]), arrs["B"]) < 1e-7
+    assert rel_err(cmf[1][2], arrs["C"]) < 1e-7
+    assert rel_err(admm_vars.auxes[0][0], arrs["aux_A0"]) < 1e-6 and rel_err(admm_vars.duals[0][0], arrs["dual_A0"]) < 1e-6
+    assert rel_err(admm_vars.auxes[1][0][1], arrs["aux_B0_Delta"]) < 1e-6
+
+
 def test_config1_known_answer(checker_engine):
     """BASELINE config 1: parafac2_aoadmm(non_negative=True, random_state=0) on the simulated data converges by the
     tolerance rules after the same number of iterations as the reference run in the build container."""
