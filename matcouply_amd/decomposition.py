@@ -490,9 +490,16 @@ def cmf_aoadmm(
         rank_id = 0
     needs_B_steps = world > 1 and (constant_B or any(r.kind == _engine.PEN_PARAFAC2 for r in native[1]))
     needs_A_steps = world > 1 and constant_A
-    if world > 1 and not all(r.kind in (_engine.PEN_NN, _engine.PEN_BOX, _engine.PEN_L1) for r in native[0]):
-        raise NotImplementedError("matrix penalties on mode 0 couple rows that live on different ranks; "
+    # mode 0 under sharding: the rows of A live on different ranks.  Row-separable penalties need nothing; an L2 ball
+    # (the README case: l2_norm_bound on A with a constant feasibility penalty) needs the r column sums of squares of
+    # A + U all-reduced in every inner iteration; other matrix penalties are not supported.
+    sharded_ball_A = world > 1 and any(r.kind == _engine.PEN_L2BALL for r in native[0])
+    if world > 1 and not all(r.kind in (_engine.PEN_NN, _engine.PEN_BOX, _engine.PEN_L1, _engine.PEN_L2BALL)
+                             for r in native[0]):
+        raise NotImplementedError("this matrix penalty on mode 0 couples rows that live on different ranks; "
                                   "not supported with group=")
+    if sharded_ball_A and not constant_A:
+        raise NotImplementedError("an L2 ball on mode 0 needs constant_feasibility_penalty (as in the reference)")
 
     def all_reduce(t, op="sum"):
         if world > 1:
@@ -584,7 +591,39 @@ def cmf_aoadmm(
                 break
         eng.C_end()
 
+    def sharded_ball_prox_A(k, rho_a):
+        """L2-ball prox on the sharded A (penalties.py:920-925): column norms over ALL rows = all-reduced partial sums"""
+        nat = native[0][k]
+        y = eng.A + nat.dual
+        if nat.non_negativity:
+            y = torch.clamp(y, min=0)
+        sq = (y.double() ** 2).sum(0)
+        all_reduce(sq)
+        nrm = torch.sqrt(sq).to(y.dtype)
+        bound = torch.as_tensor(nat.p0, dtype=y.dtype, device=y.device)
+        z = y * (bound / torch.maximum(nrm, bound))
+        nat.dual.copy_(eng.A - (z - nat.dual))
+        nat.aux.copy_(z)
+
     def do_update_A():
+        if sharded_ball_A and not has_ext[0]:
+            eng.A_begin()
+            all_reduce(eng.A_rho_max(), "max")
+            eng.A_factor()
+            rho_a = eng.rho(0).cpu().numpy()
+            n_it = inner_n_iter_max if native[0] else min(1, inner_n_iter_max)
+            for _ in range(n_it):
+                A_old = eng.A.clone() if check_inner else None
+                eng.A_solve()
+                for k, nat in enumerate(native[0]):
+                    if nat.kind == _engine.PEN_L2BALL:
+                        sharded_ball_prox_A(k, rho_a)
+                    else:
+                        host_prox_matrix(0, k, eng.A, rho_a, True)
+                if inner_converged(eng.A, A_old, 0):
+                    break
+            eng.A_end()
+            return
         if has_ext[0]:
             eng.A_begin()
             if constant_A:

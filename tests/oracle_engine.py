@@ -191,6 +191,27 @@ class OracleEngine:
                 self._n(reg.aux)[...] = Z
         self.by_products = (self.rhs_A, self.Q)
 
+    # step form of the A inner loop (host-evaluated / cross-rank prox in between), as HipEngine exposes it
+    def A_factor(self):
+        n = len(self.regs[0])
+        self.rho_A_used = np.full_like(self.rho_A, float(self.rho_max_A[0])) if self.constant_A else self.rho_A
+        self.Linv_A = np.linalg.inv(self.Q + (self.rho_A_used * n + self.l2[0])[:, None, None] * np.eye(self.r)) \
+            if self.I else self.Q
+
+    def A_solve(self):
+        T = self.rhs_A.copy()
+        for reg in self.regs[0]:
+            T += self.rho_A_used[:, None] * (self._n(reg.aux) - self._n(reg.dual))
+        self._n(self.A)[...] = np.einsum("ik,ikj->ij", T, self.Linv_A)
+
+    def A_end(self):
+        self.by_products = (self.rhs_A, self.Q)
+
+    def rho(self, mode):
+        if mode == 0:
+            return torch.as_tensor(np.asarray(self.rho_A_used, dtype=np.float64))
+        raise NotImplementedError("checker engine: rho() is implemented for mode 0 only")
+
     def update_A(self):
         self.A_begin()
         self.A_finish()

@@ -17,6 +17,10 @@ CASES = {
     "c3_nn_l1C": dict(non_negative=True, l1_penalty={2: 0.1}),
     "pf2_ball_constant": dict(parafac2=True, l2_norm_bound={1: 1.0}, non_negative={0: True},
                               constant_feasibility_penalty=True),
+    # the stack of the reference's README (README.rst:66-91): L2 ball on A (column norms over rows that live on different
+    # ranks), PARAFAC2 + unimodality + L2 ball on the B_i, L1 on C, constant feasibility penalty
+    "readme_stack": dict(non_negative=True, l1_penalty={2: 0.1}, l2_norm_bound=[1, 1, 0], parafac2=True,
+                         unimodal={1: True}, constant_feasibility_penalty=True),
 }
 
 
@@ -42,6 +46,12 @@ def _explicit_state(case, mats, r, seed=9):
     if case == "c3_nn_l1C":
         regs[0] = [("nn", mk((I, r)), mk((I, r)))]
         regs[1] = [("nn", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
+        regs[2] = [("l1nn", mk((K, r)), mk((K, r)))]
+    elif case == "readme_stack":
+        regs[0] = [("ballnn", mk((I, r)), mk((I, r)))]
+        regs[1] = [("pf2", ([np.eye(m.shape[0], r) for m in mats], mk((r, r))), [mk((m.shape[0], r)) for m in mats]),
+                   ("uninn", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats]),
+                   ("ballnn", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
         regs[2] = [("l1nn", mk((K, r)), mk((K, r)))]
     else:
         regs[0] = [("nn", mk((I, r)), mk((I, r)))]
@@ -71,6 +81,10 @@ def _build(regs_spec, lo, hi):
                 out[m].append(pen.Parafac2(aux_init=aux, dual_init=dual))
             elif kind == "ball":
                 out[m].append(pen.L2Ball(1.0, aux_init=aux, dual_init=dual))
+            elif kind == "ballnn":
+                out[m].append(pen.L2Ball(1.0, non_negativity=True, aux_init=aux, dual_init=dual))
+            elif kind == "uninn":
+                out[m].append(pen.Unimodality(non_negativity=True, aux_init=aux, dual_init=dual))
     return out
 
 

@@ -97,11 +97,17 @@ mk = lambda shp: rs.uniform(size=shp)
 auxA, dualA, auxC, dualC = mk((6, 4)), mk((6, 4)), mk((24, 4)), mk((24, 4))
 P0 = [np.eye(j, 4) for j in J]; D0 = mk((4, 4)); dualP = [mk((j, 4)) for j in J]
 auxL, dualL = [mk((j, 4)) for j in J], [mk((j, 4)) for j in J]
+auxU, dualU = [mk((j, 4)) for j in J], [mk((j, 4)) for j in J]
+README_STACK = os.environ.get("STACK") == "readme"  # README.rst:66-91 of the reference: L2 ball on A, unimodal B_i
 def run(lo, hi, group):
     regs = [[pen.NonNegativity(aux_init=auxA[lo:hi].copy(), dual_init=dualA[lo:hi].copy())],
             [pen.Parafac2(aux_init=([p.copy() for p in P0[lo:hi]], D0.copy()), dual_init=[d.copy() for d in dualP[lo:hi]]),
              pen.L2Ball(1.0, aux_init=[a.copy() for a in auxL[lo:hi]], dual_init=[d.copy() for d in dualL[lo:hi]])],
             [pen.L1Penalty(0.05, non_negativity=True, aux_init=auxC.copy(), dual_init=dualC.copy())]]
+    if README_STACK:
+        regs[0] = [pen.L2Ball(1.0, non_negativity=True, aux_init=auxA[lo:hi].copy(), dual_init=dualA[lo:hi].copy())]
+        regs[1].insert(1, pen.Unimodality(non_negativity=True, aux_init=[a.copy() for a in auxU[lo:hi]],
+                                          dual_init=[d.copy() for d in dualU[lo:hi]]))
     return dec.cmf_aoadmm(mats[lo:hi], 4, init=(None, (A0[lo:hi].copy(), [b.copy() for b in B0[lo:hi]], C0.copy())), regs=regs,
                           n_iter_max=5, tol=None, absolute_tol=None, return_errors=True, constant_feasibility_penalty=True,
                           group=group)
@@ -118,12 +124,15 @@ dist.destroy_process_group()
 '''
 
 
-def test_two_ranks_sharing_the_gpu_equal_single_process(tmp_path):
+@pytest.mark.parametrize("stack", ["pf2", "readme"])
+def test_two_ranks_sharing_the_gpu_equal_single_process(tmp_path, stack):
     """cmf_aoadmm(group=) with the REAL engine: 2 processes share cuda:0, collectives over gloo (RCCL refuses two ranks on one
-    device); PARAFAC2 + constant feasibility penalty exercise every reduction of the step path."""
+    device); PARAFAC2 + constant feasibility penalty exercise every reduction of the step path; the "readme" stack adds the
+    L2 ball on the sharded A (all-reduced column norms) and unimodality on the B_i."""
     script = tmp_path / "sharded.py"
     script.write_text(SHARDED)
-    env = dict(os.environ, REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300))
+    env = dict(os.environ, REPO=REPO, MASTER_ADDR="127.0.0.1", STACK=stack,
+               MASTER_PORT=str(29600 + (os.getpid() + 7 * len(stack)) % 300))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", env["MASTER_PORT"], str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
