@@ -48,6 +48,9 @@ CONFIGS["c5s"] = dict(I=1024, J=512, K=256, r=32,
                             [{"kind": "l1", "reg_strength": 0.1, "non_negativity": True}]],
                       desc="c5 penalty stack (NN + L1 + L2Ball + Unimodal + PARAFAC2) at I=1024 J_i=512 K=256 rank=32 "
                            "(config 5 itself is I=8192 J=2048 K=1024: 68.7 GB of X)")
+CONFIGS["c5"] = dict(CONFIGS["c5s"], I=8192, J=2048, K=1024, desc="c5: I=8192 J_i=2048 K=1024 rank=32 fp32 (X = 68.7 GB), "
+                     "NN + L1 + L2Ball + Unimodal + PARAFAC2; fits one MI355X (128 GB in use), shards over --gpus N")
+CONFIGS["c5_8th"] = dict(CONFIGS["c5"], I=1024, desc="one eighth of config 5 (the per-rank shard of an 8-GPU run): I=1024 J_i=2048 K=1024 rank=32")
 CONFIGS["c5_32nd"] = dict(CONFIGS["c5s"], I=256, J=2048, K=1024, desc="1/32 of config 5: I=256 J_i=2048 K=1024 rank=32, full penalty stack")
 CONFIGS["c3_8th"] = dict(CONFIGS["c3"], I=128, desc="one eighth of config 3 (the per-rank shard of an 8-GPU run): I=128 J_i=512 K=256 rank=16")
 CONFIGS["c3_half"] = dict(CONFIGS["c3"], I=512, desc="one half of config 3 (the per-rank shard of a 2-GPU run): I=512 J_i=512 K=256 rank=16")
@@ -70,12 +73,25 @@ def make_shard(cfg, rank, world, device, seed=0):
     g.manual_seed(seed)
     C_true = torch.rand((K, r), generator=g, device=device)
     g.manual_seed(seed + 1000 + rank)
+    row_ptr = np.arange(I_loc + 1, dtype=np.int64) * J
+    if 4.0 * I_loc * J * K > 8e9:  # config 5 (68.7 GB of X): generated 64 slabs at a time, unimodal non-negative B_i*
+        X = torch.empty((I_loc * J, K), dtype=torch.float32, device=device)
+        t = torch.linspace(0, 1, J, device=device)[None, :, None]
+        for i0 in range(0, I_loc, 64):
+            n = min(64, I_loc - i0)
+            A_t = torch.rand((n, r), generator=g, device=device) + 0.1
+            mu = torch.rand((n, 1, r), generator=g, device=device)
+            sig = 0.05 + 0.2 * torch.rand((n, 1, r), generator=g, device=device)
+            Xc = torch.einsum("ijr,ir,kr->ijk", torch.exp(-0.5 * ((t - mu) / sig) ** 2), A_t, C_true)
+            Xc += 0.05 * torch.randn(Xc.shape, generator=g, device=device)
+            X[i0 * J:(i0 + n) * J] = Xc.reshape(n * J, K)
+            del Xc
+        return X, row_ptr, I_loc
     A_true = torch.rand((I_loc, r), generator=g, device=device) + 0.1
     B_true = torch.rand((I_loc, J, r), generator=g, device=device)
     X = torch.einsum("ijr,ir,kr->ijk", B_true, A_true, C_true)
     X += 0.05 * torch.randn(X.shape, generator=g, device=device)
     X = X.reshape(I_loc * J, K).contiguous()
-    row_ptr = np.arange(I_loc + 1, dtype=np.int64) * J
     return X, row_ptr, I_loc
 
 
@@ -329,9 +345,11 @@ def main():
     if prof:
         avg_ms, slot, n = max(prof)
         achieved = alg_bytes[slot] / (avg_ms * 1e-3) / 1e9
+        traffic = pmc_traffic(eng.kernel_variant(slot))
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(eng.kernel_variant(slot)),
-                        traffic_source="profiles/r1_%s_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % args.config,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                        traffic_source=("profiles/r1_%s_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                        "passes)" % args.config) if traffic is not None else None,
                         kernel=eng.kernel_variant(slot),
                         kernel_role=names[slot], avg_us=round(avg_ms * 1e3, 2), launches_timed=n,
                         launches_in_timed_region=args.steps, event_stride=prof_stride,
