@@ -1067,14 +1067,14 @@ static __device__ __forceinline__ int wave_min_i(int v) {
 // (direction = block parity; the right-to-left one stores its errors instead of searching the split), then a second
 // launch searches the split with the same comparisons in the same order and emits.  Halves the serial chain.
 template <int MODE>
-__global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__ ext, int n_slabs, float *__restrict__ F,
+__global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const int *__restrict__ ext, int n_slabs, float *__restrict__ F,
                                                          RegSet regs, int k, int r, UniScratch sc) {
     __shared__ double ring_d[2][MODE == 2 ? 1 : RC4 * 64];
     __shared__ int ring_i[MODE == 2 ? 1 : RC4 * 64];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;  // MODE 2: four waves work on the same 64 columns
     const bool do_L = MODE == 0 || (MODE == 1 && (blockIdx.x & 1) == 0);
     const bool do_R = MODE == 0 || (MODE == 1 && (blockIdx.x & 1) == 1);
-    const long t = (long)(MODE == 1 ? blockIdx.x >> 1 : blockIdx.x) * 64 + threadIdx.x;
+    const long t = (long)(MODE == 1 ? blockIdx.x >> 1 : blockIdx.x) * 64 + lane;
     const bool live = t < (long)n_slabs * r;  // no early exit: the emit loops use wave-wide reductions
     const int slab = live ? (int)(t / r) : 0, col = live ? (int)(t - (long)slab * r) : 0;
     const int s = ext[slab], e = ext[slab + 1];
@@ -1214,35 +1214,61 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__
         }
     }
     if (MODE == 1) return;
-    if (MODE == 2 && n > 0) {  // the split search of sweep 2, from the stored errors (same sums, same order)
-        double best = errL[(eb + n) * rs + col];
-        const double *epl = errL + (eb + n - 1) * rs + col;
-        const double *epr = errR + (eb + 1) * rs + col;
-        constexpr int SB = 16;
-        double ln[SB], rn_[SB];
-#pragma unroll
-        for (int j = 0; j < SB; ++j) {
-            const long o = (long)min(j, n - 1) * rs;
-            ln[j] = epl[-o], rn_[j] = epr[o];
-        }
-        for (int i0 = 0; i0 < n; i0 += SB) {
-            double lb[SB], rb[SB];
-#pragma unroll
-            for (int j = 0; j < SB; ++j) lb[j] = ln[j], rb[j] = rn_[j];
+    if (MODE == 2) {
+        // the split search of sweep 2 from the stored errors: the same sums compared in the same order (minimum total,
+        // ties -> largest i = smallest split).  Each of the four waves scans a quarter of the positions, the partial
+        // results are combined in ascending order of i; then wave 0 emits the left fit and wave 1 the right one.
+        __shared__ double sbest[4][64];
+        __shared__ int sidx[4][64];
+        double bw = 0.0;
+        int iw = -1;
+        if (n > 0) {
+            const int q4 = (n + 3) >> 2;
+            const int ia = wv * q4, ib = min(ia + q4, n);
+            const double *epl = errL + (eb + n - 1) * rs + col;
+            const double *epr = errR + (eb + 1) * rs + col;
+            constexpr int SB = 16;
+            double ln[SB], rn_[SB];
 #pragma unroll
             for (int j = 0; j < SB; ++j) {
-                const long o = (long)min(i0 + SB + j, n - 1) * rs;
+                const long o = (long)min(ia + j, n - 1) * rs;
                 ln[j] = epl[-o], rn_[j] = epr[o];
             }
+            for (int i0 = ia; i0 < ib; i0 += SB) {
+                double lb[SB], rb[SB];
 #pragma unroll
-            for (int j = 0; j < SB; ++j) {
-                const int i = i0 + j;
-                if (i < n) {
-                    const double tot = lb[j] + rb[j];
-                    if (tot <= best) {
-                        best = tot;
-                        split = n - 1 - i;
+                for (int j = 0; j < SB; ++j) lb[j] = ln[j], rb[j] = rn_[j];
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const long o = (long)min(i0 + SB + j, n - 1) * rs;
+                    ln[j] = epl[-o], rn_[j] = epr[o];
+                }
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const int i = i0 + j;
+                    if (i < ib) {
+                        const double tot = lb[j] + rb[j];
+                        if (iw < 0 || tot <= bw) {
+                            bw = tot;
+                            iw = i;
+                        }
                     }
+                }
+            }
+        }
+        sbest[wv][lane] = bw;
+        sidx[wv][lane] = iw;
+        __syncthreads();
+        if (wv >= 2) return;
+        if (n > 0) {
+            double best = errL[(eb + n) * rs + col];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int i = sidx[w][lane];
+                const double b4 = sbest[w][lane];
+                if (i >= 0 && b4 <= best) {
+                    best = b4;
+                    split = n - 1 - i;
                 }
             }
         }
@@ -1251,7 +1277,9 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__
     // Left fit: chain from position split-1 downwards.
     constexpr int EB = 16;
     const int nm1 = max(n - 1, 0);
-    {
+    // stores of lanes that have nothing to write at a position go to a per-lane sink (an unused scratch array)
+    float *sink = reinterpret_cast<float *>(sc.cum2) + ((long)blockIdx.x * 64 + lane) * 2 + (MODE == 2 ? wv : 0);
+    if (MODE != 2 || wv == 0) {
         const UniRec *rp = recL + (long)s * rs + col;
         float *zp = Z + (long)s * rs + col;
         int rem = 0;
@@ -1267,18 +1295,19 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__
 #pragma unroll
             for (int u = 0; u < EB; ++u) rn[u] = rp[(long)min(max(j0 - EB - u, 0), nm1) * rs];
 #pragma unroll
-            for (int u = 0; u < EB; ++u) {
-                const int j = j0 - u;
-                if (j >= 0 && j < split) {
-                    if (rem == 0) z = rb[u].lev, rem = rb[u].len;
-                    zp[(long)j * rs] = z;
-                    rem -= 1;
-                }
+            for (int u = 0; u < EB; ++u) {  // branch-free (a branch around the stores would turn the counted waits on
+                const int j = j0 - u;       // the next batch's loads into waits for every store of this one)
+                const bool on = j >= 0 && j < split;
+                const bool take = on && rem == 0;
+                z = take ? rb[u].lev : z;
+                rem = take ? rb[u].len : rem;
+                *(on ? zp + (long)j * rs : sink) = z;
+                rem -= on ? 1 : 0;
             }
         }
     }
     // Right fit: chain from position split upwards (records of sweep 2 extend to the right of their position).
-    {
+    if (MODE != 2 || wv == 1) {
         const UniRec *rp = recR + (long)s * rs + col;
         float *zp = Z + (long)s * rs + col;
         int rem = 0;
@@ -1299,11 +1328,12 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v4(const int *__restrict__
 #pragma unroll
             for (int u = 0; u < EB; ++u) {
                 const int j = j0 + u;
-                if (j >= split && j < n) {
-                    if (rem == 0) z = rb[u].lev, rem = rb[u].len;
-                    zp[(long)j * rs] = z;
-                    rem -= 1;
-                }
+                const bool on = j >= split && j < n;
+                const bool take = on && rem == 0;
+                z = take ? rb[u].lev : z;
+                rem = take ? rb[u].len : rem;
+                *(on ? zp + (long)j * rs : sink) = z;
+                rem -= on ? 1 : 0;
             }
         }
     }
@@ -2252,7 +2282,7 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                 if (wave_split) {
                     hipLaunchKernelGGL(k_slab_unimodal_v4<1>, dim3(2 * nwav), dim3(64), 0, c->stream, mv.ext, mv.n_slabs,
                                        mv.F, rs, k, c->r, sc);
-                    hipLaunchKernelGGL(k_slab_unimodal_v4<2>, dim3(nwav), dim3(64), 0, c->stream, mv.ext, mv.n_slabs, mv.F,
+                    hipLaunchKernelGGL(k_slab_unimodal_v4<2>, dim3(nwav), dim3(256), 0, c->stream, mv.ext, mv.n_slabs, mv.F,
                                        rs, k, c->r, sc);
                 } else {
                     hipLaunchKernelGGL(k_slab_unimodal_v4<0>, dim3(nwav), dim3(64), 0, c->stream, mv.ext, mv.n_slabs, mv.F,
