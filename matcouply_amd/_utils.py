@@ -61,6 +61,33 @@ def get_shapes(matrices):
     return [shape(matrix) for matrix in matrices]
 
 
+def get_padded_tensor_shape(matrices):
+    """(I, max J_i, K) of the zero-padded stack; all matrices must share K (_utils.py:33-46)"""
+    K = shape(matrices[0])[1]
+    J = -float("inf")
+    for matrix in matrices:
+        J_i, K_i = shape(matrix)
+        if K_i != K:
+            raise ValueError("All matrices must have the same number of columns")
+        J = max(J_i, J)
+    return len(matrices), J, K
+
+
+def create_padded_tensor(matrices):
+    """third-order tensor whose frontal slabs are the matrices, zero-padded to the longest one (_utils.py:49-54)"""
+    I, J, K = get_padded_tensor_shape(matrices)
+    first = matrices[0]
+    if is_torch(first):
+        import torch
+
+        out = torch.zeros((I, J, K), dtype=first.dtype, device=first.device)
+    else:
+        out = np.zeros((I, J, K), dtype=np.asarray(first).dtype)
+    for i, matrix in enumerate(matrices):
+        out[i, : shape(matrix)[0]] = matrix if is_torch(first) else np.asarray(matrix)
+    return out
+
+
 def to_numpy(x):
     if is_torch(x):
         return x.detach().cpu().numpy()

@@ -25,3 +25,25 @@ def get_simple_simulated_data(noise_level=0.2, random_state=1):
     scale_factor = np.linalg.norm(np.stack(matrices)) / np.linalg.norm(np.stack(noise))
     matrices = [M + noise_level * scale_factor * N for M, N in zip(matrices, noise)]
     return matrices, cmf
+
+
+def _needs_download(name, where):
+    raise NotImplementedError(
+        f"matcouply_amd.data.{name}: this dataset of the reference ({where}) is fetched / unpacked from files that are not "
+        "part of this build (no network, no bundled archives).  Load the data yourself and pass the list of matrices to "
+        "matcouply_amd.decomposition.cmf_aoadmm / parafac2_aoadmm.")
+
+
+def get_bike_data():
+    """Bike-sharing data of three Norwegian cities (data.py:98-150 of the reference): not available in this build."""
+    _needs_download("get_bike_data", "data.py:98-150")
+
+
+def get_semiconductor_etch_raw_data(download_data=True, save_data=True):
+    """Semiconductor etch raw data (data.py:153-201 of the reference, downloaded from eigenvector.com): not available."""
+    _needs_download("get_semiconductor_etch_raw_data", "data.py:153-201")
+
+
+def get_semiconductor_etch_machine_data(download_data=True, save_data=True):
+    """Semiconductor etch machine data (data.py:204-260 of the reference): not available in this build."""
+    _needs_download("get_semiconductor_etch_machine_data", "data.py:204-260")

@@ -341,3 +341,19 @@ def test_cmf_from_cp_and_parafac2_tensors():
                 lambda: CMF.from_CPTensor((None, (A, B, C)), shapes=[(9, 5)] * 4)):
         with pytest.raises(ValueError):
             bad()
+
+
+def test_padded_tensor_utils_and_gated_datasets():
+    """_utils.py:33-54 of the reference; the downloadable datasets raise a clear error instead of an AttributeError"""
+    from matcouply_amd import data
+    from matcouply_amd._utils import create_padded_tensor, get_padded_tensor_shape
+
+    mats = [np.ones((2, 3)), 2 * np.ones((4, 3)), 3 * np.ones((1, 3))]
+    assert get_padded_tensor_shape(mats) == (3, 4, 3)
+    t = create_padded_tensor(mats)
+    assert t.shape == (3, 4, 3) and t[0, 2:].sum() == 0 and t[1].sum() == 24 and t[2, 0, 0] == 3
+    with pytest.raises(ValueError):
+        create_padded_tensor([np.ones((2, 3)), np.ones((2, 4))])
+    for fn in (data.get_bike_data, data.get_semiconductor_etch_raw_data, data.get_semiconductor_etch_machine_data):
+        with pytest.raises(NotImplementedError):
+            fn()
