@@ -17,7 +17,7 @@ from typing import NamedTuple, Optional
 import numpy as np
 
 from . import _engine, penalties
-from ._utils import check_random_state, get_svd, is_iterable, is_tensor, is_torch, shape, torch
+from ._utils import check_random_state, get_svd, is_iterable, is_tensor, is_torch, shape, to_numpy, torch
 from .coupled_matrices import CoupledMatrixFactorization
 
 __all__ = ["compute_feasibility_gaps", "ADMMVars", "DiagnosticMetrics", "cmf_aoadmm", "parafac2_aoadmm",
@@ -122,6 +122,64 @@ def compute_feasibility_gaps(cmf, regs, A_aux_list, B_aux_list, C_aux_list):
               for B_reg, B_is_aux in zip(regs[1], B_aux_list)]
     C_gaps = [np.sqrt(_sq(C_reg.subtract_from_aux(C_aux, C))) / C_norm for C_reg, C_aux in zip(regs[2], C_aux_list)]
     return A_gaps, B_gaps, C_gaps
+
+
+def _check_inner_convergence(factor_matrix, old_factor_matrix, cmf, reg_list, aux_list, mode, inner_tol):
+    """Inner stopping rule on host objects (:92-116): relative change and every feasibility gap of the mode below
+    `inner_tol`.  (Inside `cmf_aoadmm` the same test runs on device tensors between the step calls.)"""
+    if not inner_tol or inner_tol < 0:
+        return False
+    if mode == 1:
+        norm = _root_sum_squared_list(factor_matrix)
+        change = _root_sum_squared_list([B_i - prev_B_i for B_i, prev_B_i in zip(factor_matrix, old_factor_matrix)])
+    else:
+        norm = np.sqrt(_sq(factor_matrix))
+        change = np.sqrt(_sq(factor_matrix - old_factor_matrix))
+    if change > inner_tol * norm:
+        return False
+    if len(reg_list) == 0:
+        return True
+    regs, auxes = [[], [], []], [[], [], []]
+    regs[mode], auxes[mode] = reg_list, aux_list
+    return max(compute_feasibility_gaps(cmf, regs, *auxes)[mode]) < inner_tol
+
+
+def _cmf_reconstruction_error(matrices, cmf, norm_matrices=None, intermediate_A_calculations=None):
+    """sqrt(max(0, ||X||^2 - 2 <X, M> + ||M||^2)) on host objects (:420-452); with the by-products of `admm_update_A`
+    (`rhses`, `cross_products`) the two model terms need no pass over the matrices (:445-449).  fp64 accumulation.
+    (Inside `cmf_aoadmm` the same quantity comes out of the A-phase kernels, `mcl_diagnostics`.)"""
+    f64 = lambda x: to_numpy(x).astype(np.float64)
+    norm_X_sq = sum(_sq(m) for m in matrices) if norm_matrices is None else float(norm_matrices) ** 2
+    weights, (A, B_is, C) = cmf
+    A = f64(A)
+    if weights is not None:
+        A = A * f64(weights)
+    if intermediate_A_calculations is None:
+        C64 = f64(C)
+        CtC = C64.T @ C64
+        inner_product = norm_cmf_sq = 0.0
+        for i, B_i in enumerate(B_is):
+            B_i = f64(B_i) * A[i]
+            inner_product += float(np.sum((f64(matrices[i]) @ C64) * B_i))
+            norm_cmf_sq += float(np.sum((B_i.T @ B_i) * CtC))
+    else:
+        A_rhses, cross_products = intermediate_A_calculations
+        inner_product = sum(float(np.sum(f64(rhs_i) * a_i)) for rhs_i, a_i in zip(A_rhses, A))
+        norm_cmf_sq = sum(float(a_i @ f64(cross_products[i]) @ a_i) for i, a_i in enumerate(A))
+    return np.sqrt(max(0.0, norm_X_sq - 2 * inner_product + norm_cmf_sq))
+
+
+def _compute_l2_penalty(cmf, l2_parameters):
+    """sum over modes of l2_m / 2 ||factor_m||^2 (:617-627)"""
+    weights, (A, B_is, C) = cmf
+    l2reg = 0
+    if l2_parameters[0]:
+        l2reg += 0.5 * l2_parameters[0] * _sq(A)
+    if l2_parameters[1]:
+        l2reg += 0.5 * l2_parameters[1] * sum(_sq(B_i) for B_i in B_is)
+    if l2_parameters[2]:
+        l2reg += 0.5 * l2_parameters[2] * _sq(C)
+    return l2reg
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -357,3 +357,34 @@ def test_padded_tensor_utils_and_gated_datasets():
     for fn in (data.get_bike_data, data.get_semiconductor_etch_raw_data, data.get_semiconductor_etch_machine_data):
         with pytest.raises(NotImplementedError):
             fn()
+
+
+def test_host_diagnostic_helpers_of_the_reference():
+    """_cmf_reconstruction_error (both forms, decomposition.py:420-452), _compute_l2_penalty (:617-627),
+    _check_inner_convergence (:92-116) on host arrays, against direct evaluation and the phase goldens of the reference."""
+    rng = np.random.RandomState(2)
+    I, K, r = 4, 6, 3
+    J = [5, 7, 4, 6]
+    A, C = rng.uniform(0.1, 1, (I, r)), rng.uniform(size=(K, r))
+    B = [rng.uniform(size=(j, r)) for j in J]
+    mats = [(b * A[i]) @ C.T + 0.1 * rng.standard_normal((b.shape[0], K)) for i, b in enumerate(B)]
+    cmf = (None, (A, B, C))
+    direct = np.sqrt(sum(np.sum((m - (b * A[i]) @ C.T) ** 2) for i, (m, b) in enumerate(zip(mats, B))))
+    np.testing.assert_allclose(dec._cmf_reconstruction_error(mats, cmf), direct, rtol=1e-10)
+    norm = np.sqrt(sum(np.sum(m ** 2) for m in mats))
+    np.testing.assert_allclose(dec._cmf_reconstruction_error(mats, cmf, norm), direct, rtol=1e-10)
+    rhses = [np.diag(b.T @ m @ C) for b, m in zip(B, mats)]
+    cross = [(b.T @ b) * (C.T @ C) for b in B]
+    np.testing.assert_allclose(dec._cmf_reconstruction_error(mats, cmf, norm, (rhses, cross)), direct, rtol=1e-9)
+    w = rng.uniform(0.5, 2, r)
+    direct_w = np.sqrt(sum(np.sum((m - (b * (A[i] * w)) @ C.T) ** 2) for i, (m, b) in enumerate(zip(mats, B))))
+    np.testing.assert_allclose(dec._cmf_reconstruction_error(mats, (w, (A, B, C))), direct_w, rtol=1e-10)
+    l2 = dec._compute_l2_penalty(cmf, [0.5, None, 2.0])
+    np.testing.assert_allclose(l2, 0.25 * np.sum(A ** 2) + np.sum(C ** 2))
+    assert dec._compute_l2_penalty(cmf, [0, 0, 0]) == 0
+    reg = pen.NonNegativity()
+    assert dec._check_inner_convergence(A, A, cmf, [reg], [A.copy()], 0, 1e-3)
+    assert not dec._check_inner_convergence(A, A + 1, cmf, [reg], [A.copy()], 0, 1e-3)
+    assert not dec._check_inner_convergence(A, A, cmf, [reg], [A + 1.0], 0, 1e-3)
+    assert not dec._check_inner_convergence(A, A, cmf, [reg], [A.copy()], 0, None)
+    assert dec._check_inner_convergence(B, [b.copy() for b in B], cmf, [], [], 1, 1e-3)
