@@ -23,7 +23,7 @@ from abc import ABC, abstractmethod
 import numpy as np
 
 from . import _engine
-from ._utils import check_random_state, get_svd, is_tensor, is_torch, shape, torch
+from ._utils import check_random_state, get_svd, is_tensor, is_torch, shape, to_numpy, torch
 
 
 # ---- small backend helpers (NumPy arrays or torch tensors) --------------------------------------------------
@@ -444,6 +444,14 @@ class UnitSimplex(HardConstraintMixin, MatrixPenalty):
 
     The reference finds the Lagrange multiplier mu of sum(max(y - mu, 0)) = 1 per column by bisection; the sorted
     cumulative-sum formula used here is the exact root of the same equation and runs on the device for torch tensors."""
+
+    def _compute_lagrange_multiplier(self, factor_matrix_column):
+        """Multiplier mu of the constraint sum(max(y - mu, 0)) = 1 for one column (penalties.py:942-966), closed form"""
+        y = to_numpy(factor_matrix_column).astype(float).ravel()
+        u = -np.sort(-y)
+        css = np.cumsum(u) - 1.0
+        k = np.nonzero(u - css / np.arange(1, len(y) + 1) > 0)[0][-1]
+        return float(css[k] / (k + 1.0))
 
     def factor_matrix_update(self, factor_matrix, feasibility_penalty, aux):
         y = factor_matrix
