@@ -1281,7 +1281,7 @@ static int launch_C_fused_t(mcl_context *c) {
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));               \
         hipLaunchKernelGGL((k_C_finish_fused<NBR, NREG, VEC_>), dim3(1), dim3(64 * n_waves), sm, c->stream, c->GR,    \
                            (int)c->K, c->r, (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[2],     \
-                           c->rhoC, c->LinvC, c->C, rs, c->opt.inner_n_iter_max, c->CtC, c->Cfrag, KC, c->NB,         \
+                           c->rhoC, c->LinvC, c->C, rs, c->opt.inner_n_iter_max, c->CtC, c->Cfrag, mcl_cfrag_chunks(c), c->NB,         \
                            c->diagC_tile, rpw);                                                                       \
     } while (0)
     if (vec) MCL_CF(true);

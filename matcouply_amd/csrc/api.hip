@@ -59,7 +59,7 @@ int64_t plan(mcl_context *c, char *base) {
         c->Mpart = b.take<float>((int64_t)c->bsegs.n_tiles * mcl_sweep_KS(c) * 256 * 16 * c->NB);
         c->part_btb = b.take<float>((int64_t)c->bsegs.n_tiles * r * r);
         c->GRpart = b.take<float>((int64_t)c->bsegs.n_tiles * (mcl_sweep_KS(c) * 256 * 16 * c->NB + 256 * c->NB * c->NB));
-        c->CfragS = (K % 256 == 0) ? nullptr : b.take<float>((int64_t)mcl_sweep_KS(c) * 256 * 16 * c->NB);
+        c->CfragS = nullptr;  // aliases Cfrag (below)
         c->sweep_cycles = b.take<long long>((int64_t)2048 * 6);
     } else {
         c->bsegs = TileMap{};
@@ -68,8 +68,10 @@ int64_t plan(mcl_context *c, char *base) {
     c->ext_A = b.take<int>(2);
     c->ext_C = b.take<int>(2);
     c->XC = b.take<float>(N * r);
-    c->Cfrag = b.take<float>((int64_t)xc_chunks(c) * 4 * c->NB * 256);
-    if (c->sweep_planned && K % 256 == 0) c->CfragS = c->Cfrag;  // same chunk count: one image serves both
+    // ONE fragment image of C serves the X C kernels (first xc_chunks chunks) and the sweep (4 KS chunks): the chunk
+    // index is the slowest one, so the shorter view is a prefix of the longer; every builder fills mcl_cfrag_chunks().
+    c->Cfrag = b.take<float>((int64_t)mcl_cfrag_chunks(c) * 4 * c->NB * 256);
+    if (c->sweep_planned) c->CfragS = c->Cfrag;
     c->CtC = b.take<float>(r * r);
     c->rhoB = b.take<float>(I);
     c->LinvB = b.take<float>(I * r * r);

@@ -733,7 +733,7 @@ int mcl_launch_reduce_partials(mcl_context *c) {
 static inline int xc_KC(const mcl_context *c) { return mcl_xc_chunks(c, nullptr); }
 
 int mcl_launch_build_cfrag(mcl_context *c) {
-    const int KC = xc_KC(c);
+    const int KC = mcl_cfrag_chunks(c);  // the image is shared with the sweep
     const long total = (long)KC * 4 * c->NB * 256;
     hipLaunchKernelGGL(k_build_cfrag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->C, (int)c->K,
                        c->r, KC, c->NB, c->Cfrag);

@@ -203,6 +203,11 @@ int mcl_contract_n_partials(const mcl_context *c);
 
 // ---- launchers implemented in sweep.hip --------------------------------------------------------------
 int mcl_sweep_KS(const mcl_context *c);          // 256-column super-chunks per tile row
+// chunks (64 columns each) of the shared fragment image of C: enough for the X C kernels and, when planned, the sweep
+static inline int mcl_cfrag_chunks(const mcl_context *c) {
+    const int xc = mcl_xc_chunks(c, nullptr);
+    return c->sweep_planned ? std::max(xc, 4 * mcl_sweep_KS(c)) : xc;
+}
 int mcl_launch_build_cfrag_sweep(mcl_context *c);
 bool mcl_sweep_shape_ok(const mcl_context *c);   // shape has a k_sweep instantiation (decides the workspace plan)
 bool mcl_sweep_eligible(const mcl_context *c);   // ... and the current penalties / options / pointers allow it
