@@ -115,8 +115,10 @@ int64_t plan(mcl_context *c, char *base) {
         c->pf2_acc = b.take<double>(I * (r * r + 1));
         c->pf2_red = b.take<float>(r * r + 1);
         c->pf2_status = b.take<int>(I);
+        c->pf2_xmin = b.take<float>(I);  // zeroed with the workspace: "no estimate yet"
     } else {
         c->pf2_status = nullptr;
+        c->pf2_xmin = nullptr;
         c->pf2_S = nullptr, c->pf2_T = nullptr, c->pf2_acc = nullptr, c->pf2_red = nullptr;
     }
     return (b.off + 255) & ~int64_t(255);

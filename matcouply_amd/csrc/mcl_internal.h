@@ -120,6 +120,7 @@ struct mcl_context {
     double *pf2_S = nullptr;    // [I, r, r]  Y_i^T Y_i (fp64)
     float *pf2_T = nullptr;     // [I, r, r]  P_i = Y_i T_i
     double *pf2_acc = nullptr;  // [I, r*r + 1] per-slab rho_i P_i^T Y_i | rho_i
+    float *pf2_xmin = nullptr;  // [I] 1 / ||(G_i / tr)^-1/2||_F of the last Newton-Schulz run: starting estimate of the next
     int *pf2_status = nullptr;  // [I] 0: Newton-Schulz converged, 1: redo with the Jacobi kernel
     float *pf2_red = nullptr;   // [r*r + 1]  sum over this context's slabs (all-reduced by a multi-GPU host)
     std::vector<int> h_row_ptr32, h_ext;
