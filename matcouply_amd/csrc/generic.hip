@@ -1556,10 +1556,23 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
                                                        int *__restrict__ status, TileStats ts, RegSet regs,
                                                        float *__restrict__ xmin_est, int scaled) {
     __shared__ double Ssm[TILES ? 256 * NB * NB : 1];
+    __shared__ float Dsm[256 * NB * NB];
     const int slab = blockIdx.x, lane = threadIdx.x;
     const int q = lane >> 4, c16 = lane & 15;
     const int n2 = r * r;
     const double *Ss = S + (long)slab * n2;
+    // everything this wave needs besides the statistics is requested up front, so its latency overlaps the tile loop:
+    // the slab's extent and weight, and Delta (staged in LDS; every product below reads it from there)
+    const int slab_rows = ext[slab + 1] - ext[slab];
+    const double rh = (double)rho[slab];
+    {
+        float dv[4 * NB * NB];
+#pragma unroll
+        for (int m = 0; m < 4 * NB * NB; ++m) dv[m] = Delta[min(lane + 64 * m, n2 - 1)];
+#pragma unroll
+        for (int m = 0; m < 4 * NB * NB; ++m)
+            if (lane + 64 * m < n2) Dsm[lane + 64 * m] = dv[m];
+    }
     if (TILES) {
         const int t0 = ts.slab_tile_ptr[slab], t1 = ts.slab_tile_ptr[slab + 1];
         const long WW = (long)ts.W * ts.W;
@@ -1603,18 +1616,25 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
             if (regs.kind[k] != MCL_PEN_L2BALL) continue;
             for (int col = lane; col < r; col += 64) {
                 double sq = 0.0;
-                for (int t = t0; t < t1; ++t) sq += ts.stat_colsq[((long)t * MCL_MAX_REGS + k) * r + col];
+                for (int tb = t0; tb < t1; tb += 8) {  // ascending order as in k_stats_reduce, 8 loads in flight
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = ts.stat_colsq[((long)min(tb + u, t1 - 1) * MCL_MAX_REGS + k) * r + col];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (tb + u < t1) sq += v[u];
+                }
                 ts.colsq[((long)k * ts.n_slabs + slab) * r + col] = sq;
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     auto Sat = [&](int i, int j) -> double {
         if (TILES) return (i < r && j < r) ? Ssm[i * r + j] : 0.0;
         return (i < r && j < r) ? Ss[i * r + j] : 0.0;
     };
-    auto Dat = [&](int i, int j) -> double { return (i < r && j < r) ? (double)Delta[i * r + j] : 0.0; };
-    if (ext[slab + 1] - ext[slab] < r) {  // fewer rows than columns: rank-deficient by construction
+    auto Dat = [&](int i, int j) -> double { return (i < r && j < r) ? (double)Dsm[i * r + j] : 0.0; };
+    if (slab_rows < r) {  // fewer rows than columns: rank-deficient by construction
         if (lane == 0) status[slab] = 1;
         return;
     }
@@ -1792,7 +1812,6 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
                 if (row < r && col < r) T[(long)slab * n2 + row * r + col] = (float)acc[v];
             }
         }
-    const double rh = (double)rho[slab];
 #pragma unroll
     for (int a = 0; a < NB; ++a)
 #pragma unroll
