@@ -1397,17 +1397,14 @@ __global__ __launch_bounds__(256) void k_pf2_gram(const int *__restrict__ ext, c
     }
 }
 
-__global__ __launch_bounds__(64) void k_pf2_algebra(const double *__restrict__ S, const float *__restrict__ Delta,
-                                                    const float *__restrict__ rho, int r, float *__restrict__ T,
-                                                    double *__restrict__ acc_out, const int *__restrict__ status) {
-    extern __shared__ double smd[];
-    if (status != nullptr && status[blockIdx.x] <= 0) return;  // already done by the Newton-Schulz kernel (-iterations)
-    if (status != nullptr && status[blockIdx.x] == 77) return;  // debugging hook
+// One slab through the Jacobi route (one wave; `smd` = 4 r^2 + r doubles of LDS, `Ssrc` = the slab's S in any address
+// space).  Called by the stand-alone kernel below and by k_pf2_algebra_ns for the slabs it cannot handle.
+static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const float *__restrict__ Delta, double rh, int r,
+                                       int slab, int lane, float *__restrict__ T, double *__restrict__ acc_out) {
     double *Sm = smd, *G = smd + r * r, *V = G + r * r, *lam = V + r * r, *D = lam + r;  // D: Delta in fp64 [r*r]
-    const int slab = blockIdx.x, lane = threadIdx.x;
     const int n2 = r * r;
     for (int e = lane; e < n2; e += 64) {
-        Sm[e] = S[(long)slab * n2 + e];
+        Sm[e] = Ssrc[e];
         D[e] = (double)Delta[e];
         V[e] = ((e / r) == (e % r)) ? 1.0 : 0.0;
     }
@@ -1494,7 +1491,6 @@ __global__ __launch_bounds__(64) void k_pf2_algebra(const double *__restrict__ S
         V[e] = sum;
     }
     __syncthreads();
-    const double rh = (double)rho[slab];
     for (int e = lane; e < n2; e += 64) {
         const int a = e / r, b = e - a * r;
         double sum = 0.0;
@@ -1503,6 +1499,16 @@ __global__ __launch_bounds__(64) void k_pf2_algebra(const double *__restrict__ S
         T[(long)slab * n2 + e] = (float)V[e];
     }
     if (lane == 0) acc_out[(long)slab * (n2 + 1) + n2] = rh;
+}
+
+__global__ __launch_bounds__(64) void k_pf2_algebra(const double *__restrict__ S, const float *__restrict__ Delta,
+                                                    const float *__restrict__ rho, int r, float *__restrict__ T,
+                                                    double *__restrict__ acc_out, const int *__restrict__ status) {
+    extern __shared__ double smd[];
+    if (status != nullptr && status[blockIdx.x] <= 0) return;  // already done by the Newton-Schulz kernel (-iterations)
+    if (status != nullptr && status[blockIdx.x] == 77) return;  // debugging hook
+    const int slab = blockIdx.x;
+    pf2_jacobi_slab(smd, S + (long)slab * r * r, Delta, (double)rho[slab], r, slab, threadIdx.x, T, acc_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1557,6 +1563,11 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
                                                        float *__restrict__ xmin_est, int scaled) {
     __shared__ double Ssm[TILES ? 256 * NB * NB : 1];
     __shared__ float Dsm[256 * NB * NB];
+    // rank <= 16: the Jacobi route of a slab this iteration cannot handle runs right here (8 KB of LDS; saves the launch of
+    // the stand-alone kernel in every inner iteration); rank 32 would need 33 KB and lose a wave per CU, so those slabs are
+    // left to k_pf2_algebra (status = 1)
+    constexpr bool INK = NB == 1;
+    __shared__ double Jsm[INK ? 4 * 256 + 16 : 1];
     const int slab = blockIdx.x, lane = threadIdx.x;
     const int q = lane >> 4, c16 = lane & 15;
     const int n2 = r * r;
@@ -1634,8 +1645,10 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
         return (i < r && j < r) ? Ss[i * r + j] : 0.0;
     };
     auto Dat = [&](int i, int j) -> double { return (i < r && j < r) ? (double)Dsm[i * r + j] : 0.0; };
+    const double *Sany = TILES ? static_cast<const double *>(Ssm) : Ss;
     if (slab_rows < r) {  // fewer rows than columns: rank-deficient by construction
         if (lane == 0) status[slab] = 1;
+        if (INK) pf2_jacobi_slab(Jsm, Sany, Delta, rh, r, slab, lane, T, acc_out);
         return;
     }
     // U1 = S Delta^T   (A = S, symmetric: A[i][k] = S[k][i];  B[k][n] = Delta[n][k])
@@ -1682,6 +1695,7 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
     tr = wave_sum_d(tr);
     if (!(tr > 0.0)) {
         if (lane == 0) status[slab] = 1;
+        if (INK) pf2_jacobi_slab(Jsm, Sany, Delta, rh, r, slab, lane, T, acc_out);
         return;
     }
     // Newton-Schulz for the inverse square root of G / tr (padding rows/cols >= r carry the identity)
@@ -1773,11 +1787,8 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
         Zt = N4;
     }
     if (!converged) {
-        if (lane == 0) {
-            status[slab] = 1;
-            acc_out[(long)slab * (n2 + 1)] = prev;      // diagnostics only: the Jacobi kernel overwrites these
-            acc_out[(long)slab * (n2 + 1) + 1] = tr;
-        }
+        if (lane == 0) status[slab] = 1;
+        if (INK) pf2_jacobi_slab(Jsm, Sany, Delta, rh, r, slab, lane, T, acc_out);
         return;
     }
     if (lane == 0) status[slab] = -it_used;  // <= 0: converged (number of Newton-Schulz iterations, for diagnostics)
@@ -2417,8 +2428,9 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                 }
 #undef MCL_NS
             }
-            hipLaunchKernelGGL(k_pf2_algebra, dim3((unsigned)c->I), dim3(64), sm, c->stream, c->pf2_S, rs.aux2[k],
-                               c->rhoB, r, c->pf2_T, c->pf2_acc, status);
+            if (status == nullptr || c->NB != 1)  // rank <= 16: the Newton-Schulz kernel runs the Jacobi route itself
+                hipLaunchKernelGGL(k_pf2_algebra, dim3((unsigned)c->I), dim3(64), sm, c->stream, c->pf2_S, rs.aux2[k],
+                                   c->rhoB, r, c->pf2_T, c->pf2_acc, status);
             if (!c->stack_fused)  // the fused finish pass applies T_i itself
                 DISPATCH_ROWS(c, vec, k_pf2_apply, grid, block, mv, (const float *)rs.dual[k], (const float *)c->pf2_T, rs.aux[k], r);
             if (c->pf2_delta_fused)  // single-process inner loop: Delta follows at once, no all-reduce in between

@@ -142,3 +142,41 @@ def test_two_ranks_sharing_the_gpu_equal_single_process(tmp_path, stack):
 
     err = json.loads(line[0].split(" ", 1)[1])
     assert max(err.values()) < 2e-5, err
+
+
+@pytest.mark.parametrize("stack", ["pf2", "pf2_ball"])
+def test_parafac2_polar_factor_routes_agree(stack):
+    """PARAFAC2's polar factors (penalties.py:1224-1250) through both native routes - Newton-Schulz on the fp64 MFMA and the
+    Jacobi eigen-solver that takes over for slabs it cannot handle - against the oracle: a slab with fewer rows than the
+    rank is rank-deficient by construction (pseudo-inverse square root), and MCL_PF2_JACOBI=1 forces the solver everywhere."""
+    import torch
+
+    from oracle import aoadmm_oracle as orc
+    from tests.helpers import engine_from_oracle_state, rel_err, to_np
+
+    r, K = 6, 20
+    J = np.array([3, 40, 17, 6, 64, 5, 130])  # slabs 0 and 5 have fewer rows than the rank
+    X, row_ptr = orc.synthetic_problem(len(J), J, K, r, seed=4, dtype=np.float64)
+    X = X.astype(np.float32).astype(np.float64)
+    regs = [[{"kind": "nn"}], [{"kind": "parafac2"}] + ([{"kind": "l2ball", "norm_bound": 1.5}] if stack == "pf2_ball" else []),
+            [{"kind": "nn"}]]
+    want = orc.random_state_for(X, row_ptr, r, regs, seed=5)
+    want.update_B()
+    saved = os.environ.pop("MCL_PF2_JACOBI", None)
+    try:
+        for forced in (False, True):
+            if forced:
+                os.environ["MCL_PF2_JACOBI"] = "1"
+            st = orc.random_state_for(X, row_ptr, r, regs, seed=5)
+            eng = engine_from_oracle_state(st)
+            eng.update_B()
+            torch.cuda.synchronize()
+            errs = dict(B=rel_err(to_np(eng.B), want.B), P=rel_err(to_np(eng.regs[1][0].aux), want.aux[1][0][0]),
+                        Delta=rel_err(to_np(eng.regs[1][0].aux2), want.aux[1][0][1]),
+                        dual=rel_err(to_np(eng.regs[1][0].dual), want.dual[1][0]))
+            assert max(errs.values()) < 1e-5, (forced, errs)
+            eng.close()
+    finally:
+        os.environ.pop("MCL_PF2_JACOBI", None)
+        if saved is not None:
+            os.environ["MCL_PF2_JACOBI"] = saved
