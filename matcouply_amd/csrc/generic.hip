@@ -1094,13 +1094,13 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
     st.sy = ring_d[0], st.q = ring_d[1], st.cw = ring_i;
     double csy, ccw, curQ, cum2;  // block being built (count kept as a double), Q including it, sum of y^2
     double tsy, tcw, tQ;          // cached top of the stack below it
-    bool has_top, neg;
+    bool has_top;
     float levf;
     auto reset = [&]() {
         st.h = 0, st.cnt = 0, st.mem_n = 0;
         cum2 = 0.0, csy = 0.0, ccw = 1.0, curQ = 0.0;
         tsy = 0.0, tcw = 1.0, tQ = 0.0;
-        has_top = false, neg = false, levf = 0.f;
+        has_top = false, levf = 0.f;
     };
     // one element: returns the prefix error; leaves (levf, ccw) = record of the block ending at this element
     auto step = [&](double v, bool first) -> double {
@@ -1119,11 +1119,13 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
             has_top = ur4_pop(st, lane, tsy, icw, tQ, gsy, gq, gcw, s, rs, col);
             tcw = (double)icw;
         }
+        // a block with a negative mean is clamped to level 0 and contributes q = 0; every block below it has a smaller
+        // mean, so their Q is exactly 0 too and the prefix error comes out as cum2 without a special case
         const double lev = csy * rcp_count(ccw);
-        neg = nonneg && csy < 0.0;
-        curQ = (has_top ? tQ : 0.0) + (neg ? 0.0 : csy * lev);
-        levf = neg ? 0.f : (float)lev;
-        return neg ? cum2 : cum2 - curQ;
+        const double levc = nonneg ? fmax(lev, 0.0) : lev;
+        curQ = (has_top ? tQ : 0.0) + csy * levc;
+        levf = (float)levc;
+        return cum2 - curQ;
     };
 
     constexpr int UB = 8;  // elements per load batch; the NEXT batch is in flight while the current one is pooled
