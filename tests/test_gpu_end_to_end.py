@@ -282,3 +282,68 @@ def test_full_size_config3_properties():
     np.testing.assert_allclose(diag3.rec_errors, diag1.rec_errors, rtol=1e-5)
     assert rel_err(cmf3[1][2].cpu().numpy(), cmf1[1][2].cpu().numpy()) < 1e-5
     assert rel_err(cmf3[1][0].cpu().numpy(), cmf1[1][0].cpu().numpy()[perm]) < 1e-5
+
+
+def test_full_size_config4_properties():
+    """BASELINE config 4 at FULL size (I=1024 ragged J_i in [128, 1024], K=256, r=16, parafac2 + L2 ball on the B_i):
+    size-independent properties - determinism, the constraints on the auxiliary variables, the PARAFAC2 structure, the fast
+    error formula, and equality of the chained row passes with the two-pass-per-inner-iteration form of the same loop."""
+    import torch
+    import bench
+    from matcouply_amd import decomposition as dec
+
+    cfg = bench.CONFIGS["c4"]
+    dev = torch.device("cuda", 0)
+    X, row_ptr, I = bench.make_shard(cfg, 0, 1, dev)
+    r = cfg["r"]
+
+    def run():
+        return dec.cmf_aoadmm(dec.PackedMatrices(X, row_ptr), r, parafac2=True, l2_norm_bound={1: 1.0}, n_iter_max=4,
+                              tol=None, absolute_tol=None, return_errors=True, return_admm_vars=True, random_state=0)
+
+    cmf1, admm1, diag1 = run()
+    cmf2, admm2, diag2 = run()
+    # 1. bitwise determinism
+    assert torch.equal(cmf1[1][0], cmf2[1][0]) and torch.equal(cmf1[1][2], cmf2[1][2]) and diag1.rec_errors == diag2.rec_errors
+    assert all(torch.equal(a, b) for a, b in zip(cmf1[1][1], cmf2[1][1]))
+    # 2. constraints hold on the auxiliary variables: P_i^T P_i = I, shared cross product, column norms <= 1
+    P_is, Delta = admm1.auxes[1][0]
+    worst = max(float((P.double().T @ P.double() - torch.eye(r, device=dev, dtype=torch.float64)).abs().max()) for P in P_is[:64])
+    assert worst < 1e-5, worst
+    ball = admm1.auxes[1][1]
+    assert max(float(torch.linalg.norm(z.double(), dim=0).max()) for z in ball) <= 1 + 1e-5
+    assert all(bool(torch.isfinite(f).all()) for f in (cmf1[1][0], cmf1[1][2], Delta))
+    # 3. fast error formula == explicit fp64 residual
+    A, C = cmf1[1][0].double(), cmf1[1][2].double()
+    num = sum(float(torch.linalg.norm(X[row_ptr[i]:row_ptr[i + 1]].double() - (cmf1[1][1][i].double() * A[i]) @ C.T) ** 2)
+              for i in range(I))
+    explicit = np.sqrt(num) / float(torch.linalg.norm(X.double()))
+    np.testing.assert_allclose(diag1.rec_errors[-1], explicit, rtol=1e-4)
+    # 4. the chained row passes (finish of inner iteration t + solve of t + 1 in one kernel), the statistics sums inside the
+    #    Newton-Schulz kernel and the merged sum + Delta kernel are re-organisations with the same arithmetic in the same
+    #    order: the un-chained form must give the same iterates
+    def run_with(env_keys):
+        saved = {k: os.environ.get(k) for k in env_keys}
+        try:
+            for k in env_keys:
+                os.environ[k] = "1"
+            return run()
+        finally:
+            for k, v in saved.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+
+    cmf3, admm3, diag3 = run_with(("MCL_NO_PASS_CHAIN", "MCL_STATS_REDUCE", "MCL_NO_PF2_DELTA_FUSION"))
+    # (the penalty-free A and C of this configuration amplify last-bit differences - the two forms contract their
+    # multiply-adds differently - by the condition number of their normal equations: 5e-6 on the error after 4 iterations)
+    np.testing.assert_allclose(diag3.rec_errors, diag1.rec_errors, rtol=2e-5)
+    assert rel_err(cmf3[1][2].cpu().numpy(), cmf1[1][2].cpu().numpy()) < 2e-4
+    assert rel_err(cmf3[1][0].cpu().numpy(), cmf1[1][0].cpu().numpy()) < 2e-4
+    # 5. plain instead of minimax-scaled Newton-Schulz steps: another route to the same polar factors (1e-8 apart); A and C
+    #    carry no penalty in this configuration, so their un-shifted normal equations amplify that difference
+    cmf4, admm4, diag4 = run_with(("MCL_NS_PLAIN",))
+    np.testing.assert_allclose(diag4.rec_errors, diag1.rec_errors, rtol=5e-5)
+    assert rel_err(cmf4[1][2].cpu().numpy(), cmf1[1][2].cpu().numpy()) < 5e-4
+    P4 = admm4.auxes[1][0][0]
+    assert max(rel_err(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(P4[:32], P_is[:32])) < 5e-4
