@@ -347,3 +347,52 @@ def test_full_size_config4_properties():
     assert rel_err(cmf4[1][2].cpu().numpy(), cmf1[1][2].cpu().numpy()) < 5e-4
     P4 = admm4.auxes[1][0][0]
     assert max(rel_err(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(P4[:32], P_is[:32])) < 5e-4
+
+
+def test_config5_stack_properties_at_scale():
+    """The full penalty stack of BASELINE config 5 (NN on A; PARAFAC2 + unimodality + L2 ball on the B_i; L1 on C) at
+    I=1024, J=512, K=256, r=32 (config 5 itself needs 128 GB: tools/run_c5_full.py / bench.py --config c5): the constraints
+    hold exactly on the auxiliary variables, runs are deterministic, and the two organisations of the unimodal kernel
+    (one lane per column / sweeps split over waves) produce the same iterates."""
+    import torch
+    import bench
+    from matcouply_amd import decomposition as dec
+
+    cfg = bench.CONFIGS["c5s"]
+    dev = torch.device("cuda", 0)
+    X, row_ptr, I = bench.make_shard(cfg, 0, 1, dev)
+    r = cfg["r"]
+
+    def run(split=None):
+        saved = os.environ.get("MCL_UNI_SPLIT")
+        try:
+            if split is not None:
+                os.environ["MCL_UNI_SPLIT"] = split
+            return dec.cmf_aoadmm(dec.PackedMatrices(X, row_ptr), r, non_negative=True, l1_penalty={2: 0.1},
+                                  l2_norm_bound={1: 1.0}, unimodal={1: True}, parafac2=True, n_iter_max=3, tol=None,
+                                  absolute_tol=None, return_errors=True, return_admm_vars=True, random_state=0)
+        finally:
+            os.environ.pop("MCL_UNI_SPLIT", None)
+            if saved is not None:
+                os.environ["MCL_UNI_SPLIT"] = saved
+
+    cmf1, admm1, diag1 = run()
+    cmf2, admm2, diag2 = run()
+    assert torch.equal(cmf1[1][0], cmf2[1][0]) and torch.equal(cmf1[1][2], cmf2[1][2]) and diag1.rec_errors == diag2.rec_errors
+    (P_is, Delta), uni, ball = admm1.auxes[1]
+    eye = torch.eye(r, device=dev, dtype=torch.float64)
+    assert max(float((P.double().T @ P.double() - eye).abs().max()) for P in P_is[:64]) < 1e-5
+    assert max(float(torch.linalg.norm(z.double(), dim=0).max()) for z in ball) <= 1 + 1e-5
+    assert min(float(z.min()) for z in ball) >= 0 and min(float(z.min()) for z in uni) >= 0
+    assert float(admm1.auxes[0][0].min()) >= 0 and float(admm1.auxes[2][0].min()) >= 0
+    # unimodal: once a column starts to decrease it never increases again
+    U = torch.stack(uni[:128])
+    dif = torch.sign(U[:, 1:] - U[:, :-1])
+    dec_seen = torch.cummax((dif < 0).int(), dim=1).values
+    assert int(((dif > 0) & (dec_seen == 1)).sum()) == 0
+    assert all(np.isfinite(diag1.rec_errors))
+    # both forms of the unimodal kernel (MCL_UNI_SPLIT=0: one lane per column; =1: sweeps split over waves)
+    cmf_a, admm_a, diag_a = run("0")
+    cmf_b, admm_b, diag_b = run("1")
+    assert all(torch.equal(a, b) for a, b in zip(admm_a.auxes[1][1], admm_b.auxes[1][1]))
+    assert diag_a.rec_errors == diag_b.rec_errors and torch.equal(cmf_a[1][2], cmf_b[1][2])
