@@ -256,8 +256,12 @@ def main():
 
     pf2 = [k for k, d in enumerate(cfg["regs"][1]) if d["kind"] == "parafac2"]
 
+    # MCL_BENCH_FORCE_STEPS=1: drive the B-phase through the step calls on ONE rank too (the path a multi-GPU run takes
+    # when PARAFAC2 needs its per-inner-iteration all-reduce) - for measuring a rank's work on a single-GPU box
+    force_steps = os.environ.get("MCL_BENCH_FORCE_STEPS") == "1"
+
     def update_B():
-        if world == 1 or not pf2:
+        if (world == 1 and not force_steps) or not pf2:
             eng.update_B()
             return
         eng.B_begin()
@@ -266,9 +270,10 @@ def main():
             eng.B_solve()
             for k in range(len(cfg["regs"][1])):
                 eng.B_prox_local(k)
-                if k in pf2:
+                if k in pf2 and world > 1:
                     dist.all_reduce(eng.B_prox_reduce_buffer(k))
                 eng.B_prox_finish(k)
+        eng.B_end()
 
     def step(it):
         update_B()

@@ -121,6 +121,10 @@ int mcl_B_prox_finish(mcl_context *ctx, int32_t k); /* PARAFAC2: Delta; all: dua
  * mcl_B_prox_reduce_buffer(k) for PARAFAC2] mcl_B_prox_finish(k).  For stacks of row-separable kinds, L2 balls and
  * PARAFAC2 the library defers the aux / dual row updates of all penalties to ONE pass issued by the last
  * mcl_B_prox_finish of the round, so the rows are only final once the whole stack has been stepped. */
+/* That pass is issued by the NEXT entry point: merged with the solve when it is mcl_B_solve (one row pass per inner
+ * iteration), on its own otherwise.  mcl_B_end issues it explicitly - call it before reading B / aux / dual buffers
+ * directly (not through the library) after the last inner iteration. */
+int mcl_B_end(mcl_context *ctx);
 int mcl_A_begin(mcl_context *ctx);           /* X C, rhs_i, Q_i, rho_i (decomposition.py:136-162) */
 float *mcl_A_rho_max(mcl_context *ctx);
 int mcl_A_finish(mcl_context *ctx);          /* systems, inner ADMM loop, by-products (decomposition.py:163-219) */

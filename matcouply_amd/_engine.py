@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "mcl_set_factors", "mcl_set_penalties", "mcl_workspace_bytes", "mcl_set_workspace", "mcl_update_B",
     "mcl_update_C_local", "mcl_c_normal_equations", "mcl_update_C_finish", "mcl_update_A", "mcl_diagnostics",
     "mcl_iterate", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
-    "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
+    "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_B_end", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
     "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
     "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_set_stride", "mcl_profile_read",
 ]
@@ -82,6 +82,7 @@ def load_library():
         "mcl_B_prox_local": (ctypes.c_int, [P, I32]),
         "mcl_B_prox_reduce_buffer": (P, [P, I32, ctypes.POINTER(I64)]),
         "mcl_B_prox_finish": (ctypes.c_int, [P, I32]),
+        "mcl_B_end": (ctypes.c_int, [P]),
         "mcl_A_begin": (ctypes.c_int, [P]),
         "mcl_A_rho_max": (P, [P]),
         "mcl_A_finish": (ctypes.c_int, [P]),
@@ -255,6 +256,10 @@ class HipEngine:
 
     def B_prox_finish(self, k):
         self._check(self.lib.mcl_B_prox_finish(self._h, k))
+
+    def B_end(self):
+        """issue the deferred prox + dual row pass of a fused stack (before reading B / aux / dual tensors directly)"""
+        self._check(self.lib.mcl_B_end(self._h))
 
     def A_begin(self):
         self._check(self.lib.mcl_A_begin(self._h))

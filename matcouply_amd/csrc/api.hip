@@ -129,11 +129,26 @@ int fail(mcl_context *c, const std::string &msg) {
     return 1;
 }
 
-int ready(mcl_context *c) {
+int ready_noflush(mcl_context *c) {
     if (!c->has_problem) return fail(c, "mcl_set_problem has not been called");
     if (!c->has_factors) return fail(c, "mcl_set_factors has not been called");
     if (!c->has_workspace) return fail(c, "mcl_set_workspace has not been called");
     return 0;
+}
+
+// The step API defers the prox + dual row pass of a fused stack (see mcl_B_prox_finish): every entry point but
+// mcl_B_solve - which merges it with its own pass - issues it first, so callers never observe the deferral.
+int flush_B_finish(mcl_context *c) {
+    if (!c->b_finish_pending) return 0;
+    c->b_finish_pending = false;
+    if (int rc = mcl_launch_rows_finish_fused(c, 1, true)) return rc;  // also leaves the mode's diagnostics table
+    c->diag_valid[1] = true;
+    return 0;
+}
+
+int ready(mcl_context *c) {
+    if (int rc = ready_noflush(c)) return rc;
+    return flush_B_finish(c);
 }
 
 int ensure_ctc(mcl_context *c) {
@@ -473,8 +488,16 @@ int mcl_B_factor(mcl_context *c) {
     return mcl_launch_B_systems(c);
 }
 
+// the finish pass of inner iteration t can be merged with the solve of t + 1 (k_rows_finish_solve_stats)
+static bool step_can_chain(const mcl_context *c) {
+    if (!c->step_fuse || !c->step_stats || getenv("MCL_NO_PASS_CHAIN")) return false;
+    int n_l2 = 0;
+    for (int k = 0; k < c->regs[1].n; ++k) n_l2 += c->regs[1].kind[k] == MCL_PEN_L2BALL;
+    return n_l2 <= 1;
+}
+
 int mcl_B_solve(mcl_context *c) {
-    if (int rc = ready(c)) return rc;
+    if (int rc = ready_noflush(c)) return rc;
     c->e1_valid = false;
     c->mseg_valid = c->grpart_valid = false;
     c->diag_valid[1] = false;
@@ -483,9 +506,16 @@ int mcl_B_solve(mcl_context *c) {
     c->step_fuse = mcl_stack_can_fuse(c, 1);
     c->step_stats = c->step_fuse && mcl_stats_can_ride_in_solve(c, 1);
     c->step_done_mask = 0;
+    if (c->b_finish_pending) {  // previous inner iteration's prox + dual pass and this solve in one kernel
+        c->b_finish_pending = false;
+        if (step_can_chain(c)) return mcl_launch_rows_finish_solve_stats(c);
+        if (int rc = mcl_launch_rows_finish_fused(c, 1, false)) return rc;
+    }
     if (c->step_stats) return mcl_launch_rows_solve_stats(c);
     return mcl_launch_rows_solve(c, 1);
 }
+
+int mcl_B_end(mcl_context *c) { return ready(c); }
 
 int mcl_B_prox_local(mcl_context *c, int32_t k) {
     if (int rc = ready(c)) return rc;
@@ -514,7 +544,8 @@ int mcl_B_prox_finish(mcl_context *c, int32_t k) {
     if (rc == 0 && c->step_fuse) {
         c->step_done_mask |= 1u << k;
         if (c->step_done_mask == (1u << c->regs[1].n) - 1u) {  // whole stack stepped: the fused row pass
-            rc = mcl_launch_rows_finish_fused(c, 1, false);
+            if (step_can_chain(c)) c->b_finish_pending = true;  // issued by the next entry point (merged into mcl_B_solve)
+            else rc = mcl_launch_rows_finish_fused(c, 1, false);
             c->step_fuse = c->step_stats = false;
         }
     }

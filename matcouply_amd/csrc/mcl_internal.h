@@ -141,6 +141,7 @@ struct mcl_context {
     bool stack_fused = false;  // generic inner loop: statistics kernels only, then one fused prox + dual row pass
     bool step_fuse = false, step_stats = false;  // the same two decisions for the current mcl_B_solve .. mcl_B_prox_* round
     unsigned step_done_mask = 0;                 // penalties finished in this round
+    bool b_finish_pending = false;  // step API: the fused prox + dual pass of the last inner iteration has not been issued yet
     bool pf2_delta_fused = false;  // single-process inner loop: k_pf2_sum_delta instead of k_pf2_sum / (all-reduce) / k_pf2_delta
     bool stats_in_solve = false;   // ... and the B-mode statistics (PARAFAC2 Gram, L2-ball column norms) already came out of
                                    // the solve pass (k_rows_solve_stats + k_stats_reduce)

@@ -628,8 +628,11 @@ def cmf_aoadmm(
                 if reg.kind == _engine.PEN_PARAFAC2:
                     all_reduce(eng.B_prox_reduce_buffer(k))
                 eng.B_prox_finish(k)
-            if inner_converged(eng.B, B_old, 1):
-                break
+            if check_inner:
+                eng.B_end()  # the convergence test reads B / aux on the host side
+                if inner_converged(eng.B, B_old, 1):
+                    break
+        eng.B_end()
 
     def do_update_C():
         gr = eng.update_C_local()

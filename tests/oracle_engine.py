@@ -122,6 +122,9 @@ class OracleEngine:
         B, U = self._n(self.B), self._n(reg.dual)
         U[...] = B - (self._aux_matrix(1, k) - U)
 
+    def B_end(self):
+        pass  # the checker engine defers nothing
+
     def update_B(self):
         self.B_begin()
         self.B_factor()
