@@ -527,11 +527,13 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
 // order (coalesced) and scatters its sum to the row-major [G | R] image.  Fixed summation order (16 interleaved groups
 // of partials, 4 chains each, then the groups in order): deterministic, identical on every rank for identical input.
 // ---------------------------------------------------------------------------------------------------------
+template <int EL>  // elements per block (64: 256-byte wave loads, PS / 64 blocks; 32: twice the blocks for small PS)
 __global__ __launch_bounds__(1024) void k_reduce_frag(const float *__restrict__ GRpart, int n_part, int K, int r, int NB,
                                                       int MS, float *__restrict__ GR) {
-    __shared__ float sm[16][64];
-    const int el = threadIdx.x & 63, pc = threadIdx.x >> 6;  // 64 elements x 16 interleaved groups of partials
-    const int e = blockIdx.x * 64 + el;
+    constexpr int NG = 1024 / EL;  // interleaved groups of partials
+    __shared__ float sm[NG][EL];
+    const int el = threadIdx.x % EL, pc = threadIdx.x / EL;
+    const int e = blockIdx.x * EL + el;
     const int W = 16 * NB, PS = MS + W * W;
     int out = -1;
     if (e < MS) {
@@ -550,13 +552,13 @@ __global__ __launch_bounds__(1024) void k_reduce_frag(const float *__restrict__ 
     if (out >= 0) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int p = pc;
-        for (; p + 48 < n_part; p += 64) {
+        for (; p + 3 * NG < n_part; p += 4 * NG) {
             s0 += GRpart[(long)p * PS + e];
-            s1 += GRpart[(long)(p + 16) * PS + e];
-            s2 += GRpart[(long)(p + 32) * PS + e];
-            s3 += GRpart[(long)(p + 48) * PS + e];
+            s1 += GRpart[(long)(p + NG) * PS + e];
+            s2 += GRpart[(long)(p + 2 * NG) * PS + e];
+            s3 += GRpart[(long)(p + 3 * NG) * PS + e];
         }
-        for (; p < n_part; p += 16) s0 += GRpart[(long)p * PS + e];
+        for (; p < n_part; p += NG) s0 += GRpart[(long)p * PS + e];
         s = (s0 + s1) + (s2 + s3);
     }
     sm[pc][el] = s;
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(1024) void k_reduce_frag(const float *__restrict__ 
     if (pc == 0 && out >= 0) {
         float t = 0.f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) t += sm[g][el];  // fixed order
+        for (int g = 0; g < NG; ++g) t += sm[g][el];  // fixed order
         GR[out] = t;
     }
 }
@@ -728,9 +730,19 @@ int mcl_launch_build_cfrag_sweep(mcl_context *c) {
 
 int mcl_launch_reduce_weighted(mcl_context *c) {
     const int MS = sweep_MS(c), W = 16 * c->NB;
-    const int blocks = (MS + W * W + 63) / 64;
-    hipLaunchKernelGGL(k_reduce_frag, dim3(blocks), dim3(1024), 0, c->stream, c->GRpart, c->n_grpart, (int)c->K, c->r,
-                       c->NB, MS, c->GR);
+    // 64 elements per block need PS / 64 blocks (68 at K = 256, rank 16: a quarter of the CUs); with 32 there are twice as many
+    int el = (MS + W * W) / 64 >= 192 ? 64 : 32;
+    if (const char *ev = getenv("MCL_REDUCE_EL")) el = atoi(ev) == 64 ? 64 : (atoi(ev) == 16 ? 16 : 32);
+    const int blocks = (MS + W * W + el - 1) / el;
+    if (el == 64)
+        hipLaunchKernelGGL(k_reduce_frag<64>, dim3(blocks), dim3(1024), 0, c->stream, c->GRpart, c->n_grpart, (int)c->K,
+                           c->r, c->NB, MS, c->GR);
+    else if (el == 32)
+        hipLaunchKernelGGL(k_reduce_frag<32>, dim3(blocks), dim3(1024), 0, c->stream, c->GRpart, c->n_grpart, (int)c->K,
+                           c->r, c->NB, MS, c->GR);
+    else
+        hipLaunchKernelGGL(k_reduce_frag<16>, dim3(blocks), dim3(1024), 0, c->stream, c->GRpart, c->n_grpart, (int)c->K,
+                           c->r, c->NB, MS, c->GR);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
