@@ -788,14 +788,23 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(const float *__restrict__
     }
     float a = A[(long)i * r + c];
     if (seg_btb != nullptr) {  // per-segment partial Grams / right-hand sides of this slab, fixed order
-        for (int sg = sg0; sg < sg1; ++sg) {
-            float v[RL];
+        constexpr int SGB = 4;  // segments fetched per batch: independent clamped loads, summed in segment order
+        for (int sb = sg0; sb < sg1; sb += SGB) {
+            float v[SGB][RL], rv[SGB];
 #pragma unroll
-            for (int j = 0; j < RL; ++j) v[j] = seg_btb[((long)sg * r + drow[j]) * r + c];
-            const float rv = seg_rhs[(long)sg * r + c];
+            for (int q = 0; q < SGB; ++q) {
+                const long sg = min(sb + q, sg1 - 1);
 #pragma unroll
-            for (int j = 0; j < RL; ++j) btbv[j] += v[j];
-            rhs_pre += rv;
+                for (int j = 0; j < RL; ++j) v[q][j] = seg_btb[(sg * r + drow[j]) * r + c];
+                rv[q] = seg_rhs[sg * r + c];
+            }
+#pragma unroll
+            for (int q = 0; q < SGB; ++q)
+                if (sb + q < sg1) {
+#pragma unroll
+                    for (int j = 0; j < RL; ++j) btbv[j] += v[q][j];
+                    rhs_pre += rv[q];
+                }
         }
     }
     float qf[RL];
