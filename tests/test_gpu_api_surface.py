@@ -180,3 +180,48 @@ def test_parafac2_polar_factor_routes_agree(stack):
         os.environ.pop("MCL_PF2_JACOBI", None)
         if saved is not None:
             os.environ["MCL_PF2_JACOBI"] = saved
+
+
+def test_step_api_defers_and_merges_the_finish_pass():
+    """The B-phase through the step calls (what a multi-GPU host drives) must leave exactly the state of the single-call
+    mcl_update_B: the library defers the fused prox + dual row pass of an inner iteration and merges it with the next
+    mcl_B_solve; mcl_B_end (or any other entry point) issues it when no solve follows."""
+    import torch
+
+    from oracle import aoadmm_oracle as orc
+    from tests.helpers import engine_from_oracle_state
+
+    r, K = 8, 40
+    J = np.array([70, 33, 129, 64, 18, 200])
+    X, row_ptr = orc.synthetic_problem(len(J), J, K, r, seed=3, dtype=np.float64)
+    X = X.astype(np.float32).astype(np.float64)
+    regs = [[{"kind": "nn"}], [{"kind": "parafac2"}, {"kind": "unimodal", "non_negativity": True},
+                               {"kind": "l2ball", "norm_bound": 1.2, "non_negativity": True}], [{"kind": "nn"}]]
+
+    def state():
+        return engine_from_oracle_state(orc.random_state_for(X, row_ptr, r, regs, seed=6))
+
+    ref = state()
+    ref.update_B()
+    torch.cuda.synchronize()
+    for explicit_end in (True, False):
+        eng = state()
+        eng.B_begin()
+        eng.B_factor()
+        for _ in range(5):
+            eng.B_solve()
+            for k in range(3):
+                eng.B_prox_local(k)
+                eng.B_prox_finish(k)
+        if explicit_end:
+            eng.B_end()
+        else:
+            eng.update_C_local()  # any other entry point issues the pending pass first
+        torch.cuda.synchronize()
+        assert torch.equal(eng.B, ref.B)
+        for k in range(3):
+            assert torch.equal(eng.regs[1][k].aux, ref.regs[1][k].aux), k
+            assert torch.equal(eng.regs[1][k].dual, ref.regs[1][k].dual), k
+        assert torch.equal(eng.regs[1][0].aux2, ref.regs[1][0].aux2)
+        eng.close()
+    ref.close()

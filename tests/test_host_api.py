@@ -388,3 +388,12 @@ def test_host_diagnostic_helpers_of_the_reference():
     assert not dec._check_inner_convergence(A, A, cmf, [reg], [A + 1.0], 0, 1e-3)
     assert not dec._check_inner_convergence(A, A, cmf, [reg], [A.copy()], 0, None)
     assert dec._check_inner_convergence(B, [b.copy() for b in B], cmf, [], [], 1, 1e-3)
+
+
+def test_bench_counts_the_cores_it_may_use():
+    """bench.py's cpu_baseline reports `cores` = the threads it actually uses: the affinity mask capped by the cgroup quota"""
+    import bench
+
+    n = bench.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    assert n <= len(os.sched_getaffinity(0))
