@@ -735,6 +735,26 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
 // Lane l = g * RP + c: column c, rows d = g * RL + j.  Per-column quantities (rhs, a, aux, dual) are replicated in
 // every group; group 0 stores them.  Same arithmetic as k_A_finish up to the association of the fp64 sums over d.
 // ---------------------------------------------------------------------------------------------------------
+// sum of a value that is non-zero only in lanes [0, RP), RP <= 32: butterfly inside the 16-lane DPP row (quad_perm xor 1,
+// xor 2, row_half_mirror, row_mirror), one cross-row step for RP = 32; every lane of the row(s) ends with the total
+template <int CTRL>
+static __device__ __forceinline__ double dpp_mov_d(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int RP>
+static __device__ __forceinline__ double lead_sum(double v) {
+    static_assert(RP <= 32, "lead lanes must fit two DPP rows");
+    v += dpp_mov_d<0xB1>(v);
+    v += dpp_mov_d<0x4E>(v);
+    v += dpp_mov_d<0x141>(v);
+    v += dpp_mov_d<0x140>(v);
+    if (RP > 16) v += __shfl_xor(v, 16);
+    return v;
+}
+
 template <int RP>
 __global__ __launch_bounds__(256) void k_A_finish_rows(const float *__restrict__ rhsA, float *__restrict__ BtB,
                                                        const float *__restrict__ CtC, int I, int r, float scale,
@@ -897,15 +917,16 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(const float *__restrict__
         if (g * RL + j < r) qa += (double)qf[j] * (double)ad[j];
     }
     qa = group_sum(qa);
-    const double inner_i = wave_sum(lead ? (double)rhs * (double)a : 0.0);
-    const double model_i = wave_sum(lead ? (double)a * qa : 0.0);
-    const double nf = wave_sum(lead ? (double)a * (double)a : 0.0);
-    const double na = wave_sum(lead ? fabs((double)a) : 0.0);
+    // the contributions live in the lead lanes [0, RP): DPP row reductions (no LDS round trips), result in lane 0
+    const double inner_i = lead_sum<RP>(lead ? (double)rhs * (double)a : 0.0);
+    const double model_i = lead_sum<RP>(lead ? (double)a * qa : 0.0);
+    const double nf = lead_sum<RP>(lead ? (double)a * (double)a : 0.0);
+    const double na = lead_sum<RP>(lead ? fabs((double)a) : 0.0);
     double gap[MCL_MAX_REGS];
 #pragma unroll
     for (int k = 0; k < MCL_MAX_REGS; ++k) {
         const double dlt = (lead && k < n) ? (double)z[k] - (double)a : 0.0;
-        gap[k] = wave_sum(dlt * dlt);
+        gap[k] = lead_sum<RP>(dlt * dlt);
     }
     if (lane == 0) {
         e1[2 * i] = inner_i;
