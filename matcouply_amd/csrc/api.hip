@@ -172,15 +172,10 @@ int ensure_xc(mcl_context *c) {
 }
 
 // fragment image of the current C for the sweep kernels
-int ensure_cfrag_sweep(mcl_context *c) {
-    if (c->CfragS == c->Cfrag) {
-        if (!c->cfrag_valid) {
-            if (int rc = mcl_launch_build_cfrag(c)) return rc;
-            c->cfrag_valid = true;
-        }
-    } else if (!c->cfrags_valid) {
-        if (int rc = mcl_launch_build_cfrag_sweep(c)) return rc;
-        c->cfrags_valid = true;
+int ensure_cfrag_sweep(mcl_context *c) {  // CfragS aliases Cfrag: one image serves the X C kernels and the sweep
+    if (!c->cfrag_valid) {
+        if (int rc = mcl_launch_build_cfrag(c)) return rc;
+        c->cfrag_valid = true;
     }
     return 0;
 }
@@ -372,7 +367,7 @@ int mcl_set_factors(mcl_context *c, float *A, float *B, float *C) {
     c->A = A, c->B = B, c->C = C;
     c->has_factors = true;
     c->b_systems_valid = false;
-    c->cfrag_valid = c->cfrags_valid = false;
+    c->cfrag_valid = false;
     c->xc_valid = c->ctc_valid = c->e1_valid = false;
     c->mseg_valid = c->grpart_valid = false;
     c->diag_valid[0] = c->diag_valid[1] = c->diag_valid[2] = false;
@@ -460,7 +455,7 @@ int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
     MCL_CHECK_HIP(c, hipMemcpyAsync(c->ext_C, c->h_ext.data() + 2, 2 * sizeof(int), hipMemcpyHostToDevice, s));
     // the host vectors must outlive the async copies: they are members of the context
     c->has_workspace = true;
-    c->cfrag_valid = c->cfrags_valid = false;
+    c->cfrag_valid = false;
     c->mseg_valid = c->grpart_valid = false;
     c->xc_valid = c->ctc_valid = c->e1_valid = c->xsq_valid = false;
     c->diag_valid[0] = c->diag_valid[1] = c->diag_valid[2] = false;
@@ -615,7 +610,6 @@ int mcl_update_C_finish(mcl_context *c) {
             c->b_systems_valid = false;
             c->ctc_valid = true;
             c->cfrag_valid = true;
-            c->cfrags_valid = false;
             c->diag_valid[2] = true;
             return 0;
         }
@@ -624,7 +618,7 @@ int mcl_update_C_finish(mcl_context *c) {
     if (int rc = mcl_launch_C_prepare(c)) return rc;
     if (c->opt.inner_n_iter_max <= 0) return 0;
     c->xc_valid = c->ctc_valid = c->e1_valid = false;
-    c->cfrag_valid = c->cfrags_valid = false;
+    c->cfrag_valid = false;
     c->b_systems_valid = false;
     if (mcl_mode_is_row_separable(c, 2)) {
         const int rc = mcl_launch_rows_fused(c, 2);
@@ -734,7 +728,7 @@ int mcl_C_begin(mcl_context *c) {
 int mcl_C_solve(mcl_context *c) {
     if (int rc = ready(c)) return rc;
     c->xc_valid = c->ctc_valid = c->e1_valid = false;
-    c->cfrag_valid = c->cfrags_valid = false;
+    c->cfrag_valid = false;
     c->b_systems_valid = false;
     c->diag_valid[2] = false;
     return mcl_launch_rows_solve(c, 2);
@@ -743,7 +737,7 @@ int mcl_C_solve(mcl_context *c) {
 int mcl_C_end(mcl_context *c) {
     if (int rc = ready(c)) return rc;
     c->xc_valid = c->ctc_valid = c->e1_valid = false;
-    c->cfrag_valid = c->cfrags_valid = false;
+    c->cfrag_valid = false;
     c->b_systems_valid = false;
     c->diag_valid[2] = false;
     return 0;

@@ -497,284 +497,9 @@ struct UniScratch {
     int *stL, *stR;
 };
 
-static __device__ void prefix_isotonic_dev(const float *__restrict__ F, const float *__restrict__ U, long base, long step,
-                                           int n, int r, int col, int nonneg, double *level, int *start, double *err,
-                                           double *sy, double *sy2, double *sw, double *cum2, long sbase, long ebase) {
-    // element idx of this pass lives at packed row (base + idx*step); scratch row sbase+idx; err row ebase+idx
-    err[ebase * r + col] = 0.0;
-    double run2 = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const long src = (base + (long)i * step) * r + col;
-        const double v = (double)(F[src] + U[src]);
-        run2 += v * v;
-        const long si = (sbase + i) * r + col;
-        cum2[si] = run2;
-        double csy = v, csy2 = v * v, csw = 1.0, lev = v;
-        int st = i;
-        while (st != 0 && lev <= level[(sbase + st - 1) * r + col]) {
-            const long p = (sbase + st - 1) * r + col;
-            csy += sy[p];
-            csy2 += sy2[p];
-            csw += sw[p];
-            lev = csy / csw;
-            st = start[p];
-        }
-        sy[si] = csy, sy2[si] = csy2, sw[si] = csw;
-        level[si] = lev;
-        start[si] = st;
-        if (nonneg && lev < 0.0)
-            err[(ebase + i + 1) * r + col] = run2;
-        else
-            err[(ebase + i + 1) * r + col] = (csy2 - csy * csy / csw) + err[(ebase + st) * r + col];
-    }
-}
-
-__global__ __launch_bounds__(64) void k_slab_unimodal(const int *__restrict__ ext, int n_slabs, float *__restrict__ F,
-                                                      RegSet regs, int k, int r, UniScratch sc) {
-    const long t = (long)blockIdx.x * 64 + threadIdx.x;
-    if (t >= (long)n_slabs * r) return;
-    const int slab = (int)(t / r), col = (int)(t - (long)slab * r);
-    const int s = ext[slab], e = ext[slab + 1], n = e - s;
-    if (n <= 0) return;
-    const int nonneg = regs.nonneg[k];
-    float *__restrict__ Z = regs.aux[k];
-    float *__restrict__ U = regs.dual[k];
-    const long eb = (long)s + slab;  // n+1 error entries per slab
-    // left pass: elements s .. e-1 ; right pass: elements e-1 .. s
-    prefix_isotonic_dev(F, U, s, 1, n, r, col, nonneg, sc.lvL, sc.stL, sc.eL, sc.sy, sc.sy2, sc.sw, sc.cum2, s, eb);
-    prefix_isotonic_dev(F, U, (long)e - 1, -1, n, r, col, nonneg, sc.lvR, sc.stR, sc.eR, sc.sy, sc.sy2, sc.sw, sc.cum2, s, eb);
-    double best = sc.eR[(eb + n) * r + col];
-    int split = 0;
-    for (int i = 0; i <= n; ++i) {
-        const double err = sc.eL[(eb + i) * r + col] + sc.eR[(eb + n - i) * r + col];
-        if (err < best) best = err, split = i;
-    }
-    double *out = sc.sy;  // reuse as the projected column
-    for (int idx = split - 1; idx >= 0;) {
-        const long si = ((long)s + idx) * r + col;
-        double lev = sc.lvL[si];
-        if (nonneg && lev < 0.0) lev = 0.0;
-        const int st = sc.stL[si];
-        for (int q = st; q <= idx; ++q) out[((long)s + q) * r + col] = lev;
-        idx = st - 1;
-    }
-    for (int idx = n - split - 1; idx >= 0;) {
-        const long si = ((long)s + idx) * r + col;
-        double lev = sc.lvR[si];
-        if (nonneg && lev < 0.0) lev = 0.0;
-        const int st = sc.stR[si];
-        for (int q = st; q <= idx; ++q) out[((long)s + (n - 1 - q)) * r + col] = lev;
-        idx = st - 1;
-    }
-    for (int q = 0; q < n; ++q) {
-        const long g = ((long)s + q) * r + col;
-        const float z = (float)out[g];
-        const float f = F[g], u = U[g];
-        Z[g] = z;
-        U[g] = f - (z - u);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// Unimodality, second version (default).  Same projection (Stout's prefix isotonic regression, both directions, best
-// split with the reference's tie rule, _unimodal_regression.py:27-104) with far less scratch traffic:
-//   * a block of the running fit is just (sum, count); the prefix error is kept incrementally as
-//         err = sum_j y_j^2 - sum_blocks q_b,   q_b = sum_b^2 / count_b  (0 for a block clamped at 0),
-//     so no per-position level / start / sum-of-squares arrays exist;
-//   * the block stack lives in a register window (top UW entries, static indexing by shifting) that spills to /
-//     refills from a column-interleaved global area only on overflow / underflow;
-//   * the right-to-left pass searches the split on the fly (t descending with '<=' == the reference's ascending scan
-//     with '<': smallest t among the minima), so only errL is stored;
-//   * the two fits are produced by re-running the pooling on [0, t) and on the reversed suffix and expanding the
-//     final block lists straight into aux (fp32); the dual update follows in a coalesced row kernel (k_rows_dual).
-// Arithmetic in fp64 as before.
-// ---------------------------------------------------------------------------------------------------------
-// Block stack of one lane: the top RC entries live in a lane-interleaved LDS ring (slot * 64 + lane: conflict-free
-// 8-byte accesses, dynamic indexing), older entries in a column-interleaved global spill area.
-#define RC 16
-struct UniRing {
-    double *sy, *sw, *sq;  // LDS [RC][64]
-    int h, cnt;            // ring index of the top entry, number of entries in the ring
-    long mem_n;            // entries spilled to global memory
-};
-
-static __device__ __forceinline__ void ur_push(UniRing &st, int lane, double sy, double sw, double q,
-                                               double *__restrict__ gsy, double *__restrict__ gsw,
-                                               double *__restrict__ gsq, long base, int r, int col) {
-    if (st.cnt == RC) {  // spill the bottom entry of the ring
-        const int b = ((st.h - RC + 1) & (RC - 1)) * 64 + lane;
-        const long idx = (base + st.mem_n) * r + col;
-        gsy[idx] = st.sy[b];
-        gsw[idx] = st.sw[b];
-        gsq[idx] = st.sq[b];
-        st.mem_n += 1;
-        st.cnt = RC - 1;
-    }
-    st.h = (st.h + 1) & (RC - 1);
-    const int t = st.h * 64 + lane;
-    st.sy[t] = sy;
-    st.sw[t] = sw;
-    st.sq[t] = q;
-    st.cnt += 1;
-}
-
-// returns false if the stack is empty; otherwise the top entry is at ring slot st.h
-static __device__ __forceinline__ bool ur_top(UniRing &st, int lane, const double *__restrict__ gsy,
-                                              const double *__restrict__ gsw, const double *__restrict__ gsq, long base,
-                                              int r, int col) {
-    if (st.cnt > 0) return true;
-    if (st.mem_n == 0) return false;
-    const int nref = st.mem_n >= 8 ? 8 : (int)st.mem_n;  // refill (independent loads, one latency)
-    for (int i = 0; i < nref; ++i) {
-        const long idx = (base + st.mem_n - 1 - i) * r + col;
-        const int t = ((st.h - i) & (RC - 1)) * 64 + lane;
-        st.sy[t] = gsy[idx];
-        st.sw[t] = gsw[idx];
-        st.sq[t] = gsq[idx];
-    }
-    st.mem_n -= nref;
-    st.cnt = nref;
-    return true;
-}
-
-__global__ __launch_bounds__(64) void k_slab_unimodal_v2(const int *__restrict__ ext, int n_slabs, float *__restrict__ F,
-                                                         RegSet regs, int k, int r, double *__restrict__ errL,
-                                                         double *__restrict__ ssy, double *__restrict__ ssw,
-                                                         double *__restrict__ ssq, int dbg) {
-    __shared__ double ring[3][RC * 64];
-    const int lane = threadIdx.x;
-    const long t = (long)blockIdx.x * 64 + threadIdx.x;
-    if (t >= (long)n_slabs * r) return;
-    const int slab = (int)(t / r), col = (int)(t - (long)slab * r);
-    const int s = ext[slab], e = ext[slab + 1], n = e - s;
-    if (n <= 0) return;
-    const int nonneg = regs.nonneg[k];
-    float *__restrict__ Z = regs.aux[k];
-    float *__restrict__ U = regs.dual[k];
-    const long eb = (long)s + slab;  // n + 1 error entries per slab
-    auto yat = [&](long pos) -> double { return (double)(F[pos * r + col] + U[pos * r + col]); };
-
-    UniRing st;
-    st.sy = ring[0], st.sw = ring[1], st.sq = ring[2];
-    double csy, csw, cq, cum2, Qb;
-    // one pooling step with element v: (csy, csw) is the top block with q = cq, st holds the blocks below it, Qb their q-sum
-    auto step = [&](double v, bool first) {
-        if (!first) {
-            Qb += cq;
-            ur_push(st, lane, csy, csw, cq, ssy, ssw, ssq, s, r, col);
-        }
-        csy = v;
-        csw = 1.0;
-        while (ur_top(st, lane, ssy, ssw, ssq, s, r, col)) {
-            const int tp = st.h * 64 + lane;
-            const double tsy = st.sy[tp], tsw = st.sw[tp];
-            if (!(csy * tsw <= tsy * csw)) break;  // mean(cur) > mean(top): done
-            Qb -= st.sq[tp];
-            csy += tsy;
-            csw += tsw;
-            st.h = (st.h - 1) & (RC - 1);
-            st.cnt -= 1;
-        }
-        cq = (nonneg && csy < 0.0) ? 0.0 : csy * csy / csw;
-    };
-    auto reset = [&]() {
-        st.h = 0;
-        st.cnt = 0;
-        st.mem_n = 0;
-        cum2 = 0.0;
-        Qb = 0.0;
-        csy = 0.0;
-        csw = 1.0;
-        cq = 0.0;
-    };
-
-    // The y loads are issued UB elements ahead (independent loads, one memory latency per batch instead of per element).
-    constexpr int UB = 8;
-    // pass 1: prefix errors, left to right
-    reset();
-    errL[eb * r + col] = 0.0;
-    for (int i0 = 0; i0 < ((dbg & 1) ? 0 : n); i0 += UB) {
-        double vb[UB];
-#pragma unroll
-        for (int j = 0; j < UB; ++j) vb[j] = yat((long)s + min(i0 + j, n - 1));
-#pragma unroll
-        for (int j = 0; j < UB; ++j) {
-            const int i = i0 + j;
-            if (i < n) {
-                const double v = vb[j];
-                cum2 += v * v;
-                step(v, i == 0);
-                errL[(eb + i + 1) * r + col] = (nonneg && csy < 0.0) ? cum2 : cum2 - (Qb + cq);
-            }
-        }
-    }
-    // pass 2: suffix errors right to left + best split (smallest t among the minima)
-    reset();
-    double best = errL[(eb + n) * r + col];
-    int split = n;
-    for (int i0 = 0; i0 < ((dbg & 2) ? 0 : n); i0 += UB) {
-        double vb[UB], eb_l[UB];
-#pragma unroll
-        for (int j = 0; j < UB; ++j) {
-            const int i = min(i0 + j, n - 1);
-            vb[j] = yat((long)e - 1 - i);
-            eb_l[j] = errL[(eb + (n - 1 - i)) * r + col];
-        }
-#pragma unroll
-        for (int j = 0; j < UB; ++j) {
-            const int i = i0 + j;
-            if (i < n) {
-                const double v = vb[j];
-                cum2 += v * v;
-                step(v, i == 0);
-                const double er = (nonneg && csy < 0.0) ? cum2 : cum2 - (Qb + cq);
-                const double tot = eb_l[j] + er;
-                if (tot <= best) {
-                    best = tot;
-                    split = n - 1 - i;
-                }
-            }
-        }
-    }
-    // passes 3 / 4: the two fits; expand the final block lists into aux and update the dual
-    // store-only: the dual update U = F - (Z - U) is done afterwards by the coalesced k_rows_dual kernel
-    auto emit = [&](long pos, double lev) {
-        if (nonneg && lev < 0.0) lev = 0.0;
-        Z[pos * r + col] = (float)lev;
-    };
-    for (int side = 0; side < 2; ++side) {
-        const int len = side == 0 ? split : n - split;
-        if (len == 0) continue;
-        reset();
-        for (int i0 = 0; i0 < ((dbg & 4) ? 0 : len); i0 += UB) {
-            double vb[UB];
-#pragma unroll
-            for (int j = 0; j < UB; ++j) {
-                const int i = min(i0 + j, len - 1);
-                vb[j] = side == 0 ? yat((long)s + i) : yat((long)e - 1 - i);
-            }
-#pragma unroll
-            for (int j = 0; j < UB; ++j)
-                if (i0 + j < len) step(vb[j], i0 + j == 0);
-        }
-        long p = 0;
-        auto emit_block = [&](double sy, double sw) {
-            const double lev = sy / sw;
-            const long cnt = (long)sw;
-            if (dbg & 8) return;
-            for (long c = 0; c < cnt; ++c, ++p) emit(side == 0 ? (long)s + p : (long)e - 1 - p, lev);
-        };
-        for (long m = 0; m < st.mem_n; ++m) emit_block(ssy[((long)s + m) * r + col], ssw[((long)s + m) * r + col]);
-        for (int i = st.cnt - 1; i >= 0; --i) {  // ring entries, bottom first
-            const int tp = ((st.h - i) & (RC - 1)) * 64 + lane;
-            emit_block(st.sy[tp], st.sw[tp]);
-        }
-        emit_block(csy, csw);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Unimodality, third version (default): the v2 algorithm with a cheaper pooling step -
+// Unimodality, previous generation (MCL_UNIMODAL_V3=1; kept as the comparison baseline of the tests and tools): three
+// pooling sweeps with (sum, count) blocks and an incrementally kept prefix error -
 //   * the block right below the one being built (the only one a step compares against) is cached in REGISTERS with its
 //     q; the common step (compare, no merge, push) touches LDS with stores only, a merge reads LDS once per popped block;
 //   * ring entries are (sum, count) only - q of a block is recomputed when it becomes the cached top;
@@ -2351,7 +2076,7 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
         case MCL_PEN_UNIMODAL: {
             const long nthreads = (long)mv.n_slabs * c->r;
             UniScratch sc = uni_scratch(c);
-            if (!getenv("MCL_UNIMODAL_V1") && !getenv("MCL_UNIMODAL_V2") && !getenv("MCL_UNIMODAL_V3")) {
+            if (!getenv("MCL_UNIMODAL_V3")) {
                 const unsigned nwav = (unsigned)((nthreads + 63) / 64);
                 // fewer columns than about one wave per SIMD: the two sweeps run concurrently in different waves
                 int wave_split = nwav <= 1024;
@@ -2369,21 +2094,10 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                     DISPATCH_ROWS(c, vec, k_rows_dual, grid, block, mv, rs, k, c->r);
                 break;
             }
-            if (getenv("MCL_UNIMODAL_V3")) {
-                hipLaunchKernelGGL(k_slab_unimodal_v3, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, c->stream,
-                                   mv.ext, mv.n_slabs, mv.F, rs, k, c->r, sc.eL, sc.sy, sc.sw);
-                if (!c->stack_fused)  // the fused finish pass updates the dual
-                    DISPATCH_ROWS(c, vec, k_rows_dual, grid, block, mv, rs, k, c->r);
-                break;
-            }
-            if (getenv("MCL_UNIMODAL_V1"))
-                hipLaunchKernelGGL(k_slab_unimodal, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, c->stream, mv.ext,
-                                   mv.n_slabs, mv.F, rs, k, c->r, sc);
-            else
-                hipLaunchKernelGGL(k_slab_unimodal_v2, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, c->stream,
-                                   mv.ext, mv.n_slabs, mv.F, rs, k, c->r, sc.eL, sc.sy, sc.sw, sc.sy2,
-                                   getenv("MCL_UNI_DBG") ? atoi(getenv("MCL_UNI_DBG")) : 0);
-            if (!getenv("MCL_UNIMODAL_V1")) DISPATCH_ROWS(c, vec, k_rows_dual, grid, block, mv, rs, k, c->r);
+            hipLaunchKernelGGL(k_slab_unimodal_v3, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, c->stream, mv.ext,
+                               mv.n_slabs, mv.F, rs, k, c->r, sc.eL, sc.sy, sc.sw);
+            if (!c->stack_fused)  // the fused finish pass updates the dual
+                DISPATCH_ROWS(c, vec, k_rows_dual, grid, block, mv, rs, k, c->r);
             break;
         }
         case MCL_PEN_TV: {
@@ -2480,7 +2194,6 @@ bool mcl_stack_can_fuse(const mcl_context *c, int mode) {
     bool slabwise = false;
     for (int k = 0; k < rs.n; ++k) {
         const int kind = rs.kind[k];
-        if (kind == MCL_PEN_UNIMODAL && (getenv("MCL_UNIMODAL_V1") || getenv("MCL_UNIMODAL_V2"))) return false;
         if (kind == MCL_PEN_L2BALL || kind == MCL_PEN_PARAFAC2 || kind == MCL_PEN_UNIMODAL) slabwise = true;
         else if (kind != MCL_PEN_NN && kind != MCL_PEN_BOX && kind != MCL_PEN_L1) return false;
     }

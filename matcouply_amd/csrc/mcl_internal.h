@@ -75,8 +75,7 @@ struct mcl_context {
     int *slab_bseg_ptr = nullptr;  // int32[I+1] first bseg of every slab
     float *Mpart = nullptr;        // [n_bsegs, K * 16 NB]  per-bseg X^T B in C-fragment order
     float *part_btb = nullptr;     // [n_bsegs, r, r]       per-bseg B^T B
-    float *CfragS = nullptr;       // C in fragment order with 4 * ceil(K / 256) chunks (== Cfrag when K % 256 == 0)
-    bool cfrags_valid = false;     // CfragS (when it is a buffer of its own) is the image of the current C
+    float *CfragS = nullptr;       // the sweep's view of the fragment image of C (aliases Cfrag: one shared image)
     float *GRpart = nullptr;       // [n_bsegs, K * 16 NB + (16 NB)^2]  per-bseg a-weighted partial of [G | R]
     int n_grpart = 0;
     long long *sweep_cycles = nullptr;  // [n_blocks, 4 waves, 6] per-section cycle counts (MCL_SWEEP_DBG & 32)
@@ -210,7 +209,6 @@ static inline int mcl_cfrag_chunks(const mcl_context *c) {
     const int xc = mcl_xc_chunks(c, nullptr);
     return c->sweep_planned ? std::max(xc, 4 * mcl_sweep_KS(c)) : xc;
 }
-int mcl_launch_build_cfrag_sweep(mcl_context *c);
 bool mcl_sweep_shape_ok(const mcl_context *c);   // shape has a k_sweep instantiation (decides the workspace plan)
 bool mcl_sweep_eligible(const mcl_context *c);   // ... and the current penalties / options / pointers allow it
 void mcl_sweep_geometry(const mcl_context *c, int *bsegs_per_wave, int *n_waves);

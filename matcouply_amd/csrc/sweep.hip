@@ -704,30 +704,6 @@ int mcl_launch_sweep(mcl_context *c) {
 #undef MCL_SW
 }
 
-// C in fragment order with 4 * KS chunks (the image k_sweep copies into LDS and k_A_rhs_from_M multiplies with).  For
-// K % 256 == 0 it IS the image of the X C kernels (CfragS aliases Cfrag, kept current by k_C_finish_fused).
-__global__ void k_build_cfrag_sweep(const float *__restrict__ C, int K, int r, int KC, int NB, float *__restrict__ Cfrag) {
-    const long total = (long)KC * 4 * NB * 256;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int m = idx & 3, lane = (idx >> 2) & 63;
-    long t = idx >> 8;
-    const int nb = t % NB;
-    t /= NB;
-    const int kq = t & 3, kc = t >> 2;
-    const int k = 64 * kc + 16 * kq + 4 * (lane >> 4) + m, col = 16 * nb + (lane & 15);
-    Cfrag[idx] = (k < K && col < r) ? C[(long)k * r + col] : 0.f;
-}
-
-int mcl_launch_build_cfrag_sweep(mcl_context *c) {
-    const int KC = 4 * mcl_sweep_KS(c);
-    const long total = (long)KC * 4 * c->NB * 256;
-    hipLaunchKernelGGL(k_build_cfrag_sweep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->C, (int)c->K,
-                       c->r, KC, c->NB, c->CfragS);
-    MCL_CHECK_HIP(c, hipGetLastError());
-    return 0;
-}
-
 int mcl_launch_reduce_weighted(mcl_context *c) {
     const int MS = sweep_MS(c), W = 16 * c->NB;
     // 64 elements per block need PS / 64 blocks (68 at K = 256, rank 16: a quarter of the CUs); with 32 there are twice as many
