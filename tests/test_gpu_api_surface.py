@@ -225,3 +225,22 @@ def test_step_api_defers_and_merges_the_finish_pass():
         assert torch.equal(eng.regs[1][0].aux2, ref.regs[1][0].aux2)
         eng.close()
     ref.close()
+
+
+@pytest.mark.parametrize("config", ["c3_8th", "c5_32nd"])
+def test_bench_two_rank_rehearsal(config):
+    """bench.py's multi-rank path (sharding, [G | R] all-reduce, PARAFAC2 step calls, max-over-ranks timing, one JSON line
+    from rank 0) with two ranks sharing cuda:0 over gloo - RCCL refuses two ranks on one device, so this rehearses
+    everything but the collective backend the driver's --gpus N runs use."""
+    import json
+
+    env = dict(os.environ, MCL_BENCH_SHARE_GPU="1", MCL_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    port = str(29700 + (os.getpid() + len(config)) % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", config]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["roofline"]["achieved"] > 0 and np.isfinite(d["final_rel_rec_error"])
