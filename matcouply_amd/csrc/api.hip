@@ -278,6 +278,7 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     if (!c) return 1;
     if (I < 0 || K < 1) return fail(c, "mcl_set_problem: need I >= 0 and K >= 1");
     if (rank < 1 || rank > MCL_MAX_RANK) return fail(c, "mcl_set_problem: rank must be in [1, 64]");
+    c->b_finish_pending = false;  // a deferred row pass of the step API refers to the buffers being replaced
     if (!row_ptr || row_ptr[0] != 0) return fail(c, "mcl_set_problem: row_ptr[0] must be 0");
     for (int64_t i = 0; i < I; ++i)
         if (row_ptr[i + 1] < row_ptr[i]) return fail(c, "mcl_set_problem: row_ptr must be non-decreasing");
@@ -364,6 +365,7 @@ int mcl_set_factors(mcl_context *c, float *A, float *B, float *C) {
     if (!c) return 1;
     if (!c->has_problem) return fail(c, "mcl_set_factors: call mcl_set_problem first");
     if ((c->I > 0 && !A) || (c->N > 0 && !B) || !C) return fail(c, "mcl_set_factors: NULL factor pointer");
+    c->b_finish_pending = false;  // a deferred row pass of the step API refers to the buffers being replaced
     c->A = A, c->B = B, c->C = C;
     c->has_factors = true;
     c->b_systems_valid = false;
@@ -378,6 +380,7 @@ int mcl_set_penalties(mcl_context *c, int32_t mode, int32_t n, const mcl_penalty
     if (!c) return 1;
     if (mode < 0 || mode > 2) return fail(c, "mcl_set_penalties: mode must be 0, 1 or 2");
     if (n < 0 || n > MCL_MAX_REGS) return fail(c, "mcl_set_penalties: at most 4 penalties per mode");
+    c->b_finish_pending = false;  // a deferred row pass of the step API refers to the buffers being replaced
     RegSet rs{};
     rs.n = n;
     for (int k = 0; k < n; ++k) {
@@ -417,6 +420,7 @@ int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
     if (!c->has_problem) return fail(c, "mcl_set_workspace: call mcl_set_problem first");
     const int64_t need = plan(c, nullptr);
     if (!workspace || bytes < need) return fail(c, "mcl_set_workspace: workspace too small");
+    c->b_finish_pending = false;  // a deferred row pass of the step API refers to the buffers being replaced
     if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(c, "mcl_set_workspace: workspace must be 256-byte aligned");
     c->ws = static_cast<char *>(workspace);
     c->ws_bytes = bytes;
