@@ -348,7 +348,44 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                                 z[k][h][v] = znew;
                             }
                 };
-                if (all_nn) {
+                if (all_nn && NREG == 1 && n_it > 0 && !(dbg & 64)) {  // MCL_SWEEP_DBG=64: the general form below
+                    // One non-negativity constraint: with y = B + U the prox and dual steps are Z = max(y, 0), U = min(y, 0)
+                    // (= B - (Z - U) without its roundings), so Z - U = |y| exactly and the next right-hand side is
+                    // rhs + rho |y|: two instructions per element and iteration (v_min, v_fma with the |.| modifier) besides
+                    // the add, Z itself only after the last iteration.
+                    constexpr int R0 = NREG > 0 ? 0 : 0;
+                    f32x4 t[NB], y[NB];
+#pragma unroll
+                    for (int h = 0; h < NB; ++h)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            t[h][v] = fmaf(rho, z[R0][h][v] - u[R0][h][v], rhs[h][v]);
+                            y[h][v] = 0.f;
+                        }
+                    for (int it = 0; it < n_it; ++it) {
+#pragma unroll
+                        for (int hp = 0; hp < NB; ++hp) {
+                            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int h = 0; h < NB; ++h)
+#pragma unroll
+                                for (int kq = 0; kq < 4; ++kq) a4 = MFMA16(LT[hp][h][kq], t[h][kq], a4);
+                            f[hp] = a4;
+                        }
+#pragma unroll
+                        for (int h = 0; h < NB; ++h)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                y[h][v] = f[h][v] + u[R0][h][v];
+                                u[R0][h][v] = fminf(y[h][v], 0.f);
+                                t[h][v] = fmaf(rho, fabsf(y[h][v]), rhs[h][v]);
+                            }
+                    }
+#pragma unroll
+                    for (int h = 0; h < NB; ++h)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) z[R0][h][v] = fmaxf(y[h][v], 0.f);
+                } else if (all_nn) {
                     for (int it = 0; it < n_it; ++it) inner_iter(std::true_type{});
                 } else {
                     for (int it = 0; it < n_it; ++it) inner_iter(std::false_type{});
