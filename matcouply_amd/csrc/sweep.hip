@@ -353,13 +353,12 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                     // (= B - (Z - U) without its roundings), so Z - U = |y| exactly and the next right-hand side is
                     // rhs + rho |y|: two instructions per element and iteration (v_min, v_fma with the |.| modifier) besides
                     // the add, Z itself only after the last iteration.
-                    constexpr int R0 = NREG > 0 ? 0 : 0;
                     f32x4 t[NB], y[NB];
 #pragma unroll
                     for (int h = 0; h < NB; ++h)
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
-                            t[h][v] = fmaf(rho, z[R0][h][v] - u[R0][h][v], rhs[h][v]);
+                            t[h][v] = fmaf(rho, z[0][h][v] - u[0][h][v], rhs[h][v]);
                             y[h][v] = 0.f;
                         }
                     for (int it = 0; it < n_it; ++it) {
@@ -376,15 +375,15 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                         for (int h = 0; h < NB; ++h)
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
-                                y[h][v] = f[h][v] + u[R0][h][v];
-                                u[R0][h][v] = fminf(y[h][v], 0.f);
+                                y[h][v] = f[h][v] + u[0][h][v];
+                                u[0][h][v] = fminf(y[h][v], 0.f);
                                 t[h][v] = fmaf(rho, fabsf(y[h][v]), rhs[h][v]);
                             }
                     }
 #pragma unroll
                     for (int h = 0; h < NB; ++h)
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) z[R0][h][v] = fmaxf(y[h][v], 0.f);
+                        for (int v = 0; v < 4; ++v) z[0][h][v] = fmaxf(y[h][v], 0.f);
                 } else if (all_nn) {
                     for (int it = 0; it < n_it; ++it) inner_iter(std::true_type{});
                 } else {
