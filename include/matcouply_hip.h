@@ -93,7 +93,7 @@ int mcl_update_B(mcl_context *ctx);
 /* admm_update_C (decomposition.py:295-344), split at the cross-slab reduction so that a multi-GPU host can
  * all-reduce the normal equations:  local -> [all-reduce over ranks of mcl_c_normal_equations()] -> finish. */
 int mcl_update_C_local(mcl_context *ctx);
-float *mcl_c_normal_equations(mcl_context *ctx, int64_t *count); /* device [G (r x r) | R (K x r)], fp32 */
+double *mcl_c_normal_equations(mcl_context *ctx, int64_t *count); /* device [G (r x r) | R (K x r)], fp64 */
 int mcl_update_C_finish(mcl_context *ctx);
 /* admm_update_A (decomposition.py:120-219); also leaves (rhses, cross_products) for the fast error formula. */
 int mcl_update_A(mcl_context *ctx);

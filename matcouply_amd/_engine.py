@@ -207,14 +207,14 @@ class HipEngine:
         self._check(self.lib.mcl_update_B(self._h))
 
     def update_C_local(self):
-        """Returns the fp32 device tensor [G | R] (r*r + K*r) to be all-reduced over ranks."""
+        """Returns the fp64 device tensor [G | R] (r*r + K*r) to be all-reduced over ranks."""
         self._check(self.lib.mcl_update_C_local(self._h))
         return self.c_normal_equations()
 
     def c_normal_equations(self):
         n = ctypes.c_int64()
         p = self.lib.mcl_c_normal_equations(self._h, ctypes.byref(n))
-        return self._view(p, n.value, self._torch.float32)
+        return self._view(p, n.value, self._torch.float64)
 
     def update_C_finish(self):
         self._check(self.lib.mcl_update_C_finish(self._h))

@@ -105,7 +105,7 @@ static __device__ __forceinline__ void gj_inverse_rows(double (&col)[GJRows<RP>:
 // CtC = C^T C  (fp64 accumulation, one workgroup; C staged through LDS in row chunks)
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ctc(const float *__restrict__ C, int K, int r, int RP,
-                                               float *__restrict__ CtC) {
+                                               float *__restrict__ CtC, double *__restrict__ CtC64) {
     // block a computes row a of CtC; thread (b = t % RP, ks = t / RP) strides over k
     __shared__ double sm[256];
     const int a = blockIdx.x;
@@ -119,20 +119,21 @@ __global__ __launch_bounds__(256) void k_ctc(const float *__restrict__ C, int K,
         double t = 0.0;
         for (int q = 0; q < nks; ++q) t += sm[q * RP + b];
         CtC[a * r + b] = (float)t;
+        CtC64[a * r + b] = t;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // B-phase systems: rho_i = 1/2 tr(CtC o a_i a_i^T) * scale ; L_i = CtC o a_i a_i^T + (rho_i n + l2) I ; L_i^-1
 // ---------------------------------------------------------------------------------------------------------
-__global__ void k_B_rho(const float *__restrict__ CtC, const float *__restrict__ A, int I, int r, float scale,
+__global__ void k_B_rho(const double *__restrict__ CtC, const float *__restrict__ A, int I, int r, float scale,
                         float *__restrict__ rhoB, float *__restrict__ rho_max) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= I) return;
     double s = 0.0;
     for (int c = 0; c < r; ++c) {
         const double a = A[(long)i * r + c];
-        s += (double)CtC[c * r + c] * a * a;
+        s += CtC[c * r + c] * a * a;
     }
     const float rho = (float)(0.5 * s * scale);
     rhoB[i] = rho;
@@ -140,16 +141,16 @@ __global__ void k_B_rho(const float *__restrict__ CtC, const float *__restrict__
 }
 
 template <int RP>
-__global__ __launch_bounds__(256) void k_B_systems(const float *__restrict__ CtC, const float *__restrict__ A, int I,
+__global__ __launch_bounds__(256) void k_B_systems(const double *__restrict__ CtC, const float *__restrict__ A, int I,
                                                    int r, float scale, float l2, int n_regs, int constant,
                                                    const float *__restrict__ rho_max, float *__restrict__ rhoB,
-                                                   float *__restrict__ Linv) {
+                                                   float *__restrict__ Linv, double *__restrict__ Linv64) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per slab
     if (i >= I) return;
     const float *a = A + (long)i * r;
     double tr = 0.0;
-    for (int c = 0; c < r; ++c) tr += (double)CtC[c * r + c] * (double)a[c] * (double)a[c];
+    for (int c = 0; c < r; ++c) tr += CtC[c * r + c] * (double)a[c] * (double)a[c];
     float rho = (float)(0.5 * tr * scale);
     if (constant) rho = rho_max[0];
     const double shift = (double)rho * n_regs + (double)l2;
@@ -159,23 +160,63 @@ __global__ __launch_bounds__(256) void k_B_systems(const float *__restrict__ CtC
 #pragma unroll
     for (int d = 0; d < RP; ++d) {
         double v = (d == lane) ? 1.0 : 0.0;
-        if (act && d < r) v = (double)CtC[d * r + lane] * (double)a[d] * ac + (d == lane ? shift : 0.0);
+        if (act && d < r) v = CtC[d * r + lane] * (double)a[d] * ac + (d == lane ? shift : 0.0);
         col[d] = v;
     }
     gj_inverse_reg<RP>(col, r, lane);
 #pragma unroll
     for (int d = 0; d < RP; ++d)
-        if (act && d < r) Linv[((long)i * r + d) * r + lane] = (float)col[d];
+        if (act && d < r) {
+            Linv[((long)i * r + d) * r + lane] = (float)col[d];
+            if (Linv64 != nullptr) Linv64[((long)i * r + d) * r + lane] = col[d];
+        }
     if (lane == 0) rhoB[i] = rho;
 }
 
-// C-phase system from the (all-reduced) normal equations [G | R]
+// Penalty-free B (decomposition.py:266-273 with an empty penalty list): B_i = ((X_i C) o a_i) L_i^-1 with un-shifted (or
+// only l2-shifted) systems - the product runs in fp64 with the fp64 inverse, one wave per tile of <= 64 rows, lane c
+// owning column c of L_i^-1; the row's right-hand side entries are fetched with v_readlane.
 template <int RP>
-__global__ __launch_bounds__(64) void k_C_prepare(const float *__restrict__ GR, int r, float scale, float l2,
-                                                  int n_regs, float *__restrict__ rhoC, float *__restrict__ LinvC) {
+__global__ __launch_bounds__(256) void k_B_solve_f64(const int *__restrict__ tile_slab, const int *__restrict__ tile_row0,
+                                                     const int *__restrict__ tile_nrows, int n_tiles,
+                                                     const float *__restrict__ XC, const float *__restrict__ A,
+                                                     const double *__restrict__ Linv64, int r, float *__restrict__ B) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const int slab = __builtin_amdgcn_readfirstlane(tile_slab[tile]);
+    const long row0 = __builtin_amdgcn_readfirstlane(tile_row0[tile]);
+    const int nrows = __builtin_amdgcn_readfirstlane(tile_nrows[tile]);
+    const bool act = lane < r;
+    const int c = act ? lane : 0;
+    double col[RP];
+#pragma unroll
+    for (int d = 0; d < RP; ++d) col[d] = (act && d < r) ? Linv64[((long)slab * r + d) * r + c] : 0.0;
+    const double a = act ? (double)A[(long)slab * r + c] : 0.0;
+    for (int j = 0; j < nrows; ++j) {
+        const double t = act ? (double)XC[(row0 + j) * r + c] * a : 0.0;
+        double acc = 0.0;
+#pragma unroll
+        for (int d = 0; d < RP; ++d)
+            if (d < r) acc = fma(readlane_f64(t, d), col[d], acc);
+        if (act) B[(row0 + j) * r + c] = (float)acc;
+    }
+}
+
+// C-phase system from the (all-reduced) fp64 normal equations [G | R]: block 0 builds and inverts G + (rho n + l2) I
+// (fp32 and fp64 copies of the inverse), the other blocks round R to the fp32 image the fp32 row kernels read.
+template <int RP>
+__global__ __launch_bounds__(64) void k_C_prepare(const double *__restrict__ GR, int r, int K, float scale, float l2,
+                                                  int n_regs, float *__restrict__ rhoC, float *__restrict__ LinvC,
+                                                  double *__restrict__ LinvC64, float *__restrict__ Rf) {
     const int lane = threadIdx.x;
+    if (blockIdx.x > 0) {
+        const long e = (long)(blockIdx.x - 1) * 64 + lane;
+        if (e < (long)K * r) Rf[e] = (float)GR[(long)r * r + e];
+        return;
+    }
     double tr = 0.0;
-    for (int c = 0; c < r; ++c) tr += (double)GR[c * r + c];
+    for (int c = 0; c < r; ++c) tr += GR[c * r + c];
     const float rho = (float)(0.5 * tr * scale);
     const double shift = (double)rho * n_regs + (double)l2;
     const bool act = lane < r;
@@ -183,14 +224,32 @@ __global__ __launch_bounds__(64) void k_C_prepare(const float *__restrict__ GR, 
 #pragma unroll
     for (int d = 0; d < RP; ++d) {
         double v = (d == lane) ? 1.0 : 0.0;
-        if (act && d < r) v = (double)GR[d * r + lane] + (d == lane ? shift : 0.0);
+        if (act && d < r) v = GR[d * r + lane] + (d == lane ? shift : 0.0);
         col[d] = v;
     }
     gj_inverse_reg<RP>(col, r, lane);
 #pragma unroll
     for (int d = 0; d < RP; ++d)
-        if (act && d < r) LinvC[d * r + lane] = (float)col[d];
+        if (act && d < r) {
+            LinvC[d * r + lane] = (float)col[d];
+            LinvC64[d * r + lane] = col[d];
+        }
     if (lane == 0) rhoC[0] = rho;
+}
+
+// Penalty-free C (decomposition.py:328-331 with an empty penalty list): C = R G^-1 is a plain least-squares solve whose
+// normal equations are not shifted, so the product is taken in fp64 from the fp64 [G | R] and rounded once.
+__global__ __launch_bounds__(256) void k_C_solve_f64(const double *__restrict__ R, const double *__restrict__ Linv, int K,
+                                                     int r, float *__restrict__ C) {
+    extern __shared__ double Ls[];
+    for (int e = threadIdx.x; e < r * r; e += 256) Ls[e] = Linv[e];
+    __syncthreads();
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)K * r) return;
+    const int k = (int)(e / r), c = (int)(e - (long)k * r);
+    double acc = 0.0;
+    for (int d = 0; d < r; ++d) acc = fma(R[(long)k * r + d], Ls[d * r + c], acc);
+    C[e] = (float)acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -216,7 +275,7 @@ template <int NBR, int NREG, bool VEC>
 static __device__ __forceinline__ void rows_fused_tile(int lane, long row0, int nrows, float rho, const float *Li,
                                                        const float *Arow, const float *__restrict__ rhs_src,
                                                        float *__restrict__ F, float *Fcopy, const RegSet &regs, int r,
-                                                       int inner, double *dg) {
+                                                       int inner, double *dg, const double *__restrict__ rhs64 = nullptr) {
     const int row16 = lane & 15, g = lane >> 4;
     constexpr int NR = NREG > 0 ? NREG : 1;
 
@@ -278,7 +337,12 @@ static __device__ __forceinline__ void rows_fused_tile(int lane, long row0, int 
 #pragma unroll
         for (int h = 0; h < NBR; ++h) {
             const int col = 16 * h + 4 * g;
-            rhs[h] = ld4(rhs_src, j, col, ok);
+            if (rhs64 != nullptr) {  // fp64 [G | R] of the C-phase, rounded on load
+#pragma unroll
+                for (int v = 0; v < 4; ++v) rhs[h][v] = (ok && col + v < r) ? (float)rhs64[j * r + col + v] : 0.f;
+            } else {
+                rhs[h] = ld4(rhs_src, j, col, ok);
+            }
 #pragma unroll
             for (int v = 0; v < 4; ++v) rhs[h][v] *= av[h][v];
 #pragma unroll
@@ -390,14 +454,16 @@ __global__ __launch_bounds__(256) void k_rows_fused(const int *__restrict__ tile
 // LDS: L^-1 [r*r] | C [K*r] (fp32).
 // ---------------------------------------------------------------------------------------------------------
 template <int NBR, int NREG, bool VEC>
-__global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict__ GR, int K, int r, float scale, float l2,
+__global__ __launch_bounds__(1024) void k_C_finish_fused(const double *__restrict__ GR, int K, int r, float scale, float l2,
                                                          float *__restrict__ rhoC, float *__restrict__ LinvC,
                                                          float *__restrict__ C, RegSet regs, int inner,
-                                                         float *__restrict__ CtC, float *__restrict__ Cfrag, int KC,
-                                                         int NBc, double *__restrict__ diag_row, int rows_per_wave) {
+                                                         float *__restrict__ CtC, double *__restrict__ CtC64,
+                                                         float *__restrict__ Cfrag, int KC, int NBc,
+                                                         double *__restrict__ diag_row, int rows_per_wave) {
     extern __shared__ float smc[];
     __shared__ double dsm[16][DIAG_COLS];
     __shared__ float rho_s;
+    __shared__ double Ls64[NREG == 0 ? 256 * NBR * NBR : 1];  // penalty-free C: the solve itself runs in fp64
     float *Ls = smc, *Cs = smc + r * r;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     constexpr int RP = 16 * NBR;
@@ -408,7 +474,7 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict
         const int cc = lane % RP, g = lane / RP;
         const bool act = cc < r;
         const int cl = act ? cc : 0;
-        float gv[RL];
+        double gv[RL];
         double tr = 0.0;
 #pragma unroll
         for (int j = 0; j < RL; ++j) {
@@ -417,7 +483,7 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict
         }
 #pragma unroll
         for (int j = 0; j < RL; ++j)
-            if (act && g * RL + j == cc) tr = (double)gv[j];
+            if (act && g * RL + j == cc) tr = gv[j];
         tr = wave_sum(tr);
         const float rho = (float)(0.5 * tr * scale);
         const double shift = (double)rho * NREG + (double)l2;
@@ -426,7 +492,7 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict
         for (int j = 0; j < RL; ++j) {
             const int d = g * RL + j;
             double v = (d == cc) ? 1.0 : 0.0;
-            if (act && d < r) v = (double)gv[j] + (d == cc ? shift : 0.0);
+            if (act && d < r) v = gv[j] + (d == cc ? shift : 0.0);
             col[j] = v;
         }
         gj_inverse_rows<RP>(col, r, lane);
@@ -436,6 +502,7 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict
             if (act && d < r) {
                 Ls[d * r + cc] = (float)col[j];
                 LinvC[d * r + cc] = (float)col[j];
+                if (NREG == 0) Ls64[d * r + cc] = col[j];
             }
         }
         if (lane == 0) {
@@ -448,7 +515,28 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict
     const long row0 = (long)rows_per_wave * wave;
     const int nrows = max(0, min(rows_per_wave, K - rows_per_wave * wave));
     double dg[DIAG_COLS];
-    rows_fused_tile<NBR, NREG, VEC>(lane, row0, nrows, rho_s, Ls, nullptr, GR + (long)r * r, C, Cs, regs, r, inner, dg);
+    if (NREG == 0) {
+        // C = R G^-1 in fp64 (un-shifted normal equations: every rounding of the product is amplified by cond(G))
+        const double *R = GR + (long)r * r;
+        double nf = 0.0, na = 0.0;
+        if (inner > 0)
+            for (int e = lane; e < nrows * r; e += 64) {
+                const int rl = e / r, cidx = e - rl * r;
+                const long j = row0 + rl;
+                double acc = 0.0;
+                for (int d = 0; d < r; ++d) acc = fma(R[j * r + d], Ls64[d * r + cidx], acc);
+                const float f = (float)acc;
+                C[j * r + cidx] = f;
+                Cs[j * r + cidx] = f;
+                nf += (double)f * (double)f;
+                na += fabs((double)f);
+            }
+        dg[0] = wave_sum(nf);
+        dg[1] = wave_sum(na);
+    } else {
+        rows_fused_tile<NBR, NREG, VEC>(lane, row0, nrows, rho_s, Ls, nullptr, nullptr, C, Cs, regs, r, inner, dg,
+                                        GR + (long)r * r);
+    }
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 2 + NREG; ++k) dsm[wave][k] = dg[k];
@@ -517,6 +605,7 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict
         for (int pr = threadIdx.x; pr < r * r; pr += blockDim.x) {
             const int a = pr / r, b = pr - a * r;
             CtC[pr] = (float)csm[a][b];
+            CtC64[pr] = csm[a][b];
         }
     }
     // fragment image of C for the X C kernels (see k_build_cfrag)
@@ -538,42 +627,43 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const float *__restrict
 //   L_i^-1 by the register Gauss-Jordan; fused inner loop on the row a_i with row-separable penalties
 //   (a_c = sum_d t_d L^-1[d][c], t_d fetched with v_readlane); per-slab terms of the fast reconstruction-error
 //   formula (:445-449) and the mode-0 diagnostics.
+// The per-slab Gram and right-hand side arrive as fp64 per-segment partials (seg_btb / seg_rhs; slab_seg_ptr == nullptr:
+// one entry per slab) and stay fp64 through Q_i, the system and the solve: only the stored by-products are rounded.
 // fused_inner == 0: only Q_i, rho_i and L_i^-1 are produced (the generic inner loop follows).
 // ---------------------------------------------------------------------------------------------------------
 template <int RP>
-__global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA, float *__restrict__ BtB,
-                                                  const float *__restrict__ CtC, int I, int r, float scale, float l2,
-                                                  int constant, const float *__restrict__ rho_max,
-                                                  float *__restrict__ rhoA, float *__restrict__ LinvA,
-                                                  float *__restrict__ A, RegSet regs, int inner, int fused_inner,
-                                                  double *__restrict__ e1, double *__restrict__ diag_row,
+__global__ __launch_bounds__(256) void k_A_finish(float *__restrict__ BtB, const double *__restrict__ CtC, int I, int r,
+                                                  float scale, float l2, int constant,
+                                                  const float *__restrict__ rho_max, float *__restrict__ rhoA,
+                                                  float *__restrict__ LinvA, float *__restrict__ A, RegSet regs, int inner,
+                                                  int fused_inner, double *__restrict__ e1, double *__restrict__ diag_row,
                                                   int next_B, float l2_B, int n_regs_B, float *__restrict__ rhoB,
                                                   float *__restrict__ LinvB, const int *__restrict__ slab_seg_ptr,
-                                                  const float *__restrict__ seg_rhs, const float *__restrict__ seg_btb,
+                                                  const double *__restrict__ seg_rhs, const double *__restrict__ seg_btb,
                                                   float *__restrict__ rhsA_out) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= I) return;
     const bool act = lane < r;
     const int c = act ? lane : 0;
-    float qcol[RP];
+    double qcol[RP];
     double col[RP];
     double tr = 0.0;
-    int sg0 = 0, sg1 = 0;
-    if (seg_btb != nullptr) {
+    int sg0 = i, sg1 = i + 1;
+    if (slab_seg_ptr != nullptr) {
         sg0 = slab_seg_ptr[i];
         sg1 = slab_seg_ptr[i + 1];
     }
     // Every global load of the kernel is issued up front, unconditionally (clamped column, masked at use): the loads
     // of one stage are all in flight together instead of one dependent L2 round trip per matrix row.
-    float ctc[RP], btbv[RP];
+    double ctc[RP], btbv[RP];
 #pragma unroll
     for (int d = 0; d < RP; ++d) {
         const int dd = d < r ? d : r - 1;
         ctc[d] = CtC[dd * r + c];
-        btbv[d] = (seg_btb != nullptr) ? 0.f : BtB[((long)i * r + dd) * r + c];
+        btbv[d] = 0.0;
     }
-    float rhs_pre = (seg_rhs != nullptr) ? 0.f : rhsA[(long)i * r + c];
+    double rhs_pre = 0.0;
     float z_pre[MCL_MAX_REGS], u_pre[MCL_MAX_REGS];
 #pragma unroll
     for (int k = 0; k < MCL_MAX_REGS; ++k) {
@@ -584,26 +674,24 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
         }
     }
     const float a_pre = A[(long)i * r + c];
-    if (seg_btb != nullptr) {  // sum the per-segment partial Grams / right-hand sides of this slab (fixed order)
-        for (int sg = sg0; sg < sg1; ++sg) {
-            float v[RP];
+    for (int sg = sg0; sg < sg1; ++sg) {  // per-segment partial Grams / right-hand sides of this slab (fixed order)
+        double v[RP];
 #pragma unroll
-            for (int d = 0; d < RP; ++d) v[d] = seg_btb[((long)sg * r + (d < r ? d : r - 1)) * r + c];
-            const float rv = seg_rhs[(long)sg * r + c];
+        for (int d = 0; d < RP; ++d) v[d] = seg_btb[((long)sg * r + (d < r ? d : r - 1)) * r + c];
+        const double rv = seg_rhs[(long)sg * r + c];
 #pragma unroll
-            for (int d = 0; d < RP; ++d) btbv[d] += v[d];
-            rhs_pre += rv;
-        }
+        for (int d = 0; d < RP; ++d) btbv[d] += v[d];
+        rhs_pre += rv;
     }
 #pragma unroll
     for (int d = 0; d < RP; ++d) {
-        float q = 0.f;
+        double q = 0.0;
         if (act && d < r) {
-            q = (float)((double)btbv[d] * (double)ctc[d]);
-            BtB[((long)i * r + d) * r + c] = q;
+            q = btbv[d] * ctc[d];
+            BtB[((long)i * r + d) * r + c] = (float)q;
         }
         qcol[d] = q;
-        if (d == lane) tr = (double)q;
+        if (d == lane) tr = q;
     }
     tr = wave_sum(act ? tr : 0.0);
     float rho = (float)(0.5 * tr * scale);
@@ -613,19 +701,19 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
 #pragma unroll
     for (int d = 0; d < RP; ++d) {
         double v = (d == lane) ? 1.0 : 0.0;
-        if (act && d < r) v = (double)qcol[d] + (d == lane ? shift : 0.0);
+        if (act && d < r) v = qcol[d] + (d == lane ? shift : 0.0);
         col[d] = v;
     }
     gj_inverse_reg<RP>(col, r, lane);
     if (lane == 0) rhoA[i] = rho;
+    const double rhs = act ? rhs_pre : 0.0;
+    if (act) rhsA_out[(long)i * r + c] = (float)rhs;  // the `rhses` by-product
     if (!fused_inner) {
 #pragma unroll
         for (int d = 0; d < RP; ++d)
             if (act && d < r) LinvA[((long)i * r + d) * r + c] = (float)col[d];
         return;
     }
-    const float rhs = act ? rhs_pre : 0.f;
-    if (act && seg_rhs != nullptr) rhsA_out[(long)i * r + c] = rhs;  // keep the `rhses` by-product available
     float z[MCL_MAX_REGS], u[MCL_MAX_REGS], thr[MCL_MAX_REGS];
 #pragma unroll
     for (int k = 0; k < MCL_MAX_REGS; ++k) {
@@ -643,14 +731,11 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
 #pragma unroll
         for (int k = 0; k < MCL_MAX_REGS; ++k)
             if (k < n) s += z[k] - u[k];
-        const float t = (n > 0) ? fmaf(rho, s, rhs) : rhs;
+        const double t = (n > 0) ? fma((double)rho, (double)s, rhs) : rhs;
         double acc = 0.0;
 #pragma unroll
         for (int d = 0; d < RP; ++d) {
-            if (d < r) {
-                const float td = readlane_f32(t, d);
-                acc += (double)td * col[d];
-            }
+            if (d < r) acc = fma(readlane_f64(t, d), col[d], acc);
         }
         a = (float)acc;
 #pragma unroll
@@ -679,10 +764,10 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
     for (int d = 0; d < RP; ++d) {
         if (d < r) {
             const float ad = readlane_f32(a, d);
-            qa += (double)qcol[d] * (double)ad;
+            qa += qcol[d] * (double)ad;
         }
     }
-    const double inner_i = wave_sum(act ? (double)rhs * (double)a : 0.0);
+    const double inner_i = wave_sum(act ? rhs * (double)a : 0.0);
     const double model_i = wave_sum(act ? (double)a * qa : 0.0);
     const double nf = wave_sum(act ? (double)a * (double)a : 0.0);
     const double na = wave_sum(act ? fabs((double)a) : 0.0);
@@ -709,7 +794,7 @@ __global__ __launch_bounds__(256) void k_A_finish(const float *__restrict__ rhsA
         for (int d = 0; d < RP; ++d) {
             const float ad = (d < r) ? readlane_f32(a, d) : 0.f;
             double v = (d == lane) ? 1.0 : 0.0;
-            if (act && d < r) v = (double)ctc[d] * (double)ad * (double)a;
+            if (act && d < r) v = ctc[d] * (double)ad * (double)a;
             if (d == lane && act) trb = v;
             col[d] = v;
         }
@@ -756,16 +841,16 @@ static __device__ __forceinline__ double lead_sum(double v) {
 }
 
 template <int RP>
-__global__ __launch_bounds__(256) void k_A_finish_rows(const float *__restrict__ rhsA, float *__restrict__ BtB,
-                                                       const float *__restrict__ CtC, int I, int r, float scale,
-                                                       float l2, int constant, const float *__restrict__ rho_max,
-                                                       float *__restrict__ rhoA, float *__restrict__ LinvA,
-                                                       float *__restrict__ A, RegSet regs, int inner, int fused_inner,
-                                                       double *__restrict__ e1, double *__restrict__ diag_row,
-                                                       int next_B, float l2_B, int n_regs_B, float *__restrict__ rhoB,
-                                                       float *__restrict__ LinvB, const int *__restrict__ slab_seg_ptr,
-                                                       const float *__restrict__ seg_rhs,
-                                                       const float *__restrict__ seg_btb, float *__restrict__ rhsA_out) {
+__global__ __launch_bounds__(256) void k_A_finish_rows(float *__restrict__ BtB, const double *__restrict__ CtC, int I,
+                                                       int r, float scale, float l2, int constant,
+                                                       const float *__restrict__ rho_max, float *__restrict__ rhoA,
+                                                       float *__restrict__ LinvA, float *__restrict__ A, RegSet regs,
+                                                       int inner, int fused_inner, double *__restrict__ e1,
+                                                       double *__restrict__ diag_row, int next_B, float l2_B,
+                                                       int n_regs_B, float *__restrict__ rhoB, float *__restrict__ LinvB,
+                                                       const int *__restrict__ slab_seg_ptr,
+                                                       const double *__restrict__ seg_rhs,
+                                                       const double *__restrict__ seg_btb, float *__restrict__ rhsA_out) {
     constexpr int RL = GJRows<RP>::RL, G = GJRows<RP>::G;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -783,19 +868,19 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(const float *__restrict__
         dok[j] = act && d < r;
         drow[j] = d < r ? d : r - 1;  // clamped: every load is unconditional
     }
-    int sg0 = 0, sg1 = 0;
-    if (seg_btb != nullptr) {
+    int sg0 = i, sg1 = i + 1;
+    if (slab_seg_ptr != nullptr) {
         sg0 = slab_seg_ptr[i];
         sg1 = slab_seg_ptr[i + 1];
     }
     // all global loads up front
-    float ctc[RL], btbv[RL];
+    double ctc[RL], btbv[RL];
 #pragma unroll
     for (int j = 0; j < RL; ++j) {
         ctc[j] = CtC[drow[j] * r + c];
-        btbv[j] = (seg_btb != nullptr) ? 0.f : BtB[((long)i * r + drow[j]) * r + c];
+        btbv[j] = 0.0;
     }
-    float rhs_pre = (seg_rhs != nullptr) ? 0.f : rhsA[(long)i * r + c];
+    double rhs_pre = 0.0;
     float z[MCL_MAX_REGS], u[MCL_MAX_REGS], thr[MCL_MAX_REGS];
     const int n = regs.n;
 #pragma unroll
@@ -807,10 +892,10 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(const float *__restrict__
         }
     }
     float a = A[(long)i * r + c];
-    if (seg_btb != nullptr) {  // per-segment partial Grams / right-hand sides of this slab, fixed order
+    {  // fp64 per-segment partial Grams / right-hand sides of this slab, fixed order
         constexpr int SGB = 4;  // segments fetched per batch: independent clamped loads, summed in segment order
         for (int sb = sg0; sb < sg1; sb += SGB) {
-            float v[SGB][RL], rv[SGB];
+            double v[SGB][RL], rv[SGB];
 #pragma unroll
             for (int q = 0; q < SGB; ++q) {
                 const long sg = min(sb + q, sg1 - 1);
@@ -827,15 +912,15 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(const float *__restrict__
                 }
         }
     }
-    float qf[RL];
+    double qf[RL];
     double tr = 0.0;
 #pragma unroll
     for (int j = 0; j < RL; ++j) {
-        float q = 0.f;
+        double q = 0.0;
         if (dok[j]) {
-            q = (float)((double)btbv[j] * (double)ctc[j]);
-            BtB[((long)i * r + drow[j]) * r + c] = q;
-            if (drow[j] == c) tr = (double)q;
+            q = btbv[j] * ctc[j];
+            BtB[((long)i * r + drow[j]) * r + c] = (float)q;
+            if (drow[j] == c) tr = q;
         }
         qf[j] = q;
     }
@@ -848,19 +933,19 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(const float *__restrict__
     for (int j = 0; j < RL; ++j) {
         const int d = g * RL + j;
         double v = (d == cc) ? 1.0 : 0.0;  // identity padding (also for the idle lanes of RP = 4)
-        if (dok[j]) v = (double)qf[j] + (d == cc ? shift : 0.0);
+        if (dok[j]) v = qf[j] + (d == cc ? shift : 0.0);
         col[j] = v;
     }
     gj_inverse_rows<RP>(col, r, in_range ? lane : cc);
     if (lane == 0) rhoA[i] = rho;
+    const double rhs = act ? rhs_pre : 0.0;
+    if (lead) rhsA_out[(long)i * r + c] = (float)rhs;  // the `rhses` by-product
     if (!fused_inner) {
 #pragma unroll
         for (int j = 0; j < RL; ++j)
             if (dok[j]) LinvA[((long)i * r + drow[j]) * r + c] = (float)col[j];
         return;
     }
-    const float rhs = act ? rhs_pre : 0.f;
-    if (lead && seg_rhs != nullptr) rhsA_out[(long)i * r + c] = rhs;
 #pragma unroll
     for (int k = 0; k < MCL_MAX_REGS; ++k) {
         if (!(k < n && act)) z[k] = u[k] = 0.f;
@@ -879,12 +964,12 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(const float *__restrict__
 #pragma unroll
         for (int k = 0; k < MCL_MAX_REGS; ++k)
             if (k < n) sacc += z[k] - u[k];
-        const float t = (n > 0) ? fmaf(rho, sacc, rhs) : rhs;
+        const double t = (n > 0) ? fma((double)rho, (double)sacc, rhs) : rhs;
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < RL; ++j) {
-            const float td = bperm_f32(g * RP + g * RL + j, t);  // t_d, d = g RL + j (column d of my own group)
-            if (g * RL + j < r) acc += (double)td * col[j];
+            const double td = bperm_f64(g * RP + g * RL + j, t);  // t_d, d = g RL + j (column d of my own group)
+            if (g * RL + j < r) acc = fma(td, col[j], acc);
         }
         a = (float)group_sum(acc);
 #pragma unroll
@@ -914,11 +999,11 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(const float *__restrict__
 #pragma unroll
     for (int j = 0; j < RL; ++j) {
         ad[j] = bperm_f32(g * RP + g * RL + j, a);  // a_d
-        if (g * RL + j < r) qa += (double)qf[j] * (double)ad[j];
+        if (g * RL + j < r) qa += qf[j] * (double)ad[j];
     }
     qa = group_sum(qa);
     // the contributions live in the lead lanes [0, RP): DPP row reductions (no LDS round trips), result in lane 0
-    const double inner_i = lead_sum<RP>(lead ? (double)rhs * (double)a : 0.0);
+    const double inner_i = lead_sum<RP>(lead ? rhs * (double)a : 0.0);
     const double model_i = lead_sum<RP>(lead ? (double)a * qa : 0.0);
     const double nf = lead_sum<RP>(lead ? (double)a * (double)a : 0.0);
     const double na = lead_sum<RP>(lead ? fabs((double)a) : 0.0);
@@ -944,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(const float *__restrict__
         for (int j = 0; j < RL; ++j) {
             const int d = g * RL + j;
             double v = (d == cc) ? 1.0 : 0.0;
-            if (dok[j]) v = (double)ctc[j] * (double)ad[j] * (double)a;
+            if (dok[j]) v = ctc[j] * (double)ad[j] * (double)a;
             if (dok[j] && d == cc) trb = v;
             col[j] = v;
         }
@@ -963,12 +1048,12 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(const float *__restrict__
 }
 
 // rho_i of the A-phase alone (needed before the systems when the feasibility penalty is constant)
-__global__ void k_A_rho(const float *__restrict__ BtB, const float *__restrict__ CtC, int I, int r, float scale,
+__global__ void k_A_rho(const double *__restrict__ BtB, const double *__restrict__ CtC, int I, int r, float scale,
                         float *__restrict__ rhoA, float *__restrict__ rho_max) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= I) return;
     double s = 0.0;
-    for (int c = 0; c < r; ++c) s += (double)BtB[((long)i * r + c) * r + c] * (double)CtC[c * r + c];
+    for (int c = 0; c < r; ++c) s += BtB[((long)i * r + c) * r + c] * CtC[c * r + c];
     const float rho = (float)(0.5 * s * scale);
     rhoA[i] = rho;
     atomicMax(reinterpret_cast<int *>(rho_max + 1), __float_as_int(rho));
@@ -1192,7 +1277,7 @@ bool mcl_mode_is_row_separable(const mcl_context *c, int mode) {
 
 int mcl_launch_ctc(mcl_context *c) {
     const int RPc = c->RP < 4 ? 4 : c->RP;
-    hipLaunchKernelGGL(k_ctc, dim3((unsigned)c->r), dim3(256), 0, c->stream, c->C, (int)c->K, c->r, RPc, c->CtC);
+    hipLaunchKernelGGL(k_ctc, dim3((unsigned)c->r), dim3(256), 0, c->stream, c->C, (int)c->K, c->r, RPc, c->CtC, c->CtC64);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
@@ -1200,7 +1285,7 @@ int mcl_launch_ctc(mcl_context *c) {
 int mcl_launch_B_rho(mcl_context *c) {
     MCL_CHECK_HIP(c, hipMemsetAsync(c->rho_max, 0, sizeof(float), c->stream));
     if (c->I == 0) return 0;
-    hipLaunchKernelGGL(k_B_rho, dim3((unsigned)((c->I + 255) / 256)), dim3(256), 0, c->stream, c->CtC, c->A, (int)c->I,
+    hipLaunchKernelGGL(k_B_rho, dim3((unsigned)((c->I + 255) / 256)), dim3(256), 0, c->stream, c->CtC64, c->A, (int)c->I,
                        c->r, (float)c->opt.feasibility_penalty_scale, c->rhoB, c->rho_max);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
@@ -1209,16 +1294,33 @@ int mcl_launch_B_rho(mcl_context *c) {
 int mcl_launch_B_systems(mcl_context *c) {
     if (c->I == 0) return 0;
     dim3 grid((unsigned)((c->I + 3) / 4)), block(256);
-    DISPATCH_RP_T(c, k_B_systems, grid, block, c->CtC, c->A, (int)c->I, c->r, (float)c->opt.feasibility_penalty_scale,
-                  (float)c->opt.l2_penalty[1], c->regs[1].n, c->opt.constant_B, c->rho_max, c->rhoB, c->LinvB);
+    DISPATCH_RP_T(c, k_B_systems, grid, block, c->CtC64, c->A, (int)c->I, c->r, (float)c->opt.feasibility_penalty_scale,
+                  (float)c->opt.l2_penalty[1], c->regs[1].n, c->opt.constant_B, c->rho_max, c->rhoB, c->LinvB, c->LinvB64);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int mcl_launch_B_solve_f64(mcl_context *c) {
+    if (c->tilesB.n_tiles == 0) return 0;
+    dim3 grid((unsigned)((c->tilesB.n_tiles + 3) / 4)), block(256);
+    DISPATCH_RP_T(c, k_B_solve_f64, grid, block, c->tilesB.slab, c->tilesB.row0, c->tilesB.nrows, c->tilesB.n_tiles, c->XC,
+                  c->A, c->LinvB64, c->r, c->B);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
 
 int mcl_launch_C_prepare(mcl_context *c) {
-    dim3 grid(1), block(64);
-    DISPATCH_RP_T(c, k_C_prepare, grid, block, c->GR, c->r, (float)c->opt.feasibility_penalty_scale,
-                  (float)c->opt.l2_penalty[2], c->regs[2].n, c->rhoC, c->LinvC);
+    dim3 grid((unsigned)(1 + (c->K * c->r + 63) / 64)), block(64);
+    DISPATCH_RP_T(c, k_C_prepare, grid, block, c->GR, c->r, (int)c->K, (float)c->opt.feasibility_penalty_scale,
+                  (float)c->opt.l2_penalty[2], c->regs[2].n, c->rhoC, c->LinvC, c->LinvC64, c->GRf + (long)c->r * c->r);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int mcl_launch_C_solve_f64(mcl_context *c) {
+    const long n = (long)c->K * c->r;
+    hipLaunchKernelGGL(k_C_solve_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), sizeof(double) * c->r * c->r, c->stream,
+                       c->GR + (long)c->r * c->r, c->LinvC64, (int)c->K, c->r, c->C);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
@@ -1261,7 +1363,7 @@ int mcl_rows_fused_dispatch(mcl_context *c, int mode, double *diag) {
     const RegSet &rs = c->regs[mode];
     const TileMap &tm = (mode == 1) ? c->tilesB : c->tilesC;
     if (tm.n_tiles == 0) return 0;
-    const float *rhs = (mode == 1) ? c->XC : c->GR + (long)c->r * c->r;
+    const float *rhs = (mode == 1) ? c->XC : c->GRf + (long)c->r * c->r;  // fp32 image of R (k_C_prepare)
     const float *Arows = (mode == 1) ? c->A : nullptr;
     const float *rho = (mode == 1) ? c->rhoB : c->rhoC;
     const float *Linv = (mode == 1) ? c->LinvB : c->LinvC;
@@ -1293,9 +1395,7 @@ int mcl_launch_rows_fused(mcl_context *c, int mode) {
 template <int NBR, int NREG>
 static int launch_C_fused_t(mcl_context *c) {
     const RegSet &rs = c->regs[2];
-    const float *rhs = c->GR + (long)c->r * c->r;
-    bool vec = (c->r % 4 == 0) && ((reinterpret_cast<uintptr_t>(rhs) & 15) == 0) &&
-               ((reinterpret_cast<uintptr_t>(c->C) & 15) == 0) && ((c->r * c->r) % 4 == 0);
+    bool vec = (c->r % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->C) & 15) == 0) && ((c->r * c->r) % 4 == 0);
     for (int k = 0; k < rs.n; ++k)
         vec = vec && ((reinterpret_cast<uintptr_t>(rs.aux[k]) & 15) == 0) && ((reinterpret_cast<uintptr_t>(rs.dual[k]) & 15) == 0);
     const int rpw = c->K <= 256 ? 16 : (c->K <= 512 ? 32 : 64);
@@ -1311,7 +1411,7 @@ static int launch_C_fused_t(mcl_context *c) {
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));               \
         hipLaunchKernelGGL((k_C_finish_fused<NBR, NREG, VEC_>), dim3(1), dim3(64 * n_waves), sm, c->stream, c->GR,    \
                            (int)c->K, c->r, (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[2],     \
-                           c->rhoC, c->LinvC, c->C, rs, c->opt.inner_n_iter_max, c->CtC, c->Cfrag, mcl_cfrag_chunks(c), c->NB,         \
+                           c->rhoC, c->LinvC, c->C, rs, c->opt.inner_n_iter_max, c->CtC, c->CtC64, c->Cfrag, mcl_cfrag_chunks(c), c->NB, \
                            c->diagC_tile, rpw);                                                                       \
     } while (0)
     if (vec) MCL_CF(true);
@@ -1348,7 +1448,7 @@ int mcl_launch_C_finish_fused(mcl_context *c) {
 int mcl_launch_A_rho(mcl_context *c) {
     MCL_CHECK_HIP(c, hipMemsetAsync(c->rho_max + 1, 0, sizeof(float), c->stream));
     if (c->I == 0) return 0;
-    hipLaunchKernelGGL(k_A_rho, dim3((unsigned)((c->I + 255) / 256)), dim3(256), 0, c->stream, c->BtB, c->CtC,
+    hipLaunchKernelGGL(k_A_rho, dim3((unsigned)((c->I + 255) / 256)), dim3(256), 0, c->stream, c->seg_btb, c->CtC64,
                        (int)c->I, c->r, (float)c->opt.feasibility_penalty_scale, c->rhoA, c->rho_max);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
@@ -1357,16 +1457,15 @@ int mcl_launch_A_rho(mcl_context *c) {
 int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     if (c->I == 0) return 0;
     // also prepare the next B-phase's systems when that is exact: fused inner loop, per-slab rho for B
-    const int next_B = (fused_inner && !c->opt.constant_B && !getenv("MCL_NO_NEXT_B")) ? 1 : 0;
+    const int next_B = (fused_inner && !c->opt.constant_B && c->regs[1].n > 0 && !getenv("MCL_NO_NEXT_B")) ? 1 : 0;
     const bool seg = c->use_seg_gram;
     dim3 grid((unsigned)((c->I + 3) / 4)), block(256);
 #define MCL_AF_ARGS                                                                                                   \
-    c->rhsA, c->BtB, c->CtC, (int)c->I, c->r, (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[0],   \
+    c->BtB, c->CtC64, (int)c->I, c->r, (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[0],          \
         c->opt.constant_A, c->rho_max, c->rhoA, c->LinvA, c->A, c->regs[0], c->opt.inner_n_iter_max,                  \
         fused_inner ? 1 : 0, c->e1, c->diagA_row, next_B, (float)c->opt.l2_penalty[1], c->regs[1].n, c->rhoB, c->LinvB, \
-        (const int *)(c->seg_from_sweep ? c->slab_bseg_ptr : c->slab_seg_ptr),                                        \
-        (const float *)(seg ? c->seg_rhs : nullptr),                                                                  \
-        (const float *)(seg ? (c->seg_from_sweep ? c->part_btb : c->seg_btb) : nullptr), c->rhsA
+        (const int *)(seg ? (c->seg_from_sweep ? c->slab_bseg_ptr : c->slab_seg_ptr) : nullptr),                      \
+        (const double *)c->seg_rhs, (const double *)((seg && c->seg_from_sweep) ? c->part_btb : c->seg_btb), c->rhsA
     // ranks 5..32: rows of every system split over the lane groups (all 64 lanes busy); 64 columns fill the wave anyway
     if (c->RP == 64 || c->RP == 4 || getenv("MCL_A_FINISH_COLS")) {
         DISPATCH_RP_T(c, k_A_finish, grid, block, MCL_AF_ARGS);

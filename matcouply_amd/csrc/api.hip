@@ -57,7 +57,7 @@ int64_t plan(mcl_context *c, char *base) {
         tm(c->bsegs, c->h_bseg_slab.size());
         c->slab_bseg_ptr = b.take<int>(I + 1);
         c->Mpart = b.take<float>((int64_t)c->bsegs.n_tiles * mcl_sweep_KS(c) * 256 * 16 * c->NB);
-        c->part_btb = b.take<float>((int64_t)c->bsegs.n_tiles * r * r);
+        c->part_btb = b.take<double>((int64_t)c->bsegs.n_tiles * r * r);
         c->GRpart = b.take<float>((int64_t)c->bsegs.n_tiles * (mcl_sweep_KS(c) * 256 * 16 * c->NB + 256 * c->NB * c->NB));
         c->CfragS = nullptr;  // aliases Cfrag (below)
         c->sweep_cycles = b.take<long long>((int64_t)2048 * 6);
@@ -73,15 +73,19 @@ int64_t plan(mcl_context *c, char *base) {
     c->Cfrag = b.take<float>((int64_t)mcl_cfrag_chunks(c) * 4 * c->NB * 256);
     if (c->sweep_planned) c->CfragS = c->Cfrag;
     c->CtC = b.take<float>(r * r);
+    c->CtC64 = b.take<double>(r * r);
     c->rhoB = b.take<float>(I);
     c->LinvB = b.take<float>(I * r * r);
+    c->LinvB64 = (c->regs[1].n == 0) ? b.take<double>(I * r * r) : nullptr;
     c->rho_max = b.take<float>(2);
-    c->partials = b.take<float>((int64_t)mcl_contract_n_partials(c) * E);
-    c->GR = b.take<float>(E);
+    c->partials = b.take<double>((int64_t)mcl_contract_n_partials(c) * E);
+    c->GR = b.take<double>(E);
+    c->GRf = b.take<float>(E);
+    c->LinvC64 = b.take<double>(r * r);
     c->rhoC = b.take<float>(1);
     c->LinvC = b.take<float>(r * r);
-    c->seg_rhs = b.take<float>((int64_t)std::max(c->segs.n_tiles, c->bsegs.n_tiles) * r);
-    c->seg_btb = b.take<float>((int64_t)c->segs.n_tiles * r * r);
+    c->seg_rhs = b.take<double>(std::max<int64_t>(std::max(c->segs.n_tiles, c->bsegs.n_tiles), I) * r);
+    c->seg_btb = b.take<double>(std::max<int64_t>(c->segs.n_tiles, I) * r * r);
     c->slab_seg_ptr = b.take<int>(I + 1);
     c->rhsA = b.take<float>(I * r);
     c->BtB = b.take<float>(I * r * r);
@@ -412,7 +416,9 @@ int mcl_set_penalties(mcl_context *c, int32_t mode, int32_t n, const mcl_penalty
 
 int64_t mcl_workspace_bytes(mcl_context *c) {
     if (!c || !c->has_problem) return -1;
-    return plan(c, nullptr);
+    const int64_t need = plan(c, nullptr);
+    if (c->has_workspace) plan(c, c->ws);  // a size query must leave an installed workspace as it was
+    return need;
 }
 
 int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
@@ -511,6 +517,7 @@ int mcl_B_solve(mcl_context *c) {
         if (int rc = mcl_launch_rows_finish_fused(c, 1, false)) return rc;
     }
     if (c->step_stats) return mcl_launch_rows_solve_stats(c);
+    if (c->regs[1].n == 0) return mcl_launch_B_solve_f64(c);
     return mcl_launch_rows_solve(c, 1);
 }
 
@@ -576,6 +583,10 @@ int mcl_update_B(mcl_context *c) {
     c->e1_valid = false;
     if (c->opt.inner_n_iter_max <= 0) return 0;
     c->mseg_valid = c->grpart_valid = false;
+    if (c->regs[1].n == 0) {  // plain least-squares update of B: un-shifted systems, solved in fp64
+        c->diag_valid[1] = false;
+        return mcl_launch_B_solve_f64(c);
+    }
     if (mcl_mode_is_row_separable(c, 1)) {
         const int rc = mcl_launch_rows_fused(c, 1);
         if (rc == 0) {
@@ -595,7 +606,7 @@ int mcl_update_C_local(mcl_context *c) {
     return mcl_launch_reduce_partials(c);
 }
 
-float *mcl_c_normal_equations(mcl_context *c, int64_t *count) {
+double *mcl_c_normal_equations(mcl_context *c, int64_t *count) {
     if (!c || !c->has_workspace) {
         if (count) *count = 0;
         return nullptr;
@@ -624,6 +635,10 @@ int mcl_update_C_finish(mcl_context *c) {
     c->xc_valid = c->ctc_valid = c->e1_valid = false;
     c->cfrag_valid = false;
     c->b_systems_valid = false;
+    if (c->regs[2].n == 0) {  // un-shifted normal equations: the solve runs in fp64
+        c->diag_valid[2] = false;
+        return mcl_launch_C_solve_f64(c);
+    }
     if (mcl_mode_is_row_separable(c, 2)) {
         const int rc = mcl_launch_rows_fused(c, 2);
         if (rc == 0) {

@@ -9,11 +9,14 @@
 // Both X passes are HBM-bound (r/2 flop per byte); v_mfma_f32_16x16x4_f32 does the contraction so that the
 // VALU stays free for address/guard work, and every global load of X is a 16-byte-per-lane load of
 // 256-byte row segments (4 rows per wave instruction).
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "mcl_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -32,19 +35,24 @@ static __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.
 // the compiler keeps DEPTH groups in flight with counted s_waitcnt vmcnt(N): rows past the segment end get a
 // zero B-operand, columns past K land in accumulator rows that are never written out.
 // ---------------------------------------------------------------------------------------------------------
-template <int KB, int NB, int VEC, int DEPTH>
+// MODE 0: R slice of blockIdx.y, and G in the blocks with blockIdx.y == 0.  Rank > 32 (NB = 4) has no registers for both
+// accumulator sets with their fp64 shadows: MODE 1 (R only) and MODE 2 (G only, one launch with gridDim.y = 1, X untouched).
+template <int KB, int NB, int VEC, int DEPTH, int MODE>
 __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X, const float *__restrict__ B,
                                                      const float *__restrict__ A, const int *__restrict__ seg_slab,
                                                      const int *__restrict__ seg_row0, const int *__restrict__ seg_rows,
                                                      int n_segs, int segs_per_wave, int K, int r,
-                                                     float *__restrict__ part, int part_stride, int dbg) {
+                                                     double *__restrict__ part, int part_stride, int flush_trips,
+                                                     int dbg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rsub = lane >> 4, c16 = lane & 15;
     const int kbase = blockIdx.y * (64 * KB);
     const int w = blockIdx.x * 4 + wave;
     const int s0 = w * segs_per_wave;
     const int s1 = min(s0 + segs_per_wave, n_segs);
-    const bool doG = (blockIdx.y == 0);
+    constexpr bool DO_R = MODE != 2;
+    constexpr int NG_ = (MODE == 1) ? 1 : NB;  // extent of the G accumulator arrays
+    const bool doG = (MODE == 2) || (MODE == 0 && blockIdx.y == 0);
 
     int kcol[KB];
 #pragma unroll
@@ -61,18 +69,48 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
         bcol[nb] = min(16 * nb + c16, r - 1);
     }
 
+    // fp32 MFMA chains are kept SHORT: every `flush_trips` trips of the group loop (and at every segment end) the fp32
+    // accumulators are added into fp64 shadows and cleared, so the rounding of a chain is relative to a few rows' worth
+    // of products, not to the running total - the normal equations of a penalty-free mode amplify every relative error
+    // of [G | R] by their condition number (decomposition.py:307-331).
     f32x4 acc[KB][4][NB];
-    f32x4 accG[NB][NB];
+    f32x4 accG[NG_][NG_];
+    f64x4 dacc[KB][4][NB];
+    f64x4 daccG[NG_][NG_];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[kb][m][nb] = zero4();
+            for (int nb = 0; nb < NB; ++nb) acc[kb][m][nb] = zero4(), dacc[kb][m][nb] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int a = 0; a < NB; ++a)
+    for (int a = 0; a < NG_; ++a)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) accG[a][b] = zero4();
+        for (int b = 0; b < NG_; ++b) accG[a][b] = zero4(), daccG[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    auto flush = [&]() {
+        if (DO_R) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) dacc[kb][m][nb][v] += (double)acc[kb][m][nb][v];
+                        acc[kb][m][nb] = zero4();
+                    }
+        }
+        if (MODE != 1 && doG) {
+#pragma unroll
+            for (int a = 0; a < NG_; ++a)
+#pragma unroll
+                for (int b = 0; b < NG_; ++b) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) daccG[a][b][v] += (double)accG[a][b][v];
+                    accG[a][b] = zero4();
+                }
+        }
+    };
 
     for (int sg = s0; sg < s1; ++sg) {
         const int slab = __builtin_amdgcn_readfirstlane(seg_slab[sg]);
@@ -89,7 +127,7 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
             const int rl = 4 * g + rsub;
             const long j = row0 + min(rl, nrows - 1);
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
+            for (int kb = 0; kb < (DO_R ? KB : 0); ++kb) {
                 if (VEC == 4) {
                     fx[d][kb] = *reinterpret_cast<const f32x4 *>(X + j * K + kcol[kb]);
                 } else {
@@ -107,43 +145,52 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
         };
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) load(d, d);
+        int trips = 0;
         for (int g = 0; g < ng; g += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 float ba[NB];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) ba[nb] = fb[d][nb] * fa[d][nb];
-                if (dbg & 1) {  // timing experiment: loads only
+                if (DO_R && (dbg & 1)) {  // timing experiment: loads only
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb) acc[kb][0][0] += fx[d][kb] * ba[0];
                     load(d, g + DEPTH + d);
                     continue;
                 }
+                if (DO_R) {
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
+                    for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
+                        for (int m = 0; m < 4; ++m)
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) acc[kb][m][nb] = MFMA16(fx[d][kb][m], ba[nb], acc[kb][m][nb]);
-                if (doG) {
+                            for (int nb = 0; nb < NB; ++nb) acc[kb][m][nb] = MFMA16(fx[d][kb][m], ba[nb], acc[kb][m][nb]);
+                }
+                if (MODE != 1 && doG) {
 #pragma unroll
-                    for (int a = 0; a < NB; ++a)
+                    for (int a = 0; a < NG_; ++a)
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) accG[a][b] = MFMA16(ba[a], ba[b], accG[a][b]);
+                        for (int b = 0; b < NG_; ++b) accG[a][b] = MFMA16(ba[a], ba[b], accG[a][b]);
                 }
                 load(d, g + DEPTH + d);
             }
+            if (++trips == flush_trips) {  // wave-uniform; no memory operation inside: the counted vmcnt waits are unaffected
+                flush();
+                trips = 0;
+            }
         }
+        flush();
     }
 
-    // deterministic cross-wave reduction through LDS, then one partial slab per block
+    // deterministic cross-wave reduction through LDS (fp64), then one fp64 partial slab per block
     constexpr int W = 16 * NB;
-    __shared__ float lds[64 * KB * W + W * W];
-    float *ldsG = lds + 64 * KB * W;
+    constexpr int LR = DO_R ? 64 * KB * W : 0, LG = (MODE != 1) ? W * W : 0;
+    __shared__ double lds[LR + LG];
+    double *ldsG = lds + LR;
     for (int wv = 0; wv < 4; ++wv) {
         if (wave == wv) {
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
+            for (int kb = 0; kb < (DO_R ? KB : 0); ++kb)
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -152,29 +199,29 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
                         for (int v = 0; v < 4; ++v) {
                             const int kl = 64 * kb + 4 * (4 * rsub + v) + m;
                             const int idx = kl * W + 16 * nb + c16;
-                            lds[idx] = (wv == 0) ? acc[kb][m][nb][v] : lds[idx] + acc[kb][m][nb][v];
+                            lds[idx] = (wv == 0) ? dacc[kb][m][nb][v] : lds[idx] + dacc[kb][m][nb][v];
                         }
-            if (doG) {
+            if (MODE != 1 && doG) {
 #pragma unroll
-                for (int a = 0; a < NB; ++a)
+                for (int a = 0; a < NG_; ++a)
 #pragma unroll
-                    for (int b = 0; b < NB; ++b)
+                    for (int b = 0; b < NG_; ++b)
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             const int idx = (16 * a + 4 * rsub + v) * W + 16 * b + c16;
-                            ldsG[idx] = (wv == 0) ? accG[a][b][v] : ldsG[idx] + accG[a][b][v];
+                            ldsG[idx] = (wv == 0) ? daccG[a][b][v] : ldsG[idx] + daccG[a][b][v];
                         }
             }
         }
         __syncthreads();
     }
-    float *out = part + (long)blockIdx.x * part_stride;
-    for (int e = threadIdx.x; e < 64 * KB * W; e += 256) {
+    double *out = part + (long)blockIdx.x * part_stride;
+    for (int e = threadIdx.x; e < LR; e += 256) {
         const int kl = e / W, n = e - kl * W;
         const int k = kbase + kl;
         if (k < K && n < r) out[r * r + k * r + n] = lds[e];
     }
-    if (doG) {
+    if (MODE != 1 && doG) {
         for (int e = threadIdx.x; e < W * W; e += 256) {
             const int a = e / W, b = e - a * W;
             if (a < r && b < r) out[a * r + b] = ldsG[e];
@@ -183,15 +230,15 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
 }
 
 // GR[e] = sum_p part[p][e]; fixed summation order (deterministic, identical on every rank for identical input)
-__global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict__ part, int n_part, int E,
-                                                         float *__restrict__ out) {
-    __shared__ float sm[4][64];
+__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ part, int n_part, int E,
+                                                         double *__restrict__ out) {
+    __shared__ double sm[4][64];
     const int el = threadIdx.x & 63, pc = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
-    float s = 0.f;
+    double s = 0.0;
     if (e < E) {
         int p = pc;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         for (; p + 12 < n_part; p += 16) {
             s0 += part[(long)p * E + e];
             s1 += part[(long)(p + 4) * E + e];
@@ -390,7 +437,7 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
                                                          const int *__restrict__ seg_row0,
                                                          const int *__restrict__ seg_rows, int n_segs,
                                                          int segs_per_wave, int K, int r,
-                                                         float *__restrict__ seg_rhs, float *__restrict__ seg_btb) {
+                                                         double *__restrict__ seg_rhs, double *__restrict__ seg_btb) {
     extern __shared__ float lds_dyn[];  // 4 waves x 16 rows x 256 floats
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, i16 = lane & 15;
@@ -438,9 +485,15 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
         }
     };
 
-    f32x4 acc[NB];
+    // four independent fp32 chains per output (one per 64-column chunk of a super-chunk), summed pairwise at the end of
+    // the block: the rounding of a K-long dot product grows with the chain length, and the B right-hand sides feed
+    // every later phase of the iteration
+    constexpr int NCH = (NB == 4) ? 1 : 4;  // rank > 32 has no registers for more than one chain
+    f32x4 acc4[NCH][NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[nb] = zero4();
+    for (int kc = 0; kc < NCH; ++kc)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc4[kc][nb] = zero4();
 
     long row0 = __builtin_amdgcn_readfirstlane(seg_row0[s0]);
     int nrows = __builtin_amdgcn_readfirstlane(seg_rows[s0]);
@@ -454,13 +507,16 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
             nrow0 = __builtin_amdgcn_readfirstlane(seg_row0[sg + 1]);
             nnrows = __builtin_amdgcn_readfirstlane(seg_rows[sg + 1]);
         }
-        float p[NB];
-        f32x4 accG[NB][NB];
+        // per-segment reductions in fp64: the products b * xc and b * b' of fp32 values are exact in fp64, so the only
+        // rounding left in rhs_i and B_i^T B_i is the fp32 rounding of X C itself (the A-phase systems of a penalty-free
+        // mode are not shifted and amplify every relative error of these sums)
+        double p[NB];
+        f64x4 accG[NB][NB];
 #pragma unroll
         for (int a = 0; a < NB; ++a) {
-            p[a] = 0.f;
+            p[a] = 0.0;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) accG[a][b] = zero4();
+            for (int b = 0; b < NB; ++b) accG[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
         }
         for (int blk = 0; blk < nblk; ++blk) {
             float bcur[NB][4];
@@ -516,10 +572,18 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
 #pragma unroll
                         for (int m = 0; m < 4; ++m)
 #pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA16(fr[kq][m], cf[kq][nb][m], acc[nb]);
+                            for (int nb = 0; nb < NB; ++nb) acc4[kc % NCH][nb] = MFMA16(fr[kq][m], cf[kq][nb][m], acc4[kc % NCH][nb]);
                 }
             }
             // epilogue of the 16-row block
+            f32x4 acc[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                if (NCH == 4) acc[nb] = (acc4[0][nb] + acc4[1][nb]) + (acc4[2 % NCH][nb] + acc4[3 % NCH][nb]);
+                else acc[nb] = acc4[0][nb];
+#pragma unroll
+                for (int kc = 0; kc < NCH; ++kc) acc4[kc][nb] = zero4();
+            }
             float bv[NB][4];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -533,10 +597,9 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
                     if (GRAM) {
                         const float b = ok ? bcur[nb][v] : 0.f;
                         bv[nb][v] = b;
-                        p[nb] = fmaf(b, acc[nb][v], p[nb]);
+                        p[nb] = fma((double)b, (double)acc[nb][v], p[nb]);
                     }
                 }
-                acc[nb] = zero4();
             }
             if (GRAM) {
 #pragma unroll
@@ -544,25 +607,27 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
 #pragma unroll
                     for (int a = 0; a < NB; ++a)
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) accG[a][b] = MFMA16(bv[a][v], bv[b][v], accG[a][b]);
+                        for (int b = 0; b < NB; ++b)
+                            accG[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)bv[a][v], (double)bv[b][v], accG[a][b], 0, 0, 0);
             }
         }
         if (GRAM) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                float t = p[nb];
+                double t = p[nb];
                 t += __shfl_xor(t, 16);
                 t += __shfl_xor(t, 32);
                 const int col = 16 * nb + i16;
                 if (q == 0 && col < r) seg_rhs[(long)sg * r + col] = t;
             }
+            // D layout of the f64 MFMA: row = (l >> 4) + 4 reg, col = l & 15
 #pragma unroll
             for (int a = 0; a < NB; ++a)
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        const int ra = 16 * a + 4 * q + v, cb = 16 * b + i16;
+                        const int ra = 16 * a + q + 4 * v, cb = 16 * b + i16;
                         if (ra < r && cb < r) seg_btb[((long)sg * r + ra) * r + cb] = accG[a][b][v];
                     }
         }
@@ -572,31 +637,34 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_slab_gram : one workgroup per slab.  rhs_i[c] = sum_j B[j][c] XC[j][c];  BtB_i = B_i^T B_i (MFMA).
+// k_slab_gram : one workgroup per slab.  rhs_i[c] = sum_j B[j][c] XC[j][c];  BtB_i = B_i^T B_i (fp64 MFMA: exact products).
+// Writes the fp64 per-slab tables k_A_finish reads (one "segment" per slab) and their fp32 images (rhses by-product,
+// k_A_e1).
 // ---------------------------------------------------------------------------------------------------------
 template <int NB>
 __global__ __launch_bounds__(256) void k_slab_gram(const float *__restrict__ B, const float *__restrict__ XC,
                                                    const int *__restrict__ row_ptr, int r, float *__restrict__ rhsA,
-                                                   float *__restrict__ BtB) {
+                                                   float *__restrict__ BtB, double *__restrict__ rhs64,
+                                                   double *__restrict__ btb64) {
     constexpr int W = 16 * NB;
-    __shared__ float ldsG[W * W];
-    __shared__ float ldsP[4][W];
+    __shared__ double ldsG[W * W];
+    __shared__ double ldsP[4][W];
     const int slab = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rsub = lane >> 4, c16 = lane & 15;
     const int s = row_ptr[slab], e = row_ptr[slab + 1];
     const int n_groups = (e - s + 3) >> 2;
-    float p[NB];
-    f32x4 accG[NB][NB];
+    double p[NB];
+    f64x4 accG[NB][NB];
 #pragma unroll
     for (int a = 0; a < NB; ++a) {
-        p[a] = 0.f;
+        p[a] = 0.0;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) accG[a][b] = zero4();
+        for (int b = 0; b < NB; ++b) accG[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
     }
     for (int g = wave; g < n_groups; g += 4) {
         const long j = (long)s + 4 * g + rsub;
-        float bv[NB];
+        double bv[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int col = 16 * nb + c16;
@@ -605,13 +673,13 @@ __global__ __launch_bounds__(256) void k_slab_gram(const float *__restrict__ B, 
                 b = B[j * r + col];
                 x = XC[j * r + col];
             }
-            bv[nb] = b;
-            p[nb] += b * x;
+            bv[nb] = (double)b;
+            p[nb] = fma((double)b, (double)x, p[nb]);
         }
 #pragma unroll
         for (int a = 0; a < NB; ++a)
 #pragma unroll
-            for (int b = 0; b < NB; ++b) accG[a][b] = MFMA16(bv[a], bv[b], accG[a][b]);
+            for (int b = 0; b < NB; ++b) accG[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[a], bv[b], accG[a][b], 0, 0, 0);
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -627,7 +695,7 @@ __global__ __launch_bounds__(256) void k_slab_gram(const float *__restrict__ B, 
                 for (int b = 0; b < NB; ++b)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        const int idx = (16 * a + 4 * rsub + v) * W + 16 * b + c16;
+                        const int idx = (16 * a + rsub + 4 * v) * W + 16 * b + c16;  // f64 MFMA D layout
                         ldsG[idx] = (wv == 0) ? accG[a][b][v] : ldsG[idx] + accG[a][b][v];
                     }
         }
@@ -635,11 +703,16 @@ __global__ __launch_bounds__(256) void k_slab_gram(const float *__restrict__ B, 
     }
     for (int t = threadIdx.x; t < W * W; t += 256) {
         const int a = t / W, b = t - a * W;
-        if (a < r && b < r) BtB[((long)slab * r + a) * r + b] = ldsG[t];
+        if (a < r && b < r) {
+            BtB[((long)slab * r + a) * r + b] = (float)ldsG[t];
+            btb64[((long)slab * r + a) * r + b] = ldsG[t];
+        }
     }
-    if (threadIdx.x < W && (int)threadIdx.x < r)
-        rhsA[(long)slab * r + threadIdx.x] =
-            (ldsP[0][threadIdx.x] + ldsP[1][threadIdx.x]) + (ldsP[2][threadIdx.x] + ldsP[3][threadIdx.x]);
+    if (threadIdx.x < W && (int)threadIdx.x < r) {
+        const double t = (ldsP[0][threadIdx.x] + ldsP[1][threadIdx.x]) + (ldsP[2][threadIdx.x] + ldsP[3][threadIdx.x]);
+        rhsA[(long)slab * r + threadIdx.x] = (float)t;
+        rhs64[(long)slab * r + threadIdx.x] = t;
+    }
 }
 
 // =========================================================================================================
@@ -677,7 +750,7 @@ static int launch_xt(mcl_context *c) {
     xt_geometry(c, &spw, &nb);
     const int E = (int)(c->K * c->r + c->r * c->r);
     if (c->segs.n_tiles == 0) {  // no rows: the partial slab is all zeros
-        MCL_CHECK_HIP(c, hipMemsetAsync(c->partials, 0, sizeof(float) * (size_t)E, c->stream));
+        MCL_CHECK_HIP(c, hipMemsetAsync(c->partials, 0, sizeof(double) * (size_t)E, c->stream));
         c->n_part = 1;
         return 0;
     }
@@ -685,19 +758,24 @@ static int launch_xt(mcl_context *c) {
     const bool vec = (c->K % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->X) & 15) == 0);
     ProfScope prof(c, 1);
     int dbg = 0, depth = 4;
+    // rows per fp32 chain ~ sqrt(N) / 4: the rounding of the fp64 total then stays near 1e-8 relative at every problem
+    // size (chains of c rows, N / c of them: ~ 3e-8 c / sqrt(3 N)); big problems flush once per segment
+    int flush_rows = (int)(0.25 * std::sqrt((double)std::max<int64_t>(c->N, 1)));
+    if (const char *e = getenv("MCL_XT_FLUSH_ROWS")) flush_rows = atoi(e);
     if (const char *e = getenv("MCL_XT_DBG")) dbg = atoi(e);
     if (const char *e = getenv("MCL_XT_DEPTH")) depth = atoi(e);
-#define MCL_XT(VEC_, DEPTH_)                                                                                          \
-    hipLaunchKernelGGL((k_contract_xt<KB, NB, VEC_, DEPTH_>), grid, dim3(256), 0, c->stream, c->X, c->B, c->A,        \
+    constexpr int RMODE = (NB == 4) ? 1 : 0;
+#define MCL_XT(VEC_, DEPTH_, MODE_, GRID_)                                                                            \
+    hipLaunchKernelGGL((k_contract_xt<KB, NB, VEC_, DEPTH_, MODE_>), GRID_, dim3(256), 0, c->stream, c->X, c->B, c->A, \
                        c->segs.slab, c->segs.row0, c->segs.nrows, c->segs.n_tiles, spw, (int)c->K, c->r, c->partials, \
-                       E, dbg)
+                       E, std::max(1, flush_rows / (4 * DEPTH_)), dbg)
     if (vec) {
-        if (depth == 8 && KB * NB <= 4) MCL_XT(4, 8);
-        else if (depth == 2) MCL_XT(4, 2);
-        else MCL_XT(4, 4);
+        if (depth == 2) MCL_XT(4, 2, RMODE, grid);
+        else MCL_XT(4, 4, RMODE, grid);
     } else {
-        MCL_XT(1, 2);
+        MCL_XT(1, 2, RMODE, grid);
     }
+    if constexpr (NB == 4) MCL_XT(1, 2, 2, dim3(nb, 1));  // G of the same row ranges into the same partial slabs
 #undef MCL_XT
     c->n_part = nb;
     char buf[96];
@@ -771,10 +849,13 @@ static int launch_xc(mcl_context *c) {
     hipLaunchKernelGGL((k_contract_xc_row<NB, CREG_, GRAM_>), dim3(g), dim3(256), sm, c->stream, c->X, c->Cfrag,     \
                        c->XC, c->B, c->segs.row0, c->segs.nrows, n_segs, spw, (int)c->K, c->r, c->seg_rhs, c->seg_btb)
         if (n_segs > 0) {
-            if (creg) {
-                if (gram) MCL_XCR(true, true);
-                else MCL_XCR(true, false);
-            } else {
+            if constexpr (NB == 1) {  // resident C fragments: K = 256, rank <= 16 only
+                if (creg) {
+                    if (gram) MCL_XCR(true, true);
+                    else MCL_XCR(true, false);
+                }
+            }
+            if (!creg) {
                 if (gram) MCL_XCR(false, true);
                 else MCL_XCR(false, false);
             }
@@ -819,13 +900,13 @@ int mcl_launch_slab_gram(mcl_context *c) {
     dim3 grid((unsigned)c->I);
     if (c->NB == 1)
         hipLaunchKernelGGL(k_slab_gram<1>, grid, dim3(256), 0, c->stream, c->B, c->XC, c->row_ptr_dev, c->r, c->rhsA,
-                           c->BtB);
+                           c->BtB, c->seg_rhs, c->seg_btb);
     else if (c->NB == 2)
         hipLaunchKernelGGL(k_slab_gram<2>, grid, dim3(256), 0, c->stream, c->B, c->XC, c->row_ptr_dev, c->r, c->rhsA,
-                           c->BtB);
+                           c->BtB, c->seg_rhs, c->seg_btb);
     else
         hipLaunchKernelGGL(k_slab_gram<4>, grid, dim3(256), 0, c->stream, c->B, c->XC, c->row_ptr_dev, c->r, c->rhsA,
-                           c->BtB);
+                           c->BtB, c->seg_rhs, c->seg_btb);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

@@ -2010,7 +2010,7 @@ static bool rows_vec_ok(const mcl_context *c, const ModeView &mv, const RegSet &
 int mcl_launch_rows_solve(mcl_context *c, int mode) {
     ModeView mv = view_of(c, mode);
     if (mv.n_tiles == 0) return 0;
-    const float *rhs = (mode == 1) ? c->XC : c->GR + (long)c->r * c->r;
+    const float *rhs = (mode == 1) ? c->XC : c->GRf + (long)c->r * c->r;  // fp32 image of R (k_C_prepare)
     const float *Arows = (mode == 1) ? c->A : nullptr;
     const float *Linv = (mode == 1) ? c->LinvB : c->LinvC;
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);

@@ -74,7 +74,7 @@ struct mcl_context {
     TileMap bsegs;  // block segments (<= 1024 rows of one slab) of k_sweep (sweep.hip)
     int *slab_bseg_ptr = nullptr;  // int32[I+1] first bseg of every slab
     float *Mpart = nullptr;        // [n_bsegs, K * 16 NB]  per-bseg X^T B in C-fragment order
-    float *part_btb = nullptr;     // [n_bsegs, r, r]       per-bseg B^T B
+    double *part_btb = nullptr;    // [n_bsegs, r, r]       per-bseg B^T B (fp64 image of the fp32 accumulators)
     float *CfragS = nullptr;       // the sweep's view of the fragment image of C (aliases Cfrag: one shared image)
     float *GRpart = nullptr;       // [n_bsegs, K * 16 NB + (16 NB)^2]  per-bseg a-weighted partial of [G | R]
     int n_grpart = 0;
@@ -86,15 +86,19 @@ struct mcl_context {
     float *XC = nullptr;        // [N, r]   X C  (cached between the A-phase and the next B-phase)
     float *Cfrag = nullptr;     // C in MFMA-fragment order for the X C kernel
     float *CtC = nullptr;       // [r, r]
+    double *CtC64 = nullptr;    // [r, r] the same product before its rounding to fp32 (systems of the A- and B-phase)
     float *rhoB = nullptr;      // [I]
     float *LinvB = nullptr;     // [I, r, r]
+    double *LinvB64 = nullptr;  // [I, r, r] fp64 copy, only when mode 1 has no penalty (fp64 solve of the un-shifted systems)
     float *rho_max = nullptr;   // [2]  (0: B-phase, 1: A-phase)
-    float *partials = nullptr;  // [n_part, K*r + r*r]
-    float *GR = nullptr;        // [r*r + K*r]
+    double *partials = nullptr; // [n_part, K*r + r*r]  per-block fp64 partials of the X^T (B o a) pass
+    double *GR = nullptr;       // [r*r + K*r]  fp64 normal equations of the C-phase (all-reduced by a multi-GPU host)
+    float *GRf = nullptr;       // fp32 image of R for the fp32 row kernels (written by k_C_prepare)
+    double *LinvC64 = nullptr;  // [r, r] fp64 copy of the C-phase inverse (penalty-free C: fp64 solve)
     float *rhoC = nullptr;      // [1]
     float *LinvC = nullptr;     // [r, r]
-    float *seg_rhs = nullptr;   // [n_segs, r]     per-segment partial rhs_i (fused X C epilogue)
-    float *seg_btb = nullptr;   // [n_segs, r, r]  per-segment partial B_i^T B_i
+    double *seg_rhs = nullptr;  // [max(n_segs, n_bsegs, I), r]  fp64 per-segment (per-bseg / per-slab) partial rhs_i
+    double *seg_btb = nullptr;  // [max(n_segs, I), r, r]        fp64 per-segment (per-slab) partial B_i^T B_i
     int *slab_seg_ptr = nullptr;  // int32[I+1] first segment of every slab
     std::vector<int> h_slab_seg_ptr;
     bool xc_with_gram = false;  // request: the next X C launch also produces seg_rhs / seg_btb
@@ -220,11 +224,13 @@ int mcl_launch_A_rhs_from_M(mcl_context *c);     // seg_rhs[bseg] = coldot(M_bse
 int mcl_launch_ctc(mcl_context *c);
 int mcl_launch_B_rho(mcl_context *c);
 int mcl_launch_B_systems(mcl_context *c);
+int mcl_launch_B_solve_f64(mcl_context *c);                      // penalty-free B: B_i = ((X_i C) o a_i) L_i^-1 in fp64
 int mcl_launch_rows_fused(mcl_context *c, int mode);             // fused inner ADMM loop, row-separable penalties
 int mcl_launch_rows_solve(mcl_context *c, int mode);
 int mcl_launch_rows_prox(mcl_context *c, int mode, int k);       // generic prox step of penalty k (local part)
 int mcl_launch_rows_prox_finish(mcl_context *c, int mode, int k);
 int mcl_launch_C_prepare(mcl_context *c);
+int mcl_launch_C_solve_f64(mcl_context *c);                      // penalty-free C: C = R G^-1 in fp64
 int mcl_launch_C_finish_fused(mcl_context *c);
 int mcl_launch_A_rho(mcl_context *c);
 int mcl_launch_A_finish(mcl_context *c, bool fused_inner);

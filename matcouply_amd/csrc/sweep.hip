@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                                                const int *__restrict__ bs_slab, const int *__restrict__ bs_row0,
                                                const int *__restrict__ bs_nrows, int n_bsegs, int bsegs_per_wave,
                                                int K, int r, int inner, float *__restrict__ Mpart,
-                                               float *__restrict__ part_btb, float *__restrict__ GRpart,
+                                               double *__restrict__ part_btb, float *__restrict__ GRpart,
                                                double *__restrict__ diag_block, int dbg,
                                                long long *__restrict__ cyc_out) {
     constexpr int KW = 256 * KS;   // floats per tile row: K rounded up to 256 (K % 4 == 0, K <= KW)
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                     for (int w = 0; w < 4; ++w) {
                         const int ra = 16 * a + 4 * q + w, cb = 16 * b + i16;
                         if (ra < r && cb < r) {
-                            part_btb[((long)bs * r + ra) * r + cb] = accG[a][b][w];
+                            part_btb[((long)bs * r + ra) * r + cb] = (double)accG[a][b][w];
                             gp[MS + ra * W + cb] = arow[ra] * arow[cb] * accG[a][b][w];
                         } else {
                             gp[MS + ra * W + cb] = 0.f;
@@ -565,9 +565,9 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
 // ---------------------------------------------------------------------------------------------------------
 template <int EL>  // elements per block (64: 256-byte wave loads, PS / 64 blocks; 32: twice the blocks for small PS)
 __global__ __launch_bounds__(1024) void k_reduce_frag(const float *__restrict__ GRpart, int n_part, int K, int r, int NB,
-                                                      int MS, float *__restrict__ GR) {
+                                                      int MS, double *__restrict__ GR) {
     constexpr int NG = 1024 / EL;  // interleaved groups of partials
-    __shared__ float sm[NG][EL];
+    __shared__ double sm[NG][EL];  // fp32 per-bseg partials, summed in fp64 (the C-phase system sees >= 1e-8 inputs)
     const int el = threadIdx.x % EL, pc = threadIdx.x / EL;
     const int e = blockIdx.x * EL + el;
     const int W = 16 * NB, PS = MS + W * W;
@@ -584,23 +584,23 @@ __global__ __launch_bounds__(1024) void k_reduce_frag(const float *__restrict__ 
         const int g = e - MS, a = g / W, b = g - a * W;
         if (a < r && b < r) out = a * r + b;
     }
-    float s = 0.f;
+    double s = 0.0;
     if (out >= 0) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int p = pc;
         for (; p + 3 * NG < n_part; p += 4 * NG) {
-            s0 += GRpart[(long)p * PS + e];
-            s1 += GRpart[(long)(p + NG) * PS + e];
-            s2 += GRpart[(long)(p + 2 * NG) * PS + e];
-            s3 += GRpart[(long)(p + 3 * NG) * PS + e];
+            s0 += (double)GRpart[(long)p * PS + e];
+            s1 += (double)GRpart[(long)(p + NG) * PS + e];
+            s2 += (double)GRpart[(long)(p + 2 * NG) * PS + e];
+            s3 += (double)GRpart[(long)(p + 3 * NG) * PS + e];
         }
-        for (; p < n_part; p += NG) s0 += GRpart[(long)p * PS + e];
+        for (; p < n_part; p += NG) s0 += (double)GRpart[(long)p * PS + e];
         s = (s0 + s1) + (s2 + s3);
     }
     sm[pc][el] = s;
     __syncthreads();
     if (pc == 0 && out >= 0) {
-        float t = 0.f;
+        double t = 0.0;
 #pragma unroll
         for (int g = 0; g < NG; ++g) t += sm[g][el];  // fixed order
         GR[out] = t;
@@ -613,28 +613,34 @@ __global__ __launch_bounds__(1024) void k_reduce_frag(const float *__restrict__ 
 // wave-row (t >> 6) = nb (mod NB); fixed-order LDS tree.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_A_rhs_from_M(const float *__restrict__ Mpart, const float *__restrict__ Cfrag,
-                                                      int MS, int NB, int r, float *__restrict__ seg_rhs) {
-    __shared__ float sm[256];
+                                                      int MS, int NB, int r, double *__restrict__ seg_rhs) {
+    __shared__ double sm[256];
     const int bs = blockIdx.x;
     const float *mp = Mpart + (long)bs * MS;
-    float s0 = 0.f, s1 = 0.f;
+    double s0 = 0.0, s1 = 0.0;  // products of fp32 values are exact in fp64
+    auto dot4 = [](const f32x4 a, const f32x4 b, double s) {
+        s = fma((double)a[0], (double)b[0], s);
+        s = fma((double)a[1], (double)b[1], s);
+        s = fma((double)a[2], (double)b[2], s);
+        return fma((double)a[3], (double)b[3], s);
+    };
     int e = threadIdx.x * 4;
     for (; e + 1024 < MS; e += 2048) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(mp + e), b = *reinterpret_cast<const f32x4 *>(Cfrag + e);
         const f32x4 c = *reinterpret_cast<const f32x4 *>(mp + e + 1024), d = *reinterpret_cast<const f32x4 *>(Cfrag + e + 1024);
-        s0 += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
-        s1 += (c[0] * d[0] + c[1] * d[1]) + (c[2] * d[2] + c[3] * d[3]);
+        s0 = dot4(a, b, s0);
+        s1 = dot4(c, d, s1);
     }
     for (; e < MS; e += 1024) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(mp + e), b = *reinterpret_cast<const f32x4 *>(Cfrag + e);
-        s0 += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+        s0 = dot4(a, b, s0);
     }
     sm[threadIdx.x] = s0 + s1;
     __syncthreads();
     // threads with the same column: lane quarters q = 0..3 of every wave w with w % NB == nb
     if ((int)threadIdx.x < 16 * NB) {
         const int nb = threadIdx.x >> 4, c16 = threadIdx.x & 15;
-        float t = 0.f;
+        double t = 0.0;
         for (int w = nb; w < 4; w += NB)
             for (int qq = 0; qq < 4; ++qq) t += sm[w * 64 + qq * 16 + c16];
         const int col = 16 * nb + c16;
@@ -660,7 +666,7 @@ bool mcl_sweep_shape_ok(const mcl_context *c) {
 
 bool mcl_sweep_eligible(const mcl_context *c) {
     if (!c->sweep_planned || !mcl_sweep_shape_ok(c)) return false;
-    if (c->regs[1].n > 2 || !mcl_mode_is_row_separable(c, 1)) return false;
+    if (c->regs[1].n == 0 || c->regs[1].n > 2 || !mcl_mode_is_row_separable(c, 1)) return false;  // n = 0: fp64 solve
     if (c->opt.inner_n_iter_max <= 0) return false;
     if (reinterpret_cast<uintptr_t>(c->X) & 15) return false;
     return true;
@@ -728,7 +734,6 @@ int mcl_launch_sweep(mcl_context *c) {
     const int ks = mcl_sweep_KS(c), n = c->regs[1].n;
 #define MCL_SW(KS_, NB_)                                  \
     switch (n) {                                          \
-        case 0: return launch_sweep_t<KS_, NB_, 0>(c);    \
         case 1: return launch_sweep_t<KS_, NB_, 1>(c);    \
         default: return launch_sweep_t<KS_, NB_, 2>(c);   \
     }

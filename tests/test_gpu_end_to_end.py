@@ -52,7 +52,9 @@ def _run_both(st, n_iter, **kw):
         constant_feasibility_penalty=(True if (st.constant_A and st.constant_B) else ("A" if st.constant_A else
                                                                                          ("B" if st.constant_B else False))),
         inner_n_iter_max=st.inner, **kw)
+    orc.POLAR_COND["max"] = 1.0
     res = orc.run(st, n_iter, tol=None, absolute_tol=None)
+    res["polar_cond"] = orc.POLAR_COND["max"]  # worst cond(Y_i Delta^T) on the oracle's trajectory
     return cmf, admm, diag, res
 
 
@@ -64,8 +66,13 @@ def _compare(cmf, admm, diag, st, res, tol, tol_rec=1e-5):
         for k, d in enumerate(st.regs[m]):
             z, u = admm.auxes[m][k], admm.duals[m][k]
             if d["kind"] == "parafac2":
-                errs[f"P{m}{k}"] = rel_err(np.concatenate(z[0]), st.aux[m][k][0])
-                errs[f"D{m}{k}"] = rel_err(z[1], st.aux[m][k][1])
+                # the orthogonal bases enter the iteration only through the auxiliary MATRIX P_i Delta (penalties.py:1303):
+                # that product and Delta are held to the flat bar; P itself is a polar factor, whose forward error is
+                # cond(Y_i Delta^T) x the float32 rounding of Y_i = B_i + U_i (1e-8 relative rms), whatever the engine
+                P_ref, D_ref = st.aux[m][k]
+                errs[f"PD{m}{k}"] = rel_err(np.concatenate(z[0]) @ np.asarray(z[1]), P_ref @ D_ref)
+                errs[f"D{m}{k}"] = rel_err(z[1], D_ref)
+                errs[f"P{m}{k}"] = rel_err(np.concatenate(z[0]), P_ref)
             else:
                 errs[f"aux{m}{k}"] = rel_err(np.concatenate(z) if m == 1 else z, st.aux[m][k])
             # duals live on the scale of their factor and are ~0 where a constraint is inactive: measure their error
@@ -74,7 +81,8 @@ def _compare(cmf, admm, diag, st, res, tol, tol_rec=1e-5):
             scale = max(np.linalg.norm(st.dual[m][k]), np.linalg.norm((st.A, st.B, st.C)[m]))
             errs[f"dual{m}{k}"] = np.linalg.norm(un - st.dual[m][k]) / scale
     # loss = rec^2 / 2 + penalties: its relative error is up to twice the rec error's
-    bound = lambda k: tol_rec if k == "rec" else (2 * tol_rec if k == "loss" else tol)
+    p_tol = max(tol, 1e-8 * res.get("polar_cond", 1.0))
+    bound = lambda k: tol_rec if k == "rec" else (2 * tol_rec if k == "loss" else (p_tol if k[0] == "P" and k[1] != "D" else tol))
     bad = {k: v for k, v in errs.items() if not (v < bound(k))}
     assert not bad, (bad, errs)
     return errs
@@ -182,25 +190,10 @@ def test_scale_parity_vs_oracle(name):
     X, row_ptr = orc.synthetic_problem(cfg["I"], J, cfg["K"], cfg["r"], seed=0, dtype=np.float64)
     X = X.astype(np.float32).astype(np.float64)  # the engine stores X in fp32: give both sides identical data
     st = orc.random_state_for(X, row_ptr, cfg["r"], cfg["regs"], seed=1)
-    tol = 1e-5
-    if any(len(m) == 0 for m in cfg["regs"]):
-        # A mode without any penalty has un-shifted (possibly ill-conditioned) rank x rank normal equations, and every
-        # fp32 rounding is amplified by their condition number.  Criterion there: within 1e-5 OR no worse than 3x what
-        # NumPy itself loses when the SAME algorithm runs in float32 (the oracle's fp32 mode vs its fp64 mode).
-        st64 = orc.random_state_for(X, row_ptr, cfg["r"], cfg["regs"], seed=1)
-        st32 = orc.random_state_for(X, row_ptr, cfg["r"], cfg["regs"], seed=1, dtype=np.float32)
-        for _ in range(3):
-            for s_ in (st64, st32):
-                s_.update_B(); s_.update_C(); s_.update_A()
-        loss32 = max(rel_err(st32.A, st64.A), rel_err(st32.B, st64.B), rel_err(st32.C, st64.C))
-        rec32 = abs(st32.rec_error_from_A_byproducts() - st64.rec_error_from_A_byproducts()) / st64.rec_error_from_A_byproducts()
-        tol = max(1e-5, 3 * loss32)
-        tol_rec = max(1e-5, 3 * rec32)
-        print(name, f"numpy-fp32 loss: factors {loss32:.1e}, rec error {rec32:.1e} -> tol {tol:.1e} / {tol_rec:.1e}")
-    else:
-        tol_rec = 1e-5
+    # flat bar, penalty-free modes included: their un-shifted normal equations are built and solved in fp64
+    # ([G | R], the per-slab Grams and right-hand sides carry fp64 across tiles)
     cmf, admm, diag, res = _run_both(st, 3)
-    errs = _compare(cmf, admm, diag, st, res, tol, tol_rec)
+    errs = _compare(cmf, admm, diag, st, res, 1e-5, 1e-5)
     print(name, {k: f"{v:.1e}" for k, v in errs.items()})
 
 

@@ -68,7 +68,8 @@ def test_one_iteration_phase_by_phase(name):
     r = st.A.shape[1]
     for it in range(2):
         eng.update_B()
-        assert eng.kernel_variant(3).startswith("k_sweep<"), "the sweep did not run: " + repr(eng.kernel_variant(3))
+        if st.regs[1]:  # a penalty-free B is a plain least-squares update: un-shifted systems, solved in fp64 (no sweep)
+            assert eng.kernel_variant(3).startswith("k_sweep<"), "the sweep did not run: " + repr(eng.kernel_variant(3))
         ref.update_B()
         torch.cuda.synchronize()
         errs = {"B": rel_err(to_np(eng.B), ref.B)}
