@@ -304,7 +304,7 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     // per-segment prologue on big problems; small problems (e.g. the per-rank shard of an 8-GPU run) get shorter
     // segments so that there are still >= ~512 of them (measured optimum on a 64 K-row shard: 128 rows).
     int64_t seg_rows = MCL_SEG_ROWS;
-    while (seg_rows > 32 && N / seg_rows < 512) seg_rows /= 2;
+    while (seg_rows > 16 && N / seg_rows < 512) seg_rows /= 2;
     if (const char *e = getenv("MCL_SEG_ROWS")) seg_rows = std::max(16, atoi(e));
     for (int64_t i = 0; i < I; ++i) {
         c->h_slab_seg_ptr[(size_t)i] = (int)c->h_seg_slab.size();

@@ -42,8 +42,7 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
                                                      const float *__restrict__ A, const int *__restrict__ seg_slab,
                                                      const int *__restrict__ seg_row0, const int *__restrict__ seg_rows,
                                                      int n_segs, int segs_per_wave, int K, int r,
-                                                     double *__restrict__ part, int part_stride, int flush_trips,
-                                                     int dbg) {
+                                                     double *__restrict__ part, int part_stride, int dbg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rsub = lane >> 4, c16 = lane & 15;
     const int kbase = blockIdx.y * (64 * KB);
@@ -69,10 +68,11 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
         bcol[nb] = min(16 * nb + c16, r - 1);
     }
 
-    // fp32 MFMA chains are kept SHORT: every `flush_trips` trips of the group loop (and at every segment end) the fp32
-    // accumulators are added into fp64 shadows and cleared, so the rounding of a chain is relative to a few rows' worth
-    // of products, not to the running total - the normal equations of a penalty-free mode amplify every relative error
-    // of [G | R] by their condition number (decomposition.py:307-331).
+    // fp32 MFMA chains end with their SEGMENT (<= 256 rows, shorter on small problems: mcl_set_problem): the fp32
+    // accumulators are then added into fp64 shadows and cleared, so the rounding of a chain is relative to one segment's
+    // worth of products, not to the running total over all the wave's segments - the normal equations of a penalty-free
+    // mode amplify every relative error of [G | R] by their condition number (decomposition.py:307-331).  With s rows
+    // per segment and N rows in all the fp64 total keeps ~ 3e-8 s / sqrt(3 N) relative rounding.
     f32x4 acc[KB][4][NB];
     f32x4 accG[NG_][NG_];
     f64x4 dacc[KB][4][NB];
@@ -145,7 +145,6 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
         };
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) load(d, d);
-        int trips = 0;
         for (int g = 0; g < ng; g += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
@@ -174,12 +173,8 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
                 }
                 load(d, g + DEPTH + d);
             }
-            if (++trips == flush_trips) {  // wave-uniform; no memory operation inside: the counted vmcnt waits are unaffected
-                flush();
-                trips = 0;
-            }
         }
-        flush();
+        flush();  // once per segment, outside the pipelined loop (a branch inside it collapses the counted vmcnt waits)
     }
 
     // deterministic cross-wave reduction through LDS (fp64), then one fp64 partial slab per block
@@ -758,17 +753,13 @@ static int launch_xt(mcl_context *c) {
     const bool vec = (c->K % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->X) & 15) == 0);
     ProfScope prof(c, 1);
     int dbg = 0, depth = 4;
-    // rows per fp32 chain ~ sqrt(N) / 4: the rounding of the fp64 total then stays near 1e-8 relative at every problem
-    // size (chains of c rows, N / c of them: ~ 3e-8 c / sqrt(3 N)); big problems flush once per segment
-    int flush_rows = (int)(0.25 * std::sqrt((double)std::max<int64_t>(c->N, 1)));
-    if (const char *e = getenv("MCL_XT_FLUSH_ROWS")) flush_rows = atoi(e);
     if (const char *e = getenv("MCL_XT_DBG")) dbg = atoi(e);
     if (const char *e = getenv("MCL_XT_DEPTH")) depth = atoi(e);
     constexpr int RMODE = (NB == 4) ? 1 : 0;
 #define MCL_XT(VEC_, DEPTH_, MODE_, GRID_)                                                                            \
     hipLaunchKernelGGL((k_contract_xt<KB, NB, VEC_, DEPTH_, MODE_>), GRID_, dim3(256), 0, c->stream, c->X, c->B, c->A, \
                        c->segs.slab, c->segs.row0, c->segs.nrows, c->segs.n_tiles, spw, (int)c->K, c->r, c->partials, \
-                       E, std::max(1, flush_rows / (4 * DEPTH_)), dbg)
+                       E, dbg)
     if (vec) {
         if (depth == 2) MCL_XT(4, 2, RMODE, grid);
         else MCL_XT(4, 4, RMODE, grid);
