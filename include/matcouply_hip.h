@@ -155,6 +155,9 @@ int mcl_profile_enable(mcl_context *ctx, int32_t capacity);
  * the kernel, so a timed loop samples its launches instead of bracketing all of them */
 int mcl_profile_set_stride(mcl_context *ctx, int32_t stride);
 int mcl_profile_read(mcl_context *ctx, int32_t which, double *total_ms, int32_t *count);
+/* The MCL_* environment switches (A/B experiments, debug paths; tools/README.md) are read once in mcl_create();
+ * this re-reads them for an existing context (tests that compare kernel forms on one problem). */
+int mcl_reload_switches(mcl_context *ctx);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = [
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_B_end", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
     "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
     "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_set_stride", "mcl_profile_read",
+    "mcl_reload_switches",
 ]
 
 
@@ -97,6 +98,7 @@ def load_library():
         "mcl_profile_enable": (ctypes.c_int, [P, I32]),
         "mcl_profile_set_stride": (ctypes.c_int, [P, I32]),
         "mcl_profile_read": (ctypes.c_int, [P, I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I32)]),
+        "mcl_reload_switches": (ctypes.c_int, [P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -314,6 +316,10 @@ class HipEngine:
         tot, n = ctypes.c_double(), ctypes.c_int32()
         self._check(self.lib.mcl_profile_read(self._h, which, ctypes.byref(tot), ctypes.byref(n)))
         return tot.value, n.value
+
+    def reload_switches(self):
+        """re-read the MCL_* environment switches (they are otherwise read once, when the context is created)"""
+        self._check(self.lib.mcl_reload_switches(self._h))
 
     def kernel_variant(self, which):
         return self.lib.mcl_kernel_variant(self._h, which).decode()

@@ -1424,7 +1424,7 @@ static int launch_C_fused_t(mcl_context *c) {
 
 // Single-workgroup C-side finish; returns -1 if the shape has no instantiation (caller uses the separate kernels)
 int mcl_launch_C_finish_fused(mcl_context *c) {
-    if (c->K > 1024 || getenv("MCL_NO_FUSED_C")) return -1;
+    if (c->K > 1024 || c->sw.no_fused_c) return -1;
     if ((size_t)(c->r * c->r + c->K * c->r) * sizeof(float) > 150 * 1024) return -1;
     const int n = c->regs[2].n;
     if (c->r <= 16) {
@@ -1457,7 +1457,7 @@ int mcl_launch_A_rho(mcl_context *c) {
 int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     if (c->I == 0) return 0;
     // also prepare the next B-phase's systems when that is exact: fused inner loop, per-slab rho for B
-    const int next_B = (fused_inner && !c->opt.constant_B && c->regs[1].n > 0 && !getenv("MCL_NO_NEXT_B")) ? 1 : 0;
+    const int next_B = (fused_inner && !c->opt.constant_B && c->regs[1].n > 0 && !c->sw.no_next_b) ? 1 : 0;
     const bool seg = c->use_seg_gram;
     dim3 grid((unsigned)((c->I + 3) / 4)), block(256);
 #define MCL_AF_ARGS                                                                                                   \
@@ -1467,7 +1467,7 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
         (const int *)(seg ? (c->seg_from_sweep ? c->slab_bseg_ptr : c->slab_seg_ptr) : nullptr),                      \
         (const double *)c->seg_rhs, (const double *)((seg && c->seg_from_sweep) ? c->part_btb : c->seg_btb), c->rhsA
     // ranks 5..32: rows of every system split over the lane groups (all 64 lanes busy); 64 columns fill the wave anyway
-    if (c->RP == 64 || c->RP == 4 || getenv("MCL_A_FINISH_COLS")) {
+    if (c->RP == 64 || c->RP == 4 || c->sw.a_finish_cols) {
         DISPATCH_RP_T(c, k_A_finish, grid, block, MCL_AF_ARGS);
     } else if (c->RP == 8) {
         hipLaunchKernelGGL((k_A_finish_rows<8>), grid, block, 0, c->stream, MCL_AF_ARGS);

@@ -128,6 +128,25 @@ int64_t plan(mcl_context *c, char *base) {
     return (b.off + 255) & ~int64_t(255);
 }
 
+void read_switches(mcl_switches &w) {
+    auto flag = [](const char *name) { return getenv(name) != nullptr; };
+    auto num = [](const char *name, int dflt) {
+        const char *e = getenv(name);
+        return e ? atoi(e) : dflt;
+    };
+    w.no_sweep = flag("MCL_NO_SWEEP"), w.no_pass_chain = flag("MCL_NO_PASS_CHAIN");
+    w.no_pf2_delta_fusion = flag("MCL_NO_PF2_DELTA_FUSION"), w.ns_plain = flag("MCL_NS_PLAIN");
+    w.pf2_jacobi = flag("MCL_PF2_JACOBI"), w.no_stack_fusion = flag("MCL_NO_STACK_FUSION");
+    w.no_solve_stats = flag("MCL_NO_SOLVE_STATS"), w.no_next_b = flag("MCL_NO_NEXT_B");
+    w.no_fused_gram = flag("MCL_NO_FUSED_GRAM"), w.no_fused_c = flag("MCL_NO_FUSED_C");
+    w.a_finish_cols = flag("MCL_A_FINISH_COLS"), w.xc_norow = flag("MCL_XC_NOROW");
+    w.unimodal_v3 = flag("MCL_UNIMODAL_V3"), w.stats_reduce = flag("MCL_STATS_REDUCE");
+    w.seg_rows = num("MCL_SEG_ROWS", 0), w.bseg_rows = num("MCL_BSEG_ROWS", 0);
+    w.xc_waves = num("MCL_XC_WAVES", 0), w.xt_waves = num("MCL_XT_WAVES", 0), w.sweep_waves = num("MCL_SWEEP_WAVES", 0);
+    w.xc_dbg = num("MCL_XC_DBG", 0), w.xt_dbg = num("MCL_XT_DBG", 0), w.xt_depth = num("MCL_XT_DEPTH", 0);
+    w.sweep_dbg = num("MCL_SWEEP_DBG", 0), w.reduce_el = num("MCL_REDUCE_EL", 0), w.uni_split = num("MCL_UNI_SPLIT", -1);
+}
+
 int fail(mcl_context *c, const std::string &msg) {
     c->err = msg;
     return 1;
@@ -153,6 +172,16 @@ int flush_B_finish(mcl_context *c) {
 int ready(mcl_context *c) {
     if (int rc = ready_noflush(c)) return rc;
     return flush_B_finish(c);
+}
+
+// Step API contract (matcouply_hip.h): after mcl_B_solve EVERY penalty of a fusable stack must be stepped before the
+// next solve / the end of the phase - the single prox + dual row pass is only issued once the stack is complete.  A host
+// that skipped an index would otherwise leave stale aux / dual rows without any error.
+int round_complete(mcl_context *c, const char *who) {
+    if (!c->step_fuse) return 0;
+    c->step_fuse = c->step_stats = false;  // report once; the host may restart the phase with mcl_B_begin
+    return fail(c, std::string(who) + ": the previous inner iteration did not step every penalty of mode 1 "
+                   "(mcl_B_prox_local / mcl_B_prox_finish for k = 0 .. n-1): its aux / dual rows were not updated");
 }
 
 int ensure_ctc(mcl_context *c) {
@@ -194,7 +223,7 @@ int generic_inner_loop(mcl_context *c, int mode) {
     // ... and with the statistics riding in the solve, the finish pass of iteration t also does the solve of t + 1
     int n_l2 = 0;
     for (int k = 0; k < c->regs[mode].n; ++k) n_l2 += c->regs[mode].kind[k] == MCL_PEN_L2BALL;
-    const bool chain = stats && n_l2 <= 1 && !getenv("MCL_NO_PASS_CHAIN");  // the chained kernel carries one L2-ball slot
+    const bool chain = stats && n_l2 <= 1 && !c->sw.no_pass_chain;  // the chained kernel carries one L2-ball slot
     for (int it = 0; it < n_it; ++it) {
         if (mode == 0) {
             if (int rc = mcl_launch_A_rows_solve(c)) return rc;
@@ -206,7 +235,7 @@ int generic_inner_loop(mcl_context *c, int mode) {
         }
         c->stack_fused = fuse;
         c->stats_in_solve = stats;
-        c->pf2_delta_fused = !getenv("MCL_NO_PF2_DELTA_FUSION");
+        c->pf2_delta_fused = !c->sw.no_pf2_delta_fusion;
         int rc = 0;
         for (int k = 0; k < c->regs[mode].n && rc == 0; ++k) {
             rc = mcl_launch_generic_prox_local(c, mode, k);
@@ -267,6 +296,7 @@ int mcl_create(mcl_context **out, int device, void *hip_stream) {
     c->stream = reinterpret_cast<hipStream_t>(hip_stream);
     c->opt.feasibility_penalty_scale = 1.0;
     c->opt.inner_n_iter_max = 5;
+    read_switches(c->sw);
     *out = c;
     return 0;
 }
@@ -305,7 +335,7 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     // segments so that there are still >= ~512 of them (measured optimum on a 64 K-row shard: 128 rows).
     int64_t seg_rows = MCL_SEG_ROWS;
     while (seg_rows > 16 && N / seg_rows < 512) seg_rows /= 2;
-    if (const char *e = getenv("MCL_SEG_ROWS")) seg_rows = std::max(16, atoi(e));
+    if (c->sw.seg_rows > 0) seg_rows = std::max(16, c->sw.seg_rows);
     for (int64_t i = 0; i < I; ++i) {
         c->h_slab_seg_ptr[(size_t)i] = (int)c->h_seg_slab.size();
         c->h_slab_tile_ptr[(size_t)i] = (int)c->h_tile_slab.size();
@@ -327,7 +357,7 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     // >= ~1024 of them (one per SIMD)
     int64_t bseg_rows = 512;
     while (bseg_rows > 64 && N / bseg_rows < 1024) bseg_rows /= 2;
-    if (const char *e = getenv("MCL_BSEG_ROWS")) bseg_rows = std::max(64, (atoi(e) / 64) * 64);
+    if (c->sw.bseg_rows > 0) bseg_rows = std::max(64, (c->sw.bseg_rows / 64) * 64);
     c->h_bseg_slab.clear(), c->h_bseg_row0.clear(), c->h_bseg_nrows.clear();
     c->h_slab_bseg_ptr.assign((size_t)I + 1, 0);
     for (int64_t i = 0; i < I; ++i) {
@@ -475,6 +505,7 @@ int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
 // ---- B-phase -------------------------------------------------------------------------------------------
 int mcl_B_begin(mcl_context *c) {
     if (int rc = ready(c)) return rc;
+    if (int rc = round_complete(c, "mcl_B_begin")) return rc;
     if (int rc = ensure_ctc(c)) return rc;
     if (int rc = ensure_xc(c)) return rc;
     if (c->opt.constant_B)
@@ -495,7 +526,7 @@ int mcl_B_factor(mcl_context *c) {
 
 // the finish pass of inner iteration t can be merged with the solve of t + 1 (k_rows_finish_solve_stats)
 static bool step_can_chain(const mcl_context *c) {
-    if (!c->step_fuse || !c->step_stats || getenv("MCL_NO_PASS_CHAIN")) return false;
+    if (!c->step_fuse || !c->step_stats || c->sw.no_pass_chain) return false;
     int n_l2 = 0;
     for (int k = 0; k < c->regs[1].n; ++k) n_l2 += c->regs[1].kind[k] == MCL_PEN_L2BALL;
     return n_l2 <= 1;
@@ -503,6 +534,7 @@ static bool step_can_chain(const mcl_context *c) {
 
 int mcl_B_solve(mcl_context *c) {
     if (int rc = ready_noflush(c)) return rc;
+    if (int rc = round_complete(c, "mcl_B_solve")) return rc;
     c->e1_valid = false;
     c->mseg_valid = c->grpart_valid = false;
     c->diag_valid[1] = false;
@@ -521,7 +553,10 @@ int mcl_B_solve(mcl_context *c) {
     return mcl_launch_rows_solve(c, 1);
 }
 
-int mcl_B_end(mcl_context *c) { return ready(c); }
+int mcl_B_end(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    return round_complete(c, "mcl_B_end");
+}
 
 int mcl_B_prox_local(mcl_context *c, int32_t k) {
     if (int rc = ready(c)) return rc;
@@ -667,7 +702,7 @@ int mcl_A_begin(mcl_context *c) {
         c->e1_valid = false;
         return 0;
     }
-    if (!c->xc_valid && !c->opt.constant_A && mcl_mode_is_row_separable(c, 0) && !getenv("MCL_NO_FUSED_GRAM")) {
+    if (!c->xc_valid && !c->opt.constant_A && mcl_mode_is_row_separable(c, 0) && !c->sw.no_fused_gram) {
         c->xc_with_gram = true;
         const int rc = ensure_xc(c);
         c->xc_with_gram = false;
@@ -869,6 +904,12 @@ int mcl_profile_read(mcl_context *c, int32_t which, double *total_ms, int32_t *c
     *total_ms = tot;
     *count = n;
     c->prof_used[which] = 0;
+    return 0;
+}
+
+int mcl_reload_switches(mcl_context *c) {
+    if (!c) return 1;
+    read_switches(c->sw);
     return 0;
 }
 

@@ -723,7 +723,7 @@ static inline int xt_KB(const mcl_context *c) {
 static inline void xt_geometry(const mcl_context *c, int *segs_per_wave, int *n_blocks) {
     const int n_segs = c->segs.n_tiles;
     int target_waves = 1024;  // 256 CUs x 4 waves: measured best (one 256-thread block per CU)
-    if (const char *e = getenv("MCL_XT_WAVES")) target_waves = atoi(e);
+    if (c->sw.xt_waves > 0) target_waves = c->sw.xt_waves;
     int spw = (n_segs + target_waves - 1) / target_waves;
     if (spw < 1) spw = 1;
     const int waves = (n_segs + spw - 1) / spw;
@@ -753,8 +753,8 @@ static int launch_xt(mcl_context *c) {
     const bool vec = (c->K % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->X) & 15) == 0);
     ProfScope prof(c, 1);
     int dbg = 0, depth = 4;
-    if (const char *e = getenv("MCL_XT_DBG")) dbg = atoi(e);
-    if (const char *e = getenv("MCL_XT_DEPTH")) depth = atoi(e);
+    dbg = c->sw.xt_dbg;
+    if (c->sw.xt_depth > 0) depth = c->sw.xt_depth;
     constexpr int RMODE = (NB == 4) ? 1 : 0;
 #define MCL_XT(VEC_, DEPTH_, MODE_, GRID_)                                                                            \
     hipLaunchKernelGGL((k_contract_xt<KB, NB, VEC_, DEPTH_, MODE_>), GRID_, dim3(256), 0, c->stream, c->X, c->B, c->A, \
@@ -815,9 +815,9 @@ static int launch_xc(mcl_context *c) {
     const int KC = xc_KC(c);
     const long nblk = (c->N + 15) / 16;
     long target_waves = 1024;  // measured best: one 256-thread block per CU
-    if (const char *e = getenv("MCL_XC_WAVES")) target_waves = atol(e);
+    if (c->sw.xc_waves > 0) target_waves = c->sw.xc_waves;
     int dbg = 0;
-    if (const char *e = getenv("MCL_XC_DBG")) dbg = atoi(e);
+    dbg = c->sw.xc_dbg;
     long bpw = (nblk + target_waves - 1) / target_waves;
     if (bpw < 1) bpw = 1;
     const long waves = (nblk + bpw - 1) / bpw;
@@ -827,7 +827,7 @@ static int launch_xc(mcl_context *c) {
     ProfScope prof(c, 0);
     int kct = 0;
     mcl_xc_chunks(c, &kct);
-    if (vec && (c->K % 256 == 0) && !getenv("MCL_XC_NOROW")) {
+    if (vec && (c->K % 256 == 0) && !c->sw.xc_norow) {
         const size_t sm = sizeof(float) * 4 * 16 * 256;
         const bool creg = (c->K == 256) && (NB == 1);
         const int n_segs = c->segs.n_tiles;

@@ -2042,7 +2042,7 @@ static UniScratch uni_scratch(mcl_context *c) {
 // The per-slab sums of the solve pass's tile statistics are taken by the PARAFAC2 Newton-Schulz kernel itself when
 // the B stack has a PARAFAC2 member handled by that kernel (otherwise k_stats_reduce runs after the solve pass).
 bool mcl_stats_reduce_in_algebra(const mcl_context *c) {
-    if (getenv("MCL_STATS_REDUCE") || getenv("MCL_PF2_JACOBI") || c->NB > 2) return false;
+    if (c->sw.stats_reduce || c->sw.pf2_jacobi || c->NB > 2) return false;
     const RegSet &rs = c->regs[1];
     for (int k = 0; k < rs.n; ++k)
         if (rs.kind[k] == MCL_PEN_PARAFAC2) return true;
@@ -2076,11 +2076,11 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
         case MCL_PEN_UNIMODAL: {
             const long nthreads = (long)mv.n_slabs * c->r;
             UniScratch sc = uni_scratch(c);
-            if (!getenv("MCL_UNIMODAL_V3")) {
+            if (!c->sw.unimodal_v3) {
                 const unsigned nwav = (unsigned)((nthreads + 63) / 64);
                 // fewer columns than about one wave per SIMD: the two sweeps run concurrently in different waves
                 int wave_split = nwav <= 1024;
-                if (const char *ev = getenv("MCL_UNI_SPLIT")) wave_split = atoi(ev);
+                if (c->sw.uni_split >= 0) wave_split = c->sw.uni_split;
                 if (wave_split) {
                     hipLaunchKernelGGL(k_slab_unimodal_v4<1>, dim3(2 * nwav), dim3(64), 0, c->stream, mv.ext, mv.n_slabs,
                                        mv.F, rs, k, c->r, sc);
@@ -2127,14 +2127,14 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
             }
             const int *status = nullptr;
-            if (c->NB <= 2 && !getenv("MCL_PF2_JACOBI")) {
+            if (c->NB <= 2 && !c->sw.pf2_jacobi) {
                 status = c->pf2_status;
                 TileStats ts{c->slab_tile_ptr, c->stat_gram, c->stat_colsq, c->colsq, 16 * c->NB, (int)c->I};
                 const bool tiles = c->stats_in_solve && mcl_stats_reduce_in_algebra(c);
 #define MCL_NS(NB_, TILES_)                                                                                          \
     hipLaunchKernelGGL((k_pf2_algebra_ns<NB_, TILES_>), dim3((unsigned)c->I), dim3(64), 0, c->stream, c->pf2_S,       \
                        rs.aux2[k], c->rhoB, mv.ext, r, c->pf2_T, c->pf2_acc, c->pf2_status, ts, rs, c->pf2_xmin,     \
-                       getenv("MCL_NS_PLAIN") ? 0 : 1)
+                       c->sw.ns_plain ? 0 : 1)
                 if (c->NB == 1) {
                     if (tiles) MCL_NS(1, true);
                     else MCL_NS(1, false);
@@ -2189,7 +2189,7 @@ int mcl_launch_generic_prox_finish(mcl_context *c, int mode, int k) {
 // host-evaluated member) can take ONE row pass for all prox + dual steps after the per-slab work (statistics; for
 // unimodality the column regressions themselves, which write the aux rows - the pass then only updates their dual).
 bool mcl_stack_can_fuse(const mcl_context *c, int mode) {
-    if (getenv("MCL_NO_STACK_FUSION")) return false;
+    if (c->sw.no_stack_fusion) return false;
     const RegSet &rs = c->regs[mode];
     bool slabwise = false;
     for (int k = 0; k < rs.n; ++k) {
@@ -2216,7 +2216,7 @@ int mcl_launch_rows_finish_fused(mcl_context *c, int mode, bool want_diag) {
 
 // mode 1 only (that is where the passes are big); needs the per-tile tables of the plan
 bool mcl_stats_can_ride_in_solve(const mcl_context *c, int mode) {
-    if (mode != 1 || getenv("MCL_NO_SOLVE_STATS")) return false;
+    if (mode != 1 || c->sw.no_solve_stats) return false;
     const RegSet &rs = c->regs[1];
     for (int k = 0; k < rs.n; ++k) {
         if (rs.kind[k] == MCL_PEN_PARAFAC2 && !c->stat_gram) return false;

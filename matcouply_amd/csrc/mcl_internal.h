@@ -40,8 +40,19 @@ struct TileMap {
     int *nrows = nullptr;  // device int32[n_tiles]
 };
 
+// MCL_* environment switches (A/B experiments, debug paths): read ONCE per context in mcl_create(), never on a launch
+// path - a getenv() is a linear scan of the environment and is not safe against a concurrent setenv().
+struct mcl_switches {
+    bool no_sweep = false, no_pass_chain = false, no_pf2_delta_fusion = false, ns_plain = false, pf2_jacobi = false;
+    bool no_stack_fusion = false, no_solve_stats = false, no_next_b = false, no_fused_gram = false, no_fused_c = false;
+    bool a_finish_cols = false, xc_norow = false, unimodal_v3 = false, stats_reduce = false;
+    int seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
+    int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
+};
+
 struct mcl_context {
     int device = 0;
+    mcl_switches sw;
     hipStream_t stream = nullptr;
     std::string err;
 

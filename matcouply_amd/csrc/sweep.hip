@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void k_A_rhs_from_M(const float *__restrict__ 
 int mcl_sweep_KS(const mcl_context *c) { return (int)((c->K + 255) / 256); }
 
 bool mcl_sweep_shape_ok(const mcl_context *c) {
-    if (getenv("MCL_NO_SWEEP")) return false;
+    if (c->sw.no_sweep) return false;
     if (c->K < 4 || c->K > 512 || c->K % 4 != 0) return false;
     if (c->NB > 2 || mcl_sweep_KS(c) * c->NB > 2) return false;
     if (c->N == 0 || c->I == 0) return false;
@@ -679,7 +679,7 @@ static inline int sweep_MS(const mcl_context *c) { return mcl_sweep_KS(c) * 256 
 void mcl_sweep_geometry(const mcl_context *c, int *bsegs_per_wave, int *n_waves) {
     const int n = std::max(c->bsegs.n_tiles, 1);
     int target_waves = 1024;
-    if (const char *e = getenv("MCL_SWEEP_WAVES")) target_waves = std::max(1, atoi(e));
+    if (c->sw.sweep_waves > 0) target_waves = c->sw.sweep_waves;
     const int spw = (n + target_waves - 1) / target_waves;
     *bsegs_per_wave = spw;
     *n_waves = (n + spw - 1) / spw;
@@ -701,7 +701,7 @@ static int launch_sweep_v(mcl_context *c) {
                        c->rhoB, c->LinvB, c->B, c->regs[1], c->bsegs.slab, c->bsegs.row0, c->bsegs.nrows, n, bpb, (int)c->K,
                        c->r,
                        c->opt.inner_n_iter_max, c->Mpart, c->part_btb, c->GRpart, c->diagB_tile,
-                       getenv("MCL_SWEEP_DBG") ? atoi(getenv("MCL_SWEEP_DBG")) : 0, c->sweep_cycles);
+                       c->sw.sweep_dbg, c->sweep_cycles);
     MCL_CHECK_HIP(c, hipGetLastError());
     c->diag_rows[1] = grid;
     c->n_grpart = n;  // one a-weighted partial per bseg
@@ -749,7 +749,7 @@ int mcl_launch_reduce_weighted(mcl_context *c) {
     const int MS = sweep_MS(c), W = 16 * c->NB;
     // 64 elements per block need PS / 64 blocks (68 at K = 256, rank 16: a quarter of the CUs); with 32 there are twice as many
     int el = (MS + W * W) / 64 >= 192 ? 64 : 32;
-    if (const char *ev = getenv("MCL_REDUCE_EL")) el = atoi(ev) == 64 ? 64 : (atoi(ev) == 16 ? 16 : 32);
+    if (c->sw.reduce_el > 0) el = c->sw.reduce_el == 64 ? 64 : (c->sw.reduce_el == 16 ? 16 : 32);
     const int blocks = (MS + W * W + el - 1) / el;
     if (el == 64)
         hipLaunchKernelGGL(k_reduce_frag<64>, dim3(blocks), dim3(1024), 0, c->stream, c->GRpart, c->n_grpart, (int)c->K,

@@ -12,6 +12,7 @@ ITS OWN contiguous range of the I matrices; the replicated C-mode normal equatio
 all-reduced over the group (RCCL on MI355X, gloo in the CPU tests).
 """
 from copy import copy
+import os
 from typing import NamedTuple, Optional
 
 import numpy as np
@@ -23,8 +24,19 @@ from .coupled_matrices import CoupledMatrixFactorization
 __all__ = ["compute_feasibility_gaps", "ADMMVars", "DiagnosticMetrics", "cmf_aoadmm", "parafac2_aoadmm",
            "PackedMatrices"]
 
-# factory of the compute engine; tests of the host / multi-GPU logic substitute a checker engine here
+# TEST-ONLY seam.  The CPU test-suite (tests/oracle_engine.py) substitutes a checker engine here to exercise the host and
+# multi-process logic without a GPU.  The substitution is honoured only under MATCOUPLY_AMD_TEST_ENGINE=1, which
+# tests/conftest.py sets and the product never does: matcouply_amd has no CPU path of its own.
 _ENGINE_FACTORY = None
+
+
+def _test_engine_factory():
+    if _ENGINE_FACTORY is None:
+        return None
+    if os.environ.get("MATCOUPLY_AMD_TEST_ENGINE") != "1":
+        raise RuntimeError("a substitute compute engine is installed outside the test-suite: matcouply_amd runs on the "
+                           "HIP engine only (set MATCOUPLY_AMD_TEST_ENGINE=1 in a test harness to allow a checker)")
+    return _ENGINE_FACTORY
 
 
 class PackedMatrices:
@@ -186,17 +198,17 @@ def _compute_l2_penalty(cmf, l2_parameters):
 # argument parsing (decomposition.py:455-614)
 # ------------------------------------------------------------------------------------------------------------
 def _listify(input_value, param_name):
+    """One value per mode from a dict {mode: value}, a scalar (broadcast) or a length-3 iterable."""
     if hasattr(input_value, "get"):
-        return [input_value.get(i, None) for i in range(3)]
-    elif not is_iterable(input_value):
-        return [input_value] * 3
-    else:
-        out = list(input_value)
-        if not len(out) == 3:
-            raise ValueError(
-                "All parameters must be a dictionary, non-iterable value or non-dictionary iterable of length 3."
-                f" {param_name} is iterable of length {len(out)}.")
-        return out
+        return [input_value.get(mode, None) for mode in range(3)]
+    if not is_iterable(input_value):
+        return [input_value, input_value, input_value]
+    per_mode = list(input_value)
+    if len(per_mode) != 3:
+        raise ValueError(
+            "All parameters must be a dictionary, non-iterable value or non-dictionary iterable of length 3."
+            f" {param_name} is iterable of length {len(per_mode)}.")
+    return per_mode
 
 
 def _parse_all_penalties(non_negative, lower_bound, upper_bound, l2_norm_bound, unimodal, parafac2, l1_penalty,
@@ -250,49 +262,115 @@ def _parse_all_penalties(non_negative, lower_bound, upper_bound, l2_norm_bound, 
 
 def _parse_mode_penalties(non_negative, lower_bound, upper_bound, l2_norm_bound, unimodal, parafac2, l1_penalty,
                           tv_penalty, generalized_l2_penalty, svd, dual_init, aux_init):
-    """Order: Parafac2, Unimodality, (GeneralizedL2), L2Ball, (TV), L1, Box, NonNegativity (decomposition.py:571-612)."""
-    if not l1_penalty:
-        l1_penalty = 0
-    regs = []
-    skip_non_negative = False
-    if parafac2:
-        regs.append(penalties.Parafac2(svd=svd, aux_init=aux_init, dual_init=dual_init))
-    if unimodal:
-        regs.append(penalties.Unimodality(non_negativity=non_negative, aux_init=aux_init, dual_init=dual_init))
-        skip_non_negative = True
-    if generalized_l2_penalty is not None and generalized_l2_penalty is not False:  # None, False or the norm matrix
-        regs.append(penalties.GeneralizedL2Penalty(generalized_l2_penalty, aux_init=aux_init, dual_init=dual_init, svd=svd))
-    if l2_norm_bound:
-        regs.append(penalties.L2Ball(l2_norm_bound, non_negativity=non_negative, aux_init=aux_init, dual_init=dual_init))
-        skip_non_negative = True
-    if tv_penalty:
-        regs.append(penalties.TotalVariationPenalty(tv_penalty, l1_strength=l1_penalty, aux_init=aux_init, dual_init=dual_init))
-        l1_penalty = 0  # already included in the total variation penalty
-    if l1_penalty:
-        regs.append(penalties.L1Penalty(l1_penalty, non_negativity=non_negative, aux_init=aux_init, dual_init=dual_init))
-        skip_non_negative = True
-    if lower_bound is not None or upper_bound is not None:
-        if lower_bound is None:
-            lower_bound = -float("inf")
-        if non_negative:
-            lower_bound = max(lower_bound, 0)
-        regs.append(penalties.Box(lower_bound, upper_bound, aux_init=aux_init, dual_init=dual_init))
-        skip_non_negative = True
-    if non_negative and not skip_non_negative:
-        regs.append(penalties.NonNegativity(aux_init=aux_init, dual_init=dual_init))
+    """Keyword arguments of one mode -> its penalty list, in the reference's order Parafac2, Unimodality,
+    GeneralizedL2, L2Ball, TV, L1, Box, NonNegativity (decomposition.py:571-612).  Table-driven: every row is
+    (is the keyword set?, constructor, does the penalty absorb the non-negativity flag?); a plain NonNegativity is only
+    appended when no earlier row absorbed the flag."""
+    init = dict(aux_init=aux_init, dual_init=dual_init)
+    l1 = l1_penalty or 0
+    has_gl2 = generalized_l2_penalty is not None and generalized_l2_penalty is not False  # None, False or the norm matrix
+    has_box = lower_bound is not None or upper_bound is not None
+
+    def box():
+        lo = -float("inf") if lower_bound is None else lower_bound
+        return penalties.Box(max(lo, 0) if non_negative else lo, upper_bound, **init)
+
+    rules = (
+        (parafac2, lambda: penalties.Parafac2(svd=svd, **init), False),
+        (unimodal, lambda: penalties.Unimodality(non_negativity=non_negative, **init), True),
+        (has_gl2, lambda: penalties.GeneralizedL2Penalty(generalized_l2_penalty, svd=svd, **init), False),
+        (l2_norm_bound, lambda: penalties.L2Ball(l2_norm_bound, non_negativity=non_negative, **init), True),
+        (tv_penalty, lambda: penalties.TotalVariationPenalty(tv_penalty, l1_strength=l1, **init), False),
+        # the L1 term rides inside the total-variation penalty when both are requested
+        (l1 and not tv_penalty, lambda: penalties.L1Penalty(l1, non_negativity=non_negative, **init), True),
+        (has_box, box, True),
+    )
+    regs, absorbed = [], False
+    for requested, build, absorbs in rules:
+        if requested:
+            regs.append(build())
+            absorbed = absorbed or absorbs
+    if non_negative and not absorbed:
+        regs.append(penalties.NonNegativity(**init))
     return regs
 
 
 def _check_feasibility(feasibility_gaps, feasibility_tol):
-    A_gaps, B_gaps, C_gaps = feasibility_gaps
-    max_feasibility_gap = -float("inf")
-    if len(A_gaps):
-        max_feasibility_gap = max((max(A_gaps), max_feasibility_gap))
-    if len(B_gaps):
-        max_feasibility_gap = max((max(B_gaps), max_feasibility_gap))
-    if len(C_gaps):
-        max_feasibility_gap = max((max(C_gaps), max_feasibility_gap))
-    return max_feasibility_gap < feasibility_tol
+    """True when every feasibility gap of every mode is below the tolerance (vacuously for no penalties)."""
+    worst = max((gap for mode_gaps in feasibility_gaps for gap in mode_gaps), default=-float("inf"))
+    return worst < feasibility_tol
+
+
+class _StopRule:
+    """The stopping test of the outer loop (decomposition.py:990-1053) as an object.  Quirks kept on purpose: the
+    absolute criterion is only looked at when `tol` is set, and it tests the newest loss."""
+
+    RELATIVE = "FEASIBILITY GAP CRITERION AND RELATIVE LOSS CRITERION SATISFIED"
+    ABSOLUTE = "FEASIBILITY GAP CRITERION AND ABSOLUTE LOSS CRITERION SATISFIED"
+    EXHAUSTED = "MAXIMUM NUMBER OF ITERATIONS REACHED"
+
+    def __init__(self, tol, absolute_tol, feasibility_tol):
+        self.tol, self.absolute_tol, self.feasibility_tol = tol, absolute_tol, feasibility_tol
+
+    @property
+    def active(self):
+        return bool(self.tol or self.absolute_tol)
+
+    def feasible(self, gaps):
+        return self.feasibility_tol and _check_feasibility(gaps, self.feasibility_tol)
+
+    def verdict(self, feasible, losses):
+        """message of the criterion that fires on the last two losses, or None"""
+        if not self.tol:
+            return None
+        relative = abs(losses[-2] - losses[-1]) < (self.tol * losses[-2])
+        absolute = losses[-1] < self.absolute_tol
+        if feasible and relative:
+            return self.RELATIVE
+        if feasible and absolute:
+            return self.ABSOLUTE
+        return None
+
+
+class _Progress:
+    """Console output of the outer loop (`verbose`: 0 / None silent, n > 0 every n-th iteration, -1 final message only)."""
+
+    def __init__(self, verbose):
+        self.verbose = verbose
+
+    def _due(self, it):
+        return bool(self.verbose) and self.verbose > 0 and it % self.verbose == 0
+
+    @staticmethod
+    def _gaps(gaps):
+        print("Feasibility gaps for A: {}".format(gaps[0]))
+        print("Feasibility gaps for the Bi-matrices: {}".format(gaps[1]))
+        print("Feasibility gaps for C: {}".format(gaps[2]))
+
+    def initial(self, gaps):
+        if self.verbose and self.verbose > 0:
+            self._gaps(gaps)
+
+    def iteration(self, it, rec_error=None, loss=None, variation=None, gaps=None):
+        if not self._due(it):
+            return
+        if gaps is None:
+            print("Coupled matrix factorization iteration={}".format(it))
+            return
+        shown = ("NOT COMPUTED",) * 3 if rec_error is None else (rec_error, loss, variation)
+        print("Coupled matrix factorization iteration={}, ".format(it)
+              + "reconstruction error={}, ".format(shown[0])
+              + ("regularized loss={}, " if rec_error is None else "regularized loss={} ").format(shown[1])
+              + "regularized loss variation={}.".format(shown[2]))
+        self._gaps(gaps)
+
+    def converged(self, it, message):
+        if self.verbose:
+            print("converged in {} iterations: {}".format(it, message))
+
+    def exhausted(self):
+        if self.verbose:
+            print("REACHED MAXIMUM NUMBER OF ITERATIONS")
 
 
 class ADMMVars(NamedTuple):
@@ -322,7 +400,8 @@ def _device():
 
 def _dtype():
     """float32 on the device; a substituted checker engine (tests) may ask for float64 state."""
-    return getattr(_ENGINE_FACTORY, "dtype", torch.float32) if _ENGINE_FACTORY is not None else torch.float32
+    sub = _test_engine_factory()
+    return getattr(sub, "dtype", torch.float32) if sub is not None else torch.float32
 
 
 def _to_dev(x, device):
@@ -497,9 +576,10 @@ def cmf_aoadmm(
     A_dual_list, B_dual_list, C_dual_list = initialize_dual(matrices, rank, regs, random_state=random_state)
 
     # ---- move everything to the device -----------------------------------------------------------------------
-    factory = _ENGINE_FACTORY or _default_engine_factory
-    device = _device() if _ENGINE_FACTORY is None else getattr(_ENGINE_FACTORY, "device", torch.device("cpu"))
-    X, row_ptr = _pack(matrices, device) if _ENGINE_FACTORY is None else _ENGINE_FACTORY.pack(matrices)
+    sub = _test_engine_factory()
+    factory = sub or _default_engine_factory
+    device = _device() if sub is None else getattr(sub, "device", torch.device("cpu"))
+    X, row_ptr = _pack(matrices, device) if sub is None else sub.pack(matrices)
     out = _Out(matrices)
     _, (A0, B0_is, C0) = cmf
     A, B, C = _to_dev(A0, device), _pack_rows(B0_is, device), _to_dev(C0, device)
@@ -513,7 +593,7 @@ def cmf_aoadmm(
     ext_aux = {}
     for mode in range(3):
         for k, (reg, aux, dual) in enumerate(zip(regs[mode], aux_lists[mode], dual_lists[mode])):
-            desc = None if check_inner else getattr(reg, "_native_descriptor", lambda: None)()
+            desc = None if check_inner else penalties.native_descriptor_of(reg)
             dual_t = _pack_rows(dual, device) if mode == 1 else _to_dev(dual, device)
             if desc is None:
                 if mode == 1:
@@ -740,15 +820,13 @@ def cmf_aoadmm(
     rec_error, gaps0, reg0 = diagnostics()
     rec_errors.append(rec_error)
     losses.append(0.5 * rec_error ** 2 + reg0)
-    A_gaps, B_gaps, C_gaps = gaps0
     feasibility_gaps.append(gaps0)
-    if verbose and verbose > 0:
-        print("Feasibility gaps for A: {}".format(A_gaps))
-        print("Feasibility gaps for the Bi-matrices: {}".format(B_gaps))
-        print("Feasibility gaps for C: {}".format(C_gaps))
+    progress = _Progress(verbose)
+    progress.initial(gaps0)
+    stop = _StopRule(tol, absolute_tol, feasibility_tol)
 
     satisfied_stopping_condition = False
-    message = "MAXIMUM NUMBER OF ITERATIONS REACHED"
+    message = _StopRule.EXHAUSTED
     feasibility_criterion = None
 
     it = -1  # Needed if n_iter_max <= 0
@@ -801,57 +879,26 @@ def cmf_aoadmm(
             if update_A:
                 do_update_A()
 
-            if tol or absolute_tol or return_errors:
-                rec_error, curr_feasibility_gaps, reg_pen = diagnostics()
-                feasibility_gaps.append(curr_feasibility_gaps)
-
-                if tol or absolute_tol:
-                    feasibility_criterion = feasibility_tol and _check_feasibility(curr_feasibility_gaps, feasibility_tol)
-                    if not feasibility_criterion and not return_errors:
-                        A_gaps, B_gaps, C_gaps = curr_feasibility_gaps
-                        if verbose and it % verbose == 0 and verbose > 0:
-                            print("Coupled matrix factorization iteration={}, ".format(it)
-                                  + "reconstruction error=NOT COMPUTED, "
-                                  + "regularized loss=NOT COMPUTED, "
-                                  + "regularized loss variation=NOT COMPUTED.")
-                            print("Feasibility gaps for A: {}".format(A_gaps))
-                            print("Feasibility gaps for the Bi-matrices: {}".format(B_gaps))
-                            print("Feasibility gaps for C: {}".format(C_gaps))
-                        continue
-
-                rec_errors.append(rec_error)
-                losses.append(0.5 * rec_error ** 2 + reg_pen)
-
-                if verbose and it % verbose == 0 and verbose > 0:
-                    A_gaps, B_gaps, C_gaps = curr_feasibility_gaps
-                    print("Coupled matrix factorization iteration={}, ".format(it)
-                          + "reconstruction error={}, ".format(rec_errors[-1])
-                          + "regularized loss={} ".format(losses[-1])
-                          + "regularized loss variation={}.".format(abs(losses[-2] - losses[-1]) / losses[-2]))
-                    print("Feasibility gaps for A: {}".format(A_gaps))
-                    print("Feasibility gaps for the Bi-matrices: {}".format(B_gaps))
-                    print("Feasibility gaps for C: {}".format(C_gaps))
-
-                if tol:
-                    rel_loss_criterion = abs(losses[-2] - losses[-1]) < (tol * losses[-2])
-                    abs_loss_criterion = losses[-1] < absolute_tol
-                    if feasibility_criterion and rel_loss_criterion:
-                        satisfied_stopping_condition = True
-                        message = "FEASIBILITY GAP CRITERION AND RELATIVE LOSS CRITERION SATISFIED"
-                        if verbose:
-                            print("converged in {} iterations: {}".format(it, message))
-                        break
-                    elif feasibility_criterion and abs_loss_criterion:
-                        satisfied_stopping_condition = True
-                        message = "FEASIBILITY GAP CRITERION AND ABSOLUTE LOSS CRITERION SATISFIED"
-                        if verbose:
-                            print("converged in {} iterations: {}".format(it, message))
-                        break
-            elif verbose and it % verbose == 0 and verbose > 0:
-                print("Coupled matrix factorization iteration={}".format(it))
+            if not (stop.active or return_errors):
+                progress.iteration(it)
+                continue
+            rec_error, gaps, reg_pen = diagnostics()
+            feasibility_gaps.append(gaps)
+            if stop.active:
+                feasibility_criterion = stop.feasible(gaps)
+                if not feasibility_criterion and not return_errors:
+                    progress.iteration(it, gaps=gaps)  # the loss is not evaluated on infeasible iterates (Q10)
+                    continue
+            rec_errors.append(rec_error)
+            losses.append(0.5 * rec_error ** 2 + reg_pen)
+            progress.iteration(it, rec_errors[-1], losses[-1], abs(losses[-2] - losses[-1]) / losses[-2], gaps)
+            fired = stop.verdict(feasibility_criterion, losses)
+            if fired is not None:
+                satisfied_stopping_condition, message = True, fired
+                progress.converged(it, message)
+                break
         else:
-            if verbose:
-                print("REACHED MAXIMUM NUMBER OF ITERATIONS")
+            progress.exhausted()
 
     if feasibility_tol and return_errors:
         _, final_gaps, _ = diagnostics()

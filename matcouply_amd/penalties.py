@@ -18,11 +18,12 @@ needs the GPL `condat_tv` package in the reference; here its prox is an own rest
 1-D TV algorithm (native kernel k_slab_tv; host version below), verified against the optimality conditions of the
 problem since that package is not available to generate reference vectors.
 """
-from abc import ABC, abstractmethod
+from abc import abstractmethod
 
 import numpy as np
 
 from . import _engine
+from ._doc_utils import InheritableDocstrings
 from ._utils import check_random_state, get_svd, is_tensor, is_torch, shape, to_numpy, torch
 
 
@@ -57,7 +58,7 @@ def _eye(n, m, like=None):
     return np.eye(n, m)
 
 
-class ADMMPenalty(ABC):
+class ADMMPenalty(metaclass=InheritableDocstrings):
     """Base class for all regularizers and constraints (penalties.py:21-366).
 
     Parameters
@@ -130,6 +131,8 @@ class ADMMPenalty(ABC):
 
     @abstractmethod
     def penalty(self, x):  # pragma: nocover
+        """Value of the penalty at `x` (a factor matrix, or the list of matrices of a multi-matrix mode); it is added to
+        the regularised loss the stopping rule looks at.  Hard constraints return 0."""
         """Compute the penalty for the given factor matrix or list of factor matrices."""
         raise NotImplementedError
 
@@ -171,11 +174,33 @@ class ADMMPenalty(ABC):
         return None
 
 
+# methods whose behaviour the native kernels restate: a subclass that overrides any of them must be evaluated on the host
+_NATIVE_CONTRACT = ("factor_matrices_update", "factor_matrix_update", "factor_matrix_row_update", "penalty",
+                    "subtract_from_auxes", "subtract_from_aux", "aux_as_matrix", "auxes_as_matrices")
+
+
+def native_descriptor_of(reg):
+    """The native-kernel descriptor of a penalty object, or None when its proximal operator must be evaluated on the
+    host: a user subclass of a built-in penalty that overrides the prox, the penalty value or the aux bookkeeping is NOT
+    routed to the built-in kernel (the reference would call the override, decomposition.py:278-285)."""
+    cls = type(reg)
+    owner = next((k for k in cls.__mro__ if "_native_descriptor" in vars(k)), None)
+    if owner is None:
+        return None
+    for name in _NATIVE_CONTRACT:
+        if getattr(cls, name, None) is not getattr(owner, name, None):
+            return None
+    return reg._native_descriptor()
+
+
 class MatricesPenalty(ADMMPenalty):
     """Penalties applied to a list of factor matrices simultaneously (penalties.py:369-386)."""
 
     @abstractmethod
     def factor_matrices_update(self, factor_matrices, feasibility_penalties, auxes):  # pragma: nocover
+        """Proximal step for all matrices of the mode at once: returns the new auxiliary variables for the points
+        `factor_matrices` (already shifted by the scaled duals), one feasibility penalty rho_i per matrix; `auxes` holds
+        the previous auxiliary variables for operators that warm-start from them."""
         raise NotImplementedError
 
 
@@ -188,6 +213,8 @@ class MatrixPenalty(MatricesPenalty):
 
     @abstractmethod
     def factor_matrix_update(self, factor_matrix, feasibility_penalty, aux):  # pragma: nocover
+        """Proximal step for one factor matrix: returns the new auxiliary matrix for the point `factor_matrix` (already
+        shifted by the scaled dual) under the feasibility penalty rho; `aux` is the previous auxiliary matrix."""
         raise NotImplementedError
 
 
@@ -202,6 +229,7 @@ class RowVectorPenalty(MatrixPenalty):
 
     @abstractmethod
     def factor_matrix_row_update(self, factor_matrix_row, feasibility_penalty, aux_row):  # pragma: nocover
+        """Proximal step for a single row of a factor matrix (the A-mode updates every row a_i with its own rho_i)."""
         raise NotImplementedError
 
 

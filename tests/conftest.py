@@ -8,6 +8,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
+# the only place that allows a substitute (checker) engine behind cmf_aoadmm: see matcouply_amd/decomposition.py
+os.environ["MATCOUPLY_AMD_TEST_ENGINE"] = "1"
 
 
 def pytest_configure(config):

@@ -108,3 +108,64 @@ def test_parafac2_variant_without_native_kernel_runs_on_the_host_path():
         if P.shape[0] >= r:
             np.testing.assert_allclose(P.T @ P, np.eye(r), atol=1e-4)
     assert diag.rec_errors[-1] < diag.rec_errors[0] and np.isfinite(diag.regularized_loss).all()
+
+
+def test_overridden_builtin_penalty_is_not_routed_to_the_native_kernel():
+    """A subclass of NonNegativity whose prox clamps at 0.1 must behave like Box(0.1, None) - not like the built-in
+    non-negativity kernel its parent class maps to (the reference calls the override, decomposition.py:278-285)."""
+    import torch
+    from matcouply_amd import penalties as pen
+
+    class AtLeastTenth(pen.NonNegativity):
+        def factor_matrix_row_update(self, factor_matrix_row, feasibility_penalty, aux_row):
+            return torch.clamp(factor_matrix_row, min=0.1)
+
+        def factor_matrix_update(self, factor_matrix, feasibility_penalty, aux):
+            return torch.clamp(factor_matrix, min=0.1)
+
+    user = _run(lambda m, a, d: AtLeastTenth(aux_init=a, dual_init=d))
+    box = _run(lambda m, a, d: pen.Box(0.1, None, aux_init=a, dual_init=d))
+    plain = _run(lambda m, a, d: pen.NonNegativity(aux_init=a, dual_init=d))
+    _close(user, box)
+    assert min(float(np.min(z)) for z in user[1].auxes[1][0]) >= 0.1 - 1e-7
+    assert rel_err(user[0][1][2], plain[0][1][2]) > 1e-3  # and it is NOT the parent's kernel
+
+
+def test_custom_penalty_written_against_the_reference_docs():
+    """The pattern of the reference's custom-penalty example (examples/plot_custom_penalty.py:213-231, re-typed): a hard
+    constraint built from HardConstraintMixin + MatrixPenalty with the docstring helper, imposing unimodality on all but
+    the last component, on the B mode of a PARAFAC2 model - through the EXTERNAL step path of the engine."""
+    import torch
+    from matcouply_amd import decomposition as dec
+    from matcouply_amd import penalties as pen
+    from matcouply_amd._doc_utils import copy_ancestor_docstring
+    from matcouply_amd._unimodal_regression import unimodal_regression
+    from matcouply_amd.data import get_simple_simulated_data
+
+    class UnimodalButLast(pen.HardConstraintMixin, pen.MatrixPenalty):
+        def __init__(self, non_negativity=False, aux_init="random_uniform", dual_init="random_uniform"):
+            super().__init__(aux_init, dual_init)
+            self.non_negativity = non_negativity
+
+        @copy_ancestor_docstring
+        def factor_matrix_update(self, factor_matrix, feasibility_penalty, aux):
+            host = factor_matrix.detach().cpu().numpy().astype(np.float64)
+            host[:, :-1] = unimodal_regression(host[:, :-1], non_negativity=self.non_negativity)
+            if self.non_negativity:
+                host = np.clip(host, 0, None)
+            return torch.as_tensor(host, dtype=factor_matrix.dtype, device=factor_matrix.device)
+
+    assert UnimodalButLast.factor_matrix_update.__doc__ == pen.MatrixPenalty.factor_matrix_update.__doc__
+    X, _ = get_simple_simulated_data(noise_level=0.2, random_state=1)
+    cmf, admm, diag = dec.parafac2_aoadmm(X, 3, n_iter_max=30, non_negative={0: True, 2: True},
+                                         regs=[[], [UnimodalButLast(non_negativity=True)], []], random_state=0,
+                                         tol=None, absolute_tol=None, return_errors=True, return_admm_vars=True)
+    assert np.isfinite(diag.regularized_loss).all() and diag.rec_errors[-1] < 0.5 * diag.rec_errors[0]
+    k = [i for i, z in enumerate(admm.auxes[1]) if not isinstance(z, tuple)][0]  # the custom penalty (PARAFAC2 is a tuple)
+    for Z in admm.auxes[1][k]:
+        Z = np.asarray(Z)
+        assert Z.min() >= 0
+        for c in range(Z.shape[1] - 1):  # rises to one peak, then falls
+            col = Z[:, c]
+            p = int(np.argmax(col))
+            assert np.all(np.diff(col[: p + 1]) >= -1e-6) and np.all(np.diff(col[p:]) <= 1e-6)

@@ -65,6 +65,7 @@ def test_unimodal_kernel_forms_agree_with_oracle(shape, nonneg, data):
             for k in saved:
                 os.environ.pop(k, None)
             os.environ.update(env)
+            eng.reload_switches()  # the library reads its switches once per context
             eng.B.copy_(B0)
             eng.regs[1][0].dual.copy_(U0)
             aux.zero_()

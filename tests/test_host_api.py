@@ -397,3 +397,56 @@ def test_bench_counts_the_cores_it_may_use():
     n = bench.usable_cores()
     assert 1 <= n <= (os.cpu_count() or 1)
     assert n <= len(os.sched_getaffinity(0))
+
+
+# ---- plugin surface: docstring helpers and subclass routing ------------------------------------------------------
+def test_doc_utils_shim_inherits_docstrings():
+    """the names user penalties import from the reference's matcouply._doc_utils (examples/plot_custom_penalty.py:213-231)"""
+    from matcouply_amd._doc_utils import InheritableDocstrings, copy_ancestor_docstring
+
+    class Mine(pen.HardConstraintMixin, pen.MatrixPenalty):
+        @copy_ancestor_docstring
+        def factor_matrix_update(self, factor_matrix, feasibility_penalty, aux):
+            return factor_matrix
+
+    assert type(Mine) is InheritableDocstrings
+    assert Mine.factor_matrix_update.__doc__ == pen.MatrixPenalty.factor_matrix_update.__doc__
+    assert Mine.factor_matrix_update.__doc__  # the ancestor documents the method
+    with pytest.raises(RuntimeError, match="already has docstring"):
+        @copy_ancestor_docstring
+        def documented():
+            """x"""
+    with pytest.raises(RuntimeError, match="does not exist in superclass"):
+        class Bad(pen.MatrixPenalty):
+            @copy_ancestor_docstring
+            def no_such_method(self):
+                pass
+
+
+def test_native_descriptor_only_for_unmodified_builtin_penalties():
+    """a subclass that overrides the prox (or the penalty value) of a built-in penalty is evaluated on the host"""
+    class Shifted(pen.NonNegativity):
+        def factor_matrix_row_update(self, factor_matrix_row, feasibility_penalty, aux_row):
+            return np.maximum(factor_matrix_row, 0.1)
+
+    class Renamed(pen.NonNegativity):  # nothing of the contract overridden: still native
+        pass
+
+    class Valued(pen.L1Penalty):
+        def penalty(self, x):
+            return 0.0
+
+    assert pen.native_descriptor_of(pen.NonNegativity()) == pen.NonNegativity()._native_descriptor()
+    assert pen.native_descriptor_of(Renamed()) == pen.NonNegativity()._native_descriptor()
+    assert pen.native_descriptor_of(Shifted()) is None
+    assert pen.native_descriptor_of(Valued(0.1)) is None
+    assert pen.native_descriptor_of(pen.UnitSimplex()) is None
+
+
+def test_substitute_engine_needs_the_test_switch(monkeypatch):
+    """the checker-engine seam of decomposition.py is inert outside the test-suite"""
+    monkeypatch.setattr(dec, "_ENGINE_FACTORY", OracleEngineFactory())
+    monkeypatch.delenv("MATCOUPLY_AMD_TEST_ENGINE")
+    X, _ = get_simple_simulated_data()
+    with pytest.raises(RuntimeError, match="outside the test-suite"):
+        dec.cmf_aoadmm(X, 3, n_iter_max=1)
