@@ -8,10 +8,15 @@
 A "step" is ONE outer AO-ADMM iteration (B-phase -> C-phase -> A-phase + per-iteration diagnostics, i.e.
 `return_errors=True` as in the reference's default loop) of `cmf_aoadmm(non_negative=True, l1_penalty={2: 0.1})`
 on synthetic data of config 3 (I=1024, J_i=512, K=256, rank 16), inputs resident in HBM.
-With N > 1 the I slabs are sharded contiguously over the ranks (fixed total problem -> "strong" scaling, as
-BASELINE.json's metric "@1/2/4/8 GPU" states); per step there is one RCCL all-reduce of the C-mode normal
-equations [G | R]; the fp64 diagnostic sums of all steps are all-reduced once at the end of the timed region
-(no stopping rule is active in this fixed-iteration workload).
+With N > 1 the I slabs are sharded over the ranks in contiguous ranges balanced by their ROWS (partition_slabs; fixed
+total problem -> "strong" scaling, as BASELINE.json's metric "@1/2/4/8 GPU" states); per step there is one RCCL
+all-reduce of the fp64 C-mode normal equations [G | R] (PARAFAC2 stacks add one small all-reduce per inner iteration);
+the fp64 diagnostic sums of all steps are all-reduced once at the end of each timed region (no stopping rule is active
+in this fixed-iteration workload).  After the run the replicated factor C is checked to be BIT-identical on all ranks.
+
+Timing: W warm-up steps, then R (default 5) timed regions of exactly K steps each, every region bracketed by a barrier
++ torch.cuda.synchronize(); per region the MAX over ranks; the reported `ms_per_step * steps` is the MEDIAN region
+(`region_ms` lists all of them) - one region of 20 steps lasts ~4 ms and a single sample of that swings by 10 %.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      dominant kernel's algorithmic bytes / HIP-event time (events recorded inside the library on the
@@ -65,7 +70,11 @@ def make_shard(cfg, rank, world, device, seed=0):
     import torch
 
     I, J, K, r = cfg["I"], cfg["J"], cfg["K"], cfg["r"]
-    lo, hi = (I * rank) // world, (I * (rank + 1)) // world
+    from matcouply_amd.decomposition import partition_slabs
+
+    J_all = np.random.RandomState(0).randint(128, 1025, I) if J == "ragged" else np.full(I, J)
+    mine = partition_slabs(J_all, world)[rank]  # contiguous range, balanced by rows (sum of J_i), not by slab count
+    lo, hi = (int(mine[0]), int(mine[-1]) + 1) if len(mine) else (0, 0)
     I_loc = hi - lo
     if J == "ragged":
         return make_ragged_shard(cfg, lo, hi, rank, device, seed)
@@ -118,8 +127,7 @@ def make_ragged_shard(cfg, lo, hi, rank, device, seed):
 
 def make_engine(cfg, X, row_ptr, I_loc, rank, device, seed=1):
     import torch
-    from matcouply_amd._engine import HipEngine, NativeReg
-    from tests.helpers import KIND
+    from matcouply_amd._engine import KIND, HipEngine, NativeReg
 
     K, r, N = cfg["K"], cfg["r"], X.shape[0]
     g = torch.Generator(device=device)
@@ -207,7 +215,13 @@ def cpu_baseline(cfg, budget_s=15.0):
     iters = 2
     t_iter = timed(I_s, iters)
     value = 1.0 / (t_iter * I / I_s)
+    survey = {"c3": 0.41, "c2": 7.5}.get(cfg.get("name"))
     return dict(value=value, unit="outer-iters/s", cores=cores, kind="port",
+                note="the port is the vectorised NumPy restatement of the reference (oracle/, pinned by the reference's "
+                     "goldens); the reference proper is slower (per-slab Python loops)",
+                reference_survey=(dict(value=survey, unit="outer-iters/s", cores=8,
+                                       where="unmodified reference, survey container (BASELINE.md section 2)")
+                                  if survey else None),
                 sample=f"{iters} outer iterations (after 1 warm-up) of the NumPy fp64 oracle on the first {I_s} of {I} slabs "
                        f"of the same synthetic workload, BLAS threads = {cores} (affinity mask capped by the cgroup CPU quota; "
                        f"os.cpu_count() = {os.cpu_count()}); value scaled by {I_s}/{I}")
@@ -219,6 +233,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -226,13 +241,13 @@ def main():
     import torch
     import torch.distributed as dist
 
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config], name=args.config)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # MCL_BENCH_SHARE_GPU=1 (+ MCL_BENCH_BACKEND=gloo): all ranks use device 0 - a functional check of the sharded path
@@ -252,7 +267,13 @@ def main():
     eng = make_engine(cfg, X, row_ptr, I_loc, rank, device)
     from matcouply_amd._engine import DIAG_LEN
 
-    ring = torch.zeros((args.steps + args.warmup, DIAG_LEN), dtype=torch.float64, device=device)
+    n_regions = max(1, args.regions)
+    ring = torch.zeros((args.warmup + n_regions * args.steps, DIAG_LEN), dtype=torch.float64, device=device)
+    n_coll = [0]  # collectives issued by this rank (counted on the host)
+
+    def all_reduce(t, **kw):
+        n_coll[0] += 1
+        dist.all_reduce(t, **kw)
 
     pf2 = [k for k, d in enumerate(cfg["regs"][1]) if d["kind"] == "parafac2"]
 
@@ -271,7 +292,7 @@ def main():
             for k in range(len(cfg["regs"][1])):
                 eng.B_prox_local(k)
                 if k in pf2 and world > 1:
-                    dist.all_reduce(eng.B_prox_reduce_buffer(k))
+                    all_reduce(eng.B_prox_reduce_buffer(k))
                 eng.B_prox_finish(k)
         eng.B_end()
 
@@ -279,7 +300,7 @@ def main():
         update_B()
         gr = eng.update_C_local()
         if world > 1:
-            dist.all_reduce(gr)
+            all_reduce(gr)
         eng.update_C_finish()
         eng.update_A()
         # no stopping rule is active (tol=None), so the per-iteration diagnostic sums stay on the device and are
@@ -297,20 +318,36 @@ def main():
     # HIP events inside the library around every `stride`-th launch of the timed region: an event pair opens ~5 us
     # dispatch gaps before and after the kernel (11 us per step when every launch is bracketed - measured), so the
     # timed loop samples ~10 launches instead of taxing all of them
-    prof_stride = max(1, args.steps // 10)
-    eng.profile_enable(args.steps, stride=prof_stride)
-    sync()
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        step(args.warmup + it)
+    prof_stride = max(1, (n_regions * args.steps) // 10)
+    eng.profile_enable(n_regions * args.steps, stride=prof_stride)
+    region_s = []
+    coll_before = n_coll[0]
+    for reg in range(n_regions):
+        first = args.warmup + reg * args.steps
+        sync()
+        t0 = time.perf_counter()
+        for it in range(args.steps):
+            step(first + it)
+        if world > 1:
+            all_reduce(ring[first:first + args.steps])
+        sync()
+        region_s.append(time.perf_counter() - t0)
     if world > 1:
-        dist.all_reduce(ring[args.warmup:])
-    sync()
-    elapsed = time.perf_counter() - t0
+        t = torch.tensor(region_s, dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # per region: the slowest rank
+        region_s = [float(v) for v in t.cpu()]
+    elapsed = float(np.median(region_s))
+    coll_per_step = (n_coll[0] - coll_before - n_regions) / max(1, n_regions * args.steps)  # without the ring reductions
+
+    # the replicated factor must be bit-identical on every rank (a divergent C would silently corrupt the fit)
+    c_identical = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        bits = eng.C.view(torch.int32).to(torch.int64)
+        chk = torch.stack([bits.sum(), (bits * torch.arange(1, bits.numel() + 1, device=device).view_as(bits)).sum()])
+        lo_, hi_ = chk.clone(), chk.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        c_identical = bool(torch.equal(lo_, hi_))
 
     # live roofline of the dominant kernel (HIP events inside the library, same stream as the kernels)
     prof = []
@@ -335,9 +372,15 @@ def main():
     def pmc_traffic(kernel_variant):
         """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), if the
         profile was taken on this configuration; counters are collected in separate runs, never inside this one."""
-        path = os.path.join(REPO, "profiles", f"r1_{args.config}_pmc_traffic.json")
-        if world != 1 or not os.path.exists(path):
+        for rnd in ("r2", "r1"):
+            path = os.path.join(REPO, "profiles", f"{rnd}_{args.config}_pmc_traffic.json")
+            if os.path.exists(path):
+                break
+        else:
             return None
+        if world != 1:
+            return None
+        pmc_traffic.source = os.path.relpath(path, REPO)
         with open(path) as f:
             kernels = json.load(f)["kernels"]
         base = kernel_variant.split("<")[0]
@@ -353,15 +396,15 @@ def main():
         traffic = pmc_traffic(eng.kernel_variant(slot))
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                        traffic_source=("profiles/r1_%s_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                        "passes)" % args.config) if traffic is not None else None,
+                        traffic_source=("static: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in separate "
+                                        "passes, not measured in this run)" % pmc_traffic.source) if traffic is not None else None,
                         kernel=eng.kernel_variant(slot),
                         kernel_role=names[slot], avg_us=round(avg_ms * 1e3, 2), launches_timed=n,
-                        launches_in_timed_region=args.steps, event_stride=prof_stride,
+                        launches_in_timed_regions=n_regions * args.steps, event_stride=prof_stride,
                         algorithmic_bytes_per_launch=int(alg_bytes[slot]),
                         all_kernels_avg_us={names[s]: round(a * 1e3, 2) for a, s, _ in prof})
 
-    final = ring[args.warmup + args.steps - 1].cpu().numpy() if args.steps else None
+    final = ring[args.warmup + n_regions * args.steps - 1].cpu().numpy() if args.steps else None
     if rank == 0:
         its = args.steps / elapsed
         S_X_tot, S_B_tot = 4.0 * N_tot * K, 4.0 * N_tot * r
@@ -377,7 +420,11 @@ def main():
             "algorithmic_bytes_per_iter": int(bytes_iter),
             "hbm_gbps_algorithmic": round(bytes_iter * its / 1e9, 1),
             "roofline": roofline,
+            "timed_regions": n_regions, "region_ms": [round(1e3 * v, 4) for v in region_s], "region_stat": "median",
         }
+        if world > 1:
+            out["collectives_per_step"] = round(coll_per_step, 2)
+            out["replicated_C_bit_identical"] = c_identical
         if final is not None:
             xsq, inner, model = final[5], final[3], final[4]
             out["final_rel_rec_error"] = round(float(np.sqrt(max(0.0, xsq - 2 * inner + model) / xsq)), 6)

@@ -18,6 +18,9 @@ DIAG_NORM_SQ, DIAG_INNER, DIAG_MODEL_SQ, DIAG_X_SQ, DIAG_REG = 0, 3, 4, 5, 8
 DIAG_LEN = 8 + 3 * MCL_MAX_REGS * 2
 
 PEN_NN, PEN_BOX, PEN_L1, PEN_L2BALL, PEN_UNIMODAL, PEN_PARAFAC2, PEN_EXTERNAL, PEN_TV = 1, 2, 3, 4, 5, 6, 7, 8
+# short names of the native kinds (descriptor dicts of bench.py / the test helpers -> enum mcl_penalty_kind)
+KIND = {"nn": PEN_NN, "box": PEN_BOX, "l1": PEN_L1, "l2ball": PEN_L2BALL, "unimodal": PEN_UNIMODAL,
+        "parafac2": PEN_PARAFAC2, "tv": PEN_TV}
 
 # every symbol include/matcouply_hip.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTED_SYMBOLS = [

@@ -22,7 +22,7 @@ from ._utils import check_random_state, get_svd, is_iterable, is_tensor, is_torc
 from .coupled_matrices import CoupledMatrixFactorization
 
 __all__ = ["compute_feasibility_gaps", "ADMMVars", "DiagnosticMetrics", "cmf_aoadmm", "parafac2_aoadmm",
-           "PackedMatrices"]
+           "PackedMatrices", "partition_slabs"]
 
 # TEST-ONLY seam.  The CPU test-suite (tests/oracle_engine.py) substitutes a checker engine here to exercise the host and
 # multi-process logic without a GPU.  The substitution is honoured only under MATCOUPLY_AMD_TEST_ENGINE=1, which
@@ -37,6 +37,43 @@ def _test_engine_factory():
         raise RuntimeError("a substitute compute engine is installed outside the test-suite: matcouply_amd runs on the "
                            "HIP engine only (set MATCOUPLY_AMD_TEST_ENGINE=1 in a test harness to allow a checker)")
     return _ENGINE_FACTORY
+
+
+def partition_slabs(n_rows, world_size, contiguous=True):
+    """Split the I coupled matrices over `world_size` ranks so that every rank holds about the same number of ROWS
+    (sum of J_i) - the per-rank work of every phase is proportional to its rows, not to its number of matrices.
+
+    n_rows: J_i for every matrix (or anything with a `.shape[0]`).  Returns a list of `world_size` index arrays; rank k
+    passes `[matrices[i] for i in parts[k]]` to `cmf_aoadmm(..., group=pg)` (the rows of A come back in that order).
+
+    contiguous=True   consecutive ranges [lo_k, hi_k): the cut after slab i is placed where the prefix sum of rows is
+                      closest to k / world_size of the total (keeps the matrices in order; imbalance <= max J_i / 2 rows);
+    contiguous=False  longest-processing-time greedy (largest matrix first onto the least loaded rank; indices sorted
+                      within a rank): within a fraction of a percent for ragged J_i such as BASELINE config 4.
+    """
+    J = np.asarray([getattr(m, "shape", (m,))[0] if not np.isscalar(m) else m for m in n_rows], dtype=np.int64)
+    I, W = len(J), int(world_size)
+    if W < 1:
+        raise ValueError("world_size must be positive")
+    if contiguous:
+        prefix = np.concatenate([[0], np.cumsum(J)])
+        total = prefix[-1]
+        cuts = [0]
+        for k in range(1, W):
+            target = total * k / W
+            i = int(np.searchsorted(prefix, target))
+            if i > 0 and abs(prefix[i - 1] - target) <= abs(prefix[min(i, I)] - target):
+                i -= 1
+            cuts.append(min(max(i, cuts[-1]), I))
+        cuts.append(I)
+        return [np.arange(cuts[k], cuts[k + 1], dtype=np.int64) for k in range(W)]
+    load = np.zeros(W, dtype=np.int64)
+    parts = [[] for _ in range(W)]
+    for i in np.argsort(-J, kind="stable"):
+        k = int(np.argmin(load))
+        parts[k].append(int(i))
+        load[k] += J[i]
+    return [np.array(sorted(p), dtype=np.int64) for p in parts]
 
 
 class PackedMatrices:

@@ -27,7 +27,7 @@ def rel_err(a, b):
 
 
 # ---- GPU helpers (only used by -m gpu tests) ---------------------------------------------------------
-KIND = {"nn": 1, "box": 2, "l1": 3, "l2ball": 4, "unimodal": 5, "parafac2": 6, "tv": 8}
+from matcouply_amd._engine import KIND  # noqa: E402  (short kind names -> enum mcl_penalty_kind)
 
 
 def native_regs(descs, aux, dual, device):

@@ -148,3 +148,24 @@ def test_two_rank_sharded_run_equals_single_process(case):
             for g, rg in zip(got_it, ref_it):
                 np.testing.assert_allclose(g, rg, rtol=1e-8, atol=1e-12)
     np.testing.assert_array_equal(results[0][3], results[1][3])
+
+
+def test_partition_slabs_balances_rows():
+    """slabs are split over ranks by their ROWS (sum of J_i), contiguous or greedy (LPT) for ragged data."""
+    import numpy as np
+    from matcouply_amd.decomposition import partition_slabs
+
+    J = np.random.RandomState(0).randint(128, 1025, 1024)  # BASELINE config 4
+    for world in (2, 4, 8):
+        for contiguous in (True, False):
+            parts = partition_slabs(J, world, contiguous=contiguous)
+            assert sorted(np.concatenate(parts).tolist()) == list(range(1024))  # a partition
+            rows = np.array([J[p].sum() for p in parts], dtype=np.float64)
+            assert rows.max() / rows.mean() <= (1.02 if contiguous else 1.001), (world, contiguous, rows)
+            if contiguous:
+                assert all(np.all(np.diff(p) == 1) for p in parts)
+    # by count it would be off by the spread of J_i; equal J_i degenerate to an even split
+    assert [len(p) for p in partition_slabs([7] * 12, 4)] == [3, 3, 3, 3]
+    assert [p.tolist() for p in partition_slabs([10, 1, 1, 1, 1, 10], 2)] == [[0, 1, 2], [3, 4, 5]]
+    assert [p.tolist() for p in partition_slabs([9, 1, 1, 1, 1, 1, 1, 1, 1, 1], 2, contiguous=False)] == [[0], list(range(1, 10))]
+    assert sum(len(p) for p in partition_slabs([5, 5, 5], 4)) == 3  # more ranks than matrices: some ranks stay empty
