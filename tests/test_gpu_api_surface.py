@@ -141,7 +141,7 @@ def test_two_ranks_sharing_the_gpu_equal_single_process(tmp_path, stack):
     import json
 
     err = json.loads(line[0].split(" ", 1)[1])
-    assert max(err.values()) < 2e-5, err
+    assert max(err.values()) < 1e-5, err
 
 
 @pytest.mark.parametrize("stack", ["pf2", "pf2_ball"])

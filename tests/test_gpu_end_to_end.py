@@ -2,9 +2,10 @@
   (a) trajectories captured from the reference (tests/golden/traj_*.npz),
   (b) the oracle on seeded inputs at sizes it finishes in seconds (BASELINE configs 2-5, down-scaled where needed),
   (c) size-independent properties at the FULL size of BASELINE config 3.
-Tolerance: 1e-5 relative (Frobenius) on short fixed trajectories, as BASELINE.json's north_star states for the fp32
-engine against the fp64 NumPy reference; the 20-iteration golden trajectories are held to 1e-4 (error accumulation of
-fp32 over 20 outer x 5 inner iterations), rec_errors to 1e-5 throughout."""
+Tolerance: a flat 1e-5 relative (Frobenius) on short fixed trajectories, penalty-free modes included, as BASELINE.json's
+north_star states for the fp32 engine against the fp64 NumPy reference; the 20-iteration golden trajectories are held
+to 3e-6 (5e-5 with a localisation proof where a discontinuous projection re-pools a column), rec_errors to 1e-5
+throughout."""
 import json
 import os
 
@@ -102,11 +103,24 @@ def test_golden_trajectories(fname):
     st = _traj_state(arrs, spec)
     cmf, admm, diag, res = _run_both(st, spec["n_iter_max"])
     np.testing.assert_allclose(diag.rec_errors, arrs["rec_errors"], rtol=1e-5)
-    np.testing.assert_allclose(diag.regularized_loss, arrs["regularized_loss"], rtol=2e-5)
+    np.testing.assert_allclose(diag.regularized_loss, arrs["regularized_loss"], rtol=1e-5)
     e = {"A": rel_err(cmf[1][0], arrs["A"]), "B": rel_err(np.concatenate(cmf[1][1]), arrs["B"]),
          "C": rel_err(cmf[1][2], arrs["C"])}
     print(fname, "20 it vs reference:", {k: f"{v:.1e}" for k, v in e.items()})
-    assert max(e.values()) < 1e-4, e
+    if max(e.values()) < 3e-6:  # measured: <= 7e-7 on six of the seven trajectories
+        return
+    # Above that, the loss must be a LOCALISED event of a discontinuous projection, not a diffuse loss of digits: the
+    # unimodal regression of the full stack (traj_c5_full) re-pools a column differently when two candidate level sets
+    # are closer than fp32 rounding (tools/traj_growth.py: B error 3e-6 at iteration 12, 2.3e-5 at 16, 82 % of it in one
+    # (slab, column) pair and 99 % in three of 45).  Bound 5e-5, and >= 90 % of the squared error in <= 3 columns.
+    assert any(d["kind"] == "unimodal" for d in spec["regs"][1]), (fname, e)
+    assert max(e.values()) < 5e-5, e
+    Bg, rp = np.concatenate(cmf[1][1]), st.row_ptr
+    err = np.array([[np.sum((Bg[rp[i]:rp[i + 1], c] - arrs["B"][rp[i]:rp[i + 1], c]) ** 2) for c in range(Bg.shape[1])]
+                    for i in range(len(rp) - 1)]).ravel()
+    share = np.sort(err)[::-1][:3].sum() / err.sum()
+    print(fname, f"share of the squared B error in the worst 3 of {err.size} (slab, column) pairs: {share:.3f}")
+    assert share > 0.9, share
 
 
 def test_seeded_keyword_run_on_gpu():
@@ -118,7 +132,7 @@ def test_seeded_keyword_run_on_gpu():
                                l2_norm_bound={1: 1.0}, parafac2=True, n_iter_max=10, tol=None, absolute_tol=None,
                                return_errors=True, random_state=0)
     np.testing.assert_allclose(diag.rec_errors, arrs["rec_errors"], rtol=1e-5)
-    assert rel_err(cmf[1][0], arrs["A"]) < 1e-4 and rel_err(np.concatenate(cmf[1][1]), arrs["B"]) < 1e-4
+    assert rel_err(cmf[1][0], arrs["A"]) < 1e-5 and rel_err(np.concatenate(cmf[1][1]), arrs["B"]) < 1e-5
 
 
 def test_readme_example_of_the_reference_on_gpu():
@@ -131,11 +145,11 @@ def test_readme_example_of_the_reference_on_gpu():
     cmf, diag = dec.cmf_aoadmm(split_rows(c1["X"], c1["row_ptr"]), 3, non_negative=True, l1_penalty={2: 0.1},
                                l2_norm_bound=[1, 1, 0], parafac2=True, unimodal={1: True}, constant_feasibility_penalty=True,
                                n_iter_max=10, tol=None, absolute_tol=None, return_errors=True, random_state=0)
-    np.testing.assert_allclose(diag.rec_errors, arrs["rec_errors"], rtol=2e-5)
-    np.testing.assert_allclose(diag.regularized_loss, arrs["regularized_loss"], rtol=5e-5)
+    np.testing.assert_allclose(diag.rec_errors, arrs["rec_errors"], rtol=1e-5)
+    np.testing.assert_allclose(diag.regularized_loss, arrs["regularized_loss"], rtol=1e-5)
     e = {"A": rel_err(cmf[1][0], arrs["A"]), "B": rel_err(np.concatenate(cmf[1][1]), arrs["B"]), "C": rel_err(cmf[1][2], arrs["C"])}
     print("README example, 10 it vs reference:", {k: f"{v:.1e}" for k, v in e.items()})
-    assert max(e.values()) < 1e-4, e
+    assert max(e.values()) < 1e-5, e
 
 
 def test_config1_converges_like_the_reference():
@@ -167,6 +181,15 @@ SCALE_CASES = {
     # config 5's matrix dimensions (K = 1024, rank 32: K-sliced X^T pass, fragment-streaming X C pass) with few slabs
     "c5_dims": dict(I=6, J="c5dims", K=1024, r=32,
                     regs=[[{"kind": "nn"}], [{"kind": "nn"}], [{"kind": "l1", "reg_strength": 0.1, "non_negativity": True}]]),
+    # ... and the same dimensions with config 5's FULL penalty stack (PARAFAC2 + unimodality + L2 ball on the B_i, NN on A,
+    # L1 on C): the combination BASELINE config 5 actually is
+    # (slab heights >= 3 r, as in config 5 itself - a PARAFAC2 slab barely taller than the rank has a nearly singular
+    # Y_i Delta^T, cond 2e4 with J_i = 33: see the polar-factor note in _compare)
+    "c5_dims_stack": dict(I=6, J="c5stack", K=1024, r=32,
+                          regs=[[{"kind": "nn"}],
+                                [{"kind": "parafac2"}, {"kind": "unimodal", "non_negativity": True},
+                                 {"kind": "l2ball", "norm_bound": 1.0, "non_negativity": True}],
+                                [{"kind": "l1", "reg_strength": 0.1, "non_negativity": True}]]),
     "k512": dict(I=10, J=300, K=512, r=16,
                  regs=[[{"kind": "nn"}], [{"kind": "parafac2"}, {"kind": "nn"}], [{"kind": "nn"}]]),
     "odd_shapes": dict(I=9, J="odd", K=37, r=5, regs=[[{"kind": "box", "min_val": 0.0, "max_val": 0.9}],
@@ -185,6 +208,8 @@ def test_scale_parity_vs_oracle(name):
         J = np.random.RandomState(0).randint(128, 1025, cfg["I"])
     elif J == "c5dims":
         J = np.array([2048, 700, 33, 1024, 515, 64])
+    elif J == "c5stack":
+        J = np.array([2048, 700, 100, 1024, 515, 130])
     elif J == "odd":
         J = np.array([1, 3, 64, 65, 17, 130, 5, 63, 2])
     X, row_ptr = orc.synthetic_problem(cfg["I"], J, cfg["K"], cfg["r"], seed=0, dtype=np.float64)

@@ -93,9 +93,7 @@ def test_one_iteration_phase_by_phase(name):
         rec = np.sqrt(max(0.0, d[E.DIAG_X_SQ] - 2 * d[E.DIAG_INNER] + d[E.DIAG_MODEL_SQ]) / d[E.DIAG_X_SQ])
         errs["rec"] = abs(rec - ref.rec_error_from_A_byproducts()) / ref.rec_error_from_A_byproducts()
         errs["normB"] = abs(d[E.DIAG_NORM_SQ + 1] - np.sum(ref.B ** 2)) / np.sum(ref.B ** 2)
-        # a mode without penalties has un-shifted, possibly ill-conditioned normal equations that amplify every fp32
-        # rounding (see test_gpu_end_to_end.test_scale_parity_vs_oracle): 1e-4 there, 1e-5 everywhere else
-        tol = 1e-4 if any(len(m) == 0 for m in st.regs) else 1e-5
+        tol = 1e-5  # flat, penalty-free modes included (their normal equations are built and solved in fp64)
         bad = {k: v for k, v in errs.items() if not (v < tol)}
         assert not bad, (name, it, bad)
     eng.close()
@@ -108,7 +106,7 @@ def test_trajectory_vs_oracle(name):
 
     st = _state(name)
     cmf, admm, diag, res = _run_both(st, 8)
-    _compare(cmf, admm, diag, st, res, 2e-5, tol_rec=2e-5)
+    _compare(cmf, admm, diag, st, res, 1e-5, tol_rec=1e-5)
 
 
 @pytest.mark.parametrize("name", ["k256_r16_nn", "k512_r16_nn", "k256_r32_nn"])
@@ -126,8 +124,8 @@ def test_sweep_equals_two_pass(name, monkeypatch):
     monkeypatch.delenv("MCL_NO_SWEEP", raising=False)
     (cs, _, ds, _), (ct, _, dt, _) = out["sweep"], out["two_pass"]
     assert rel_err(cs[1][0], ct[1][0]) < 1e-5 and rel_err(cs[1][2], ct[1][2]) < 1e-5
-    assert rel_err(np.concatenate(cs[1][1]), np.concatenate(ct[1][1])) < 2e-5
-    assert max(abs(a - b) / b for a, b in zip(ds.rec_errors, dt.rec_errors)) < 2e-5
+    assert rel_err(np.concatenate(cs[1][1]), np.concatenate(ct[1][1])) < 1e-5
+    assert max(abs(a - b) / b for a, b in zip(ds.rec_errors, dt.rec_errors)) < 1e-5
 
 
 def test_by_products_are_not_reused_out_of_order():

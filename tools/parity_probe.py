@@ -35,6 +35,7 @@ def case_state(name):
     J = cfg["J"]
     if isinstance(J, str):
         J = {"ragged": np.random.RandomState(0).randint(128, 1025, cfg["I"]), "c5dims": np.array([2048, 700, 33, 1024, 515, 64]),
+             "c5stack": np.array([2048, 700, 100, 1024, 515, 130]),
              "odd": np.array([1, 3, 64, 65, 17, 130, 5, 63, 2])}[J]
     X, row_ptr = orc.synthetic_problem(cfg["I"], J, cfg["K"], cfg["r"], seed=0, dtype=np.float64)
     X = X.astype(np.float32).astype(np.float64)
