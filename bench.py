@@ -302,9 +302,9 @@ def main():
         if world > 1:
             all_reduce(gr)
         eng.update_C_finish()
-        eng.update_A()
         # no stopping rule is active (tol=None), so the per-iteration diagnostic sums stay on the device and are
         # all-reduced ONCE for all iterations at the end of the timed region (one collective per step remains: [G | R])
+        eng.update_A()
         eng.diagnostics(include_replicated=(rank == 0), out=ring[it])
 
     def sync():

@@ -840,21 +840,31 @@ static __device__ __forceinline__ double lead_sum(double v) {
     return v;
 }
 
+// What the A-phase finish absorbs from its predecessor on the sweep path: Mpart != nullptr - the sweep left
+// M_bseg = X_bseg^T B_bseg per bseg (C-fragment order) and the wave forms rhs_i = sum_bsegs coldot(M_bseg, C) itself
+// (decomposition.py:147-152): one launch (k_A_rhs_from_M) and its boundary less per outer iteration.
+// (Measured and NOT kept: letting the last workgroup to finish also reduce the diagnostics tables - the 256-way ticket
+// fan-in on one counter plus the epilogue cost 9 us, the k_diag_final launch it replaced 4.8 us.)
+struct AFuse {
+    const float *Mpart, *Cfrag;
+    int MS, NBm;
+};
+
+// one wave = one slab
 template <int RP>
-__global__ __launch_bounds__(256) void k_A_finish_rows(float *__restrict__ BtB, const double *__restrict__ CtC, int I,
-                                                       int r, float scale, float l2, int constant,
-                                                       const float *__restrict__ rho_max, float *__restrict__ rhoA,
-                                                       float *__restrict__ LinvA, float *__restrict__ A, RegSet regs,
-                                                       int inner, int fused_inner, double *__restrict__ e1,
-                                                       double *__restrict__ diag_row, int next_B, float l2_B,
-                                                       int n_regs_B, float *__restrict__ rhoB, float *__restrict__ LinvB,
-                                                       const int *__restrict__ slab_seg_ptr,
-                                                       const double *__restrict__ seg_rhs,
-                                                       const double *__restrict__ seg_btb, float *__restrict__ rhsA_out) {
+static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int lane, float *__restrict__ BtB,
+                                                          const double *__restrict__ CtC, int r, float scale, float l2,
+                                                          int constant, const float *__restrict__ rho_max,
+                                                          float *__restrict__ rhoA, float *__restrict__ LinvA,
+                                                          float *__restrict__ A, const RegSet &regs, int inner,
+                                                          int fused_inner, double *__restrict__ e1,
+                                                          double *__restrict__ diag_row, int next_B, float l2_B,
+                                                          int n_regs_B, float *__restrict__ rhoB,
+                                                          float *__restrict__ LinvB, const int *__restrict__ slab_seg_ptr,
+                                                          const double *__restrict__ seg_rhs,
+                                                          const double *__restrict__ seg_btb,
+                                                          float *__restrict__ rhsA_out, const AFuse &F) {
     constexpr int RL = GJRows<RP>::RL, G = GJRows<RP>::G;
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= I) return;
     const int cc = lane % RP, g = lane / RP;
     const bool in_range = lane < GJRows<RP>::LANES;  // RP = 4 uses 16 lanes only
     const bool act = in_range && cc < r;
@@ -901,7 +911,7 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(float *__restrict__ BtB, 
                 const long sg = min(sb + q, sg1 - 1);
 #pragma unroll
                 for (int j = 0; j < RL; ++j) v[q][j] = seg_btb[(sg * r + drow[j]) * r + c];
-                rv[q] = seg_rhs[sg * r + c];
+                rv[q] = (F.Mpart == nullptr) ? seg_rhs[sg * r + c] : 0.0;
             }
 #pragma unroll
             for (int q = 0; q < SGB; ++q)
@@ -911,6 +921,39 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(float *__restrict__ BtB, 
                     rhs_pre += rv[q];
                 }
         }
+    }
+    if (F.Mpart != nullptr) {
+        // rhs_i[c] = sum_k M_i[k][c] C[k][c] over the slab's bsegs, both operands in C-fragment order (element
+        // ((chunk * NB + nb) * 64 + l) * 4 + m <-> k = 16 chunk + 4 (l >> 4) + m, column 16 nb + (l & 15)): the wave streams
+        // M_bseg with 1 KB loads, fp64 accumulation (products of fp32 values are exact), the four lane quarters of a
+        // column are summed by two butterfly steps and the column's sum is fetched into the lanes that own it
+        double pa[2][2] = {{0.0, 0.0}, {0.0, 0.0}};  // [nb][chain]: two chains per column block shorten the FMA dependency
+        for (int sg = sg0; sg < sg1; ++sg) {
+            const float *mp = F.Mpart + (long)sg * F.MS;
+            for (int e0 = 0; e0 < F.MS; e0 += 4096) {  // 16 chunks per trip (MS is a multiple of 4096): 32 loads in flight
+                f32x4 mv[16], cv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    mv[q] = *reinterpret_cast<const f32x4 *>(mp + e0 + 256 * q + 4 * lane);
+                    cv[q] = *reinterpret_cast<const f32x4 *>(F.Cfrag + e0 + 256 * q + 4 * lane);
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    double d = (double)mv[q][0] * (double)cv[q][0];
+                    d = fma((double)mv[q][1], (double)cv[q][1], d);
+                    d = fma((double)mv[q][2], (double)cv[q][2], d);
+                    d = fma((double)mv[q][3], (double)cv[q][3], d);
+                    // chunk index = e >> 8 = 16 * trip + q: nb = chunk % NB
+                    if (F.NBm == 2 && (q & 1)) pa[1][(q >> 1) & 1] += d;
+                    else pa[0][(q >> (F.NBm == 2 ? 1 : 0)) & 1] += d;
+                }
+            }
+        }
+        double acc0 = pa[0][0] + pa[0][1], acc1 = pa[1][0] + pa[1][1];
+        acc0 += __shfl_xor(acc0, 16), acc1 += __shfl_xor(acc1, 16);
+        acc0 += __shfl_xor(acc0, 32), acc1 += __shfl_xor(acc1, 32);
+        const double v0 = bperm_f64(cc & 15, acc0), v1 = bperm_f64(cc & 15, acc1);
+        rhs_pre = (cc < 16) ? v0 : v1;
     }
     double qf[RL];
     double tr = 0.0;
@@ -1045,6 +1088,25 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(float *__restrict__ BtB, 
             if (dok[j]) LinvB[((long)i * r + drow[j]) * r + c] = (float)col[j];
         if (lane == 0) rhoB[i] = rb;
     }
+}
+
+template <int RP>
+__global__ __launch_bounds__(256) void k_A_finish_rows(float *__restrict__ BtB, const double *__restrict__ CtC, int I,
+                                                       int r, float scale, float l2, int constant,
+                                                       const float *__restrict__ rho_max, float *__restrict__ rhoA,
+                                                       float *__restrict__ LinvA, float *__restrict__ A, RegSet regs,
+                                                       int inner, int fused_inner, double *__restrict__ e1,
+                                                       double *__restrict__ diag_row, int next_B, float l2_B,
+                                                       int n_regs_B, float *__restrict__ rhoB, float *__restrict__ LinvB,
+                                                       const int *__restrict__ slab_seg_ptr,
+                                                       const double *__restrict__ seg_rhs,
+                                                       const double *__restrict__ seg_btb, float *__restrict__ rhsA_out,
+                                                       AFuse F) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= I) return;
+    a_finish_rows_slab<RP>(i, lane, BtB, CtC, r, scale, l2, constant, rho_max, rhoA, LinvA, A, regs, inner, fused_inner, e1,
+                           diag_row, next_B, l2_B, n_regs_B, rhoB, LinvB, slab_seg_ptr, seg_rhs, seg_btb, rhsA_out, F);
 }
 
 // rho_i of the A-phase alone (needed before the systems when the feasibility penalty is constant)
@@ -1466,15 +1528,22 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
         fused_inner ? 1 : 0, c->e1, c->diagA_row, next_B, (float)c->opt.l2_penalty[1], c->regs[1].n, c->rhoB, c->LinvB, \
         (const int *)(seg ? (c->seg_from_sweep ? c->slab_bseg_ptr : c->slab_seg_ptr) : nullptr),                      \
         (const double *)c->seg_rhs, (const double *)((seg && c->seg_from_sweep) ? c->part_btb : c->seg_btb), c->rhsA
+    // what the row-split kernel absorbs: rhs_i from the sweep's M_bseg
+    AFuse F{};
+    if (c->a_rhs_from_M) {
+        F.Mpart = c->Mpart, F.Cfrag = c->CfragS, F.NBm = c->NB;
+        F.MS = mcl_sweep_KS(c) * 256 * 16 * c->NB;
+    }
+    const bool rows_kernel = !(c->RP == 64 || c->RP == 4 || c->sw.a_finish_cols);
     // ranks 5..32: rows of every system split over the lane groups (all 64 lanes busy); 64 columns fill the wave anyway
-    if (c->RP == 64 || c->RP == 4 || c->sw.a_finish_cols) {
+    if (!rows_kernel) {
         DISPATCH_RP_T(c, k_A_finish, grid, block, MCL_AF_ARGS);
     } else if (c->RP == 8) {
-        hipLaunchKernelGGL((k_A_finish_rows<8>), grid, block, 0, c->stream, MCL_AF_ARGS);
+        hipLaunchKernelGGL((k_A_finish_rows<8>), grid, block, 0, c->stream, MCL_AF_ARGS, F);
     } else if (c->RP == 16) {
-        hipLaunchKernelGGL((k_A_finish_rows<16>), grid, block, 0, c->stream, MCL_AF_ARGS);
+        hipLaunchKernelGGL((k_A_finish_rows<16>), grid, block, 0, c->stream, MCL_AF_ARGS, F);
     } else {
-        hipLaunchKernelGGL((k_A_finish_rows<32>), grid, block, 0, c->stream, MCL_AF_ARGS);
+        hipLaunchKernelGGL((k_A_finish_rows<32>), grid, block, 0, c->stream, MCL_AF_ARGS, F);
     }
 #undef MCL_AF_ARGS
     MCL_CHECK_HIP(c, hipGetLastError());

@@ -99,6 +99,7 @@ int64_t plan(mcl_context *c, char *base) {
     c->diag_sums = b.take<double>(3 * DIAG_COLS + 2);
     c->xsq_part = b.take<double>(1024);
     c->x_sq = b.take<double>(1);
+
     // generic (non row-separable) path scratch
     const int64_t maxrows = std::max<int64_t>(N, std::max<int64_t>(I, K));
     c->colsq = b.take<double>(std::max<int64_t>(I, 1) * r * MCL_MAX_REGS);  // one table per penalty slot (fused stack)
@@ -141,6 +142,7 @@ void read_switches(mcl_switches &w) {
     w.no_fused_gram = flag("MCL_NO_FUSED_GRAM"), w.no_fused_c = flag("MCL_NO_FUSED_C");
     w.a_finish_cols = flag("MCL_A_FINISH_COLS"), w.xc_norow = flag("MCL_XC_NOROW");
     w.unimodal_v3 = flag("MCL_UNIMODAL_V3"), w.stats_reduce = flag("MCL_STATS_REDUCE");
+    w.no_a_fusion = flag("MCL_NO_A_FUSION");
     w.seg_rows = num("MCL_SEG_ROWS", 0), w.bseg_rows = num("MCL_BSEG_ROWS", 0);
     w.xc_waves = num("MCL_XC_WAVES", 0), w.xt_waves = num("MCL_XT_WAVES", 0), w.sweep_waves = num("MCL_SWEEP_WAVES", 0);
     w.xc_dbg = num("MCL_XC_DBG", 0), w.xt_dbg = num("MCL_XT_DBG", 0), w.xt_depth = num("MCL_XT_DEPTH", 0);
@@ -693,10 +695,14 @@ int mcl_A_begin(mcl_context *c) {
     // constant-rho pre-pass (k_A_rho) needs the assembled per-slab Gram, so it keeps the separate kernel.
     c->use_seg_gram = false;
     c->seg_from_sweep = false;
+    c->a_rhs_from_M = false;
     if (c->mseg_valid && !c->opt.constant_A && mcl_mode_is_row_separable(c, 0)) {
         // the sweep left M_i = X_i^T B_i per bseg: rhs_i = coldot(M_i, C), no pass over X
         if (int rc = ensure_cfrag_sweep(c)) return rc;
-        if (int rc = mcl_launch_A_rhs_from_M(c)) return rc;
+        // rank 5..32: the finish kernel forms rhs_i from M_bseg itself (one launch less); otherwise a separate pass
+        c->a_rhs_from_M = (c->RP == 8 || c->RP == 16 || c->RP == 32) && !c->sw.a_finish_cols && !c->sw.no_a_fusion;
+        if (!c->a_rhs_from_M)
+            if (int rc = mcl_launch_A_rhs_from_M(c)) return rc;
         c->use_seg_gram = true;
         c->seg_from_sweep = true;
         c->e1_valid = false;
@@ -801,6 +807,7 @@ int mcl_C_end(mcl_context *c) {
 int mcl_diagnostics(mcl_context *c, double *out, int32_t include_replicated) {
     if (int rc = ready(c)) return rc;
     if (!out) return fail(c, "mcl_diagnostics: out is NULL");
+
     if (!c->xsq_valid) {
         if (int rc = mcl_launch_x_sq(c)) return rc;
         c->xsq_valid = true;
