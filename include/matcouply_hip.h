@@ -140,6 +140,13 @@ int mcl_C_begin(mcl_context *ctx);           /* rho, L^-1 from the reduced norma
 int mcl_C_solve(mcl_context *ctx);           /* decomposition.py:328-331 */
 int mcl_C_end(mcl_context *ctx);             /* invalidates everything derived from C */
 
+/* ---- the step after the solver: dense reconstruction (replaces cmf_to_matrices, coupled_matrices.py:365-497) ---------- */
+/* M_i = (B_i diag(weights o a_i)) C^T for all matrices, packed along rows like X.  Stateless (no context): A [I, r],
+ * B packed [N, r], C [K, r], weights [r] or NULL, slab_of_row int32 [N] (matrix index of every packed row), out [N, K] -
+ * all device pointers; enqueued on hip_stream. */
+int mcl_cmf_to_packed(const float *A, const float *B, const float *C, const float *weights, const int32_t *slab_of_row,
+                      int64_t N, int64_t K, int32_t rank, float *out, void *hip_stream);
+
 /* ---- introspection for tests / profiling ------------------------------------------------------------- */
 /* device pointers to internal by-products: 0 rhses [I, r], 1 cross_products [I, r, r], 2 X C [sum J_i, r],
  * 3 rho_B [I], 4 rho_A [I], 5 rho_C [1] */

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmatcouply_hip.so")
-SOURCES = ["contract.hip", "admm.hip", "generic.hip", "sweep.hip", "api.hip"]
+SOURCES = ["contract.hip", "admm.hip", "generic.hip", "sweep.hip", "reconstruct.hip", "api.hip"]
 
 
 def _stale():

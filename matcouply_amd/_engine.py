@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_B_end", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
     "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
     "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_set_stride", "mcl_profile_read",
-    "mcl_reload_switches",
+    "mcl_reload_switches", "mcl_cmf_to_packed",
 ]
 
 
@@ -102,6 +102,7 @@ def load_library():
         "mcl_profile_set_stride": (ctypes.c_int, [P, I32]),
         "mcl_profile_read": (ctypes.c_int, [P, I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I32)]),
         "mcl_reload_switches": (ctypes.c_int, [P]),
+        "mcl_cmf_to_packed": (ctypes.c_int, [P, P, P, P, P, I64, I64, I32, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -113,6 +114,31 @@ def load_library():
 
 class EngineError(RuntimeError):
     pass
+
+
+def cmf_to_packed(A, B, C, row_ptr, weights=None):
+    """Dense reconstruction on the device: packed [sum J_i, K] float32 tensor with rows row_ptr[i] .. row_ptr[i+1] equal to
+    (B_i diag(weights o a_i)) C^T.  A [I, r], B packed [N, r], C [K, r]: contiguous float32 CUDA tensors."""
+    import torch
+
+    lib = load_library()
+    for name, t in (("A", A), ("B", B), ("C", C)) + ((("weights", weights),) if weights is not None else ()):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise EngineError(f"{name} must be a contiguous float32 CUDA tensor")
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    N, K, r = int(B.shape[0]), int(C.shape[0]), int(C.shape[1])
+    if int(row_ptr[-1]) != N or A.shape != (len(row_ptr) - 1, r) or B.shape[1] != r:
+        raise EngineError("factor shapes do not match")
+    counts = torch.as_tensor(np.diff(row_ptr), device=B.device)
+    slab = torch.repeat_interleave(torch.arange(len(row_ptr) - 1, device=B.device, dtype=torch.int32), counts)
+    out = torch.empty((N, K), dtype=torch.float32, device=B.device)
+    with torch.cuda.device(B.device):
+        stream = torch.cuda.current_stream(B.device).cuda_stream
+        rc = lib.mcl_cmf_to_packed(A.data_ptr(), B.data_ptr(), C.data_ptr(), weights.data_ptr() if weights is not None else None,
+                                   slab.data_ptr(), N, K, r, out.data_ptr(), ctypes.c_void_p(stream))
+    if rc != 0:
+        raise EngineError("mcl_cmf_to_packed failed")
+    return out
 
 
 class NativeReg:

@@ -139,11 +139,32 @@ def _validate_cmf(cmf):
     return tuple(shapes), rank
 
 
+def _on_device(A, B_is, C):
+    """factors held as torch tensors on a HIP device: the dense converters then run in the native kernel"""
+    return all(is_torch(t) and t.is_cuda for t in [A, C] + list(B_is))
+
+
+def _device_matrices(weights, A, B_is, C):
+    """all dense matrices of device-resident factors in ONE native launch (csrc/reconstruct.hip), as row views of the
+    packed result; float32 like everything the engine computes"""
+    import torch
+    from . import _engine
+
+    f32 = lambda t: t.detach().to(torch.float32).contiguous()
+    row_ptr = np.concatenate([[0], np.cumsum([int(B_i.shape[0]) for B_i in B_is])]).astype(np.int64)
+    B = torch.cat([f32(B_i) for B_i in B_is], 0) if len(B_is) else f32(A).new_zeros((0, int(C.shape[1])))
+    packed = _engine.cmf_to_packed(f32(A), B, f32(C), row_ptr, weights=None if weights is None else f32(weights))
+    return [packed[row_ptr[i]:row_ptr[i + 1]] for i in range(len(B_is))]
+
+
 def cmf_to_matrix(cmf, matrix_idx, validate=True):
     """Dense matrix i: (B_i * a_i) C^T (:365-423)."""
     if validate:
         cmf = CoupledMatrixFactorization(cmf)
     weights, (A, B_is, C) = cmf
+    if _on_device(A, B_is, C):
+        i = range(len(B_is))[matrix_idx]
+        return _device_matrices(weights, A[i:i + 1], [B_is[i]], C)[0]
     a = A[matrix_idx]
     if weights is not None:
         a = a * weights
@@ -161,6 +182,8 @@ def cmf_to_matrices(cmf, validate=True):
     if validate:
         cmf = CoupledMatrixFactorization(cmf)
     weights, (A, B_is, C) = cmf
+    if _on_device(A, B_is, C):
+        return _device_matrices(weights, A, B_is, C)
     if weights is not None:
         A = A * weights
         weights = None
@@ -180,7 +203,7 @@ def cmf_to_tensor(cmf, validate=True):
     matrices = cmf_to_matrices(cmf, validate=False)
     lengths = [B_i.shape[0] for B_i in B_is]
     if is_torch(C):
-        tensor = C.new_zeros((A.shape[0], max(lengths), C.shape[0]))
+        tensor = matrices[0].new_zeros((A.shape[0], max(lengths), C.shape[0]))
     else:
         tensor = np.zeros((A.shape[0], max(lengths), C.shape[0]), dtype=matrices[0].dtype)
     for i, (matrix_, length) in enumerate(zip(matrices, lengths)):

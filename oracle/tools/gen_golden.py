@@ -19,6 +19,9 @@ Fixture families:
   G5  more_penalties.npz  GeneralizedL2Penalty / UnitSimplex: prox vectors and a 10-iteration
                           trajectory with a graph-Laplacian penalty on the B_i and the unit simplex on C
                           (`python oracle/tools/gen_golden.py --only more` regenerates just this family)
+  G7  converters_inits.npz  random_coupled_matrices (random.py:9-66), the dense converters cmf_to_matrices / tensor /
+                          unfolded / vec (coupled_matrices.py:365-799) on its output, and init="svd" / "threshold_svd"
+                          (decomposition.py:41-54): initial factors + a 5-iteration trajectory (`--only converters`)
   G6  readme_example.npz   the call of the reference's README (README.rst:66-91: non_negative, L1 on C, L2 balls on
                           A and B_i, PARAFAC2, unimodality, constant feasibility penalty, random_state=0), 10 iterations
                           (`--only readme`)
@@ -545,8 +548,56 @@ def gen_readme():
     print(f"readme_example: rec {diag.rec_errors[0]:.6f} -> {diag.rec_errors[-1]:.6f}; regs per mode {arrays['n_regs']}")
 
 
+def gen_converters_inits():
+    """random_coupled_matrices + dense converters + SVD-based initialisers of the reference, as data."""
+    from matcouply import coupled_matrices as ref_cm
+    from matcouply.random import random_coupled_matrices as ref_random
+
+    arrays = {}
+    shapes = [(7, 6), (4, 6), (9, 6), (5, 6)]
+    rank = 3
+    arrays["shapes"] = np.array(shapes)
+    for tag, kw in (("norm", dict()), ("raw", dict(normalise_factors=False)), ("normB", dict(normalise_factors=False, normalise_B=True))):
+        cmf = ref_random(shapes, rank, random_state=3, **kw)
+        weights, (A, B_is, C) = cmf
+        arrays[f"rc_{tag}_weights"], arrays[f"rc_{tag}_A"], arrays[f"rc_{tag}_C"] = np.asarray(weights), np.asarray(A), np.asarray(C)
+        arrays[f"rc_{tag}_B"] = pack_rows([np.asarray(B) for B in B_is])
+    cmf = ref_random(shapes, rank, random_state=3)  # the normalised one, with non-trivial weights
+    arrays["cv_matrices"] = pack_rows([np.asarray(m) for m in ref_cm.cmf_to_matrices(cmf)])
+    arrays["cv_matrix_2"] = np.asarray(ref_cm.cmf_to_matrix(cmf, 2))
+    arrays["cv_tensor"] = np.asarray(ref_cm.cmf_to_tensor(cmf))
+    for mode in range(3):
+        arrays[f"cv_unfolded_{mode}"] = np.asarray(ref_cm.cmf_to_unfolded(cmf, mode))
+    arrays["cv_unfolded_2_nopad"] = np.asarray(ref_cm.cmf_to_unfolded(cmf, 2, pad=False))
+    arrays["cv_vec"] = np.asarray(ref_cm.cmf_to_vec(cmf))
+    arrays["cv_vec_nopad"] = np.asarray(ref_cm.cmf_to_vec(cmf, pad=False))
+    full = ref_random(shapes, rank, full=True, random_state=3)
+    arrays["rc_full"] = pack_rows([np.asarray(m) for m in full])
+
+    # SVD-based initialisers on config-1 data, and what the solver makes of them in 5 iterations
+    X, _ = get_simple_simulated_data(noise_level=0.2, random_state=1)
+    X = [np.asarray(x) for x in X]
+    for init in ("svd", "threshold_svd"):
+        cmf0 = ref_dec.initialize_cmf(X, 3, init, svd_fun=SVD, random_state=None, init_params=None)
+        _, (A0, B0, C0) = cmf0
+        arrays[f"init_{init}_A"], arrays[f"init_{init}_C"] = np.asarray(A0), np.asarray(C0)
+        arrays[f"init_{init}_B"] = pack_rows([np.asarray(B) for B in B0])
+        cmf, diag = ref_dec.cmf_aoadmm(X, 3, init=init, non_negative=True, n_iter_max=5, tol=None, absolute_tol=None,
+                                       return_errors=True, random_state=0, aux_init="zeros", dual_init="zeros")
+        _, (A, B_is, C) = cmf
+        arrays[f"run_{init}_A"], arrays[f"run_{init}_C"] = np.asarray(A), np.asarray(C)
+        arrays[f"run_{init}_B"] = pack_rows([np.asarray(B) for B in B_is])
+        arrays[f"run_{init}_rec_errors"] = np.asarray(diag.rec_errors)
+        print(f"init={init}: rec {diag.rec_errors[0]:.6f} -> {diag.rec_errors[-1]:.6f}")
+    np.savez_compressed(os.path.join(OUT, "converters_inits.npz"), **arrays)
+    print("converters_inits:", len(arrays), "arrays")
+
+
 if __name__ == "__main__":
     print("reference version", matcouply.__version__)
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "converters":
+        gen_converters_inits()
+        sys.exit(0)
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "more":
         gen_more_penalties()
         sys.exit(0)
@@ -559,5 +610,6 @@ if __name__ == "__main__":
     gen_stopping()
     gen_more_penalties()
     gen_readme()
+    gen_converters_inits()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"total fixture bytes: {total}")
