@@ -194,13 +194,17 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
             // collapse to the pessimistic merge of both paths and drains the prefetch at every block.
             auto issue_x = [&](auto dc, int blk) {  // 16 rows x K columns, one 1 KB row segment per wave load
                 constexpr int d = decltype(dc)::value;
+                // scalar addressing: ONE 64-bit product per block, then a 32-bit row offset per row (row clamped into
+                // the wave's range: a negative tmax - a block past the end - lands every row on the last valid one).
+                // The per-row 64-bit products cost ~10 scalar instructions per row, and with one wave per SIMD every
+                // instruction of the wave, scalar ones included, takes an issue slot of its own.
+                const long blk_off = (base + 16 * (long)blk) * K;
+                const int tmax = wn - 1 - 16 * blk;
 #pragma unroll
                 for (int sc = 0; sc < KS; ++sc)
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        const long j = base + min(16 * blk + t, wn - 1);
-                        xr[d][sc][t] = *reinterpret_cast<const f32x4 *>(X + uniform_off(j * K) + xcol[sc]);
-                    }
+                    for (int t = 0; t < 16; ++t)
+                        xr[d][sc][t] = *reinterpret_cast<const f32x4 *>(X + uniform_off(blk_off + (long)(min(t, tmax) * K)) + xcol[sc]);
             };
             // aux / dual rows go straight into the registers the inner loop works on.  They are issued AFTER the slot's
             // previous block has stored its rows, so the registers are never live across the load and the compiler
