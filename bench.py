@@ -362,7 +362,7 @@ def main():
     n_B = len(cfg["regs"][1])
     # algorithmic bytes per launch (reads + writes): X^T pass reads X and B; the X C pass reads X, writes XC and - with the
     # fused per-slab Gram epilogue - also reads B; the fused B rows read XC/aux/dual and write B/aux/dual
-    xc_fused = "GRAM=1" in eng.kernel_variant(0)
+    xc_fused = "GRAM=" in eng.kernel_variant(0) and "GRAM=0" not in eng.kernel_variant(0)
     # the one-pass sweep reads X once, reads aux/dual and writes B/aux/dual (X C never reaches memory)
     alg_bytes = {0: S_X + (2 if xc_fused else 1) * S_B, 1: S_X + S_B, 2: (2 + 4 * n_B) * S_B, 3: S_X + (1 + 4 * n_B) * S_B}
     for slot in range(4):

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void k_contract_xc(const float *__restrict__ X
 // k_slab_gram pass (a 2 S_B re-read and a launch).
 // CREG: K == 256 and NB == 1: the 64 C-fragment registers stay resident.
 // ---------------------------------------------------------------------------------------------------------
-template <int NB, bool CREG, bool GRAM>
+template <int NB, bool CREG, int GRAM>
 __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict__ X, const float *__restrict__ Cfrag,
                                                          float *__restrict__ XC, const float *__restrict__ B,
                                                          const int *__restrict__ seg_row0,
@@ -502,16 +502,20 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
             nrow0 = __builtin_amdgcn_readfirstlane(seg_row0[sg + 1]);
             nnrows = __builtin_amdgcn_readfirstlane(seg_rows[sg + 1]);
         }
-        // per-segment reductions in fp64: the products b * xc and b * b' of fp32 values are exact in fp64, so the only
-        // rounding left in rhs_i and B_i^T B_i is the fp32 rounding of X C itself (the A-phase systems of a penalty-free
-        // mode are not shifted and amplify every relative error of these sums)
+        // per-segment reductions.  GRAM == 2 (penalty-free A: its systems are not shifted and amplify every relative
+        // error of these sums): fp64 throughout - the products b * xc and b * b' of fp32 values are exact in fp64, so the
+        // only rounding left in rhs_i and B_i^T B_i is the fp32 rounding of X C itself.  GRAM == 1 (penalised A): fp32
+        // chains over the segment's <= 256 rows (4 fp32 MFMAs per block instead of 4 NB^2 fp64 ones at twice the cycles:
+        // 12 % of the kernel at rank 32), widened to fp64 when the segment is stored.
         double p[NB];
+        float pf[NB];
         f64x4 accG[NB][NB];
+        f32x4 accGf[NB][NB];
 #pragma unroll
         for (int a = 0; a < NB; ++a) {
-            p[a] = 0.0;
+            p[a] = 0.0, pf[a] = 0.f;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) accG[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+            for (int b = 0; b < NB; ++b) accG[a][b] = f64x4{0.0, 0.0, 0.0, 0.0}, accGf[a][b] = zero4();
         }
         for (int blk = 0; blk < nblk; ++blk) {
             float bcur[NB][4];
@@ -592,7 +596,8 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
                     if (GRAM) {
                         const float b = ok ? bcur[nb][v] : 0.f;
                         bv[nb][v] = b;
-                        p[nb] = fma((double)b, (double)acc[nb][v], p[nb]);
+                        if (GRAM == 2) p[nb] = fma((double)b, (double)acc[nb][v], p[nb]);
+                        else pf[nb] = fmaf(b, acc[nb][v], pf[nb]);
                     }
                 }
             }
@@ -602,28 +607,33 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
 #pragma unroll
                     for (int a = 0; a < NB; ++a)
 #pragma unroll
-                        for (int b = 0; b < NB; ++b)
-                            accG[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)bv[a][v], (double)bv[b][v], accG[a][b], 0, 0, 0);
+                        for (int b = 0; b < NB; ++b) {
+                            if (GRAM == 2)
+                                accG[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)bv[a][v], (double)bv[b][v], accG[a][b], 0, 0, 0);
+                            else
+                                accGf[a][b] = MFMA16(bv[a][v], bv[b][v], accGf[a][b]);
+                        }
             }
         }
         if (GRAM) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                double t = p[nb];
+                double t = (GRAM == 2) ? p[nb] : (double)pf[nb];
                 t += __shfl_xor(t, 16);
                 t += __shfl_xor(t, 32);
                 const int col = 16 * nb + i16;
                 if (q == 0 && col < r) seg_rhs[(long)sg * r + col] = t;
             }
-            // D layout of the f64 MFMA: row = (l >> 4) + 4 reg, col = l & 15
 #pragma unroll
             for (int a = 0; a < NB; ++a)
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        const int ra = 16 * a + q + 4 * v, cb = 16 * b + i16;
-                        if (ra < r && cb < r) seg_btb[((long)sg * r + ra) * r + cb] = accG[a][b][v];
+                        // D layouts: f64 MFMA row = (l >> 4) + 4 reg, f32 MFMA row = 4 (l >> 4) + reg; col = l & 15
+                        const int ra = 16 * a + ((GRAM == 2) ? q + 4 * v : 4 * q + v), cb = 16 * b + i16;
+                        const double val = (GRAM == 2) ? accG[a][b][v] : (double)accGf[a][b][v];
+                        if (ra < r && cb < r) seg_btb[((long)sg * r + ra) * r + cb] = val;
                     }
         }
         row0 = nrow0;
@@ -835,26 +845,34 @@ static int launch_xc(mcl_context *c) {
         int spw = (n_segs + tw - 1) / tw;
         if (spw < 1) spw = 1;
         const unsigned g = (unsigned)(((n_segs + spw - 1) / spw + 3) / 4);
-        const bool gram = c->xc_with_gram;
+        // 0: X C only; 1: + per-segment rhs / Gram in fp32 chains (penalised A); 2: in fp64 (penalty-free A)
+        int gram = !c->xc_with_gram ? 0 : (c->regs[0].n == 0 ? 2 : 1);
+        if (NB == 4 && gram == 2) gram = 0;  // rank > 32 has no registers for the fp64 Gram tiles: k_slab_gram follows
 #define MCL_XCR(CREG_, GRAM_)                                                                                        \
     hipLaunchKernelGGL((k_contract_xc_row<NB, CREG_, GRAM_>), dim3(g), dim3(256), sm, c->stream, c->X, c->Cfrag,     \
                        c->XC, c->B, c->segs.row0, c->segs.nrows, n_segs, spw, (int)c->K, c->r, c->seg_rhs, c->seg_btb)
         if (n_segs > 0) {
             if constexpr (NB == 1) {  // resident C fragments: K = 256, rank <= 16 only
                 if (creg) {
-                    if (gram) MCL_XCR(true, true);
-                    else MCL_XCR(true, false);
+                    if (gram == 2) MCL_XCR(true, 2);
+                    else if (gram == 1) MCL_XCR(true, 1);
+                    else MCL_XCR(true, 0);
                 }
             }
             if (!creg) {
-                if (gram) MCL_XCR(false, true);
-                else MCL_XCR(false, false);
+                if (gram == 2) {
+                    if constexpr (NB < 4) MCL_XCR(false, 2);
+                } else if (gram == 1) {
+                    MCL_XCR(false, 1);
+                } else {
+                    MCL_XCR(false, 0);
+                }
             }
         }
 #undef MCL_XCR
-        c->xc_did_gram = gram;
+        c->xc_did_gram = gram != 0;
         char buf[96];
-        snprintf(buf, sizeof buf, "k_contract_xc_row<NB=%d,CREG=%d,GRAM=%d>", NB, creg ? 1 : 0, gram ? 1 : 0);
+        snprintf(buf, sizeof buf, "k_contract_xc_row<NB=%d,CREG=%d,GRAM=%d>", NB, creg ? 1 : 0, gram);
         c->variant[0] = buf;
         MCL_CHECK_HIP(c, hipGetLastError());
         return 0;
