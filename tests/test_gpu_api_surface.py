@@ -244,3 +244,47 @@ def test_bench_two_rank_rehearsal(config):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["roofline"]["achieved"] > 0 and np.isfinite(d["final_rel_rec_error"])
+
+
+RCCL_ONE_RANK = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["REPO"])
+import numpy as np, torch, torch.distributed as dist
+from matcouply_amd import decomposition as dec
+from oracle import aoadmm_oracle as orc
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))  # backend "nccl" IS RCCL on ROCm
+J = np.array([40, 25, 64, 33, 90, 17])
+X, row_ptr = orc.synthetic_problem(6, J, 24, 4, seed=0, dtype=np.float64)
+mats = [X[row_ptr[i]:row_ptr[i+1]] for i in range(6)]
+kw = dict(non_negative={0: True}, parafac2=True, l2_norm_bound={1: 1.0}, l1_penalty={2: 0.05}, n_iter_max=5, tol=None,
+          absolute_tol=None, return_errors=True, constant_feasibility_penalty=True, random_state=0)
+cmf_g, diag_g = dec.cmf_aoadmm(mats, 4, group=dist.group.WORLD, **kw)   # step path: every reduction goes through RCCL
+cmf_1, diag_1 = dec.cmf_aoadmm(mats, 4, **kw)                           # single-call path
+err = dict(A=float(np.linalg.norm(cmf_g[1][0] - cmf_1[1][0]) / np.linalg.norm(cmf_1[1][0])),
+           C=float(np.linalg.norm(cmf_g[1][2] - cmf_1[1][2]) / np.linalg.norm(cmf_1[1][2])),
+           rec=float(max(abs(a - b) / b for a, b in zip(diag_g.rec_errors, diag_1.rec_errors))))
+print("RCCL_RESULT " + json.dumps(err), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_step_path_over_rccl_on_one_rank(tmp_path):
+    """The collectives of the sharded path on the REAL backend: `init_process_group("nccl", device_id=...)` (= RCCL) with a
+    world of one rank on this box's GPU - fp64 SUM all-reduce of [G | R] on a view of the library's workspace, fp32 MAX
+    all-reduces of the feasibility penalties, the PARAFAC2 reduction per inner iteration, the fp64 diagnostics vector, a
+    barrier.  (Two ranks need two devices: RCCL refuses to share one; that case runs over gloo above.)"""
+    script = tmp_path / "rccl_one.py"
+    script.write_text(RCCL_ONE_RANK)
+    port = str(29300 + os.getpid() % 300)
+    env = dict(os.environ, REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", port, str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RCCL_RESULT")]
+    assert line, out.stdout[-2000:] + out.stderr[-3000:]
+    import json
+
+    err = json.loads(line[0].split(" ", 1)[1])
+    assert max(err.values()) < 1e-5, err
