@@ -305,7 +305,9 @@ def main():
         # no stopping rule is active (tol=None), so the per-iteration diagnostic sums stay on the device and are
         # all-reduced ONCE for all iterations at the end of the timed region (one collective per step remains: [G | R])
         eng.update_A()
-        eng.diagnostics(include_replicated=(rank == 0), out=ring[it])
+        # deferred: the reduction of the diagnostics tables rides on the next step's C-phase reduction kernel (what
+        # mcl_iterate - the fixed-count loop behind cmf_aoadmm - does between its iterations); flushed at the region end
+        eng.diagnostics_deferred(include_replicated=(rank == 0), out=ring[it])
 
     def sync():
         if world > 1:
@@ -314,6 +316,7 @@ def main():
 
     for it in range(args.warmup):
         step(it)
+    eng.flush_diagnostics()
     sync()
     # HIP events inside the library around every `stride`-th launch of the timed region: an event pair opens ~5 us
     # dispatch gaps before and after the kernel (11 us per step when every launch is bracketed - measured), so the
@@ -328,6 +331,7 @@ def main():
         t0 = time.perf_counter()
         for it in range(args.steps):
             step(first + it)
+        eng.flush_diagnostics()
         if world > 1:
             all_reduce(ring[first:first + args.steps])
         sync()

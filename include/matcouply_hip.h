@@ -103,6 +103,14 @@ int mcl_update_A(mcl_context *ctx);
  * over ranks is exact.  If no A-phase by-products are current, they are recomputed with a pass over X
  * (decomposition.py:430-444). */
 int mcl_diagnostics(mcl_context *ctx, double *out, int32_t include_replicated);
+/* mcl_diagnostics whose table reduction MAY be issued later: when the next calls on this context are mcl_update_B and
+ * mcl_update_C_local on the one-pass path, it rides on a spare workgroup of the C-phase reduction kernel instead of a launch
+ * of its own (the per-iteration pattern B -> C_local -> [all-reduce] -> C_finish -> A -> diagnostics of a fixed-count loop).
+ * `out` is written at the latest when ANY other entry point of the context, or mcl_flush_diagnostics(), has been called;
+ * the factors / tables it reports are those at the time of THIS call.  Same values as mcl_diagnostics up to the association
+ * of the fp64 sums. */
+int mcl_diagnostics_deferred(mcl_context *ctx, double *out, int32_t include_replicated);
+int mcl_flush_diagnostics(mcl_context *ctx);
 /* n outer iterations B -> C -> A on ONE device (decomposition.py:945-988); if diag_ring != NULL,
  * MCL_DIAG_LEN doubles are appended per iteration (device memory, n * MCL_DIAG_LEN doubles). */
 int mcl_iterate(mcl_context *ctx, int32_t n_iter, int32_t update_A, int32_t update_B, int32_t update_C,

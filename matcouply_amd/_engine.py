@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
     "mcl_create", "mcl_destroy", "mcl_last_error", "mcl_version", "mcl_set_problem", "mcl_set_options",
     "mcl_set_factors", "mcl_set_penalties", "mcl_workspace_bytes", "mcl_set_workspace", "mcl_update_B",
     "mcl_update_C_local", "mcl_c_normal_equations", "mcl_update_C_finish", "mcl_update_A", "mcl_diagnostics",
+    "mcl_diagnostics_deferred", "mcl_flush_diagnostics",
     "mcl_iterate", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_B_end", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
     "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
@@ -78,6 +79,8 @@ def load_library():
         "mcl_update_C_finish": (ctypes.c_int, [P]),
         "mcl_update_A": (ctypes.c_int, [P]),
         "mcl_diagnostics": (ctypes.c_int, [P, P, I32]),
+        "mcl_diagnostics_deferred": (ctypes.c_int, [P, P, I32]),
+        "mcl_flush_diagnostics": (ctypes.c_int, [P]),
         "mcl_iterate": (ctypes.c_int, [P, I32, I32, I32, I32, P]),
         "mcl_B_begin": (ctypes.c_int, [P]),
         "mcl_B_rho_max": (P, [P]),
@@ -259,6 +262,18 @@ class HipEngine:
             out = torch.empty(DIAG_LEN, dtype=torch.float64, device=self.device)
         self._check(self.lib.mcl_diagnostics(self._h, out.data_ptr(), int(include_replicated)))
         return out
+
+    def diagnostics_deferred(self, include_replicated=True, out=None):
+        """diagnostics() whose reduction may ride on the next C-phase reduction kernel; `out` is complete once any other
+        call of this engine (or flush_diagnostics()) has been made"""
+        torch = self._torch
+        if out is None:
+            out = torch.empty(DIAG_LEN, dtype=torch.float64, device=self.device)
+        self._check(self.lib.mcl_diagnostics_deferred(self._h, out.data_ptr(), int(include_replicated)))
+        return out
+
+    def flush_diagnostics(self):
+        self._check(self.lib.mcl_flush_diagnostics(self._h))
 
     def iterate(self, n_iter, update_A=True, update_B=True, update_C=True, diag_ring=None):
         ptr = diag_ring.data_ptr() if diag_ring is not None else None

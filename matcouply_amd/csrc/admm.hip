@@ -1194,15 +1194,6 @@ __global__ __launch_bounds__(256) void k_sum_doubles(const double *__restrict__ 
 }
 
 
-struct DiagTables {
-    const double *tab[3];
-    int rows[3];
-    int nreg[3];
-    const double *e1;
-    int I;
-    const double *xsq;
-};
-
 static __device__ double block_colsum(const double *__restrict__ tab, int n_rows, int ncols, int col, double *sm) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int e = threadIdx.x;
@@ -1595,7 +1586,7 @@ int mcl_launch_x_sq(mcl_context *c) {
     return 0;
 }
 
-int mcl_launch_diag_final(mcl_context *c, double *out, int include_replicated, bool a_from_rows) {
+DiagTables mcl_diag_tables(const mcl_context *c, bool a_from_rows) {
     DiagTables T;
     T.tab[0] = a_from_rows ? c->diagA_row : c->diagA_tile;
     T.rows[0] = a_from_rows ? (int)c->I : c->tilesA.n_tiles;
@@ -1603,7 +1594,15 @@ int mcl_launch_diag_final(mcl_context *c, double *out, int include_replicated, b
     T.tab[2] = c->diagC_tile, T.rows[2] = c->diag_rows[2];
     for (int m = 0; m < 3; ++m) T.nreg[m] = c->regs[m].n;
     T.e1 = c->e1, T.I = (int)c->I, T.xsq = c->x_sq;
+    return T;
+}
+
+int mcl_launch_diag_tables(mcl_context *c, const DiagTables &T, double *out, int include_replicated) {
     hipLaunchKernelGGL(k_diag_final, dim3(3 * DIAG_COLS + 3), dim3(256), 0, c->stream, T, include_replicated, out);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
+}
+
+int mcl_launch_diag_final(mcl_context *c, double *out, int include_replicated, bool a_from_rows) {
+    return mcl_launch_diag_tables(c, mcl_diag_tables(c, a_from_rows), out, include_replicated);
 }

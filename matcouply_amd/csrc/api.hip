@@ -94,7 +94,9 @@ int64_t plan(mcl_context *c, char *base) {
     c->e1 = b.take<double>(2 * I);
     c->diagA_row = b.take<double>(I * DIAG_COLS);
     c->diagA_tile = b.take<double>((int64_t)c->tilesA.n_tiles * DIAG_COLS);
-    c->diagB_tile = b.take<double>((int64_t)c->tilesB.n_tiles * DIAG_COLS);
+    c->diagB_bufs[0] = b.take<double>((int64_t)c->tilesB.n_tiles * DIAG_COLS);
+    c->diagB_bufs[1] = b.take<double>((int64_t)c->tilesB.n_tiles * DIAG_COLS);
+    c->diagB_tile = c->diagB_bufs[c->diagB_parity];
     c->diagC_tile = b.take<double>((int64_t)c->tilesC.n_tiles * DIAG_COLS);
     c->diag_sums = b.take<double>(3 * DIAG_COLS + 2);
     c->xsq_part = b.take<double>(1024);
@@ -142,7 +144,7 @@ void read_switches(mcl_switches &w) {
     w.no_fused_gram = flag("MCL_NO_FUSED_GRAM"), w.no_fused_c = flag("MCL_NO_FUSED_C");
     w.a_finish_cols = flag("MCL_A_FINISH_COLS"), w.xc_norow = flag("MCL_XC_NOROW");
     w.unimodal_v3 = flag("MCL_UNIMODAL_V3"), w.stats_reduce = flag("MCL_STATS_REDUCE");
-    w.no_a_fusion = flag("MCL_NO_A_FUSION");
+    w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER");
     w.seg_rows = num("MCL_SEG_ROWS", 0), w.bseg_rows = num("MCL_BSEG_ROWS", 0);
     w.xc_waves = num("MCL_XC_WAVES", 0), w.xt_waves = num("MCL_XT_WAVES", 0), w.sweep_waves = num("MCL_SWEEP_WAVES", 0);
     w.xc_dbg = num("MCL_XC_DBG", 0), w.xt_dbg = num("MCL_XT_DBG", 0), w.xt_depth = num("MCL_XT_DEPTH", 0);
@@ -171,8 +173,17 @@ int flush_B_finish(mcl_context *c) {
     return 0;
 }
 
+// A deferred diagnostics reduction that nothing has picked up yet is issued as a launch of its own: every entry point
+// but the two a deferral is meant to cross (mcl_update_B on the sweep path, mcl_update_C_local) starts with this.
+int flush_diag(mcl_context *c) {
+    if (!c->diag_pending) return 0;
+    c->diag_pending = false;
+    return mcl_launch_diag_tables(c, c->diag_pending_T, c->diag_pending_out, c->diag_pending_incl);
+}
+
 int ready(mcl_context *c) {
     if (int rc = ready_noflush(c)) return rc;
+    if (int rc = flush_diag(c)) return rc;
     return flush_B_finish(c);
 }
 
@@ -517,13 +528,17 @@ int mcl_B_begin(mcl_context *c) {
 
 float *mcl_B_rho_max(mcl_context *c) { return c ? c->rho_max : nullptr; }
 
-int mcl_B_factor(mcl_context *c) {
-    if (int rc = ready(c)) return rc;
+static int B_factor_impl(mcl_context *c) {
     if (c->b_systems_valid) {  // built by the preceding A-finish from the same a_i and CtC
         c->b_systems_valid = false;
         return 0;
     }
     return mcl_launch_B_systems(c);
+}
+
+int mcl_B_factor(mcl_context *c) {
+    if (int rc = ready(c)) return rc;
+    return B_factor_impl(c);
 }
 
 // the finish pass of inner iteration t can be merged with the solve of t + 1 (k_rows_finish_solve_stats)
@@ -596,14 +611,19 @@ int mcl_B_prox_finish(mcl_context *c, int32_t k) {
 }
 
 int mcl_update_B(mcl_context *c) {
-    if (int rc = ready(c)) return rc;
+    if (c && c->diag_pending && ready_noflush(c) == 0 && !c->b_finish_pending && mcl_sweep_eligible(c)) {
+        // a deferred diagnostics reduction survives the sweep (which writes the OTHER mode-1 table) and rides on the
+        // C-phase reduction that follows it
+    } else if (int rc = ready(c)) {
+        return rc;
+    }
     if (mcl_sweep_eligible(c)) {
         // one pass over X: B-phase fused with the per-bseg X^T B / B^T B that the C- and A-phases need (sweep.hip)
         if (int rc = ensure_ctc(c)) return rc;
         if (int rc = ensure_cfrag_sweep(c)) return rc;
         if (c->opt.constant_B)
             if (int rc = mcl_launch_B_rho(c)) return rc;
-        if (int rc = mcl_B_factor(c)) return rc;
+        if (int rc = B_factor_impl(c)) return rc;
         c->e1_valid = false;
         const int rc = mcl_launch_sweep(c);
         if (rc > 0) return rc;
@@ -614,6 +634,7 @@ int mcl_update_B(mcl_context *c) {
             return 0;
         }
         c->sweep_planned = false;  // the device refused the kernel's LDS size: two-pass path from now on
+        if (int rc2 = flush_diag(c)) return rc2;
     }
     if (int rc = mcl_B_begin(c)) return rc;
     if (int rc = mcl_B_factor(c)) return rc;
@@ -637,6 +658,8 @@ int mcl_update_B(mcl_context *c) {
 
 // ---- C-phase -------------------------------------------------------------------------------------------
 int mcl_update_C_local(mcl_context *c) {
+    if (c && c->diag_pending && ready_noflush(c) == 0 && !c->b_finish_pending && c->mseg_valid && c->grpart_valid)
+        return mcl_launch_reduce_weighted(c);  // ... with the deferred diagnostics reduction on its spare workgroup
     if (int rc = ready(c)) return rc;
     if (c->mseg_valid && c->grpart_valid) return mcl_launch_reduce_weighted(c);
     if (int rc = mcl_launch_contract_xt(c)) return rc;
@@ -832,6 +855,24 @@ int mcl_diagnostics(mcl_context *c, double *out, int32_t include_replicated) {
     return mcl_launch_diag_final(c, out, include_replicated, true);
 }
 
+int mcl_diagnostics_deferred(mcl_context *c, double *out, int32_t include_replicated) {
+    if (!c) return 1;
+    if (!out) return fail(c, "mcl_diagnostics_deferred: out is NULL");
+    if (int rc = ready(c)) return rc;  // also issues an older deferred reduction
+    // deferrable: every table is current and ||X||^2 is known, i.e. mcl_diagnostics() would only launch its reduction
+    if (!(c->xsq_valid && c->e1_valid && c->diag_valid[0] && c->diag_valid[1] && c->diag_valid[2]) || c->sw.no_diag_defer)
+        return mcl_diagnostics(c, out, include_replicated);
+    c->diag_pending_T = mcl_diag_tables(c, true);
+    c->diag_pending_out = out, c->diag_pending_incl = include_replicated ? 1 : 0;
+    c->diag_pending = true;
+    return 0;
+}
+
+int mcl_flush_diagnostics(mcl_context *c) {
+    if (!c) return 1;
+    return flush_diag(c);
+}
+
 int mcl_iterate(mcl_context *c, int32_t n_iter, int32_t update_A, int32_t update_B, int32_t update_C,
                 double *diag_ring) {
     if (int rc = ready(c)) return rc;
@@ -844,10 +885,16 @@ int mcl_iterate(mcl_context *c, int32_t n_iter, int32_t update_A, int32_t update
         }
         if (update_A)
             if (int rc = mcl_update_A(c)) return rc;
-        if (diag_ring)
-            if (int rc = mcl_diagnostics(c, diag_ring + (int64_t)it * MCL_DIAG_LEN, 1)) return rc;
+        if (diag_ring) {
+            // between two iterations the reduction of the diagnostics tables is deferred: it rides on the next C-phase
+            // reduction kernel when that is the sweep path's, and is issued on its own otherwise
+            double *slot = diag_ring + (int64_t)it * MCL_DIAG_LEN;
+            const int rc = (it + 1 < n_iter && update_B && update_C) ? mcl_diagnostics_deferred(c, slot, 1)
+                                                                      : mcl_diagnostics(c, slot, 1);
+            if (rc) return rc;
+        }
     }
-    return 0;
+    return flush_diag(c);
 }
 
 float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {

@@ -32,6 +32,17 @@ struct RegSet {
     float *aux2[MCL_MAX_REGS];
 };
 
+// The per-row / per-tile fp64 diagnostic tables of the three modes and what else the MCL_DIAG_LEN vector is made of
+// (k_diag_final, and the spare workgroup of k_reduce_frag that takes over a DEFERRED reduction: admm.hip / sweep.hip).
+struct DiagTables {
+    const double *tab[3];
+    int rows[3];
+    int nreg[3];
+    const double *e1;
+    int I;
+    const double *xsq;
+};
+
 // Row tiling of a packed [rows, r] matrix: every wave tile holds <= 64 rows of ONE slab.
 struct TileMap {
     int n_tiles = 0;
@@ -46,7 +57,7 @@ struct mcl_switches {
     bool no_sweep = false, no_pass_chain = false, no_pf2_delta_fusion = false, ns_plain = false, pf2_jacobi = false;
     bool no_stack_fusion = false, no_solve_stats = false, no_next_b = false, no_fused_gram = false, no_fused_c = false;
     bool a_finish_cols = false, xc_norow = false, unimodal_v3 = false, stats_reduce = false;
-    bool no_a_fusion = false;
+    bool no_a_fusion = false, no_diag_defer = false;
     int seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
     int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
 };
@@ -129,6 +140,15 @@ struct mcl_context {
     double *xsq_part = nullptr;    // [1024]
     int *ext_A = nullptr, *ext_C = nullptr;  // int32[2] slab extents {0, I} / {0, K} for the single-slab modes
     double *x_sq = nullptr;     // [1]
+    // deferred diagnostics (mcl_diagnostics_deferred): the reduction of the tables rides on a spare workgroup of the NEXT
+    // C-phase reduction kernel instead of a launch of its own; the sweep alternates between two B tables so that the
+    // tables of iteration t stay intact while the sweep of t + 1 writes its own
+    double *diagB_bufs[2] = {nullptr, nullptr};
+    int diagB_parity = 0;
+    bool diag_pending = false;
+    DiagTables diag_pending_T{};
+    double *diag_pending_out = nullptr;
+    int diag_pending_incl = 1;
     // launch fusion of the A-phase finish (admm.hip: AFuse)
     bool a_rhs_from_M = false;       // k_A_finish_rows forms rhs_i from the sweep's M_bseg itself
 
@@ -253,6 +273,8 @@ int mcl_launch_A_rows_solve(mcl_context *c);
 int mcl_launch_A_e1(mcl_context *c, bool btb_is_q);
 int mcl_launch_rows_diag(mcl_context *c, int mode);
 int mcl_launch_diag_final(mcl_context *c, double *out, int include_replicated, bool a_from_rows);
+DiagTables mcl_diag_tables(const mcl_context *c, bool a_from_rows);  // the tables as they stand now
+int mcl_launch_diag_tables(mcl_context *c, const DiagTables &T, double *out, int include_replicated);
 int mcl_launch_x_sq(mcl_context *c);
 bool mcl_mode_is_row_separable(const mcl_context *c, int mode);
 bool mcl_stack_can_fuse(const mcl_context *c, int mode);          // generic.hip

@@ -567,9 +567,67 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
 // order (coalesced) and scatters its sum to the row-major [G | R] image.  Fixed summation order (16 interleaved groups
 // of partials, 4 chains each, then the groups in order): deterministic, identical on every rank for identical input.
 // ---------------------------------------------------------------------------------------------------------
+// A deferred diagnostics reduction (mcl_diagnostics_deferred) rides on TWO spare workgroups of this kernel: each of their
+// 32 waves takes one of the 3 DIAG_COLS + 2 column sums of k_diag_final (lanes stride the rows, butterfly sum: fixed
+// order) while the other workgroups reduce [G | R] - no launch of its own on the critical path, and no wave with more
+// than one dependent chain of loads (with one spare workgroup the kernel grew from 5.8 to 8.3 us).
+#define MCL_PIGGY_BLOCKS 2
+struct DiagPiggy {
+    DiagTables T;
+    double *out;  // nullptr: no spare workgroup was launched
+    int include_replicated;
+};
+
+static __device__ void diag_piggy_block(const DiagPiggy &P, int which) {
+    const int lane = threadIdx.x & 63, n_waves = MCL_PIGGY_BLOCKS * (blockDim.x >> 6);
+    const int wave = which * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    constexpr int NS = 3 * DIAG_COLS + 2;
+    for (int b = wave; b < NS; b += n_waves) {
+        const double *tab;
+        int rows, ncols, col, t = -1;
+        if (b < 3 * DIAG_COLS) {
+            t = b / DIAG_COLS, col = b - t * DIAG_COLS;
+            tab = P.T.tab[t], rows = (t < 2 || P.include_replicated) ? P.T.rows[t] : 0, ncols = DIAG_COLS;
+        } else {
+            col = b - 3 * DIAG_COLS, tab = P.T.e1, rows = P.T.I, ncols = 2;
+        }
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int e = lane;
+        for (; e + 192 < rows; e += 256) {
+            s0 += tab[(long)e * ncols + col];
+            s1 += tab[(long)(e + 64) * ncols + col];
+            s2 += tab[(long)(e + 128) * ncols + col];
+            s3 += tab[(long)(e + 192) * ncols + col];
+        }
+        for (; e < rows; e += 64) s0 += tab[(long)e * ncols + col];
+        const double s = wave_sum((s0 + s1) + (s2 + s3));
+        if (lane != 0) continue;
+        double *out = P.out;
+        if (t < 0) {
+            out[col == 0 ? MCL_DIAG_INNER : MCL_DIAG_MODEL_SQ] = s;
+        } else if (col == 0) {
+            out[MCL_DIAG_NORM_SQ + t] = s;
+        } else if (col == 1) {
+            for (int k = 0; k < MCL_MAX_REGS; ++k) out[MCL_DIAG_REG + (t * MCL_MAX_REGS + k) * 2 + 1] = (k < P.T.nreg[t]) ? s : 0.0;
+        } else {
+            const int k = col - 2;
+            out[MCL_DIAG_REG + (t * MCL_MAX_REGS + k) * 2] = (k < P.T.nreg[t]) ? s : 0.0;
+        }
+    }
+    if (threadIdx.x == 0 && which == 0) {
+        P.out[MCL_DIAG_X_SQ] = P.T.xsq[0];
+        P.out[6] = 0.0;
+        P.out[7] = 0.0;
+    }
+}
+
 template <int EL>  // elements per block (64: 256-byte wave loads, PS / 64 blocks; 32: twice the blocks for small PS)
 __global__ __launch_bounds__(1024) void k_reduce_frag(const float *__restrict__ GRpart, int n_part, int K, int r, int NB,
-                                                      int MS, double *__restrict__ GR) {
+                                                      int MS, double *__restrict__ GR, DiagPiggy piggy) {
+    if (piggy.out != nullptr && blockIdx.x >= gridDim.x - MCL_PIGGY_BLOCKS) {  // the spare workgroups
+        diag_piggy_block(piggy, (int)(gridDim.x - 1 - blockIdx.x));
+        return;
+    }
     constexpr int NG = 1024 / EL;  // interleaved groups of partials
     __shared__ double sm[NG][EL];  // fp32 per-bseg partials, summed in fp64 (the C-phase system sees >= 1e-8 inputs)
     const int el = threadIdx.x % EL, pc = threadIdx.x / EL;
@@ -701,6 +759,10 @@ static int launch_sweep_v(mcl_context *c) {
         (void)hipGetLastError();
         return -1;  // caller falls back to the two-pass path
     }
+    // the sweep alternates between two diagnostics tables of mode 1: a deferred reduction of the previous iteration's
+    // tables (mcl_diagnostics_deferred) may still be waiting for the coming C-phase reduction kernel
+    c->diagB_parity ^= 1;
+    c->diagB_tile = c->diagB_bufs[c->diagB_parity];
     hipLaunchKernelGGL((k_sweep<KS, NB, NREG, DEPTH, NW, VEC>), dim3(grid), dim3(64 * NW), sm, c->stream, c->X, c->CfragS, c->A,
                        c->rhoB, c->LinvB, c->B, c->regs[1], c->bsegs.slab, c->bsegs.row0, c->bsegs.nrows, n, bpb, (int)c->K,
                        c->r,
@@ -754,16 +816,21 @@ int mcl_launch_reduce_weighted(mcl_context *c) {
     // 64 elements per block need PS / 64 blocks (68 at K = 256, rank 16: a quarter of the CUs); with 32 there are twice as many
     int el = (MS + W * W) / 64 >= 192 ? 64 : 32;
     if (c->sw.reduce_el > 0) el = c->sw.reduce_el == 64 ? 64 : (c->sw.reduce_el == 16 ? 16 : 32);
-    const int blocks = (MS + W * W + el - 1) / el;
+    DiagPiggy piggy{};
+    if (c->diag_pending) {  // a deferred diagnostics reduction takes a spare workgroup of this launch
+        piggy.T = c->diag_pending_T, piggy.out = c->diag_pending_out, piggy.include_replicated = c->diag_pending_incl;
+        c->diag_pending = false;
+    }
+    const int blocks = (MS + W * W + el - 1) / el + (piggy.out ? MCL_PIGGY_BLOCKS : 0);
     if (el == 64)
         hipLaunchKernelGGL(k_reduce_frag<64>, dim3(blocks), dim3(1024), 0, c->stream, c->GRpart, c->n_grpart, (int)c->K,
-                           c->r, c->NB, MS, c->GR);
+                           c->r, c->NB, MS, c->GR, piggy);
     else if (el == 32)
         hipLaunchKernelGGL(k_reduce_frag<32>, dim3(blocks), dim3(1024), 0, c->stream, c->GRpart, c->n_grpart, (int)c->K,
-                           c->r, c->NB, MS, c->GR);
+                           c->r, c->NB, MS, c->GR, piggy);
     else
         hipLaunchKernelGGL(k_reduce_frag<16>, dim3(blocks), dim3(1024), 0, c->stream, c->GRpart, c->n_grpart, (int)c->K,
-                           c->r, c->NB, MS, c->GR);
+                           c->r, c->NB, MS, c->GR, piggy);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

@@ -884,9 +884,10 @@ def cmf_aoadmm(
                 do_update_C()
             if update_A:
                 do_update_A()
-            if ring is not None:
-                eng.diagnostics(include_replicated=(rank_id == 0), out=ring[it])
+            if ring is not None:  # the table reduction rides on the next iteration's C-phase reduction kernel
+                eng.diagnostics_deferred(include_replicated=(rank_id == 0), out=ring[it])
         if ring is not None:
+            eng.flush_diagnostics()
             all_reduce(ring)
             for row in ring.cpu().numpy():
                 rec_error, gaps, reg = read_diag(row)

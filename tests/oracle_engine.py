@@ -257,6 +257,12 @@ class OracleEngine:
             if diag_ring is not None:
                 self.diagnostics(out=diag_ring[it])
 
+    def diagnostics_deferred(self, include_replicated=True, out=None):
+        return self.diagnostics(include_replicated=include_replicated, out=out)  # the checker has nothing to defer
+
+    def flush_diagnostics(self):
+        pass
+
     def close(self):
         pass
 

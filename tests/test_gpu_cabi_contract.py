@@ -60,3 +60,47 @@ def test_incomplete_step_round_is_an_error():
         eng.B_prox_local(k); eng.B_prox_finish(k)
     eng.B_end()
     eng.close()
+
+
+def test_deferred_diagnostics_equal_immediate_ones():
+    """mcl_diagnostics_deferred: the reduction rides on the next C-phase reduction kernel (sweep path) or is flushed by the
+    next other entry point; the vector must describe the factors at the time of the call and equal mcl_diagnostics."""
+    import torch
+    from matcouply_amd._engine import DIAG_LEN
+
+    nn = {"kind": "nn"}
+    regs = [[nn], [nn], [{"kind": "l1", "reg_strength": 0.05, "non_negativity": True}]]
+    from oracle import aoadmm_oracle as orc
+
+    J = np.full(12, 96)
+    X, row_ptr = orc.synthetic_problem(len(J), J, 64, 8, seed=5, dtype=np.float64)  # sweep-eligible shape
+    X = X.astype(np.float32).astype(np.float64)
+
+    def run(deferred, n=4):
+        st = orc.random_state_for(X, row_ptr, 8, regs, seed=6)
+        eng = engine_from_oracle_state(st)
+        ring = torch.full((n, DIAG_LEN), float("nan"), dtype=torch.float64, device="cuda")
+        for it in range(n):
+            eng.update_B(); eng.update_C_local(); eng.update_C_finish(); eng.update_A()
+            (eng.diagnostics_deferred if deferred else eng.diagnostics)(out=ring[it])
+        assert eng.kernel_variant(3).startswith("k_sweep<")
+        if deferred:
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(ring[n - 1]).all())       # the last one is still pending ...
+            eng.flush_diagnostics()                            # ... until flushed (or any other call)
+        torch.cuda.synchronize()
+        out = ring.cpu().numpy()
+        eng.close()
+        return out
+
+    a, b = run(False), run(True)
+    assert np.isfinite(b).all()
+    np.testing.assert_allclose(b, a, rtol=1e-13, atol=1e-300)
+    # iterate() defers between its iterations and flushes at the end
+    st = orc.random_state_for(X, row_ptr, 8, regs, seed=6)
+    eng = engine_from_oracle_state(st)
+    ring = torch.zeros((4, DIAG_LEN), dtype=torch.float64, device="cuda")
+    eng.iterate(4, diag_ring=ring)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(ring.cpu().numpy(), a, rtol=1e-13, atol=1e-300)
+    eng.close()

@@ -35,12 +35,26 @@ def xt():
 def xc():
     eng.update_C_finish(); eng.B_begin()
 
+def xca():  # the X C pass as the A-phase issues it (fused per-segment Gram epilogue)
+    eng.update_C_finish(); eng.A_begin()
+
+for seg in os.environ.get("SEGS", "256").split(","):
+    os.environ["MCL_SEG_ROWS"] = seg
+    eng = bench.make_engine(cfg, X, row_ptr, I_loc, 0, dev)  # segment length is fixed when the problem is set
+    eng.update_B(); eng.update_C_local(); eng.update_C_finish(); eng.update_A()
+    for waves in (1024, 2048, 4096):
+        os.environ.update(MCL_XT_WAVES=str(waves), MCL_XC_WAVES=str(waves))
+        eng.reload_switches()
+        print(f"seg={seg} waves={waves}: xt {prof(xt, 1):.1f} us   xc+gram {prof(xca, 0):.1f} us  [{eng.kernel_variant(0)}]", flush=True)
+os.environ.pop("MCL_SEG_ROWS", None)
 for waves in (512, 1024, 2048):
     os.environ.update(MCL_XT_WAVES=str(waves))
+    eng.reload_switches()
     print(f"xt kernel (events) waves={waves}: {prof(xt, 1):.1f} us")
 for norow in ("", "1"):
     for waves in (512, 1024, 2048, 4096):
         if norow: os.environ["MCL_XC_NOROW"] = "1"
         else: os.environ.pop("MCL_XC_NOROW", None)
         os.environ.update(MCL_XC_WAVES=str(waves))
+        eng.reload_switches()
         print(f"xc kernel (events) norow={norow or 0} waves={waves}: {prof(xc, 0):.1f} us  [{eng.kernel_variant(0)}]")
