@@ -176,10 +176,55 @@ __global__ __launch_bounds__(256) void k_B_systems(const double *__restrict__ Ct
 // Penalty-free B (decomposition.py:266-273 with an empty penalty list): B_i = ((X_i C) o a_i) L_i^-1 with un-shifted (or
 // only l2-shifted) systems - the product runs in fp64 with the fp64 inverse, one wave per tile of <= 64 rows, lane c
 // owning column c of L_i^-1; the row's right-hand side entries are fetched with v_readlane.
+// X C in fp64 for that solve: the un-shifted systems would amplify the rounding of an fp32 contraction (1e-7 over a
+// K-long chain) by their condition number - the products of fp32 values are exact in fp64, so XC64 carries only the
+// final fp64 roundings.  A wave owns 16 packed rows; per 16 columns of K: lane (i = l & 15, kk = l >> 4) holds
+// X[row0 + i][k0 + 4 kk .. + 3], step s of the fp64 MFMA pairs it with C[k0 + 4 kk + s][16 nb + (l & 15)]
+// (D: row = (l >> 4) + 4 reg, col = l & 15).  Only used when mode 1 has no penalty: a rare, accuracy-first path.
+template <int NB>
+__global__ __launch_bounds__(256) void k_contract_xc_f64(const float *__restrict__ X, const float *__restrict__ C, long N,
+                                                         int K, int r, double *__restrict__ XC64) {
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (row0 >= N) return;
+    const int i = lane & 15, kk = lane >> 4;
+    const long jx = min(row0 + i, N - 1);
+    f64x4 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        float xv[4], cv[NB][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = k0 + 4 * kk + s;
+            xv[s] = (k < K) ? X[jx * K + k] : 0.f;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int col = 16 * nb + i;
+                cv[nb][s] = (k < K && col < r) ? C[(long)k * r + col] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xv[s], (double)cv[nb][s], acc[nb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const long j = row0 + kk + 4 * v;
+            const int col = 16 * nb + i;
+            if (j < N && col < r) XC64[j * r + col] = acc[nb][v];
+        }
+}
+
 template <int RP>
 __global__ __launch_bounds__(256) void k_B_solve_f64(const int *__restrict__ tile_slab, const int *__restrict__ tile_row0,
                                                      const int *__restrict__ tile_nrows, int n_tiles,
-                                                     const float *__restrict__ XC, const float *__restrict__ A,
+                                                     const double *__restrict__ XC, const float *__restrict__ A,
                                                      const double *__restrict__ Linv64, int r, float *__restrict__ B) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -194,7 +239,7 @@ __global__ __launch_bounds__(256) void k_B_solve_f64(const int *__restrict__ til
     for (int d = 0; d < RP; ++d) col[d] = (act && d < r) ? Linv64[((long)slab * r + d) * r + c] : 0.0;
     const double a = act ? (double)A[(long)slab * r + c] : 0.0;
     for (int j = 0; j < nrows; ++j) {
-        const double t = act ? (double)XC[(row0 + j) * r + c] * a : 0.0;
+        const double t = act ? XC[(row0 + j) * r + c] * a : 0.0;
         double acc = 0.0;
 #pragma unroll
         for (int d = 0; d < RP; ++d)
@@ -1355,8 +1400,17 @@ int mcl_launch_B_systems(mcl_context *c) {
 
 int mcl_launch_B_solve_f64(mcl_context *c) {
     if (c->tilesB.n_tiles == 0) return 0;
+    {  // X C in fp64 (one inner iteration per phase for a penalty-free mode: computed right here)
+        const dim3 g((unsigned)(((c->N + 15) / 16 + 3) / 4));
+        if (c->NB == 1)
+            hipLaunchKernelGGL(k_contract_xc_f64<1>, g, dim3(256), 0, c->stream, c->X, c->C, (long)c->N, (int)c->K, c->r, c->XC64);
+        else if (c->NB == 2)
+            hipLaunchKernelGGL(k_contract_xc_f64<2>, g, dim3(256), 0, c->stream, c->X, c->C, (long)c->N, (int)c->K, c->r, c->XC64);
+        else
+            hipLaunchKernelGGL(k_contract_xc_f64<4>, g, dim3(256), 0, c->stream, c->X, c->C, (long)c->N, (int)c->K, c->r, c->XC64);
+    }
     dim3 grid((unsigned)((c->tilesB.n_tiles + 3) / 4)), block(256);
-    DISPATCH_RP_T(c, k_B_solve_f64, grid, block, c->tilesB.slab, c->tilesB.row0, c->tilesB.nrows, c->tilesB.n_tiles, c->XC,
+    DISPATCH_RP_T(c, k_B_solve_f64, grid, block, c->tilesB.slab, c->tilesB.row0, c->tilesB.nrows, c->tilesB.n_tiles, c->XC64,
                   c->A, c->LinvB64, c->r, c->B);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;

@@ -77,6 +77,7 @@ int64_t plan(mcl_context *c, char *base) {
     c->rhoB = b.take<float>(I);
     c->LinvB = b.take<float>(I * r * r);
     c->LinvB64 = (c->regs[1].n == 0) ? b.take<double>(I * r * r) : nullptr;
+    c->XC64 = (c->regs[1].n == 0) ? b.take<double>(N * r) : nullptr;
     c->rho_max = b.take<float>(2);
     c->partials = b.take<double>((int64_t)mcl_contract_n_partials(c) * E);
     c->GR = b.take<double>(E);
@@ -636,15 +637,23 @@ int mcl_update_B(mcl_context *c) {
         c->sweep_planned = false;  // the device refused the kernel's LDS size: two-pass path from now on
         if (int rc2 = flush_diag(c)) return rc2;
     }
+    if (c->regs[1].n == 0) {
+        // plain least-squares update of B: un-shifted (or only l2-shifted) systems - X C, the inverse and the product in fp64
+        if (int rc = ensure_ctc(c)) return rc;
+        if (c->opt.constant_B)
+            if (int rc = mcl_launch_B_rho(c)) return rc;
+        if (int rc = B_factor_impl(c)) return rc;
+        c->e1_valid = false;
+        if (c->opt.inner_n_iter_max <= 0) return 0;
+        c->mseg_valid = c->grpart_valid = false;
+        c->diag_valid[1] = false;
+        return mcl_launch_B_solve_f64(c);
+    }
     if (int rc = mcl_B_begin(c)) return rc;
     if (int rc = mcl_B_factor(c)) return rc;
     c->e1_valid = false;
     if (c->opt.inner_n_iter_max <= 0) return 0;
     c->mseg_valid = c->grpart_valid = false;
-    if (c->regs[1].n == 0) {  // plain least-squares update of B: un-shifted systems, solved in fp64
-        c->diag_valid[1] = false;
-        return mcl_launch_B_solve_f64(c);
-    }
     if (mcl_mode_is_row_separable(c, 1)) {
         const int rc = mcl_launch_rows_fused(c, 1);
         if (rc == 0) {

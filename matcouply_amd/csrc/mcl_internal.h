@@ -113,6 +113,7 @@ struct mcl_context {
     float *rhoB = nullptr;      // [I]
     float *LinvB = nullptr;     // [I, r, r]
     double *LinvB64 = nullptr;  // [I, r, r] fp64 copy, only when mode 1 has no penalty (fp64 solve of the un-shifted systems)
+    double *XC64 = nullptr;     // [N, r]  X C in fp64 for that solve (same condition)
     float *rho_max = nullptr;   // [2]  (0: B-phase, 1: A-phase)
     double *partials = nullptr; // [n_part, K*r + r*r]  per-block fp64 partials of the X^T (B o a) pass
     double *GR = nullptr;       // [r*r + K*r]  fp64 normal equations of the C-phase (all-reduced by a multi-GPU host)
