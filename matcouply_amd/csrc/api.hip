@@ -732,7 +732,11 @@ int mcl_A_begin(mcl_context *c) {
         // the sweep left M_i = X_i^T B_i per bseg: rhs_i = coldot(M_i, C), no pass over X
         if (int rc = ensure_cfrag_sweep(c)) return rc;
         // rank 5..32: the finish kernel forms rhs_i from M_bseg itself (one launch less); otherwise a separate pass
-        c->a_rhs_from_M = (c->RP == 8 || c->RP == 16 || c->RP == 32) && !c->sw.a_finish_cols && !c->sw.no_a_fusion;
+        // ... as long as a slab has few bsegs: ONE wave streams all M_bseg of its slab (16 KB each at K = 256), while the
+        // separate kernel spreads them over a workgroup per bseg (a 1/8 shard of config 3 cuts its slabs into 8 bsegs:
+        // 27 us fused vs 5 + 13 us apart)
+        c->a_rhs_from_M = (c->RP == 8 || c->RP == 16 || c->RP == 32) && !c->sw.a_finish_cols && !c->sw.no_a_fusion &&
+                          c->bsegs.n_tiles <= 2 * c->I;
         if (!c->a_rhs_from_M)
             if (int rc = mcl_launch_A_rhs_from_M(c)) return rc;
         c->use_seg_gram = true;
