@@ -49,7 +49,10 @@ static __device__ __forceinline__ long uniform_off(long v) {
     return (long)(((unsigned long long)hi << 32) | lo);
 }
 
-template <int KS, int NB, int NREG, int DEPTH, int NW, bool VEC>
+// DBG: the MCL_SWEEP_DBG experiments (phase elimination, per-section cycle counters: tools/run_dbg.sh, sweep_cycles.py)
+// are compiled into a second instantiation of the config-2/3 variants only; the production kernels carry none of it
+// (the counters alone cost 12 registers in kernels that sit at the 512-register limit).
+template <int KS, int NB, int NREG, int DEPTH, int NW, bool VEC, bool DBG = false>
 __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, const float *__restrict__ Cfrag,
                                                const float *__restrict__ A, const float *__restrict__ rhoB,
                                                const float *__restrict__ LinvB, float *__restrict__ Bout, RegSet regs,
@@ -57,8 +60,9 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                                                const int *__restrict__ bs_nrows, int n_bsegs, int bsegs_per_wave,
                                                int K, int r, int inner, float *__restrict__ Mpart,
                                                double *__restrict__ part_btb, float *__restrict__ GRpart,
-                                               double *__restrict__ diag_block, int dbg,
+                                               double *__restrict__ diag_block, int dbg_rt,
                                                long long *__restrict__ cyc_out) {
+    const int dbg = DBG ? dbg_rt : 0;
     constexpr int KW = 256 * KS;   // floats per tile row: K rounded up to 256 (K % 4 == 0, K <= KW)
     constexpr int KC = 4 * KS;     // 64-column chunks
     constexpr int W = 16 * NB;
@@ -763,11 +767,23 @@ static int launch_sweep_v(mcl_context *c) {
     // tables (mcl_diagnostics_deferred) may still be waiting for the coming C-phase reduction kernel
     c->diagB_parity ^= 1;
     c->diagB_tile = c->diagB_bufs[c->diagB_parity];
-    hipLaunchKernelGGL((k_sweep<KS, NB, NREG, DEPTH, NW, VEC>), dim3(grid), dim3(64 * NW), sm, c->stream, c->X, c->CfragS, c->A,
-                       c->rhoB, c->LinvB, c->B, c->regs[1], c->bsegs.slab, c->bsegs.row0, c->bsegs.nrows, n, bpb, (int)c->K,
-                       c->r,
-                       c->opt.inner_n_iter_max, c->Mpart, c->part_btb, c->GRpart, c->diagB_tile,
-                       c->sw.sweep_dbg, c->sweep_cycles);
+#define MCL_SWEEP_LAUNCH(DBG_)                                                                                         \
+    hipLaunchKernelGGL((k_sweep<KS, NB, NREG, DEPTH, NW, VEC, DBG_>), dim3(grid), dim3(64 * NW), sm, c->stream, c->X,    \
+                       c->CfragS, c->A, c->rhoB, c->LinvB, c->B, c->regs[1], c->bsegs.slab, c->bsegs.row0, c->bsegs.nrows, \
+                       n, bpb, (int)c->K, c->r, c->opt.inner_n_iter_max, c->Mpart, c->part_btb, c->GRpart, c->diagB_tile, \
+                       c->sw.sweep_dbg, c->sweep_cycles)
+    bool launched = false;
+    if constexpr (KS == 1 && NB == 1 && VEC) {  // the instrumented twin exists for the config-2/3 variants only
+        if (c->sw.sweep_dbg != 0) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<KS, NB, NREG, DEPTH, NW, VEC, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) == hipSuccess) {
+                MCL_SWEEP_LAUNCH(true);
+                launched = true;
+            }
+        }
+    }
+    if (!launched) MCL_SWEEP_LAUNCH(false);
+#undef MCL_SWEEP_LAUNCH
     MCL_CHECK_HIP(c, hipGetLastError());
     c->diag_rows[1] = grid;
     c->n_grpart = n;  // one a-weighted partial per bseg
