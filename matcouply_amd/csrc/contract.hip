@@ -151,6 +151,9 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
                 float ba[NB];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) ba[nb] = fb[d][nb] * fa[d][nb];
+                // (kept on purpose: besides the loads-only timing experiment, this never-taken branch pins the order
+                // "MFMAs of the slot, then its next loads" - with it removed the scheduler interleaves the loads with the
+                // MFMAs and the counted vmcnt waits drop from 12..15 to 8..12: 6 % slower at K = 1024, measured)
                 if (DO_R && (dbg & 1)) {  // timing experiment: loads only
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb) acc[kb][0][0] += fx[d][kb] * ba[0];
