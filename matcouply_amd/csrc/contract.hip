@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "mcl_internal.h"
 
@@ -645,6 +646,170 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_contract_xc_256 : the K = 256, rank <= 16 case of k_contract_xc_row (C fragments resident in 64 registers) with TWO
+// 16-row blocks of X in flight per wave instead of one (32 KB per wave, 128 KB per CU): a wave walks the 16-row blocks of
+// all its segments as one flat sequence through a 2-slot register ring; block b + 2 is requested as soon as block b sits
+// in the LDS tile.  Same arithmetic, tile layout, epilogue and per-segment outputs as k_contract_xc_row.  Config 4:
+// 180 -> 164 us (a third slot: 164 us - two blocks cover the latency; MCL_XC_DEPTH1=1 selects the one-slot kernel).
+// The flat walk: `cur` is the block being multiplied, `pre` the one being requested (two blocks ahead); past the wave's last
+// block `pre` keeps pointing at the last valid rows (unconditional clamped loads, nothing stored).
+// ---------------------------------------------------------------------------------------------------------
+template <int GRAM, int D>
+__global__ __launch_bounds__(256) void k_contract_xc_256(const float *__restrict__ X, const float *__restrict__ Cfrag,
+                                                         float *__restrict__ XC, const float *__restrict__ B,
+                                                         const int *__restrict__ seg_row0,
+                                                         const int *__restrict__ seg_rows, int n_segs,
+                                                         int segs_per_wave, int r, double *__restrict__ seg_rhs,
+                                                         double *__restrict__ seg_btb) {
+    extern __shared__ float lds_dyn[];  // 4 waves x 16 rows x 256 floats
+    constexpr int K = 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, i16 = lane & 15;
+    float *L = lds_dyn + wave * (16 * 256);
+    const int w = blockIdx.x * 4 + wave;
+    const int s0 = w * segs_per_wave;
+    const int s1 = min(s0 + segs_per_wave, n_segs);
+    if (s0 >= s1) return;
+
+    f32x4 creg[4][4];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq)
+            creg[kc][kq] = *reinterpret_cast<const f32x4 *>(Cfrag + (((long)kc * 4 + kq) * 64 + lane) * 4);
+    const int bcol = min(i16, r - 1);
+
+    struct Cursor {
+        int sg, blk, nblk, nrows;
+        long row0;
+    };
+    auto seg_at = [&](Cursor &c, int sg) {
+        c.sg = sg, c.blk = 0;
+        c.row0 = __builtin_amdgcn_readfirstlane(seg_row0[sg]);
+        c.nrows = __builtin_amdgcn_readfirstlane(seg_rows[sg]);
+        c.nblk = (c.nrows + 15) >> 4;
+    };
+    auto advance = [&](Cursor &c) {  // wave-uniform
+        if (c.blk + 1 < c.nblk) {
+            c.blk += 1;
+        } else if (c.sg + 1 < s1) {
+            seg_at(c, c.sg + 1);
+        } else {
+            c.blk = c.nblk;  // past the end: rows clamp to the last valid one
+        }
+    };
+    int total = 0;
+    for (int sg = s0; sg < s1; ++sg) total += (__builtin_amdgcn_readfirstlane(seg_rows[sg]) + 15) >> 4;
+
+    f32x4 xr[D][16];
+    float bnx[D][4];
+    auto issue = [&](auto dc, const Cursor &c) {
+        constexpr int d = decltype(dc)::value;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const long j = c.row0 + min(16 * c.blk + t, c.nrows - 1);
+            xr[d][t] = *reinterpret_cast<const f32x4 *>(X + j * K + 4 * lane);
+        }
+        if (GRAM) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const long j = c.row0 + min(16 * c.blk + 4 * q + v, c.nrows - 1);
+                bnx[d][v] = B[j * r + bcol];
+            }
+        }
+    };
+
+    Cursor cur, pre;
+    seg_at(cur, s0);
+    seg_at(pre, s0);
+    issue(std::integral_constant<int, 0>{}, pre);
+    advance(pre);
+    __builtin_amdgcn_sched_barrier(0);
+    if (D > 1) {
+        issue(std::integral_constant<int, (D > 1 ? 1 : 0)>{}, pre);
+        advance(pre);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (D > 2) {
+        issue(std::integral_constant<int, (D > 2 ? 2 : 0)>{}, pre);
+        advance(pre);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    double p = 0.0;
+    float pf = 0.f;
+    f64x4 accG = {0.0, 0.0, 0.0, 0.0};
+    f32x4 accGf = zero4();
+    auto body = [&](auto dc, bool live) {
+        constexpr int d = decltype(dc)::value;
+        float bcur[4];
+        if (GRAM) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) bcur[v] = bnx[d][v];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4 *>(L + t * 256 + ((lane ^ t) << 2)) = xr[d][t];
+        issue(dc, pre);  // the slot is free again: its next block (two ahead) goes out now
+        advance(pre);
+        f32x4 acc4[4];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            acc4[kc] = zero4();
+            f32x4 fr[4];
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq)
+                fr[kq] = *reinterpret_cast<const f32x4 *>(L + i16 * 256 + (((16 * kc + 4 * kq + q) ^ i16) << 2));
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc4[kc] = MFMA16(fr[kq][m], creg[kc][kq][m], acc4[kc]);
+        }
+        const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+        if (!live) return;  // the dummy half of an odd trip: nothing stored (wave-uniform)
+        float bv[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int rl = 16 * cur.blk + 4 * q + v;
+            const bool ok = (rl < cur.nrows) && (i16 < r);
+            if (ok) XC[(cur.row0 + rl) * r + i16] = acc[v];
+            if (GRAM) {
+                const float b = ok ? bcur[v] : 0.f;
+                bv[v] = b;
+                if (GRAM == 2) p = fma((double)b, (double)acc[v], p);
+                else pf = fmaf(b, acc[v], pf);
+            }
+        }
+        if (GRAM) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if (GRAM == 2) accG = __builtin_amdgcn_mfma_f64_16x16x4f64((double)bv[v], (double)bv[v], accG, 0, 0, 0);
+                else accGf = MFMA16(bv[v], bv[v], accGf);
+            }
+            if (cur.blk == cur.nblk - 1) {  // the segment ends with this block: its reductions go out (wave-uniform)
+                double t = (GRAM == 2) ? p : (double)pf;
+                t += __shfl_xor(t, 16);
+                t += __shfl_xor(t, 32);
+                if (q == 0 && i16 < r) seg_rhs[(long)cur.sg * r + i16] = t;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int ra = (GRAM == 2) ? q + 4 * v : 4 * q + v;  // D layouts of the f64 / f32 MFMA
+                    const double val = (GRAM == 2) ? accG[v] : (double)accGf[v];
+                    if (ra < r && i16 < r) seg_btb[((long)cur.sg * r + ra) * r + i16] = val;
+                }
+                p = 0.0, pf = 0.f;
+                accG = f64x4{0.0, 0.0, 0.0, 0.0}, accGf = zero4();
+            }
+        }
+        advance(cur);
+    };
+    for (int b = 0; b < total; b += D) {
+        body(std::integral_constant<int, 0>{}, true);
+        if (D > 1) body(std::integral_constant<int, (D > 1 ? 1 : 0)>{}, b + 1 < total);
+        if (D > 2) body(std::integral_constant<int, (D > 2 ? 2 : 0)>{}, b + 2 < total);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // k_slab_gram : one workgroup per slab.  rhs_i[c] = sum_j B[j][c] XC[j][c];  BtB_i = B_i^T B_i (fp64 MFMA: exact products).
 // Writes the fp64 per-slab tables k_A_finish reads (one "segment" per slab) and their fp32 images (rhses by-product,
 // k_A_e1).
@@ -856,7 +1021,15 @@ static int launch_xc(mcl_context *c) {
                        c->XC, c->B, c->segs.row0, c->segs.nrows, n_segs, spw, (int)c->K, c->r, c->seg_rhs, c->seg_btb)
         if (n_segs > 0) {
             if constexpr (NB == 1) {  // resident C fragments: K = 256, rank <= 16 only
-                if (creg) {
+                if (creg && !c->sw.xc_depth1) {  // two blocks of X in flight per wave
+#define MCL_XC256(GRAM_)                                                                                              \
+    hipLaunchKernelGGL((k_contract_xc_256<GRAM_, 2>), dim3(g), dim3(256), sm, c->stream, c->X, c->Cfrag, c->XC, c->B,    \
+                       c->segs.row0, c->segs.nrows, n_segs, spw, c->r, c->seg_rhs, c->seg_btb)
+                    if (gram == 2) MCL_XC256(2);
+                    else if (gram == 1) MCL_XC256(1);
+                    else MCL_XC256(0);
+#undef MCL_XC256
+                } else if (creg) {
                     if (gram == 2) MCL_XCR(true, 2);
                     else if (gram == 1) MCL_XCR(true, 1);
                     else MCL_XCR(true, 0);
@@ -875,7 +1048,8 @@ static int launch_xc(mcl_context *c) {
 #undef MCL_XCR
         c->xc_did_gram = gram != 0;
         char buf[96];
-        snprintf(buf, sizeof buf, "k_contract_xc_row<NB=%d,CREG=%d,GRAM=%d>", NB, creg ? 1 : 0, gram);
+        if (creg && !c->sw.xc_depth1) snprintf(buf, sizeof buf, "k_contract_xc_256<DEPTH=2,GRAM=%d>", gram);
+        else snprintf(buf, sizeof buf, "k_contract_xc_row<NB=%d,CREG=%d,GRAM=%d>", NB, creg ? 1 : 0, gram);
         c->variant[0] = buf;
         MCL_CHECK_HIP(c, hipGetLastError());
         return 0;
