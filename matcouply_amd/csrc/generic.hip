@@ -10,11 +10,7 @@
 #include "mcl_internal.h"
 #include "rows_mfma.h"
 
-static __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+static __device__ __forceinline__ double wave_sum_d(double v) { return wave_sum(v); }  // DPP + readlane (rows_mfma.h)
 
 static __device__ __forceinline__ float prox_elem_g(int kind, int nonneg, float p0, float p1, float thr, float y) {
     switch (kind) {

@@ -18,10 +18,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #endif
 
+// Sum of a double over the 64 lanes, the total in every lane.  Four DPP steps inside each 16-lane row (quad_perm xor 1,
+// xor 2, row_half_mirror, row_mirror: a few cycles each), then the four row totals through v_readlane - a butterfly of
+// six ds_bpermute pairs costs ~1200 cycles of dependent latency, which bounded the Newton-Schulz iteration of the
+// PARAFAC2 kernel (one norm per step) and the tail of every row pass.  Fixed association: ((r0 + r1) + (r2 + r3)).
+template <int CTRL>
+static __device__ __forceinline__ double dpp_mov_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ double readlane_f64_u(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 static __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_mov_f64<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+    v += dpp_mov_f64<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+    v += dpp_mov_f64<0x141>(v);  // row_half_mirror
+    v += dpp_mov_f64<0x140>(v);  // row_mirror: every lane of a row holds the row's total
+    return (readlane_f64_u(v, 0) + readlane_f64_u(v, 16)) + (readlane_f64_u(v, 32) + readlane_f64_u(v, 48));
 }
 
 // elementwise prox of the row-separable penalties (penalties.py:503-586)
