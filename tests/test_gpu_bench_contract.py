@@ -1,0 +1,57 @@
+"""-m gpu: bench.py honours the driver's contract - ONE JSON line from rank 0 with the named fields - on one rank, and its
+sharded code path (row-balanced partition, fp64 [G | R] all-reduce, deferred diagnostics, bit-identity check of the
+replicated factor) runs end to end with two ranks sharing this box's GPU over gloo (RCCL needs one device per rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def _last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_single_rank_line():
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--config", "c2", "--steps", "6",
+                          "--warmup", "2", "--regions", "3", "--cpu-budget", "2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert all(k in d for k in REQUIRED), sorted(set(REQUIRED) - set(d))
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"]
+    assert len(d["region_ms"]) == 3 and abs(d["ms_per_step"] * d["steps"] - sorted(d["region_ms"])[1]) < 1e-3
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or str(r["traffic_source"]).startswith("static: profiles/")
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # a --gpus value that does not match the launch is refused instead of silently re-labelled
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
+@pytest.mark.parametrize("config", ["c3_8th", "c4"])
+def test_two_ranks_sharing_the_gpu(config):
+    env = dict(os.environ, MCL_BENCH_SHARE_GPU="1", MCL_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    port = str(29400 + (os.getpid() + len(config)) % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(REPO, "bench.py"), "--gpus", "2", "--config", config, "--steps", "4",
+           "--warmup", "2", "--regions", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"] is None
+    assert d["replicated_C_bit_identical"] is True
+    assert d["collectives_per_step"] == (6.0 if config == "c4" else 1.0)  # [G | R] (+ PARAFAC2 per inner iteration)
+    assert 0 < d["final_rel_rec_error"] < 1
