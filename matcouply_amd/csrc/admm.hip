@@ -313,18 +313,64 @@ __global__ __launch_bounds__(256) void k_C_solve_f64(const double *__restrict__ 
 // Per-tile diagnostics (fp64): ||f||^2, sum|f|, ||z_k - f||^2.
 // ---------------------------------------------------------------------------------------------------------
 
+// One block of 16 rows of the fused inner loop in a wave's registers: rhs (already rounded to fp32), aux and dual.
+// All loads are unconditional (padding lanes re-read a valid address of the same row: their values only ever meet the
+// zero entries of the L^-1 fragments and are never stored), so they leave back to back and a caller can issue them
+// long before the values are needed (k_C_finish_fused: under the Gauss-Jordan of wave 0).
+template <int NBR, int NREG, bool VEC>
+struct RowBlock {
+    static constexpr int NR = NREG > 0 ? NREG : 1;
+    f32x4 rhs[NBR], z[NR][NBR], u[NR][NBR];
+
+    static __device__ __forceinline__ f32x4 ld4(const float *__restrict__ base, long j, int col, int r) {
+        if (VEC) return *reinterpret_cast<const f32x4 *>(base + j * r + (col < r ? col : 0));
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = base[j * r + min(col + q, r - 1)];
+        return v;
+    }
+    // j: a VALID row for every lane (lanes past the tile's end pass the tile's first row)
+    __device__ __forceinline__ void load(int lane, long j, int r, const float *__restrict__ rhs_src,
+                                         const double *__restrict__ rhs64, const RegSet &regs) {
+        const int g = lane >> 4;
+#pragma unroll
+        for (int h = 0; h < NBR; ++h) {
+            const int col = 16 * h + 4 * g;
+            if (rhs64 != nullptr) {  // fp64 [G | R] of the C-phase, rounded on load
+                if (VEC) {
+                    const double *src = rhs64 + j * r + (col < r ? col : 0);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) rhs[h][v] = (float)src[v];
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) rhs[h][v] = (float)rhs64[j * r + min(col + v, r - 1)];
+                }
+            } else {
+                rhs[h] = ld4(rhs_src, j, col, r);
+            }
+#pragma unroll
+            for (int k = 0; k < NREG; ++k) {
+                z[k][h] = ld4(regs.aux[k], j, col, r);
+                u[k][h] = ld4(regs.dual[k], j, col, r);
+            }
+        }
+    }
+};
+
 // One wave's share of the fused inner loop: a tile of <= 64 rows [row0, row0 + nrows) of one slab.
 // Li: the slab's L^-1 (global or LDS), Arow: the slab's a_i or nullptr, Fcopy: optional second destination (LDS).
+// pre: the tile's first row block, loaded by the caller (or nullptr).
 // Returns the tile's diagnostic sums (already reduced over the wave) in dg[0..1+NREG].
 template <int NBR, int NREG, bool VEC>
 static __device__ __forceinline__ void rows_fused_tile(int lane, long row0, int nrows, float rho, const float *Li,
                                                        const float *Arow, const float *__restrict__ rhs_src,
                                                        float *__restrict__ F, float *Fcopy, const RegSet &regs, int r,
-                                                       int inner, double *dg, const double *__restrict__ rhs64 = nullptr) {
+                                                       int inner, double *dg, const double *__restrict__ rhs64 = nullptr,
+                                                       const RowBlock<NBR, NREG, VEC> *pre = nullptr) {
     const int row16 = lane & 15, g = lane >> 4;
     constexpr int NR = NREG > 0 ? NREG : 1;
 
-    // A-operand fragments of (L^-1)^T
+    // A-operand fragments of (L^-1)^T (clamped addresses, masked values: the reads leave together)
     float LT[NBR][NBR][4];
 #pragma unroll
     for (int hp = 0; hp < NBR; ++hp)
@@ -333,7 +379,8 @@ static __device__ __forceinline__ void rows_fused_tile(int lane, long row0, int 
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
                 const int k = 16 * h + 4 * g + kq, c = 16 * hp + row16;
-                LT[hp][h][kq] = (k < r && c < r) ? Li[k * r + c] : 0.f;
+                const float v = Li[min(k, r - 1) * r + min(c, r - 1)];
+                LT[hp][h][kq] = (k < r && c < r) ? v : 0.f;
             }
     float av[NBR][4];
 #pragma unroll
@@ -343,25 +390,17 @@ static __device__ __forceinline__ void rows_fused_tile(int lane, long row0, int 
             const int col = 16 * h + 4 * g + v;
             av[h][v] = (Arow != nullptr && col < r) ? Arow[col] : 1.f;
         }
-    float thr[NR];
+    ProxClamp prox[NR];  // branch-free prox of the row-separable penalties (penalties.py:503-586)
 #pragma unroll
-    for (int k = 0; k < NR; ++k) thr[k] = (k < NREG) ? regs.p0[k] / rho : 0.f;
+    for (int k = 0; k < NR; ++k) {
+        if (k < NREG) prox[k].set(regs.kind[k], regs.nonneg[k], regs.p0[k], regs.p1[k], regs.p0[k] / rho);
+        else prox[k].set(0, 0, 0.f, 0.f, 0.f);
+    }
 
     double nf = 0.0, na = 0.0, gap[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) gap[k] = 0.0;
 
-    auto ld4 = [&](const float *__restrict__ base, long j, int col, bool ok) -> f32x4 {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (VEC) {
-            if (ok && col < r) v = *reinterpret_cast<const f32x4 *>(base + j * r + col);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (ok && col + q < r) v[q] = base[j * r + col + q];
-        }
-        return v;
-    };
     auto st4 = [&](float *__restrict__ base, long j, int col, bool ok, f32x4 v) {
         if (VEC) {
             if (ok && col < r) *reinterpret_cast<f32x4 *>(base + j * r + col) = v;
@@ -378,23 +417,19 @@ static __device__ __forceinline__ void rows_fused_tile(int lane, long row0, int 
         if (16 * rb >= nrows) break;  // wave-uniform
         const bool ok = 16 * rb + row16 < nrows;
         const long j = (long)row0 + 16 * rb + (ok ? row16 : 0);
-        f32x4 rhs[NBR], z[NR][NBR], u[NR][NBR], f[NBR];
+        RowBlock<NBR, NREG, VEC> blk;
+        if (rb == 0 && pre != nullptr)
+            blk = *pre;
+        else
+            blk.load(lane, j, r, rhs_src, rhs64, regs);
+        f32x4(&rhs)[NBR] = blk.rhs;
+        f32x4(&z)[NR][NBR] = blk.z;
+        f32x4(&u)[NR][NBR] = blk.u;
+        f32x4 f[NBR];
 #pragma unroll
         for (int h = 0; h < NBR; ++h) {
-            const int col = 16 * h + 4 * g;
-            if (rhs64 != nullptr) {  // fp64 [G | R] of the C-phase, rounded on load
-#pragma unroll
-                for (int v = 0; v < 4; ++v) rhs[h][v] = (ok && col + v < r) ? (float)rhs64[j * r + col + v] : 0.f;
-            } else {
-                rhs[h] = ld4(rhs_src, j, col, ok);
-            }
 #pragma unroll
             for (int v = 0; v < 4; ++v) rhs[h][v] *= av[h][v];
-#pragma unroll
-            for (int k = 0; k < NREG; ++k) {
-                z[k][h] = ld4(regs.aux[k], j, col, ok);
-                u[k][h] = ld4(regs.dual[k], j, col, ok);
-            }
             f[h] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         for (int it = 0; it < n_it; ++it) {
@@ -420,14 +455,12 @@ static __device__ __forceinline__ void rows_fused_tile(int lane, long row0, int 
             }
 #pragma unroll
             for (int k = 0; k < NREG; ++k) {
-                const int kind = regs.kind[k], nn = regs.nonneg[k];
-                const float p0 = regs.p0[k], p1 = regs.p1[k];
 #pragma unroll
                 for (int h = 0; h < NBR; ++h)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const float y = f[h][v] + u[k][h][v];
-                        const float zn = prox_elem(kind, nn, p0, p1, thr[k], y);
+                        const float zn = prox[k](y);
                         u[k][h][v] = f[h][v] - (zn - u[k][h][v]);
                         z[k][h][v] = zn;
                     }
@@ -512,6 +545,14 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const double *__restric
     float *Ls = smc, *Cs = smc + r * r;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     constexpr int RP = 16 * NBR;
+    // up to 16 waves, 16 / 32 / 64 rows each: short tiles keep the serial 5-iteration chain per wave short
+    const long row0 = (long)rows_per_wave * wave;
+    const int nrows = max(0, min(rows_per_wave, K - rows_per_wave * wave));
+    // every wave's first row block (R rows from the fp64 [G | R], aux, dual) is requested BEFORE the system is built:
+    // the round trips run under wave 0's Gauss-Jordan instead of after the barrier
+    RowBlock<NBR, NREG, VEC> pre;
+    if (NREG > 0 && nrows > 0)
+        pre.load(lane, row0 + ((lane & 15) < nrows ? (lane & 15) : 0), r, nullptr, GR + (long)r * r, regs);
     if (wave == 0) {
         // system in the row-split layout of GJRows<RP> (lane = g * RP + c holds rows g * RL + j of column c): all loads in
         // flight at once (clamped indices, masked at use), all 64 lanes busy in the Gauss-Jordan
@@ -556,9 +597,6 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const double *__restric
         }
     }
     __syncthreads();
-    // up to 16 waves, 16 / 32 / 64 rows each: short tiles keep the serial 5-iteration chain per wave short
-    const long row0 = (long)rows_per_wave * wave;
-    const int nrows = max(0, min(rows_per_wave, K - rows_per_wave * wave));
     double dg[DIAG_COLS];
     if (NREG == 0) {
         // C = R G^-1 in fp64 (un-shifted normal equations: every rounding of the product is amplified by cond(G))
@@ -580,7 +618,7 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const double *__restric
         dg[1] = wave_sum(na);
     } else {
         rows_fused_tile<NBR, NREG, VEC>(lane, row0, nrows, rho_s, Ls, nullptr, nullptr, C, Cs, regs, r, inner, dg,
-                                        GR + (long)r * r);
+                                        GR + (long)r * r, &pre);
     }
     if (lane == 0) {
 #pragma unroll
@@ -759,23 +797,25 @@ __global__ __launch_bounds__(256) void k_A_finish(float *__restrict__ BtB, const
             if (act && d < r) LinvA[((long)i * r + d) * r + c] = (float)col[d];
         return;
     }
-    float z[MCL_MAX_REGS], u[MCL_MAX_REGS], thr[MCL_MAX_REGS];
+    float z[MCL_MAX_REGS], u[MCL_MAX_REGS], on[MCL_MAX_REGS];
+    ProxClamp prox[MCL_MAX_REGS];
 #pragma unroll
     for (int k = 0; k < MCL_MAX_REGS; ++k) {
-        z[k] = u[k] = thr[k] = 0.f;
+        z[k] = u[k] = 0.f;
         if (k < n && act) {
             z[k] = z_pre[k];
             u[k] = u_pre[k];
         }
-        if (k < n) thr[k] = regs.p0[k] / rho;
+        on[k] = (k < n) ? 1.f : 0.f;  // the inner loop is branch-free: absent penalties are masked out of the sum
+        if (k < n) prox[k].set(regs.kind[k], regs.nonneg[k], regs.p0[k], regs.p1[k], regs.p0[k] / rho);
+        else prox[k].set(0, 0, 0.f, 0.f, 0.f);
     }
     float a = act ? a_pre : 0.f;
     const int n_it = (n == 0 && inner > 1) ? 1 : inner;
     for (int it = 0; it < n_it; ++it) {
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < MCL_MAX_REGS; ++k)
-            if (k < n) s += z[k] - u[k];
+        for (int k = 0; k < MCL_MAX_REGS; ++k) s = fmaf(on[k], z[k] - u[k], s);  // = s + (z - u) exactly when on
         const double t = (n > 0) ? fma((double)rho, (double)s, rhs) : rhs;
         double acc = 0.0;
 #pragma unroll
@@ -785,12 +825,10 @@ __global__ __launch_bounds__(256) void k_A_finish(float *__restrict__ BtB, const
         a = (float)acc;
 #pragma unroll
         for (int k = 0; k < MCL_MAX_REGS; ++k) {
-            if (k < n) {
-                const float y = a + u[k];
-                const float zn = prox_elem(regs.kind[k], regs.nonneg[k], regs.p0[k], regs.p1[k], thr[k], y);
-                u[k] = a - (zn - u[k]);
-                z[k] = zn;
-            }
+            const float y = a + u[k];
+            const float zn = prox[k](y);
+            u[k] = a - (zn - u[k]);
+            z[k] = zn;
         }
     }
     if (act) {
@@ -936,7 +974,8 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
         btbv[j] = 0.0;
     }
     double rhs_pre = 0.0;
-    float z[MCL_MAX_REGS], u[MCL_MAX_REGS], thr[MCL_MAX_REGS];
+    float z[MCL_MAX_REGS], u[MCL_MAX_REGS], on[MCL_MAX_REGS];
+    ProxClamp prox[MCL_MAX_REGS];
     const int n = regs.n;
 #pragma unroll
     for (int k = 0; k < MCL_MAX_REGS; ++k) {
@@ -1037,7 +1076,9 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
 #pragma unroll
     for (int k = 0; k < MCL_MAX_REGS; ++k) {
         if (!(k < n && act)) z[k] = u[k] = 0.f;
-        thr[k] = (k < n) ? regs.p0[k] / rho : 0.f;
+        on[k] = (k < n) ? 1.f : 0.f;
+        if (k < n) prox[k].set(regs.kind[k], regs.nonneg[k], regs.p0[k], regs.p1[k], regs.p0[k] / rho);
+        else prox[k].set(0, 0, 0.f, 0.f, 0.f);
     }
     if (!act) a = 0.f;
     // sum over the G row groups of one column: lanes c, RP + c, ... (fixed association)
@@ -1050,8 +1091,7 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
     for (int it = 0; it < n_it; ++it) {
         float sacc = 0.f;
 #pragma unroll
-        for (int k = 0; k < MCL_MAX_REGS; ++k)
-            if (k < n) sacc += z[k] - u[k];
+        for (int k = 0; k < MCL_MAX_REGS; ++k) sacc = fmaf(on[k], z[k] - u[k], sacc);  // = sacc + (z - u) exactly when on
         const double t = (n > 0) ? fma((double)rho, (double)sacc, rhs) : rhs;
         double acc = 0.0;
 #pragma unroll
@@ -1062,12 +1102,10 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
         a = (float)group_sum(acc);
 #pragma unroll
         for (int k = 0; k < MCL_MAX_REGS; ++k) {
-            if (k < n) {
-                const float y = a + u[k];
-                const float zn = prox_elem(regs.kind[k], regs.nonneg[k], regs.p0[k], regs.p1[k], thr[k], y);
-                u[k] = a - (zn - u[k]);
-                z[k] = zn;
-            }
+            const float y = a + u[k];
+            const float zn = prox[k](y);
+            u[k] = a - (zn - u[k]);
+            z[k] = zn;
         }
     }
     if (!act) a = 0.f;

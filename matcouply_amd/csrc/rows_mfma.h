@@ -55,6 +55,23 @@ static __device__ __forceinline__ float prox_elem(int kind, int nonneg, float p0
     }
 }
 
+// branch-free form of prox_elem with identical results:  prox(y) = clamp(y - clamp(y, pa, pb), plo, phi), clamp = v_med3_f32
+//   NN: (-inf, 0 | -inf, inf)   Box: (0, 0 | lo, hi)   L1: (-thr, thr | -inf, inf)   L1 + NN: (-inf, thr | -inf, inf)
+// The finish kernels run one wave per SIMD with a serial dependence chain: every branch in their inner loop is exposed.
+struct ProxClamp {
+    float pa, pb, plo, phi;
+    __device__ __forceinline__ void set(int kind, int nonneg, float p0, float p1, float thr) {
+        pa = pb = 0.f;
+        plo = -INFINITY, phi = INFINITY;
+        if (kind == MCL_PEN_NN) pa = -INFINITY;
+        if (kind == MCL_PEN_BOX) plo = p0, phi = p1;
+        if (kind == MCL_PEN_L1) pa = nonneg ? -INFINITY : -thr, pb = thr;
+    }
+    __device__ __forceinline__ float operator()(float y) const {
+        return __builtin_amdgcn_fmed3f(y - __builtin_amdgcn_fmed3f(y, pa, pb), plo, phi);
+    }
+};
+
 template <int NBR>
 struct RowMat {
     float m[NBR][NBR][4];  // m[h'][h][kq] = M[16h + 4g + kq][16h' + row16]
