@@ -933,6 +933,39 @@ struct AFuse {
     int MS, NBm;
 };
 
+// sum_k M[k][c] C[k][c] over the bsegs sgA, sgA + step, ... < sgB, both operands in C-fragment order (element
+// ((chunk * NB + nb) * 64 + l) * 4 + m <-> k = 16 chunk + 4 (l >> 4) + m, column 16 nb + (l & 15)): the wave streams
+// M_bseg with 1 KB loads, fp64 accumulation (products of fp32 values are exact), the four lane quarters of a column are
+// summed by two butterfly steps: every lane ends with the sums of columns (l & 15) and 16 + (l & 15) in acc0 / acc1.
+static __device__ __forceinline__ void m_coldot(const AFuse &F, int sgA, int sgB, int step, int lane, double &acc0,
+                                                double &acc1) {
+    double pa[2][2] = {{0.0, 0.0}, {0.0, 0.0}};  // [nb][chain]: two chains per column block shorten the FMA dependency
+    for (int sg = sgA; sg < sgB; sg += step) {
+        const float *mp = F.Mpart + (long)sg * F.MS;
+        for (int e0 = 0; e0 < F.MS; e0 += 4096) {  // 16 chunks per trip (MS is a multiple of 4096): 32 loads in flight
+            f32x4 mv[16], cv[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                mv[q] = *reinterpret_cast<const f32x4 *>(mp + e0 + 256 * q + 4 * lane);
+                cv[q] = *reinterpret_cast<const f32x4 *>(F.Cfrag + e0 + 256 * q + 4 * lane);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                double d = (double)mv[q][0] * (double)cv[q][0];
+                d = fma((double)mv[q][1], (double)cv[q][1], d);
+                d = fma((double)mv[q][2], (double)cv[q][2], d);
+                d = fma((double)mv[q][3], (double)cv[q][3], d);
+                // chunk index = e >> 8 = 16 * trip + q: nb = chunk % NB
+                if (F.NBm == 2 && (q & 1)) pa[1][(q >> 1) & 1] += d;
+                else pa[0][(q >> (F.NBm == 2 ? 1 : 0)) & 1] += d;
+            }
+        }
+    }
+    acc0 = pa[0][0] + pa[0][1], acc1 = pa[1][0] + pa[1][1];
+    acc0 += __shfl_xor(acc0, 16), acc1 += __shfl_xor(acc1, 16);
+    acc0 += __shfl_xor(acc0, 32), acc1 += __shfl_xor(acc1, 32);
+}
+
 // one wave = one slab
 template <int RP>
 static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int lane, float *__restrict__ BtB,
@@ -946,7 +979,8 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
                                                           float *__restrict__ LinvB, const int *__restrict__ slab_seg_ptr,
                                                           const double *__restrict__ seg_rhs,
                                                           const double *__restrict__ seg_btb,
-                                                          float *__restrict__ rhsA_out, const AFuse &F) {
+                                                          float *__restrict__ rhsA_out, const AFuse &F,
+                                                          const double *rhs_lds = nullptr) {
     constexpr int RL = GJRows<RP>::RL, G = GJRows<RP>::G;
     const int cc = lane % RP, g = lane / RP;
     const bool in_range = lane < GJRows<RP>::LANES;  // RP = 4 uses 16 lanes only
@@ -1006,36 +1040,13 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
                 }
         }
     }
-    if (F.Mpart != nullptr) {
-        // rhs_i[c] = sum_k M_i[k][c] C[k][c] over the slab's bsegs, both operands in C-fragment order (element
-        // ((chunk * NB + nb) * 64 + l) * 4 + m <-> k = 16 chunk + 4 (l >> 4) + m, column 16 nb + (l & 15)): the wave streams
-        // M_bseg with 1 KB loads, fp64 accumulation (products of fp32 values are exact), the four lane quarters of a
-        // column are summed by two butterfly steps and the column's sum is fetched into the lanes that own it
-        double pa[2][2] = {{0.0, 0.0}, {0.0, 0.0}};  // [nb][chain]: two chains per column block shorten the FMA dependency
-        for (int sg = sg0; sg < sg1; ++sg) {
-            const float *mp = F.Mpart + (long)sg * F.MS;
-            for (int e0 = 0; e0 < F.MS; e0 += 4096) {  // 16 chunks per trip (MS is a multiple of 4096): 32 loads in flight
-                f32x4 mv[16], cv[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    mv[q] = *reinterpret_cast<const f32x4 *>(mp + e0 + 256 * q + 4 * lane);
-                    cv[q] = *reinterpret_cast<const f32x4 *>(F.Cfrag + e0 + 256 * q + 4 * lane);
-                }
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    double d = (double)mv[q][0] * (double)cv[q][0];
-                    d = fma((double)mv[q][1], (double)cv[q][1], d);
-                    d = fma((double)mv[q][2], (double)cv[q][2], d);
-                    d = fma((double)mv[q][3], (double)cv[q][3], d);
-                    // chunk index = e >> 8 = 16 * trip + q: nb = chunk % NB
-                    if (F.NBm == 2 && (q & 1)) pa[1][(q >> 1) & 1] += d;
-                    else pa[0][(q >> (F.NBm == 2 ? 1 : 0)) & 1] += d;
-                }
-            }
-        }
-        double acc0 = pa[0][0] + pa[0][1], acc1 = pa[1][0] + pa[1][1];
-        acc0 += __shfl_xor(acc0, 16), acc1 += __shfl_xor(acc1, 16);
-        acc0 += __shfl_xor(acc0, 32), acc1 += __shfl_xor(acc1, 32);
+    if (rhs_lds != nullptr) {
+        // k_A_finish_rows_wide: the four waves of the workgroup each took a quarter of the slab's bsegs
+        rhs_pre = (rhs_lds[cc] + rhs_lds[32 + cc]) + (rhs_lds[64 + cc] + rhs_lds[96 + cc]);
+    } else if (F.Mpart != nullptr) {
+        // rhs_i[c] = sum_k M_i[k][c] C[k][c] over the slab's bsegs; the column's sum is fetched into the lanes that own it
+        double acc0, acc1;
+        m_coldot(F, sg0, sg1, 1, lane, acc0, acc1);
         const double v0 = bperm_f64(cc & 15, acc0), v1 = bperm_f64(cc & 15, acc1);
         rhs_pre = (cc < 16) ? v0 : v1;
     }
@@ -1190,6 +1201,35 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(float *__restrict__ BtB, 
     if (i >= I) return;
     a_finish_rows_slab<RP>(i, lane, BtB, CtC, r, scale, l2, constant, rho_max, rhoA, LinvA, A, regs, inner, fused_inner, e1,
                            diag_row, next_B, l2_B, n_regs_B, rhoB, LinvB, slab_seg_ptr, seg_rhs, seg_btb, rhsA_out, F);
+}
+
+// One workgroup per slab: its four waves share the slab's M_bseg stream (rhs_i = sum over bsegs of coldot(M_bseg, C)),
+// then wave 0 finishes the slab as in k_A_finish_rows.  For slabs cut into 3..8 bsegs (the per-rank shards of a multi-GPU
+// run): one wave alone would stream them for longer than the k_A_rhs_from_M launch this replaces costs.
+template <int RP>
+__global__ __launch_bounds__(256) void k_A_finish_rows_wide(float *__restrict__ BtB, const double *__restrict__ CtC, int I,
+                                                            int r, float scale, float l2, int constant,
+                                                            const float *__restrict__ rho_max, float *__restrict__ rhoA,
+                                                            float *__restrict__ LinvA, float *__restrict__ A, RegSet regs,
+                                                            int inner, int fused_inner, double *__restrict__ e1,
+                                                            double *__restrict__ diag_row, int next_B, float l2_B,
+                                                            int n_regs_B, float *__restrict__ rhoB,
+                                                            float *__restrict__ LinvB,
+                                                            const int *__restrict__ slab_seg_ptr,
+                                                            const double *__restrict__ seg_rhs,
+                                                            const double *__restrict__ seg_btb,
+                                                            float *__restrict__ rhsA_out, AFuse F) {
+    __shared__ double part[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x;
+    double a0, a1;
+    m_coldot(F, slab_seg_ptr[i] + wave, slab_seg_ptr[i + 1], 4, lane, a0, a1);
+    if (lane < 16) part[wave][lane] = a0, part[wave][16 + lane] = a1;
+    __syncthreads();
+    if (wave != 0) return;
+    a_finish_rows_slab<RP>(i, lane, BtB, CtC, r, scale, l2, constant, rho_max, rhoA, LinvA, A, regs, inner, fused_inner, e1,
+                           diag_row, next_B, l2_B, n_regs_B, rhoB, LinvB, slab_seg_ptr, seg_rhs, seg_btb, rhsA_out, F,
+                           &part[0][0]);
 }
 
 // rho_i of the A-phase alone (needed before the systems when the feasibility penalty is constant)
@@ -1621,6 +1661,11 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     // ranks 5..32: rows of every system split over the lane groups (all 64 lanes busy); 64 columns fill the wave anyway
     if (!rows_kernel) {
         DISPATCH_RP_T(c, k_A_finish, grid, block, MCL_AF_ARGS);
+    } else if (c->a_rhs_wide) {
+        const dim3 gw((unsigned)c->I);
+        if (c->RP == 8) hipLaunchKernelGGL((k_A_finish_rows_wide<8>), gw, block, 0, c->stream, MCL_AF_ARGS, F);
+        else if (c->RP == 16) hipLaunchKernelGGL((k_A_finish_rows_wide<16>), gw, block, 0, c->stream, MCL_AF_ARGS, F);
+        else hipLaunchKernelGGL((k_A_finish_rows_wide<32>), gw, block, 0, c->stream, MCL_AF_ARGS, F);
     } else if (c->RP == 8) {
         hipLaunchKernelGGL((k_A_finish_rows<8>), grid, block, 0, c->stream, MCL_AF_ARGS, F);
     } else if (c->RP == 16) {

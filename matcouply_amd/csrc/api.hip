@@ -145,7 +145,7 @@ void read_switches(mcl_switches &w) {
     w.no_fused_gram = flag("MCL_NO_FUSED_GRAM"), w.no_fused_c = flag("MCL_NO_FUSED_C");
     w.a_finish_cols = flag("MCL_A_FINISH_COLS"), w.xc_norow = flag("MCL_XC_NOROW");
     w.unimodal_v3 = flag("MCL_UNIMODAL_V3"), w.stats_reduce = flag("MCL_STATS_REDUCE");
-    w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1");
+    w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_a_wide = flag("MCL_NO_A_WIDE"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1");
     w.seg_rows = num("MCL_SEG_ROWS", 0), w.bseg_rows = num("MCL_BSEG_ROWS", 0);
     w.xc_waves = num("MCL_XC_WAVES", 0), w.xt_waves = num("MCL_XT_WAVES", 0), w.sweep_waves = num("MCL_SWEEP_WAVES", 0);
     w.xc_dbg = num("MCL_XC_DBG", 0), w.xt_dbg = num("MCL_XT_DBG", 0), w.xt_depth = num("MCL_XT_DEPTH", 0);
@@ -728,15 +728,17 @@ int mcl_A_begin(mcl_context *c) {
     c->use_seg_gram = false;
     c->seg_from_sweep = false;
     c->a_rhs_from_M = false;
+    c->a_rhs_wide = false;
     if (c->mseg_valid && !c->opt.constant_A && mcl_mode_is_row_separable(c, 0)) {
         // the sweep left M_i = X_i^T B_i per bseg: rhs_i = coldot(M_i, C), no pass over X
         if (int rc = ensure_cfrag_sweep(c)) return rc;
-        // rank 5..32: the finish kernel forms rhs_i from M_bseg itself (one launch less); otherwise a separate pass
-        // ... as long as a slab has few bsegs: ONE wave streams all M_bseg of its slab (16 KB each at K = 256), while the
-        // separate kernel spreads them over a workgroup per bseg (a 1/8 shard of config 3 cuts its slabs into 8 bsegs:
-        // 27 us fused vs 5 + 13 us apart)
-        c->a_rhs_from_M = (c->RP == 8 || c->RP == 16 || c->RP == 32) && !c->sw.a_finish_cols && !c->sw.no_a_fusion &&
-                          c->bsegs.n_tiles <= 2 * c->I;
+        // rank 5..32: the finish kernel forms rhs_i from M_bseg itself (one launch less); otherwise a separate pass.
+        // Up to 2 bsegs per slab ONE wave streams the slab's M_bseg (16 KB each at K = 256) in front of its Gauss-Jordan;
+        // up to 8 (a 1/8 shard of config 3 cuts its slabs into 8 bsegs: one wave 27 us vs 5 + 13 us apart) the four waves
+        // of a workgroup per slab share them (k_A_finish_rows_wide); beyond that the separate kernel, a workgroup per bseg
+        const bool fusable = (c->RP == 8 || c->RP == 16 || c->RP == 32) && !c->sw.a_finish_cols && !c->sw.no_a_fusion;
+        c->a_rhs_wide = fusable && c->bsegs.n_tiles > 2 * c->I && c->bsegs.n_tiles <= 8 * c->I && !c->sw.no_a_wide;
+        c->a_rhs_from_M = fusable && (c->bsegs.n_tiles <= 2 * c->I || c->a_rhs_wide);
         if (!c->a_rhs_from_M)
             if (int rc = mcl_launch_A_rhs_from_M(c)) return rc;
         c->use_seg_gram = true;

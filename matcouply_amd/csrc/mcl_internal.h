@@ -57,7 +57,7 @@ struct mcl_switches {
     bool no_sweep = false, no_pass_chain = false, no_pf2_delta_fusion = false, ns_plain = false, pf2_jacobi = false;
     bool no_stack_fusion = false, no_solve_stats = false, no_next_b = false, no_fused_gram = false, no_fused_c = false;
     bool a_finish_cols = false, xc_norow = false, unimodal_v3 = false, stats_reduce = false;
-    bool no_a_fusion = false, no_diag_defer = false, xc_depth1 = false;
+    bool no_a_fusion = false, no_a_wide = false, no_diag_defer = false, xc_depth1 = false;
     int seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
     int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
 };
@@ -152,6 +152,7 @@ struct mcl_context {
     int diag_pending_incl = 1;
     // launch fusion of the A-phase finish (admm.hip: AFuse)
     bool a_rhs_from_M = false;       // k_A_finish_rows forms rhs_i from the sweep's M_bseg itself
+    bool a_rhs_wide = false;         // ... with one workgroup (four waves) per slab: k_A_finish_rows_wide
 
     double *colsq = nullptr;    // [max(I,1), r]   per-slab column sums of squares (L2Ball)
     double *uni_f64 = nullptr;  // unimodal regression scratch: 8 fp64 arrays of (rows + slabs) * r
