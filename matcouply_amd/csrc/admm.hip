@@ -4,6 +4,8 @@
 // Reference sites: B1/B3-B5 (decomposition.py:240-256), B6-B9 (:259-285), C2-C3 (:319-338),
 // A1/A3-A6 (:138,155-213), E1-E3 (:404-417, 445-452, 916-921), prox: penalties.py:503-586.
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "mcl_internal.h"
 #include "rows_mfma.h"
@@ -72,10 +74,44 @@ static __device__ __forceinline__ float bperm_f32(int src_lane, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
 
+template <class F, int... Ps>
+static __device__ __forceinline__ void static_for_seq(F &&f, std::integer_sequence<int, Ps...>) {
+    (f(std::integral_constant<int, Ps>{}), ...);
+}
+
 template <int RP>
 static __device__ __forceinline__ void gj_inverse_rows(double (&col)[GJRows<RP>::RL], int r, int lane) {
     constexpr int RL = GJRows<RP>::RL;
     const int c = lane % RP, g = lane / RP;
+    if constexpr (RP == 16) {
+        // a lane group is exactly one DPP row of 16 lanes: M[i][p] of the lane's own rows is lane p of its row, which
+        // row_newbcast delivers as an operand modifier of a v_mov (a few cycles) - the ds_bpermute round trips through the
+        // LDS crossbar (8 of the 10 per pivot) were on the dependent chain of every elimination step
+        static_for_seq(
+            [&](auto P) {
+                constexpr int p = decltype(P)::value;
+                if (p < r) {  // wave-uniform
+                    constexpr int pg = p / RL, pj = p % RL;
+                    const double pivot = readlane_f64(col[pj], pg * RP + p);
+                    double cp[RL];
+#pragma unroll
+                    for (int j = 0; j < RL; ++j) cp[j] = dpp_mov_f64<0x150 + p>(col[j]);  // M[g RL + j][p]
+                    const double prow = bperm_f64(pg * RP + c, col[pj]);                  // M[p][c]
+                    double piv = __builtin_amdgcn_rcp(pivot);
+                    piv = fma(fma(-pivot, piv, 1.0), piv, piv);
+                    piv = fma(fma(-pivot, piv, 1.0), piv, piv);
+                    const double myp = (c == p) ? piv : prow * piv;
+#pragma unroll
+                    for (int j = 0; j < RL; ++j) {
+                        const bool is_p = (g == pg) && (j == pj);
+                        const double upd = (c == p) ? -cp[j] * piv : col[j] - cp[j] * myp;
+                        col[j] = is_p ? myp : upd;
+                    }
+                }
+            },
+            std::make_integer_sequence<int, 16>{});
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
         if (p < r) {  // wave-uniform
