@@ -88,6 +88,7 @@ int64_t plan(mcl_context *c, char *base) {
     c->seg_rhs = b.take<double>(std::max<int64_t>(std::max(c->segs.n_tiles, c->bsegs.n_tiles), I) * r);
     c->seg_btb = b.take<double>(std::max<int64_t>(c->segs.n_tiles, I) * r * r);
     c->slab_seg_ptr = b.take<int>(I + 1);
+    c->wave_seg_ptr = b.take<int>((int64_t)c->h_wave_seg_ptr.size());
     c->rhsA = b.take<float>(I * r);
     c->BtB = b.take<float>(I * r * r);
     c->rhoA = b.take<float>(I);
@@ -344,19 +345,40 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     c->h_seg_slab.clear(), c->h_seg_row0.clear(), c->h_seg_nrows.clear();
     c->h_slab_seg_ptr.assign((size_t)I + 1, 0);
     c->h_slab_tile_ptr.assign((size_t)I + 1, 0);
-    // segment = work unit of the two X passes: <= seg_rows rows of one slab.  256 rows (256 KB at K = 256) amortise the
-    // per-segment prologue on big problems; small problems (e.g. the per-rank shard of an 8-GPU run) get shorter
-    // segments so that there are still >= ~512 of them (measured optimum on a 64 K-row shard: 128 rows).
+    // segment = work unit of the two X passes: <= MCL_SEG_ROWS rows of one slab (256 rows - 256 KB at K = 256 - amortise the
+    // per-segment prologue, and the fp32 accumulation chains of the passes end with their segment).  Every wave of the
+    // passes owns a contiguous range of segments (wave_seg_ptr) holding the same number of 16-row blocks: the passes
+    // run one wave per SIMD side by side, so the longest wave IS the kernel's duration - with ragged slabs a fixed number
+    // of segments per wave left the longest wave 32 % above the mean (config 4: 48 blocks vs 36.4).  Segments are
+    // therefore also cut where a wave's quota ends.  Up to 1024 waves (256 CUs x 4: measured best); small problems (e.g.
+    // the per-rank shard of an 8-GPU run) keep >= 512 waves of >= 1 block, as long as there are 8 blocks for each of
+    // them (measured optimum on a 64 K-row shard: 512 waves of 128 rows).
     int64_t seg_rows = MCL_SEG_ROWS;
-    while (seg_rows > 16 && N / seg_rows < 512) seg_rows /= 2;
-    if (c->sw.seg_rows > 0) seg_rows = std::max(16, c->sw.seg_rows);
+    if (c->sw.seg_rows > 0) seg_rows = std::max(16, (c->sw.seg_rows / 16) * 16);
+    int64_t total_units = 0;  // 16-row blocks, a slab's last partial block counts as one
+    for (int64_t i = 0; i < I; ++i) total_units += (row_ptr[i + 1] - row_ptr[i] + 15) / 16;
+    int64_t target_waves = 1024;
+    if (c->sw.xc_waves > 0) target_waves = c->sw.xc_waves;
+    else if (c->sw.xt_waves > 0) target_waves = c->sw.xt_waves;
+    int64_t n_waves = std::min<int64_t>(target_waves, std::max<int64_t>(std::min<int64_t>(512, total_units), total_units / 8));
+    n_waves = std::max<int64_t>(n_waves, 1);
+    const int64_t quota = std::max<int64_t>(1, (total_units + n_waves - 1) / n_waves);
+    c->h_wave_seg_ptr.assign(1, 0);
+    int64_t used = 0;
     for (int64_t i = 0; i < I; ++i) {
         c->h_slab_seg_ptr[(size_t)i] = (int)c->h_seg_slab.size();
         c->h_slab_tile_ptr[(size_t)i] = (int)c->h_tile_slab.size();
-        for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; j += seg_rows) {
+        for (int64_t j = row_ptr[i]; j < row_ptr[i + 1];) {
+            const int64_t take = std::min<int64_t>(std::min<int64_t>(seg_rows, row_ptr[i + 1] - j), (quota - used) * 16);
             c->h_seg_slab.push_back((int)i);
             c->h_seg_row0.push_back((int)j);
-            c->h_seg_nrows.push_back((int)std::min<int64_t>(seg_rows, row_ptr[i + 1] - j));
+            c->h_seg_nrows.push_back((int)take);
+            j += take;
+            used += (take + 15) / 16;
+            if (used >= quota) {  // the wave is full
+                c->h_wave_seg_ptr.push_back((int)c->h_seg_slab.size());
+                used = 0;
+            }
         }
         for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; ++j) c->h_slab_of_row[(size_t)j] = (int)i;
         for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; j += 64) {
@@ -365,6 +387,8 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
             c->h_tile_nrows.push_back((int)std::min<int64_t>(64, row_ptr[i + 1] - j));
         }
     }
+    if (used > 0) c->h_wave_seg_ptr.push_back((int)c->h_seg_slab.size());
+    c->n_seg_waves = (int)c->h_wave_seg_ptr.size() - 1;
     c->h_slab_seg_ptr[(size_t)I] = (int)c->h_seg_slab.size();
     c->h_slab_tile_ptr[(size_t)I] = (int)c->h_tile_slab.size();
     // bsegs of the one-pass sweep: <= 512 rows of one slab per WAVE, shorter on small problems so that there are still
@@ -497,6 +521,7 @@ int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
     MCL_CHECK_HIP(c, up(c->segs.row0, c->h_seg_row0));
     MCL_CHECK_HIP(c, up(c->segs.nrows, c->h_seg_nrows));
     MCL_CHECK_HIP(c, up(c->slab_seg_ptr, c->h_slab_seg_ptr));
+    MCL_CHECK_HIP(c, up(c->wave_seg_ptr, c->h_wave_seg_ptr));
     MCL_CHECK_HIP(c, up(c->slab_tile_ptr, c->h_slab_tile_ptr));
     if (c->sweep_planned) {
         MCL_CHECK_HIP(c, up(c->bsegs.slab, c->h_bseg_slab));

@@ -42,14 +42,16 @@ template <int KB, int NB, int VEC, int DEPTH, int MODE>
 __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X, const float *__restrict__ B,
                                                      const float *__restrict__ A, const int *__restrict__ seg_slab,
                                                      const int *__restrict__ seg_row0, const int *__restrict__ seg_rows,
-                                                     int n_segs, int segs_per_wave, int K, int r,
+                                                     const int *__restrict__ wave_seg_ptr, int n_waves, int K, int r,
                                                      double *__restrict__ part, int part_stride, int dbg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rsub = lane >> 4, c16 = lane & 15;
     const int kbase = blockIdx.y * (64 * KB);
     const int w = blockIdx.x * 4 + wave;
-    const int s0 = w * segs_per_wave;
-    const int s1 = min(s0 + segs_per_wave, n_segs);
+    // the wave's segments: a contiguous range with (nearly) the same number of 16-row blocks in every wave
+    // (mcl_set_problem balances ragged slabs); waves past the end have an empty range
+    const int s0 = wave_seg_ptr[min(w, n_waves)];
+    const int s1 = wave_seg_ptr[min(w + 1, n_waves)];
     constexpr bool DO_R = MODE != 2;
     constexpr int NG_ = (MODE == 1) ? 1 : NB;  // extent of the G accumulator arrays
     const bool doG = (MODE == 2) || (MODE == 0 && blockIdx.y == 0);
@@ -434,8 +436,8 @@ template <int NB, bool CREG, int GRAM>
 __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict__ X, const float *__restrict__ Cfrag,
                                                          float *__restrict__ XC, const float *__restrict__ B,
                                                          const int *__restrict__ seg_row0,
-                                                         const int *__restrict__ seg_rows, int n_segs,
-                                                         int segs_per_wave, int K, int r,
+                                                         const int *__restrict__ seg_rows,
+                                                         const int *__restrict__ wave_seg_ptr, int n_waves, int K, int r,
                                                          double *__restrict__ seg_rhs, double *__restrict__ seg_btb) {
     extern __shared__ float lds_dyn[];  // 4 waves x 16 rows x 256 floats
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -443,8 +445,8 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
     float *L = lds_dyn + wave * (16 * 256);
     const int SC = K >> 8;  // super-chunks per row block
     const int w = blockIdx.x * 4 + wave;
-    const int s0 = w * segs_per_wave;
-    const int s1 = min(s0 + segs_per_wave, n_segs);
+    if (w >= n_waves) return;
+    const int s0 = wave_seg_ptr[w], s1 = wave_seg_ptr[w + 1];
     if (s0 >= s1) return;
 
     constexpr int CR = CREG ? 4 : 1;
@@ -658,8 +660,9 @@ template <int GRAM, int D>
 __global__ __launch_bounds__(256) void k_contract_xc_256(const float *__restrict__ X, const float *__restrict__ Cfrag,
                                                          float *__restrict__ XC, const float *__restrict__ B,
                                                          const int *__restrict__ seg_row0,
-                                                         const int *__restrict__ seg_rows, int n_segs,
-                                                         int segs_per_wave, int r, double *__restrict__ seg_rhs,
+                                                         const int *__restrict__ seg_rows,
+                                                         const int *__restrict__ wave_seg_ptr, int n_waves, int r,
+                                                         double *__restrict__ seg_rhs,
                                                          double *__restrict__ seg_btb) {
     extern __shared__ float lds_dyn[];  // 4 waves x 16 rows x 256 floats
     constexpr int K = 256;
@@ -667,8 +670,8 @@ __global__ __launch_bounds__(256) void k_contract_xc_256(const float *__restrict
     const int q = lane >> 4, i16 = lane & 15;
     float *L = lds_dyn + wave * (16 * 256);
     const int w = blockIdx.x * 4 + wave;
-    const int s0 = w * segs_per_wave;
-    const int s1 = min(s0 + segs_per_wave, n_segs);
+    if (w >= n_waves) return;
+    const int s0 = wave_seg_ptr[w], s1 = wave_seg_ptr[w + 1];
     if (s0 >= s1) return;
 
     f32x4 creg[4][4];
@@ -898,29 +901,13 @@ static inline int xt_KB(const mcl_context *c) {
     return need < kb ? (need <= 1 ? 1 : (need <= 2 ? 2 : 4)) : kb;
 }
 
-static inline void xt_geometry(const mcl_context *c, int *segs_per_wave, int *n_blocks) {
-    const int n_segs = c->segs.n_tiles;
-    int target_waves = 1024;  // 256 CUs x 4 waves: measured best (one 256-thread block per CU)
-    if (c->sw.xt_waves > 0) target_waves = c->sw.xt_waves;
-    int spw = (n_segs + target_waves - 1) / target_waves;
-    if (spw < 1) spw = 1;
-    const int waves = (n_segs + spw - 1) / spw;
-    int nb = (waves + 3) / 4;
-    if (nb < 1) nb = 1;
-    *segs_per_wave = spw;
-    *n_blocks = nb;
-}
-
-int mcl_contract_n_partials(const mcl_context *c) {
-    int spw, nb;
-    xt_geometry(c, &spw, &nb);
-    return nb;
-}
+// both X passes run one wave per entry of the balanced wave -> segment table of mcl_set_problem (<= 1024 waves = 256 CUs x 4:
+// measured best, one 256-thread block per CU)
+int mcl_contract_n_partials(const mcl_context *c) { return std::max(1, (c->n_seg_waves + 3) / 4); }
 
 template <int KB, int NB>
 static int launch_xt(mcl_context *c) {
-    int spw, nb;
-    xt_geometry(c, &spw, &nb);
+    const int nb = mcl_contract_n_partials(c);
     const int E = (int)(c->K * c->r + c->r * c->r);
     if (c->segs.n_tiles == 0) {  // no rows: the partial slab is all zeros
         MCL_CHECK_HIP(c, hipMemsetAsync(c->partials, 0, sizeof(double) * (size_t)E, c->stream));
@@ -936,7 +923,7 @@ static int launch_xt(mcl_context *c) {
     constexpr int RMODE = (NB == 4) ? 1 : 0;
 #define MCL_XT(VEC_, DEPTH_, MODE_, GRID_)                                                                            \
     hipLaunchKernelGGL((k_contract_xt<KB, NB, VEC_, DEPTH_, MODE_>), GRID_, dim3(256), 0, c->stream, c->X, c->B, c->A, \
-                       c->segs.slab, c->segs.row0, c->segs.nrows, c->segs.n_tiles, spw, (int)c->K, c->r, c->partials, \
+                       c->segs.slab, c->segs.row0, c->segs.nrows, c->wave_seg_ptr, c->n_seg_waves, (int)c->K, c->r, c->partials, \
                        E, dbg)
     if (vec) {
         if (depth == 2) MCL_XT(4, 2, RMODE, grid);
@@ -1009,22 +996,20 @@ static int launch_xc(mcl_context *c) {
         const size_t sm = sizeof(float) * 4 * 16 * 256;
         const bool creg = (c->K == 256) && (NB == 1);
         const int n_segs = c->segs.n_tiles;
-        int tw = (int)target_waves;
-        int spw = (n_segs + tw - 1) / tw;
-        if (spw < 1) spw = 1;
-        const unsigned g = (unsigned)(((n_segs + spw - 1) / spw + 3) / 4);
+        const unsigned g = (unsigned)((c->n_seg_waves + 3) / 4);
         // 0: X C only; 1: + per-segment rhs / Gram in fp32 chains (penalised A); 2: in fp64 (penalty-free A)
         int gram = !c->xc_with_gram ? 0 : (c->regs[0].n == 0 ? 2 : 1);
         if (NB == 4 && gram == 2) gram = 0;  // rank > 32 has no registers for the fp64 Gram tiles: k_slab_gram follows
 #define MCL_XCR(CREG_, GRAM_)                                                                                        \
     hipLaunchKernelGGL((k_contract_xc_row<NB, CREG_, GRAM_>), dim3(g), dim3(256), sm, c->stream, c->X, c->Cfrag,     \
-                       c->XC, c->B, c->segs.row0, c->segs.nrows, n_segs, spw, (int)c->K, c->r, c->seg_rhs, c->seg_btb)
+                       c->XC, c->B, c->segs.row0, c->segs.nrows, c->wave_seg_ptr, c->n_seg_waves, (int)c->K, c->r, c->seg_rhs, \
+                       c->seg_btb)
         if (n_segs > 0) {
             if constexpr (NB == 1) {  // resident C fragments: K = 256, rank <= 16 only
                 if (creg && !c->sw.xc_depth1) {  // two blocks of X in flight per wave
 #define MCL_XC256(GRAM_)                                                                                              \
     hipLaunchKernelGGL((k_contract_xc_256<GRAM_, 2>), dim3(g), dim3(256), sm, c->stream, c->X, c->Cfrag, c->XC, c->B,    \
-                       c->segs.row0, c->segs.nrows, n_segs, spw, c->r, c->seg_rhs, c->seg_btb)
+                       c->segs.row0, c->segs.nrows, c->wave_seg_ptr, c->n_seg_waves, c->r, c->seg_rhs, c->seg_btb)
                     if (gram == 2) MCL_XC256(2);
                     else if (gram == 1) MCL_XC256(1);
                     else MCL_XC256(0);

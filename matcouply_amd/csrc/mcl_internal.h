@@ -124,6 +124,9 @@ struct mcl_context {
     double *seg_rhs = nullptr;  // [max(n_segs, n_bsegs, I), r]  fp64 per-segment (per-bseg / per-slab) partial rhs_i
     double *seg_btb = nullptr;  // [max(n_segs, I), r, r]        fp64 per-segment (per-slab) partial B_i^T B_i
     int *slab_seg_ptr = nullptr;  // int32[I+1] first segment of every slab
+    int *wave_seg_ptr = nullptr;  // int32[n_seg_waves+1] first segment of every wave of the X passes (balanced by blocks)
+    std::vector<int> h_wave_seg_ptr;
+    int n_seg_waves = 0;
     std::vector<int> h_slab_seg_ptr;
     bool xc_with_gram = false;  // request: the next X C launch also produces seg_rhs / seg_btb
     bool xc_did_gram = false;   // the last X C launch produced them
