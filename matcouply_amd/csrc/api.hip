@@ -56,6 +56,7 @@ int64_t plan(mcl_context *c, char *base) {
     if (c->sweep_planned) {
         tm(c->bsegs, c->h_bseg_slab.size());
         c->slab_bseg_ptr = b.take<int>(I + 1);
+        c->wave_bseg_ptr = b.take<int>((int64_t)c->h_wave_bseg_ptr.size());
         c->Mpart = b.take<float>((int64_t)c->bsegs.n_tiles * mcl_sweep_KS(c) * 256 * 16 * c->NB);
         c->part_btb = b.take<double>((int64_t)c->bsegs.n_tiles * r * r);
         c->GRpart = b.take<float>((int64_t)c->bsegs.n_tiles * (mcl_sweep_KS(c) * 256 * 16 * c->NB + 256 * c->NB * c->NB));
@@ -63,7 +64,7 @@ int64_t plan(mcl_context *c, char *base) {
         c->sweep_cycles = b.take<long long>((int64_t)2048 * 6);
     } else {
         c->bsegs = TileMap{};
-        c->slab_bseg_ptr = nullptr, c->Mpart = nullptr, c->part_btb = nullptr, c->GRpart = nullptr, c->CfragS = nullptr;
+        c->slab_bseg_ptr = nullptr, c->wave_bseg_ptr = nullptr, c->Mpart = nullptr, c->part_btb = nullptr, c->GRpart = nullptr, c->CfragS = nullptr;
     }
     c->ext_A = b.take<int>(2);
     c->ext_C = b.take<int>(2);
@@ -396,16 +397,36 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     int64_t bseg_rows = 512;
     while (bseg_rows > 64 && N / bseg_rows < 1024) bseg_rows /= 2;
     if (c->sw.bseg_rows > 0) bseg_rows = std::max(64, (c->sw.bseg_rows / 64) * 64);
+    // The waves of the sweep (<= 1024, one per SIMD) own contiguous bseg ranges with (nearly) the same number of 16-row
+    // blocks, like the segments above; a bseg is cut at a wave's quota only when the overshoot would exceed 2 blocks
+    // (every cut costs a 2 x 16 KB partial at K = 256).  Problems with at most one bseg per wave are left alone.
+    int64_t n_uncut = 0;
+    for (int64_t i = 0; i < I; ++i) n_uncut += (row_ptr[i + 1] - row_ptr[i] + bseg_rows - 1) / bseg_rows;
+    const int64_t sweep_waves = c->sw.sweep_waves > 0 ? c->sw.sweep_waves : 1024;
+    const bool one_each = n_uncut <= sweep_waves;
+    const int64_t bquota = one_each ? 0 : (total_units + sweep_waves - 1) / sweep_waves, btol = 2;
     c->h_bseg_slab.clear(), c->h_bseg_row0.clear(), c->h_bseg_nrows.clear();
     c->h_slab_bseg_ptr.assign((size_t)I + 1, 0);
+    c->h_wave_bseg_ptr.assign(1, 0);
+    int64_t bused = 0;
     for (int64_t i = 0; i < I; ++i) {
         c->h_slab_bseg_ptr[(size_t)i] = (int)c->h_bseg_slab.size();
-        for (int64_t j = row_ptr[i]; j < row_ptr[i + 1]; j += bseg_rows) {
+        for (int64_t j = row_ptr[i]; j < row_ptr[i + 1];) {
+            int64_t take = std::min<int64_t>(bseg_rows, row_ptr[i + 1] - j);
+            if (!one_each && bused + (take + 15) / 16 > bquota + btol) take = (bquota - bused) * 16;  // >= 16: bused < bquota
             c->h_bseg_slab.push_back((int)i);
             c->h_bseg_row0.push_back((int)j);
-            c->h_bseg_nrows.push_back((int)std::min<int64_t>(bseg_rows, row_ptr[i + 1] - j));
+            c->h_bseg_nrows.push_back((int)take);
+            j += take;
+            bused += (take + 15) / 16;
+            if (one_each || bused >= bquota) {
+                c->h_wave_bseg_ptr.push_back((int)c->h_bseg_slab.size());
+                bused = 0;
+            }
         }
     }
+    if (bused > 0) c->h_wave_bseg_ptr.push_back((int)c->h_bseg_slab.size());
+    c->n_bseg_waves = (int)c->h_wave_bseg_ptr.size() - 1;
     c->h_slab_bseg_ptr[(size_t)I] = (int)c->h_bseg_slab.size();
     auto single = [](int64_t rows, std::vector<int> &s, std::vector<int> &r0, std::vector<int> &nr) {
         s.clear(), r0.clear(), nr.clear();
@@ -528,6 +549,7 @@ int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
         MCL_CHECK_HIP(c, up(c->bsegs.row0, c->h_bseg_row0));
         MCL_CHECK_HIP(c, up(c->bsegs.nrows, c->h_bseg_nrows));
         MCL_CHECK_HIP(c, up(c->slab_bseg_ptr, c->h_slab_bseg_ptr));
+        MCL_CHECK_HIP(c, up(c->wave_bseg_ptr, c->h_wave_bseg_ptr));
     }
     c->h_ext = {0, (int)c->I, 0, (int)c->K};
     MCL_CHECK_HIP(c, hipMemcpyAsync(c->ext_A, c->h_ext.data(), 2 * sizeof(int), hipMemcpyHostToDevice, s));

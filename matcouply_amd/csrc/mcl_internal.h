@@ -124,6 +124,9 @@ struct mcl_context {
     double *seg_rhs = nullptr;  // [max(n_segs, n_bsegs, I), r]  fp64 per-segment (per-bseg / per-slab) partial rhs_i
     double *seg_btb = nullptr;  // [max(n_segs, I), r, r]        fp64 per-segment (per-slab) partial B_i^T B_i
     int *slab_seg_ptr = nullptr;  // int32[I+1] first segment of every slab
+    int *wave_bseg_ptr = nullptr;  // int32[n_bseg_waves+1] first bseg of every wave of the sweep
+    std::vector<int> h_wave_bseg_ptr;
+    int n_bseg_waves = 0;
     int *wave_seg_ptr = nullptr;  // int32[n_seg_waves+1] first segment of every wave of the X passes (balanced by blocks)
     std::vector<int> h_wave_seg_ptr;
     int n_seg_waves = 0;
@@ -255,7 +258,6 @@ static inline int mcl_cfrag_chunks(const mcl_context *c) {
 }
 bool mcl_sweep_shape_ok(const mcl_context *c);   // shape has a k_sweep instantiation (decides the workspace plan)
 bool mcl_sweep_eligible(const mcl_context *c);   // ... and the current penalties / options / pointers allow it
-void mcl_sweep_geometry(const mcl_context *c, int *bsegs_per_wave, int *n_waves);
 int mcl_launch_sweep(mcl_context *c);            // B-phase + per-bseg X^T B, B^T B in one pass over X
 int mcl_launch_reduce_weighted(mcl_context *c);  // GR = sum of the sweep blocks' a-weighted partials
 int mcl_launch_A_rhs_from_M(mcl_context *c);     // seg_rhs[bseg] = coldot(M_bseg, C)

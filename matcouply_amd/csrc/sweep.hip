@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                                                const float *__restrict__ A, const float *__restrict__ rhoB,
                                                const float *__restrict__ LinvB, float *__restrict__ Bout, RegSet regs,
                                                const int *__restrict__ bs_slab, const int *__restrict__ bs_row0,
-                                               const int *__restrict__ bs_nrows, int n_bsegs, int bsegs_per_wave,
+                                               const int *__restrict__ bs_nrows, const int *__restrict__ wave_bseg_ptr, int n_waves,
                                                int K, int r, int inner, float *__restrict__ Mpart,
                                                double *__restrict__ part_btb, float *__restrict__ GRpart,
                                                double *__restrict__ diag_block, int dbg_rt,
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
     };
 
     const int wg = blockIdx.x * NW + wave;  // global wave index
-    const int bs0 = min(wg * bsegs_per_wave, n_bsegs);
-    const int bs1 = min(bs0 + bsegs_per_wave, n_bsegs);
+    const int bs0 = wave_bseg_ptr[min(wg, n_waves)];  // the wave's bsegs (balanced by blocks: mcl_set_problem)
+    const int bs1 = wave_bseg_ptr[min(wg + 1, n_waves)];
 
     double nf = 0.0, na = 0.0, gap[NR];
 #pragma unroll
@@ -740,22 +740,10 @@ bool mcl_sweep_eligible(const mcl_context *c) {
 
 static inline int sweep_MS(const mcl_context *c) { return mcl_sweep_KS(c) * 256 * 16 * c->NB; }
 
-// waves of the sweep: `bsegs_per_wave` consecutive bsegs each; 1024 waves = one per SIMD (the register file and the LDS
-// tiles allow one or two).  n_waves is rounded up to whole blocks by the launcher (idle waves have an empty range).
-void mcl_sweep_geometry(const mcl_context *c, int *bsegs_per_wave, int *n_waves) {
-    const int n = std::max(c->bsegs.n_tiles, 1);
-    int target_waves = 1024;
-    if (c->sw.sweep_waves > 0) target_waves = c->sw.sweep_waves;
-    const int spw = (n + target_waves - 1) / target_waves;
-    *bsegs_per_wave = spw;
-    *n_waves = (n + spw - 1) / spw;
-}
-
 template <int KS, int NB, int NREG, int NW, int DEPTH, bool VEC>
 static int launch_sweep_v(mcl_context *c) {
     const int n = c->bsegs.n_tiles;
-    int bpb, n_waves;
-    mcl_sweep_geometry(c, &bpb, &n_waves);
+    const int n_waves = c->n_bseg_waves;  // <= 1024 = one per SIMD (the register file and the LDS tiles allow one or two)
     const int grid = (n_waves + NW - 1) / NW;
     const size_t sm = sizeof(float) * (size_t)(NW * 16 * 256 * KS + 256 * KS * 16 * NB);  // up to the full 160 KB
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<KS, NB, NREG, DEPTH, NW, VEC>),
@@ -770,7 +758,7 @@ static int launch_sweep_v(mcl_context *c) {
 #define MCL_SWEEP_LAUNCH(DBG_)                                                                                         \
     hipLaunchKernelGGL((k_sweep<KS, NB, NREG, DEPTH, NW, VEC, DBG_>), dim3(grid), dim3(64 * NW), sm, c->stream, c->X,    \
                        c->CfragS, c->A, c->rhoB, c->LinvB, c->B, c->regs[1], c->bsegs.slab, c->bsegs.row0, c->bsegs.nrows, \
-                       n, bpb, (int)c->K, c->r, c->opt.inner_n_iter_max, c->Mpart, c->part_btb, c->GRpart, c->diagB_tile, \
+                       c->wave_bseg_ptr, n_waves, (int)c->K, c->r, c->opt.inner_n_iter_max, c->Mpart, c->part_btb, c->GRpart, c->diagB_tile, \
                        c->sw.sweep_dbg, c->sweep_cycles)
     bool launched = false;
     if constexpr (KS == 1 && NB == 1 && VEC) {  // the instrumented twin exists for the config-2/3 variants only
