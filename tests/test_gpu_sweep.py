@@ -128,6 +128,24 @@ def test_sweep_equals_two_pass(name, monkeypatch):
     assert max(abs(a - b) / b for a, b in zip(ds.rec_errors, dt.rec_errors)) < 1e-5
 
 
+@pytest.mark.parametrize("name,waves", [("k256_ragged_tails", 3), ("k256_r16_nn", 5), ("k512_r12_l1_box", 2)])
+def test_balanced_wave_partition_with_cuts(name, waves, monkeypatch):
+    """With fewer waves than work units the planner cuts bsegs / segments where a wave's quota of 16-row blocks ends
+    (ragged slabs: csrc/api.hip, mcl_set_problem).  MCL_SWEEP_WAVES / MCL_XC_WAVES force that regime on a small problem:
+    the sweep and the two-pass kernels must still agree with the oracle to 1e-5."""
+    from tests.test_gpu_end_to_end import _compare, _run_both
+
+    monkeypatch.setenv("MCL_SWEEP_WAVES", str(waves))
+    monkeypatch.setenv("MCL_XC_WAVES", str(waves))
+    st = _state(name)
+    cmf, admm, diag, res = _run_both(st, 4)
+    _compare(cmf, admm, diag, st, res, 1e-5, tol_rec=1e-5)
+    monkeypatch.setenv("MCL_NO_SWEEP", "1")  # the X C / X^T passes over the cut segments
+    st = _state(name)
+    cmf, admm, diag, res = _run_both(st, 4)
+    _compare(cmf, admm, diag, st, res, 1e-5, tol_rec=1e-5)
+
+
 def test_by_products_are_not_reused_out_of_order():
     """The sweep weights its [G | R] partials with the a_i of the moment and its M_i belongs to the B it wrote: an A update
     before the C-phase, a second C-phase, or new factors must all fall back to passes over X with current operands."""
