@@ -59,7 +59,7 @@ int64_t plan(mcl_context *c, char *base) {
         c->wave_bseg_ptr = b.take<int>((int64_t)c->h_wave_bseg_ptr.size());
         c->Mpart = b.take<float>((int64_t)c->bsegs.n_tiles * mcl_sweep_KS(c) * 256 * 16 * c->NB);
         c->part_btb = b.take<double>((int64_t)c->bsegs.n_tiles * r * r);
-        c->GRpart = b.take<float>((int64_t)c->bsegs.n_tiles * (mcl_sweep_KS(c) * 256 * 16 * c->NB + 256 * c->NB * c->NB));
+        c->GRpart = b.take<float>((int64_t)c->bsegs.n_tiles * (256 * c->NB * c->NB + 16 * c->NB));
         c->CfragS = nullptr;  // aliases Cfrag (below)
         c->sweep_cycles = b.take<long long>((int64_t)2048 * 6);
     } else {

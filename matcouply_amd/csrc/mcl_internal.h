@@ -99,7 +99,7 @@ struct mcl_context {
     float *Mpart = nullptr;        // [n_bsegs, K * 16 NB]  per-bseg X^T B in C-fragment order
     double *part_btb = nullptr;    // [n_bsegs, r, r]       per-bseg B^T B (fp64 image of the fp32 accumulators)
     float *CfragS = nullptr;       // the sweep's view of the fragment image of C (aliases Cfrag: one shared image)
-    float *GRpart = nullptr;       // [n_bsegs, K * 16 NB + (16 NB)^2]  per-bseg a-weighted partial of [G | R]
+    float *GRpart = nullptr;       // [n_bsegs, (16 NB)^2 + 16 NB]  per-bseg a-weighted Gram and the a_i it was weighted with
     int n_grpart = 0;
     long long *sweep_cycles = nullptr;  // [n_blocks, 4 waves, 6] per-section cycle counts (MCL_SWEEP_DBG & 32)
     bool grpart_valid = false;     // GRpart was weighted with the current A (and mseg_valid)

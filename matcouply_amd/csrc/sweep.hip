@@ -505,7 +505,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
         // ---- flush this bseg straight from the accumulators (fragment order: 1 KB per store instruction)
         {
             float *mp = Mpart + (long)bs * MS;
-            float *gp = GRpart + (long)bs * (MS + W * W);
+            float *gp = GRpart + (long)bs * (W * W + W);  // [weighted Gram | a_i]: k_reduce_frag weights M_bseg itself
             const float *arow = A + (long)slab * r;
             float a_c[NB];
 #pragma unroll
@@ -519,8 +519,11 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                         const f32x4 val = {accM[kb][0][nb][w], accM[kb][1][nb][w], accM[kb][2][nb][w], accM[kb][3][nb][w]};
                         const int e = ((((kb * 4 + w) * NB + nb) * 64 + lane) << 2);
                         *reinterpret_cast<f32x4 *>(mp + e) = val;
-                        *reinterpret_cast<f32x4 *>(gp + e) = val * a_c[nb];  // column 16 nb + i16 of M diag(a)
                     }
+            if (q == 0) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) gp[W * W + 16 * nb + i16] = a_c[nb];  // the a_i of the moment (0 in padding)
+            }
 #pragma unroll
             for (int a = 0; a < NB; ++a)
 #pragma unroll
@@ -530,9 +533,9 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                         const int ra = 16 * a + 4 * q + w, cb = 16 * b + i16;
                         if (ra < r && cb < r) {
                             part_btb[((long)bs * r + ra) * r + cb] = (double)accG[a][b][w];
-                            gp[MS + ra * W + cb] = arow[ra] * arow[cb] * accG[a][b][w];
+                            gp[ra * W + cb] = arow[ra] * arow[cb] * accG[a][b][w];
                         } else {
-                            gp[MS + ra * W + cb] = 0.f;
+                            gp[ra * W + cb] = 0.f;
                         }
                     }
         }
@@ -626,8 +629,9 @@ static __device__ void diag_piggy_block(const DiagPiggy &P, int which) {
 }
 
 template <int EL>  // elements per block (64: 256-byte wave loads, PS / 64 blocks; 32: twice the blocks for small PS)
-__global__ __launch_bounds__(1024) void k_reduce_frag(const float *__restrict__ GRpart, int n_part, int K, int r, int NB,
-                                                      int MS, double *__restrict__ GR, DiagPiggy piggy) {
+__global__ __launch_bounds__(1024) void k_reduce_frag(const float *__restrict__ Mpart, const float *__restrict__ GRpart,
+                                                      int n_part, int K, int r, int NB, int MS, double *__restrict__ GR,
+                                                      DiagPiggy piggy) {
     if (piggy.out != nullptr && blockIdx.x >= gridDim.x - MCL_PIGGY_BLOCKS) {  // the spare workgroups
         diag_piggy_block(piggy, (int)(gridDim.x - 1 - blockIdx.x));
         return;
@@ -637,8 +641,10 @@ __global__ __launch_bounds__(1024) void k_reduce_frag(const float *__restrict__ 
     const int el = threadIdx.x % EL, pc = threadIdx.x / EL;
     const int e = blockIdx.x * EL + el;
     const int W = 16 * NB, PS = MS + W * W;
-    int out = -1;
+    const int GS = W * W + W;  // per-bseg row of GRpart: the a-weighted Gram, then the a_i the sweep ran with
+    int out = -1, wcol = 0;    // R = sum_bsegs M_bseg diag(a_i): the fp32 product M a is the one the sweep used to store
     if (e < MS) {
+        wcol = W * W + 16 * ((e >> 8) % NB) + ((e >> 2) & 15);
         const int m = e & 3, ln = (e >> 2) & 63;
         int t = e >> 8;
         const int nb = t % NB;
@@ -654,13 +660,28 @@ __global__ __launch_bounds__(1024) void k_reduce_frag(const float *__restrict__ 
     if (out >= 0) {
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int p = pc;
-        for (; p + 3 * NG < n_part; p += 4 * NG) {
-            s0 += (double)GRpart[(long)p * PS + e];
-            s1 += (double)GRpart[(long)(p + NG) * PS + e];
-            s2 += (double)GRpart[(long)(p + 2 * NG) * PS + e];
-            s3 += (double)GRpart[(long)(p + 3 * NG) * PS + e];
+        if (e < MS) {
+            for (; p + 3 * NG < n_part; p += 4 * NG) {
+                const float m0 = Mpart[(long)p * MS + e], m1 = Mpart[(long)(p + NG) * MS + e];
+                const float m2 = Mpart[(long)(p + 2 * NG) * MS + e], m3 = Mpart[(long)(p + 3 * NG) * MS + e];
+                const float a0 = GRpart[(long)p * GS + wcol], a1 = GRpart[(long)(p + NG) * GS + wcol];
+                const float a2 = GRpart[(long)(p + 2 * NG) * GS + wcol], a3 = GRpart[(long)(p + 3 * NG) * GS + wcol];
+                s0 += (double)(m0 * a0);
+                s1 += (double)(m1 * a1);
+                s2 += (double)(m2 * a2);
+                s3 += (double)(m3 * a3);
+            }
+            for (; p < n_part; p += NG) s0 += (double)(Mpart[(long)p * MS + e] * GRpart[(long)p * GS + wcol]);
+        } else {
+            const int g = e - MS;
+            for (; p + 3 * NG < n_part; p += 4 * NG) {
+                s0 += (double)GRpart[(long)p * GS + g];
+                s1 += (double)GRpart[(long)(p + NG) * GS + g];
+                s2 += (double)GRpart[(long)(p + 2 * NG) * GS + g];
+                s3 += (double)GRpart[(long)(p + 3 * NG) * GS + g];
+            }
+            for (; p < n_part; p += NG) s0 += (double)GRpart[(long)p * GS + g];
         }
-        for (; p < n_part; p += NG) s0 += (double)GRpart[(long)p * PS + e];
         s = (s0 + s1) + (s2 + s3);
     }
     sm[pc][el] = s;
@@ -827,14 +848,14 @@ int mcl_launch_reduce_weighted(mcl_context *c) {
     }
     const int blocks = (MS + W * W + el - 1) / el + (piggy.out ? MCL_PIGGY_BLOCKS : 0);
     if (el == 64)
-        hipLaunchKernelGGL(k_reduce_frag<64>, dim3(blocks), dim3(1024), 0, c->stream, c->GRpart, c->n_grpart, (int)c->K,
-                           c->r, c->NB, MS, c->GR, piggy);
+        hipLaunchKernelGGL(k_reduce_frag<64>, dim3(blocks), dim3(1024), 0, c->stream, c->Mpart, c->GRpart, c->n_grpart,
+                           (int)c->K, c->r, c->NB, MS, c->GR, piggy);
     else if (el == 32)
-        hipLaunchKernelGGL(k_reduce_frag<32>, dim3(blocks), dim3(1024), 0, c->stream, c->GRpart, c->n_grpart, (int)c->K,
-                           c->r, c->NB, MS, c->GR, piggy);
+        hipLaunchKernelGGL(k_reduce_frag<32>, dim3(blocks), dim3(1024), 0, c->stream, c->Mpart, c->GRpart, c->n_grpart,
+                           (int)c->K, c->r, c->NB, MS, c->GR, piggy);
     else
-        hipLaunchKernelGGL(k_reduce_frag<16>, dim3(blocks), dim3(1024), 0, c->stream, c->GRpart, c->n_grpart, (int)c->K,
-                           c->r, c->NB, MS, c->GR, piggy);
+        hipLaunchKernelGGL(k_reduce_frag<16>, dim3(blocks), dim3(1024), 0, c->stream, c->Mpart, c->GRpart, c->n_grpart,
+                           (int)c->K, c->r, c->NB, MS, c->GR, piggy);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
