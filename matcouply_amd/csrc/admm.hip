@@ -101,11 +101,12 @@ static __device__ __forceinline__ void gj_inverse_rows(double (&col)[GJRows<RP>:
                     piv = fma(fma(-pivot, piv, 1.0), piv, piv);
                     piv = fma(fma(-pivot, piv, 1.0), piv, piv);
                     const double myp = (c == p) ? piv : prow * piv;
+                    // column p itself becomes -M[i][p] piv = fma(-M[i][p], piv, 0): one select on the addend instead of
+                    // two products and a select on the result (the elimination is bound by instruction issue)
 #pragma unroll
                     for (int j = 0; j < RL; ++j) {
-                        const bool is_p = (g == pg) && (j == pj);
-                        const double upd = (c == p) ? -cp[j] * piv : col[j] - cp[j] * myp;
-                        col[j] = is_p ? myp : upd;
+                        const double upd = fma(-cp[j], myp, (c == p) ? 0.0 : col[j]);
+                        col[j] = (j == pj && g == pg) ? myp : upd;
                     }
                 }
             },
