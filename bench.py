@@ -239,6 +239,9 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
+    # RCCL shares device buffers between the ranks of a node through dmabuf IPC; the legacy IPC mode is not supported by the
+    # host driver of this pool (hipIpcGetMemHandle: invalid argument) - keep the setting the image exports
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
