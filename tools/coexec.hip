@@ -1,6 +1,7 @@
 // Do VALU instructions of the SAME wave issue while its MFMAs execute?  (1 wave per SIMD, like k_sweep.)
 //   mode 0: 64 independent MFMAs, then 192 VALU FMAs          mode 1: the same work, 1 MFMA : 3 VALU interleaved
 //   mode 2: MFMAs only                                         mode 3: VALU only
+// The same four modes with v_mfma_f32_32x32x2_f32 (16 passes, 32 of them = the same 2048 busy cycles): k32<MODE>.
 // build: hipcc --offload-arch=gfx950 -O3 tools/coexec.hip -o gpurun_out/coexec
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -50,6 +51,67 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MF32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k32(float *out, int iters, float seed) {
+    f32x16 acc[8];
+    float v[12];
+    for (int i = 0; i < 8; ++i)
+        for (int e = 0; e < 16; ++e) acc[i][e] = seed;
+    for (int i = 0; i < 12; ++i) v[i] = seed + i + threadIdx.x;
+    const float a = seed * 1.0001f, b = seed * 0.9999f;
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0 || MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = MF32(a, b, acc[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MODE == 0 || MODE == 3) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int i = 0; i < 12; ++i) v[i] = fmaf(v[i], a, b);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc[i] = MF32(a, b, acc[i]);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const int q = ((r * 8 + i) * 6 + j) % 12;
+                        v[q] = fmaf(v[q], a, b);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i)
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    for (int i = 0; i < 12; ++i) s += v[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int MODE>
+void run32(float *out) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    k32<MODE><<<256, 256>>>(out, 10, 1.f);
+    hipEventRecord(e0);
+    k32<MODE><<<256, 256>>>(out, 2000, 1.f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("32x32x2 mode %d: %.1f us per 2000 iterations -> %.0f cycles/iter at 2.4 GHz (32 MFMA = 2048 busy, 192 VALU = 768 issue)\n", MODE,
+           ms * 1e3, ms * 1e-3 / 2000 * 2.4e9);
+}
+
 template <int MODE>
 void run(float *out) {
     hipEvent_t e0, e1;
@@ -66,5 +128,6 @@ void run(float *out) {
 int main() {
     float *out; hipMalloc(&out, 256 * 256 * 4);
     run<2>(out); run<3>(out); run<0>(out); run<1>(out);
+    run32<2>(out); run32<3>(out); run32<0>(out); run32<1>(out);
     return 0;
 }
