@@ -157,7 +157,8 @@ int mcl_cmf_to_packed(const float *A, const float *B, const float *C, const floa
 
 /* ---- introspection for tests / profiling ------------------------------------------------------------- */
 /* device pointers to internal by-products: 0 rhses [I, r], 1 cross_products [I, r, r], 2 X C [sum J_i, r],
- * 3 rho_B [I], 4 rho_A [I], 5 rho_C [1] */
+ * 3 rho_B [I], 4 rho_A [I], 5 rho_C [1]; the planner's int32 tables (read the bits): 12 / 13 first row and length of every
+ * segment of the X passes, 14 first segment of every wave; 15 / 16 / 17 the same for the bsegs of the one-pass sweep */
 float *mcl_internal_buffer(mcl_context *ctx, int32_t which, int64_t *count);
 /* name of the kernel variant chosen for the current problem: which = 0 X C pass, 1 X^T B pass, 2 fused B-phase rows,
  * 3 one-pass sweep (B-phase + X^T B in a single pass over X; empty when the problem is not eligible) */

@@ -976,6 +976,14 @@ float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {
         case 10: p = reinterpret_cast<float *>(c->pf2_S), n = c->pf2_S ? 2 * c->I * (int64_t)c->r * c->r : 0; break;
         case 11: p = reinterpret_cast<float *>(c->sweep_cycles), n = c->sweep_cycles ? (int64_t)2048 * 6 * 2 : 0; break;
         case 8: p = reinterpret_cast<float *>(c->pf2_status), n = c->pf2_status ? c->I : 0; break;  // int32 bits
+        // the planner's work-unit tables (int32 bits): segments of the X passes, bsegs of the sweep, and the first
+        // unit of every wave (mcl_set_problem)
+        case 12: p = reinterpret_cast<float *>(c->segs.row0), n = c->segs.n_tiles; break;
+        case 13: p = reinterpret_cast<float *>(c->segs.nrows), n = c->segs.n_tiles; break;
+        case 14: p = reinterpret_cast<float *>(c->wave_seg_ptr), n = c->n_seg_waves + 1; break;
+        case 15: p = reinterpret_cast<float *>(c->bsegs.row0), n = c->bsegs.n_tiles; break;
+        case 16: p = reinterpret_cast<float *>(c->bsegs.nrows), n = c->bsegs.n_tiles; break;
+        case 17: p = reinterpret_cast<float *>(c->wave_bseg_ptr), n = c->wave_bseg_ptr ? c->n_bseg_waves + 1 : 0; break;
         default: break;
     }
     if (count) *count = n;

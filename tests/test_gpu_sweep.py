@@ -146,6 +146,36 @@ def test_balanced_wave_partition_with_cuts(name, waves, monkeypatch):
     _compare(cmf, admm, diag, st, res, 1e-5, tol_rec=1e-5)
 
 
+def test_wave_partition_is_balanced_on_ragged_slabs():
+    """The X passes and the sweep run one wave per SIMD side by side: the longest wave is the kernel's duration.  On the
+    ragged slabs of BASELINE config 4 (J_i in [128, 1024]) every wave must hold the same number of 16-row blocks (segments:
+    exactly the quota; bsegs: at most 2 blocks above it), the units must tile every slab and no unit may exceed its cap."""
+    import torch
+    from matcouply_amd._engine import HipEngine, NativeReg, KIND
+
+    J = np.random.RandomState(0).randint(128, 1025, 1024)
+    row_ptr = np.concatenate([[0], np.cumsum(J)]).astype(np.int64)
+    N, K, r = int(row_ptr[-1]), 256, 16
+    dev = torch.device("cuda:0")
+    X = torch.zeros((N, K), dtype=torch.float32, device=dev)
+    f = lambda *shape: torch.rand(shape, dtype=torch.float32, device=dev)
+    nn = lambda rows: NativeReg(KIND["nn"], f(rows, r), torch.zeros((rows, r), dtype=torch.float32, device=dev))
+    eng = HipEngine(X, row_ptr, r, f(len(J), r), f(N, r), f(K, r), [[nn(len(J))], [nn(N)], [nn(K)]])
+    ints = lambda which: eng.internal(which).view(torch.int32).cpu().numpy().astype(np.int64)
+    for (i_row0, i_n, i_ptr, cap, tol) in ((12, 13, 14, 256, 0), (15, 16, 17, 512, 2)):
+        row0, n, ptr = ints(i_row0), ints(i_n), ints(i_ptr)
+        assert n.min() >= 1 and n.max() <= cap
+        assert np.array_equal(row0, np.concatenate([[0], np.cumsum(n)[:-1]])) and row0[-1] + n[-1] == N  # a tiling of the rows
+        slab_of = np.searchsorted(row_ptr, row0, side="right") - 1
+        assert np.all(row0 + n <= row_ptr[slab_of + 1])                       # no unit crosses a slab boundary
+        assert ptr[0] == 0 and ptr[-1] == len(n) and np.all(np.diff(ptr) >= 1) and len(ptr) - 1 <= 1024
+        blocks = np.add.reduceat((n + 15) // 16, ptr[:-1])
+        quota = -(-int(((J + 15) // 16).sum()) // 1024)
+        assert blocks.max() <= quota + tol, (blocks.max(), quota)
+        assert blocks.max() <= 1.06 * blocks[:-1].mean()                        # was 1.32 with a fixed count of units per wave
+    eng.close()
+
+
 def test_by_products_are_not_reused_out_of_order():
     """The sweep weights its [G | R] partials with the a_i of the moment and its M_i belongs to the B it wrote: an A update
     before the C-phase, a second C-phase, or new factors must all fall back to passes over X with current operands."""
