@@ -1686,7 +1686,7 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     c->BtB, c->CtC64, (int)c->I, c->r, (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[0],          \
         c->opt.constant_A, c->rho_max, c->rhoA, c->LinvA, c->A, c->regs[0], c->opt.inner_n_iter_max,                  \
         fused_inner ? 1 : 0, c->e1, c->diagA_row, next_B, (float)c->opt.l2_penalty[1], c->regs[1].n, c->rhoB, c->LinvB, \
-        (const int *)(seg ? (c->seg_from_sweep ? c->slab_bseg_ptr : c->slab_seg_ptr) : nullptr),                      \
+        (const int *)(seg ? (c->seg_from_sweep ? c->slab_part_ptr : c->slab_seg_ptr) : nullptr),                      \
         (const double *)c->seg_rhs, (const double *)((seg && c->seg_from_sweep) ? c->part_btb : c->seg_btb), c->rhsA
     // what the row-split kernel absorbs: rhs_i from the sweep's M_bseg
     AFuse F{};

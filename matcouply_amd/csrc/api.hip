@@ -57,6 +57,8 @@ int64_t plan(mcl_context *c, char *base) {
         tm(c->bsegs, c->h_bseg_slab.size());
         c->slab_bseg_ptr = b.take<int>(I + 1);
         c->wave_bseg_ptr = b.take<int>((int64_t)c->h_wave_bseg_ptr.size());
+        c->bseg_part = b.take<int>((int64_t)c->h_bseg_part.size());
+        c->slab_part_ptr = b.take<int>(I + 1);
         c->Mpart = b.take<float>((int64_t)c->bsegs.n_tiles * mcl_sweep_KS(c) * 256 * 16 * c->NB);
         c->part_btb = b.take<double>((int64_t)c->bsegs.n_tiles * r * r);
         c->GRpart = b.take<float>((int64_t)c->bsegs.n_tiles * (256 * c->NB * c->NB + 16 * c->NB));
@@ -64,7 +66,7 @@ int64_t plan(mcl_context *c, char *base) {
         c->sweep_cycles = b.take<long long>((int64_t)2048 * 6);
     } else {
         c->bsegs = TileMap{};
-        c->slab_bseg_ptr = nullptr, c->wave_bseg_ptr = nullptr, c->Mpart = nullptr, c->part_btb = nullptr, c->GRpart = nullptr, c->CfragS = nullptr;
+        c->slab_bseg_ptr = nullptr, c->wave_bseg_ptr = nullptr, c->bseg_part = nullptr, c->slab_part_ptr = nullptr, c->Mpart = nullptr, c->part_btb = nullptr, c->GRpart = nullptr, c->CfragS = nullptr;
     }
     c->ext_A = b.take<int>(2);
     c->ext_C = b.take<int>(2);
@@ -147,7 +149,7 @@ void read_switches(mcl_switches &w) {
     w.no_fused_gram = flag("MCL_NO_FUSED_GRAM"), w.no_fused_c = flag("MCL_NO_FUSED_C");
     w.a_finish_cols = flag("MCL_A_FINISH_COLS"), w.xc_norow = flag("MCL_XC_NOROW");
     w.unimodal_v3 = flag("MCL_UNIMODAL_V3"), w.stats_reduce = flag("MCL_STATS_REDUCE");
-    w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_a_wide = flag("MCL_NO_A_WIDE"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1");
+    w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_a_wide = flag("MCL_NO_A_WIDE"), w.no_bseg_groups = flag("MCL_NO_BSEG_GROUPS"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1");
     w.seg_rows = num("MCL_SEG_ROWS", 0), w.bseg_rows = num("MCL_BSEG_ROWS", 0);
     w.xc_waves = num("MCL_XC_WAVES", 0), w.xt_waves = num("MCL_XT_WAVES", 0), w.sweep_waves = num("MCL_SWEEP_WAVES", 0);
     w.xc_dbg = num("MCL_XC_DBG", 0), w.xt_dbg = num("MCL_XT_DBG", 0), w.xt_depth = num("MCL_XT_DEPTH", 0);
@@ -428,6 +430,28 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     if (bused > 0) c->h_wave_bseg_ptr.push_back((int)c->h_bseg_slab.size());
     c->n_bseg_waves = (int)c->h_wave_bseg_ptr.size() - 1;
     c->h_slab_bseg_ptr[(size_t)I] = (int)c->h_bseg_slab.size();
+    // Partials of the sweep (M = X^T B, B^T B, the a-weighted Gram: one 16 KB image at K = 256).  One bseg per wave and
+    // short bsegs (small problems: per-rank shards, config 2): the four waves of a workgroup whose bsegs lie in the same
+    // slab add their accumulators in LDS and write ONE partial (k_sweep<.., GRP>: K <= 256, rank <= 16).
+    {
+        const int nbs = (int)c->h_bseg_slab.size();
+        const bool can_group = one_each && K <= 256 && c->NB == 1 && bseg_rows < 512 && !c->sw.no_bseg_groups &&
+                               c->sw.sweep_dbg == 0;
+        c->h_bseg_part.assign((size_t)nbs, 0);
+        int parts = 0;
+        for (int b0 = 0; b0 < nbs; b0 += 4) {
+            const bool g4 = can_group && b0 + 3 < nbs && c->h_bseg_slab[(size_t)b0] == c->h_bseg_slab[(size_t)b0 + 3];
+            for (int b = b0; b < std::min(b0 + 4, nbs); ++b) c->h_bseg_part[(size_t)b] = g4 ? (parts | (1 << 30)) : parts++;
+            if (g4) ++parts;
+        }
+        c->n_parts = parts;
+        c->h_slab_part_ptr.assign((size_t)I + 1, parts);
+        for (int64_t i = I - 1; i >= 0; --i) {
+            const int b = c->h_slab_bseg_ptr[(size_t)i];
+            c->h_slab_part_ptr[(size_t)i] = (b < c->h_slab_bseg_ptr[(size_t)i + 1]) ? (c->h_bseg_part[(size_t)b] & 0x3fffffff)
+                                                                                    : c->h_slab_part_ptr[(size_t)i + 1];
+        }
+    }
     auto single = [](int64_t rows, std::vector<int> &s, std::vector<int> &r0, std::vector<int> &nr) {
         s.clear(), r0.clear(), nr.clear();
         for (int64_t j = 0; j < rows; j += 64) {
@@ -550,6 +574,8 @@ int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
         MCL_CHECK_HIP(c, up(c->bsegs.nrows, c->h_bseg_nrows));
         MCL_CHECK_HIP(c, up(c->slab_bseg_ptr, c->h_slab_bseg_ptr));
         MCL_CHECK_HIP(c, up(c->wave_bseg_ptr, c->h_wave_bseg_ptr));
+        MCL_CHECK_HIP(c, up(c->bseg_part, c->h_bseg_part));
+        MCL_CHECK_HIP(c, up(c->slab_part_ptr, c->h_slab_part_ptr));
     }
     c->h_ext = {0, (int)c->I, 0, (int)c->K};
     MCL_CHECK_HIP(c, hipMemcpyAsync(c->ext_A, c->h_ext.data(), 2 * sizeof(int), hipMemcpyHostToDevice, s));
@@ -784,8 +810,8 @@ int mcl_A_begin(mcl_context *c) {
         // up to 8 (a 1/8 shard of config 3 cuts its slabs into 8 bsegs: one wave 27 us vs 5 + 13 us apart) the four waves
         // of a workgroup per slab share them (k_A_finish_rows_wide); beyond that the separate kernel, a workgroup per bseg
         const bool fusable = (c->RP == 8 || c->RP == 16 || c->RP == 32) && !c->sw.a_finish_cols && !c->sw.no_a_fusion;
-        c->a_rhs_wide = fusable && c->bsegs.n_tiles > 2 * c->I && c->bsegs.n_tiles <= 8 * c->I && !c->sw.no_a_wide;
-        c->a_rhs_from_M = fusable && (c->bsegs.n_tiles <= 2 * c->I || c->a_rhs_wide);
+        c->a_rhs_wide = fusable && c->n_parts > 2 * c->I && c->n_parts <= 8 * c->I && !c->sw.no_a_wide;
+        c->a_rhs_from_M = fusable && (c->n_parts <= 2 * c->I || c->a_rhs_wide);
         if (!c->a_rhs_from_M)
             if (int rc = mcl_launch_A_rhs_from_M(c)) return rc;
         c->use_seg_gram = true;

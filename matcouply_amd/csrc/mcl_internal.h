@@ -57,7 +57,7 @@ struct mcl_switches {
     bool no_sweep = false, no_pass_chain = false, no_pf2_delta_fusion = false, ns_plain = false, pf2_jacobi = false;
     bool no_stack_fusion = false, no_solve_stats = false, no_next_b = false, no_fused_gram = false, no_fused_c = false;
     bool a_finish_cols = false, xc_norow = false, unimodal_v3 = false, stats_reduce = false;
-    bool no_a_fusion = false, no_a_wide = false, no_diag_defer = false, xc_depth1 = false;
+    bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_diag_defer = false, xc_depth1 = false;
     int seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
     int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
 };
@@ -124,6 +124,12 @@ struct mcl_context {
     double *seg_rhs = nullptr;  // [max(n_segs, n_bsegs, I), r]  fp64 per-segment (per-bseg / per-slab) partial rhs_i
     double *seg_btb = nullptr;  // [max(n_segs, I), r, r]        fp64 per-segment (per-slab) partial B_i^T B_i
     int *slab_seg_ptr = nullptr;  // int32[I+1] first segment of every slab
+    // partials of the sweep: normally one per bseg; when every wave holds one short bseg, the four bsegs of a workgroup
+    // that belong to the same slab share ONE (bit 30 of bseg_part: k_sweep<.., GRP>)
+    int *bseg_part = nullptr;       // int32[n_bsegs] partial index (| 1 << 30: grouped)
+    int *slab_part_ptr = nullptr;   // int32[I+1] first partial of every slab
+    std::vector<int> h_bseg_part, h_slab_part_ptr;
+    int n_parts = 0;
     int *wave_bseg_ptr = nullptr;  // int32[n_bseg_waves+1] first bseg of every wave of the sweep
     std::vector<int> h_wave_bseg_ptr;
     int n_bseg_waves = 0;

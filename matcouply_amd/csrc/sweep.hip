@@ -52,7 +52,7 @@ static __device__ __forceinline__ long uniform_off(long v) {
 // DBG: the MCL_SWEEP_DBG experiments (phase elimination, per-section cycle counters: tools/run_dbg.sh, sweep_cycles.py)
 // are compiled into a second instantiation of the config-2/3 variants only; the production kernels carry none of it
 // (the counters alone cost 12 registers in kernels that sit at the 512-register limit).
-template <int KS, int NB, int NREG, int DEPTH, int NW, bool VEC, bool DBG = false>
+template <int KS, int NB, int NREG, int DEPTH, int NW, bool VEC, bool DBG = false, bool GRP = false>
 __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, const float *__restrict__ Cfrag,
                                                const float *__restrict__ A, const float *__restrict__ rhoB,
                                                const float *__restrict__ LinvB, float *__restrict__ Bout, RegSet regs,
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                                                int K, int r, int inner, float *__restrict__ Mpart,
                                                double *__restrict__ part_btb, float *__restrict__ GRpart,
                                                double *__restrict__ diag_block, int dbg_rt,
-                                               long long *__restrict__ cyc_out) {
+                                               long long *__restrict__ cyc_out, const int *__restrict__ bs_part) {
     const int dbg = DBG ? dbg_rt : 0;
     constexpr int KW = 256 * KS;   // floats per tile row: K rounded up to 256 (K % 4 == 0, K <= KW)
     constexpr int KC = 4 * KS;     // 64-column chunks
@@ -502,42 +502,100 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
             }
         }
 
-        // ---- flush this bseg straight from the accumulators (fragment order: 1 KB per store instruction)
+        // ---- flush this bseg straight from the accumulators (fragment order: 1 KB per store instruction).
+        // The partial a bseg goes to is the planner's (mcl_set_problem): normally its own; GRP - short bsegs, every wave of
+        // the workgroup holding ONE bseg of the SAME slab (bit 30 of bs_part, workgroup-uniform) - the four waves first add
+        // their accumulators through the LDS tiles (no longer read by anybody) in the fixed order ((w0 + w1) + w2) + w3 and
+        // flush ONE partial: a quarter of the partial traffic of the sweep, of k_reduce_frag and of the A-phase on the
+        // per-rank shards of a multi-GPU run and on config 2, where a bseg is 64 rows
         {
-            float *mp = Mpart + (long)bs * MS;
-            float *gp = GRpart + (long)bs * (W * W + W);  // [weighted Gram | a_i]: k_reduce_frag weights M_bseg itself
+            const int pinfo = __builtin_amdgcn_readfirstlane(bs_part[bs]);
+            const int part = pinfo & 0x3fffffff;
+            const bool grouped = GRP && (pinfo >> 30) != 0;
+            float *mp = Mpart + (long)part * MS;
+            float *gp = GRpart + (long)part * (W * W + W);  // [weighted Gram | a_i]: k_reduce_frag weights M_part itself
             const float *arow = A + (long)slab * r;
             float a_c[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) a_c[nb] = (16 * nb + i16 < r) ? arow[16 * nb + i16] : 0.f;
-#pragma unroll
-            for (int kb = 0; kb < KC; ++kb)
-#pragma unroll
-                for (int w = 0; w < 4; ++w)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const f32x4 val = {accM[kb][0][nb][w], accM[kb][1][nb][w], accM[kb][2][nb][w], accM[kb][3][nb][w]};
-                        const int e = ((((kb * 4 + w) * NB + nb) * 64 + lane) << 2);
-                        *reinterpret_cast<f32x4 *>(mp + e) = val;
-                    }
-            if (q == 0) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) gp[W * W + 16 * nb + i16] = a_c[nb];  // the a_i of the moment (0 in padding)
-            }
+            constexpr int NI = KC * 4 * NB;  // 1 KB fragments of a partial
+            f32x4 gsum[NB][NB];
 #pragma unroll
             for (int a = 0; a < NB; ++a)
 #pragma unroll
-                for (int b = 0; b < NB; ++b)
+                for (int b = 0; b < NB; ++b) gsum[a][b] = accG[a][b];
+            bool writer = true;  // this wave writes the Gram / weights of the partial
+            if (grouped) {
+                static_assert(!GRP || NI % NW == 0, "fragments split evenly over the waves");
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const int ra = 16 * a + 4 * q + w, cb = 16 * b + i16;
-                        if (ra < r && cb < r) {
-                            part_btb[((long)bs * r + ra) * r + cb] = (double)accG[a][b][w];
-                            gp[ra * W + cb] = arow[ra] * arow[cb] * accG[a][b][w];
-                        } else {
-                            gp[ra * W + cb] = 0.f;
+                for (int kb = 0; kb < KC; ++kb)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const f32x4 val = {accM[kb][0][nb][w], accM[kb][1][nb][w], accM[kb][2][nb][w], accM[kb][3][nb][w]};
+                            *reinterpret_cast<f32x4 *>(L + ((((kb * 4 + w) * NB + nb) * 64 + lane) << 2)) = val;
                         }
-                    }
+                __syncthreads();
+#pragma unroll
+                for (int ii = 0; ii < NI / NW; ++ii) {
+                    const int e = ((wave * (NI / NW) + ii) * 64 + lane) << 2;
+                    f32x4 t = *reinterpret_cast<const f32x4 *>(lds_dyn + e);
+#pragma unroll
+                    for (int wv = 1; wv < NW; ++wv) t += *reinterpret_cast<const f32x4 *>(lds_dyn + wv * (16 * KW) + e);
+                    *reinterpret_cast<f32x4 *>(mp + e) = t;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int a = 0; a < NB; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) *reinterpret_cast<f32x4 *>(L + (((a * NB + b) * 64 + lane) << 2)) = accG[a][b];
+                __syncthreads();
+                writer = wave == 0;
+                if (writer) {
+#pragma unroll
+                    for (int a = 0; a < NB; ++a)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            f32x4 t = *reinterpret_cast<const f32x4 *>(lds_dyn + (((a * NB + b) * 64 + lane) << 2));
+#pragma unroll
+                            for (int wv = 1; wv < NW; ++wv)
+                                t += *reinterpret_cast<const f32x4 *>(lds_dyn + wv * (16 * KW) + (((a * NB + b) * 64 + lane) << 2));
+                            gsum[a][b] = t;
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < KC; ++kb)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const f32x4 val = {accM[kb][0][nb][w], accM[kb][1][nb][w], accM[kb][2][nb][w], accM[kb][3][nb][w]};
+                            const int e = ((((kb * 4 + w) * NB + nb) * 64 + lane) << 2);
+                            *reinterpret_cast<f32x4 *>(mp + e) = val;
+                        }
+            }
+            if (writer) {
+                if (q == 0) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) gp[W * W + 16 * nb + i16] = a_c[nb];  // the a_i of the moment (0 in padding)
+                }
+#pragma unroll
+                for (int a = 0; a < NB; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const int ra = 16 * a + 4 * q + w, cb = 16 * b + i16;
+                            if (ra < r && cb < r) {
+                                part_btb[((long)part * r + ra) * r + cb] = (double)gsum[a][b][w];
+                                gp[ra * W + cb] = arow[ra] * arow[cb] * gsum[a][b][w];
+                            } else {
+                                gp[ra * W + cb] = 0.f;
+                            }
+                        }
+            }
         }
     }
 
@@ -776,26 +834,43 @@ static int launch_sweep_v(mcl_context *c) {
     // tables (mcl_diagnostics_deferred) may still be waiting for the coming C-phase reduction kernel
     c->diagB_parity ^= 1;
     c->diagB_tile = c->diagB_bufs[c->diagB_parity];
-#define MCL_SWEEP_LAUNCH(DBG_)                                                                                         \
-    hipLaunchKernelGGL((k_sweep<KS, NB, NREG, DEPTH, NW, VEC, DBG_>), dim3(grid), dim3(64 * NW), sm, c->stream, c->X,    \
+#define MCL_SWEEP_LAUNCH(DBG_, GRP_)                                                                                   \
+    hipLaunchKernelGGL((k_sweep<KS, NB, NREG, DEPTH, NW, VEC, DBG_, GRP_>), dim3(grid), dim3(64 * NW), sm, c->stream, c->X,    \
                        c->CfragS, c->A, c->rhoB, c->LinvB, c->B, c->regs[1], c->bsegs.slab, c->bsegs.row0, c->bsegs.nrows, \
                        c->wave_bseg_ptr, n_waves, (int)c->K, c->r, c->opt.inner_n_iter_max, c->Mpart, c->part_btb, c->GRpart, c->diagB_tile, \
-                       c->sw.sweep_dbg, c->sweep_cycles)
+                       c->sw.sweep_dbg, c->sweep_cycles, c->bseg_part)
     bool launched = false;
     if constexpr (KS == 1 && NB == 1 && VEC) {  // the instrumented twin exists for the config-2/3 variants only
         if (c->sw.sweep_dbg != 0) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<KS, NB, NREG, DEPTH, NW, VEC, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) == hipSuccess) {
-                MCL_SWEEP_LAUNCH(true);
+                MCL_SWEEP_LAUNCH(true, false);
                 launched = true;
             }
         }
     }
-    if (!launched) MCL_SWEEP_LAUNCH(false);
+    if constexpr (KS == 1 && NB == 1) {  // the instantiations with the grouped flush (mcl_set_problem only groups for them)
+        if (!launched && c->n_parts < n) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<KS, NB, NREG, DEPTH, NW, VEC, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
+                (void)hipGetLastError();
+                return -1;
+            }
+            MCL_SWEEP_LAUNCH(false, true);
+            launched = true;
+        }
+    }
+    if (!launched) {
+        if (c->n_parts < n) {
+            c->err = "k_sweep: grouped partials planned for a kernel without the grouped flush";
+            return 1;
+        }
+        MCL_SWEEP_LAUNCH(false, false);
+    }
 #undef MCL_SWEEP_LAUNCH
     MCL_CHECK_HIP(c, hipGetLastError());
     c->diag_rows[1] = grid;
-    c->n_grpart = n;  // one a-weighted partial per bseg
+    c->n_grpart = c->n_parts;  // one partial per bseg, or per group of four bsegs of a slab
     char buf[96];
     snprintf(buf, sizeof buf, "k_sweep<KS=%d,NB=%d,NREG=%d,DEPTH=%d,NW=%d,VEC=%d>", KS, NB, NREG, DEPTH, NW, VEC ? 4 : 1);
     c->variant[3] = buf;
@@ -861,7 +936,7 @@ int mcl_launch_reduce_weighted(mcl_context *c) {
 }
 
 int mcl_launch_A_rhs_from_M(mcl_context *c) {
-    hipLaunchKernelGGL(k_A_rhs_from_M, dim3(c->bsegs.n_tiles), dim3(256), 0, c->stream, c->Mpart, c->CfragS, sweep_MS(c),
+    hipLaunchKernelGGL(k_A_rhs_from_M, dim3(c->n_parts), dim3(256), 0, c->stream, c->Mpart, c->CfragS, sweep_MS(c),
                        c->NB, c->r, c->seg_rhs);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
