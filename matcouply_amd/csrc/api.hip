@@ -805,13 +805,13 @@ int mcl_A_begin(mcl_context *c) {
     if (c->mseg_valid && !c->opt.constant_A && mcl_mode_is_row_separable(c, 0)) {
         // the sweep left M_i = X_i^T B_i per bseg: rhs_i = coldot(M_i, C), no pass over X
         if (int rc = ensure_cfrag_sweep(c)) return rc;
-        // rank 5..32: the finish kernel forms rhs_i from M_bseg itself (one launch less); otherwise a separate pass.
-        // Up to 2 bsegs per slab ONE wave streams the slab's M_bseg (16 KB each at K = 256) in front of its Gauss-Jordan;
-        // up to 8 (a 1/8 shard of config 3 cuts its slabs into 8 bsegs: one wave 27 us vs 5 + 13 us apart) the four waves
-        // of a workgroup per slab share them (k_A_finish_rows_wide); beyond that the separate kernel, a workgroup per bseg
+        // rank 5..32: the finish kernel forms rhs_i from the sweep's M partials itself (one launch less); otherwise a
+        // separate pass.  One partial per slab: the finishing wave streams it (16 KB at K = 256) in front of its
+        // Gauss-Jordan; 2..8 partials (per-rank shards of config 3: one wave alone took 27 us for 8, against 5 + 13 us
+        // apart): the four waves of a workgroup per slab share them (k_A_finish_rows_wide); beyond that the separate kernel
         const bool fusable = (c->RP == 8 || c->RP == 16 || c->RP == 32) && !c->sw.a_finish_cols && !c->sw.no_a_fusion;
-        c->a_rhs_wide = fusable && c->n_parts > 2 * c->I && c->n_parts <= 8 * c->I && !c->sw.no_a_wide;
-        c->a_rhs_from_M = fusable && (c->n_parts <= 2 * c->I || c->a_rhs_wide);
+        c->a_rhs_wide = fusable && c->n_parts > c->I && c->n_parts <= 8 * c->I && !c->sw.no_a_wide;
+        c->a_rhs_from_M = fusable && (c->n_parts <= c->I || c->a_rhs_wide);
         if (!c->a_rhs_from_M)
             if (int rc = mcl_launch_A_rhs_from_M(c)) return rc;
         c->use_seg_gram = true;
