@@ -420,7 +420,7 @@ def main():
         bytes_iter = (S_X_tot + (1 + 4 * n_B) * S_B_tot) if swept else (2 * S_X_tot + (5 + 4 * n_B) * S_B_tot)
         out = {
             "metric": "AO-ADMM outer-iters/sec", "value": round(its, 2), "unit": "outer-iters/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 6),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["desc"], "I": cfg["I"], "J": cfg["J"], "sum_J": N_tot, "K": K, "rank": r,
                        "inner_n_iter_max": 5, "diagnostics_every_iteration": True,

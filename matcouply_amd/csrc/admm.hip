@@ -974,30 +974,36 @@ struct AFuse {
 // ((chunk * NB + nb) * 64 + l) * 4 + m <-> k = 16 chunk + 4 (l >> 4) + m, column 16 nb + (l & 15)): the wave streams
 // M_bseg with 1 KB loads, fp64 accumulation (products of fp32 values are exact), the four lane quarters of a column are
 // summed by two butterfly steps: every lane ends with the sums of columns (l & 15) and 16 + (l & 15) in acc0 / acc1.
-static __device__ __forceinline__ void m_coldot(const AFuse &F, int sgA, int sgB, int step, int lane, double &acc0,
-                                                double &acc1) {
-    double pa[2][2] = {{0.0, 0.0}, {0.0, 0.0}};  // [nb][chain]: two chains per column block shorten the FMA dependency
+template <int NQ>  // chunks of 256 floats per trip: 16 (partial images of K >= 256: MS is a multiple of 4096) or 8 (K <= 128: MS = 2048)
+static __device__ __forceinline__ void m_coldot_q(const AFuse &F, int sgA, int sgB, int step, int lane, double (&pa)[2][2]) {
     for (int sg = sgA; sg < sgB; sg += step) {
         const float *mp = F.Mpart + (long)sg * F.MS;
-        for (int e0 = 0; e0 < F.MS; e0 += 4096) {  // 16 chunks per trip (MS is a multiple of 4096): 32 loads in flight
-            f32x4 mv[16], cv[16];
+        for (int e0 = 0; e0 < F.MS; e0 += 256 * NQ) {  // 2 NQ loads in flight
+            f32x4 mv[NQ], cv[NQ];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 mv[q] = *reinterpret_cast<const f32x4 *>(mp + e0 + 256 * q + 4 * lane);
                 cv[q] = *reinterpret_cast<const f32x4 *>(F.Cfrag + e0 + 256 * q + 4 * lane);
             }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 double d = (double)mv[q][0] * (double)cv[q][0];
                 d = fma((double)mv[q][1], (double)cv[q][1], d);
                 d = fma((double)mv[q][2], (double)cv[q][2], d);
                 d = fma((double)mv[q][3], (double)cv[q][3], d);
-                // chunk index = e >> 8 = 16 * trip + q: nb = chunk % NB
+                // chunk index = e >> 8 = NQ * trip + q: nb = chunk % NB
                 if (F.NBm == 2 && (q & 1)) pa[1][(q >> 1) & 1] += d;
                 else pa[0][(q >> (F.NBm == 2 ? 1 : 0)) & 1] += d;
             }
         }
     }
+}
+
+static __device__ __forceinline__ void m_coldot(const AFuse &F, int sgA, int sgB, int step, int lane, double &acc0,
+                                                double &acc1) {
+    double pa[2][2] = {{0.0, 0.0}, {0.0, 0.0}};  // [nb][chain]: two chains per column block shorten the FMA dependency
+    if ((F.MS & 4095) == 0) m_coldot_q<16>(F, sgA, sgB, step, lane, pa);
+    else m_coldot_q<8>(F, sgA, sgB, step, lane, pa);
     acc0 = pa[0][0] + pa[0][1], acc1 = pa[1][0] + pa[1][1];
     acc0 += __shfl_xor(acc0, 16), acc1 += __shfl_xor(acc1, 16);
     acc0 += __shfl_xor(acc0, 32), acc1 += __shfl_xor(acc1, 32);
@@ -1692,7 +1698,7 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     AFuse F{};
     if (c->a_rhs_from_M) {
         F.Mpart = c->Mpart, F.Cfrag = c->CfragS, F.NBm = c->NB;
-        F.MS = mcl_sweep_KS(c) * 256 * 16 * c->NB;
+        F.MS = mcl_sweep_KC(c) * 64 * 16 * c->NB;
     }
     const bool rows_kernel = !(c->RP == 64 || c->RP == 4 || c->sw.a_finish_cols);
     // ranks 5..32: rows of every system split over the lane groups (all 64 lanes busy); 64 columns fill the wave anyway

@@ -59,7 +59,7 @@ int64_t plan(mcl_context *c, char *base) {
         c->wave_bseg_ptr = b.take<int>((int64_t)c->h_wave_bseg_ptr.size());
         c->bseg_part = b.take<int>((int64_t)c->h_bseg_part.size());
         c->slab_part_ptr = b.take<int>(I + 1);
-        c->Mpart = b.take<float>((int64_t)c->bsegs.n_tiles * mcl_sweep_KS(c) * 256 * 16 * c->NB);
+        c->Mpart = b.take<float>((int64_t)c->bsegs.n_tiles * mcl_sweep_KC(c) * 64 * 16 * c->NB);
         c->part_btb = b.take<double>((int64_t)c->bsegs.n_tiles * r * r);
         c->GRpart = b.take<float>((int64_t)c->bsegs.n_tiles * (256 * c->NB * c->NB + 16 * c->NB));
         c->CfragS = nullptr;  // aliases Cfrag (below)
@@ -149,7 +149,7 @@ void read_switches(mcl_switches &w) {
     w.no_fused_gram = flag("MCL_NO_FUSED_GRAM"), w.no_fused_c = flag("MCL_NO_FUSED_C");
     w.a_finish_cols = flag("MCL_A_FINISH_COLS"), w.xc_norow = flag("MCL_XC_NOROW");
     w.unimodal_v3 = flag("MCL_UNIMODAL_V3"), w.stats_reduce = flag("MCL_STATS_REDUCE");
-    w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_a_wide = flag("MCL_NO_A_WIDE"), w.no_bseg_groups = flag("MCL_NO_BSEG_GROUPS"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1");
+    w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_a_wide = flag("MCL_NO_A_WIDE"), w.no_bseg_groups = flag("MCL_NO_BSEG_GROUPS"), w.no_sweep_half = flag("MCL_NO_SWEEP_HALF"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1");
     w.seg_rows = num("MCL_SEG_ROWS", 0), w.bseg_rows = num("MCL_BSEG_ROWS", 0);
     w.xc_waves = num("MCL_XC_WAVES", 0), w.xt_waves = num("MCL_XT_WAVES", 0), w.sweep_waves = num("MCL_SWEEP_WAVES", 0);
     w.xc_dbg = num("MCL_XC_DBG", 0), w.xt_dbg = num("MCL_XT_DBG", 0), w.xt_depth = num("MCL_XT_DEPTH", 0);

@@ -57,7 +57,7 @@ struct mcl_switches {
     bool no_sweep = false, no_pass_chain = false, no_pf2_delta_fusion = false, ns_plain = false, pf2_jacobi = false;
     bool no_stack_fusion = false, no_solve_stats = false, no_next_b = false, no_fused_gram = false, no_fused_c = false;
     bool a_finish_cols = false, xc_norow = false, unimodal_v3 = false, stats_reduce = false;
-    bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_diag_defer = false, xc_depth1 = false;
+    bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_sweep_half = false, no_diag_defer = false, xc_depth1 = false;
     int seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
     int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
 };
@@ -257,10 +257,11 @@ int mcl_contract_n_partials(const mcl_context *c);
 
 // ---- launchers implemented in sweep.hip --------------------------------------------------------------
 int mcl_sweep_KS(const mcl_context *c);          // 256-column super-chunks per tile row
+int mcl_sweep_KC(const mcl_context *c);          // 64-column chunks per tile row (2: the half-width kernels for K <= 128)
 // chunks (64 columns each) of the shared fragment image of C: enough for the X C kernels and, when planned, the sweep
 static inline int mcl_cfrag_chunks(const mcl_context *c) {
     const int xc = mcl_xc_chunks(c, nullptr);
-    return c->sweep_planned ? std::max(xc, 4 * mcl_sweep_KS(c)) : xc;
+    return c->sweep_planned ? std::max(xc, mcl_sweep_KC(c)) : xc;
 }
 bool mcl_sweep_shape_ok(const mcl_context *c);   // shape has a k_sweep instantiation (decides the workspace plan)
 bool mcl_sweep_eligible(const mcl_context *c);   // ... and the current penalties / options / pointers allow it

@@ -63,8 +63,13 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                                                double *__restrict__ diag_block, int dbg_rt,
                                                long long *__restrict__ cyc_out, const int *__restrict__ bs_part) {
     const int dbg = DBG ? dbg_rt : 0;
-    constexpr int KW = 256 * KS;   // floats per tile row: K rounded up to 256 (K % 4 == 0, K <= KW)
-    constexpr int KC = 4 * KS;     // 64-column chunks
+    // KS = 0: the half-width form for K <= 128 (config 2) - tile rows of 128 floats, a wave load / LDS store covers TWO
+    // rows (lanes 0..31 row 2t, lanes 32..63 row 2t + 1): half the MFMAs, LDS traffic and partial bytes of the 256-wide form
+    constexpr bool HALF = KS == 0;
+    constexpr int KSA = HALF ? 1 : KS;           // 256-column super-chunks (array extents)
+    constexpr int XL = HALF ? 8 : 16;            // wave loads per super-chunk of a 16-row block
+    constexpr int KW = HALF ? 128 : 256 * KS;    // floats per tile row: K rounded up (K % 4 == 0, K <= KW)
+    constexpr int KC = KW / 64;                  // 64-column chunks
     constexpr int W = 16 * NB;
     constexpr int MS = KW * W;     // floats per M partial
     constexpr int NR = NREG > 0 ? NREG : 1;
@@ -90,7 +95,11 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
     float bsel[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) bsel[v] = (i16 == 4 * q + v) ? 1.f : 0.f;
-    const int wr_lo = (lane & 15) << 2, wr_hi = (lane >> 4) << 6;  // tile write: row t, slot 64sc + lane -> (lane ^ t)
+    // tile write: row t, slot 64 sc + lane -> physical slot (lane ^ t) in the low 4 bits.  HALF: row 2t + hi (hi = lane >> 5),
+    // slot lane & 31: ((slot & 15) ^ (2t + hi)) = ((slot & 15) ^ hi) ^ 2t, so the per-lane part still precedes an immediate
+    const int hi = lane >> 5;
+    const int wr_lo = HALF ? (((lane & 15) ^ hi) << 2) : ((lane & 15) << 2);
+    const int wr_hi = HALF ? (hi * KW + (((lane & 31) >> 4) << 6)) : ((lane >> 4) << 6);
 
     for (int e = threadIdx.x * 4; e < MS; e += 4 * NT)
         *reinterpret_cast<f32x4 *>(Cs + e) = *reinterpret_cast<const f32x4 *>(Cfrag + e);
@@ -188,10 +197,10 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
             // column offset of this lane in super-chunk sc, clamped into the row when K is not a multiple of 256: the
             // padding columns then hold copies of real (finite) data that only ever meet zero C fragments, and the rows
             // of M they produce (k >= K) are never read
-            unsigned xcol[KS];
+            unsigned xcol[KSA];
 #pragma unroll
-            for (int sc = 0; sc < KS; ++sc) xcol[sc] = (unsigned)min(256 * sc + 4 * lane, K - 4);
-            f32x4 xr[DEPTH][KS][16];
+            for (int sc = 0; sc < KSA; ++sc) xcol[sc] = (unsigned)min(256 * sc + 4 * (HALF ? (lane & 31) : lane), K - 4);
+            f32x4 xr[DEPTH][KSA][XL];
             f32x4 zs[DEPTH][NR][NB], us[DEPTH][NR][NB];  // aux / dual rows of the slot's block, updated IN PLACE
             // Stage block `blk` of this wave into ring slot d.  Every load is unconditional (rows clamped into the
             // wave's range, scalar arithmetic): a branch around loads makes the compiler's counted s_waitcnt vmcnt(N)
@@ -204,11 +213,21 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                 // instruction of the wave, scalar ones included, takes an issue slot of its own.
                 const long blk_off = (base + 16 * (long)blk) * K;
                 const int tmax = wn - 1 - 16 * blk;
+                if (HALF) {
+                    // two rows per load: the upper half-wave adds one row (K floats) unless that row lies past the end
 #pragma unroll
-                for (int sc = 0; sc < KS; ++sc)
+                    for (int t = 0; t < XL; ++t) {
+                        const unsigned up = (2 * t + 1 <= tmax) ? (unsigned)K : 0u;  // wave-uniform
+                        xr[d][0][t] = *reinterpret_cast<const f32x4 *>(X + uniform_off(blk_off + (long)(min(2 * t, tmax) * K)) +
+                                                                       (xcol[0] + (hi ? up : 0u)));
+                    }
+                } else {
 #pragma unroll
-                    for (int t = 0; t < 16; ++t)
-                        xr[d][sc][t] = *reinterpret_cast<const f32x4 *>(X + uniform_off(blk_off + (long)(min(t, tmax) * K)) + xcol[sc]);
+                    for (int sc = 0; sc < KSA; ++sc)
+#pragma unroll
+                        for (int t = 0; t < 16; ++t)
+                            xr[d][sc][t] = *reinterpret_cast<const f32x4 *>(X + uniform_off(blk_off + (long)(min(t, tmax) * K)) + xcol[sc]);
+                }
             };
             // aux / dual rows go straight into the registers the inner loop works on.  They are issued AFTER the slot's
             // previous block has stored its rows, so the registers are never live across the load and the compiler
@@ -257,11 +276,17 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                 asm volatile("" : "+v"(wl), "+v"(l4));
                 const float *csl = Cs + l4;
                 // ---- registers -> LDS tile (row t, 16-B slot 64 sc + lane, physical slot XORed with the row)
+                if (HALF) {
 #pragma unroll
-                for (int sc = 0; sc < KS; ++sc)
+                    for (int t = 0; t < XL; ++t)
+                        *reinterpret_cast<f32x4 *>(L + 2 * t * KW + wr_hi + (wl ^ ((2 * t) << 2))) = xr[d][0][t];
+                } else {
 #pragma unroll
-                    for (int t = 0; t < 16; ++t)
-                        *reinterpret_cast<f32x4 *>(L + t * KW + 256 * sc + wr_hi + (wl ^ (t << 2))) = xr[d][sc][t];
+                    for (int sc = 0; sc < KSA; ++sc)
+#pragma unroll
+                        for (int t = 0; t < 16; ++t)
+                            *reinterpret_cast<f32x4 *>(L + t * KW + 256 * sc + wr_hi + (wl ^ (t << 2))) = xr[d][sc][t];
+                }
                 f32x4(&z)[NR][NB] = zs[d];
                 f32x4(&u)[NR][NB] = us[d];
                 // the X slot is free again: its next block goes out now and stays in flight for DEPTH block times
@@ -276,7 +301,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                 // (double buffer by hand); the scheduling barriers keep the compiler from hoisting every LDS read of the
                 // block to the top (register pressure: the M accumulators and the staging registers take half the file)
                 {
-                    constexpr int DB = (KS * NB == 1 && NW == 4) ? 2 : 1;  // no registers left for a second buffer otherwise
+                    constexpr int DB = (KS <= 1 && NB == 1 && NW == 4) ? 2 : 1;  // no registers left for a second buffer otherwise
                     f32x4 cf[DB][4][NB], fr[DB][4];
                     auto ld1 = [&](int sl, int kc) {
 #pragma unroll
@@ -464,7 +489,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                 tick(3, t0);
                 // ---- (4) M += X_blk^T B_blk ; B^T B += B_blk^T B_blk
                 {
-                    constexpr int DB = (KS * NB == 1 && NW == 4) ? 2 : 1;
+                    constexpr int DB = (KS <= 1 && NB == 1 && NW == 4) ? 2 : 1;
                     f32x4 xa[DB][4];
                     auto ld4x = [&](int sl, int kb) {
 #pragma unroll
@@ -799,6 +824,8 @@ __global__ __launch_bounds__(256) void k_A_rhs_from_M(const float *__restrict__ 
 // Shapes the sweep kernel is instantiated for: K <= 512 and K % 4 == 0 (tile rows of 256 or 512 floats in LDS, 16-byte
 // row accesses of X; other K are zero-padded through the C fragments), Kpad * NB <= 512 (accumulator registers).
 int mcl_sweep_KS(const mcl_context *c) { return (int)((c->K + 255) / 256); }
+// 64-column chunks of a tile row / of the M partials: 2 for the half-width kernels (K <= 128, rank <= 16), else 4 per 256
+int mcl_sweep_KC(const mcl_context *c) { return (c->K <= 128 && c->NB == 1 && !c->sw.no_sweep_half) ? 2 : 4 * mcl_sweep_KS(c); }
 
 bool mcl_sweep_shape_ok(const mcl_context *c) {
     if (c->sw.no_sweep) return false;
@@ -817,14 +844,15 @@ bool mcl_sweep_eligible(const mcl_context *c) {
     return true;
 }
 
-static inline int sweep_MS(const mcl_context *c) { return mcl_sweep_KS(c) * 256 * 16 * c->NB; }
+static inline int sweep_MS(const mcl_context *c) { return mcl_sweep_KC(c) * 64 * 16 * c->NB; }
 
 template <int KS, int NB, int NREG, int NW, int DEPTH, bool VEC>
 static int launch_sweep_v(mcl_context *c) {
     const int n = c->bsegs.n_tiles;
     const int n_waves = c->n_bseg_waves;  // <= 1024 = one per SIMD (the register file and the LDS tiles allow one or two)
     const int grid = (n_waves + NW - 1) / NW;
-    const size_t sm = sizeof(float) * (size_t)(NW * 16 * 256 * KS + 256 * KS * 16 * NB);  // up to the full 160 KB
+    constexpr int KWH = KS == 0 ? 128 : 256 * KS;
+    const size_t sm = sizeof(float) * (size_t)(NW * 16 * KWH + KWH * 16 * NB);  // up to the full 160 KB
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<KS, NB, NREG, DEPTH, NW, VEC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
         (void)hipGetLastError();
@@ -849,7 +877,7 @@ static int launch_sweep_v(mcl_context *c) {
             }
         }
     }
-    if constexpr (KS == 1 && NB == 1) {  // the instantiations with the grouped flush (mcl_set_problem only groups for them)
+    if constexpr (KS <= 1 && NB == 1) {  // the instantiations with the grouped flush (mcl_set_problem only groups for them)
         if (!launched && c->n_parts < n) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<KS, NB, NREG, DEPTH, NW, VEC, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
@@ -892,7 +920,7 @@ static int launch_sweep_t(mcl_context *c) {
     // 4 waves per block = one per SIMD (the kernel needs > 256 registers); K = 256, r <= 16 has room for a second
     // staging slot.  (Measured: 8 leaner waves per block = two per SIMD run no faster - fp32 MFMA and VALU work of two
     // waves do not co-execute (SQ_VALU_MFMA_COEXEC_CYCLES = 0) - and double the per-bseg partial traffic.)
-    return launch_sweep_w<KS, NB, NREG, 4, (KS * NB == 1) ? 2 : 1>(c);
+    return launch_sweep_w<KS, NB, NREG, 4, (KS <= 1 && NB == 1) ? 2 : 1>(c);
 }
 
 int mcl_launch_sweep(mcl_context *c) {
@@ -904,6 +932,7 @@ int mcl_launch_sweep(mcl_context *c) {
         default: return launch_sweep_t<KS_, NB_, 2>(c);   \
     }
     if (c->NB == 1) {
+        if (mcl_sweep_KC(c) == 2) { MCL_SW(0, 1) }
         if (ks == 1) { MCL_SW(1, 1) }
         MCL_SW(2, 1)
     }
