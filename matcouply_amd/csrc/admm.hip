@@ -1084,8 +1084,8 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
         }
     }
     if (rhs_lds != nullptr) {
-        // k_A_finish_rows_wide: the four waves of the workgroup each took a quarter of the slab's bsegs
-        rhs_pre = (rhs_lds[cc] + rhs_lds[32 + cc]) + (rhs_lds[64 + cc] + rhs_lds[96 + cc]);
+        // k_A_finish_rows_wide: the other three waves of the workgroup stream the slab's partials of M while this wave builds
+        // and inverts the system; their column sums are picked up behind the workgroup barrier after the Gauss-Jordan
     } else if (F.Mpart != nullptr) {
         // rhs_i[c] = sum_k M_i[k][c] C[k][c] over the slab's bsegs; the column's sum is fetched into the lanes that own it
         double acc0, acc1;
@@ -1119,6 +1119,10 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
     }
     gj_inverse_rows<RP>(col, r, in_range ? lane : cc);
     if (lane == 0) rhoA[i] = rho;
+    if (rhs_lds != nullptr) {
+        __syncthreads();
+        rhs_pre = (rhs_lds[cc] + rhs_lds[32 + cc]) + rhs_lds[64 + cc];
+    }
     const double rhs = act ? rhs_pre : 0.0;
     if (lead) rhsA_out[(long)i * r + c] = (float)rhs;  // the `rhses` by-product
     if (!fused_inner) {
@@ -1246,9 +1250,10 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(float *__restrict__ BtB, 
                            diag_row, next_B, l2_B, n_regs_B, rhoB, LinvB, slab_seg_ptr, seg_rhs, seg_btb, rhsA_out, F);
 }
 
-// One workgroup per slab: its four waves share the slab's M_bseg stream (rhs_i = sum over bsegs of coldot(M_bseg, C)),
-// then wave 0 finishes the slab as in k_A_finish_rows.  For slabs cut into 3..8 bsegs (the per-rank shards of a multi-GPU
-// run): one wave alone would stream them for longer than the k_A_rhs_from_M launch this replaces costs.
+// One workgroup per slab: waves 1..3 stream the slab's partials of M (rhs_i = sum over partials of coldot(M_part, C)) WHILE
+// wave 0 loads, builds and inverts the slab's system; one workgroup barrier behind the Gauss-Jordan hands the column sums
+// over, then wave 0 finishes the slab as in k_A_finish_rows.  Used whenever the finish forms rhs_i itself (1..8 partials
+// per slab): the M stream (16 KB per partial at K = 256, two 32-load trips) leaves the critical path of the iteration.
 template <int RP>
 __global__ __launch_bounds__(256) void k_A_finish_rows_wide(float *__restrict__ BtB, const double *__restrict__ CtC, int I,
                                                             int r, float scale, float l2, int constant,
@@ -1262,14 +1267,16 @@ __global__ __launch_bounds__(256) void k_A_finish_rows_wide(float *__restrict__ 
                                                             const double *__restrict__ seg_rhs,
                                                             const double *__restrict__ seg_btb,
                                                             float *__restrict__ rhsA_out, AFuse F) {
-    __shared__ double part[4][32];
+    __shared__ double part[3][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x;
-    double a0, a1;
-    m_coldot(F, slab_seg_ptr[i] + wave, slab_seg_ptr[i + 1], 4, lane, a0, a1);
-    if (lane < 16) part[wave][lane] = a0, part[wave][16 + lane] = a1;
-    __syncthreads();
-    if (wave != 0) return;
+    if (wave != 0) {
+        double a0, a1;
+        m_coldot(F, slab_seg_ptr[i] + wave - 1, slab_seg_ptr[i + 1], 3, lane, a0, a1);
+        if (lane < 16) part[wave - 1][lane] = a0, part[wave - 1][16 + lane] = a1;
+        __syncthreads();  // pairs with the barrier of wave 0 behind its Gauss-Jordan (a_finish_rows_slab)
+        return;
+    }
     a_finish_rows_slab<RP>(i, lane, BtB, CtC, r, scale, l2, constant, rho_max, rhoA, LinvA, A, regs, inner, fused_inner, e1,
                            diag_row, next_B, l2_B, n_regs_B, rhoB, LinvB, slab_seg_ptr, seg_rhs, seg_btb, rhsA_out, F,
                            &part[0][0]);

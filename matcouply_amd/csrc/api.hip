@@ -806,11 +806,14 @@ int mcl_A_begin(mcl_context *c) {
         // the sweep left M_i = X_i^T B_i per bseg: rhs_i = coldot(M_i, C), no pass over X
         if (int rc = ensure_cfrag_sweep(c)) return rc;
         // rank 5..32: the finish kernel forms rhs_i from the sweep's M partials itself (one launch less); otherwise a
-        // separate pass.  One partial per slab: the finishing wave streams it (16 KB at K = 256) in front of its
-        // Gauss-Jordan; 2..8 partials (per-rank shards of config 3: one wave alone took 27 us for 8, against 5 + 13 us
-        // apart): the four waves of a workgroup per slab share them (k_A_finish_rows_wide); beyond that the separate kernel
+        // separate pass.  Up to 8 partials per slab a workgroup per slab streams them on three waves while the fourth inverts
+        // the system (k_A_finish_rows_wide; one wave alone took 27 us for 8 partials, against 5 + 13 us apart); one partial
+        // per slab on big problems: the finishing wave streams it (16 KB at K = 256) in front of its Gauss-Jordan; more
+        // than 8: the separate kernel
         const bool fusable = (c->RP == 8 || c->RP == 16 || c->RP == 32) && !c->sw.a_finish_cols && !c->sw.no_a_fusion;
-        c->a_rhs_wide = fusable && c->n_parts > c->I && c->n_parts <= 8 * c->I && !c->sw.no_a_wide;
+        // (with one partial per slab only while all the workgroups are resident at once - two per CU: beyond 512 slabs a
+        // second round of workgroups would cost more than the overlap returns, config 3: +4 us)
+        c->a_rhs_wide = fusable && c->n_parts <= 8 * c->I && (c->n_parts > c->I || c->I <= 512) && !c->sw.no_a_wide;
         c->a_rhs_from_M = fusable && (c->n_parts <= c->I || c->a_rhs_wide);
         if (!c->a_rhs_from_M)
             if (int rc = mcl_launch_A_rhs_from_M(c)) return rc;
