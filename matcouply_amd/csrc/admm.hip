@@ -1254,7 +1254,9 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(float *__restrict__ BtB, 
 // wave 0 loads, builds and inverts the slab's system; one workgroup barrier behind the Gauss-Jordan hands the column sums
 // over, then wave 0 finishes the slab as in k_A_finish_rows.  Used whenever the finish forms rhs_i itself (1..8 partials
 // per slab): the M stream (16 KB per partial at K = 256, two 32-load trips) leaves the critical path of the iteration.
-template <int RP>
+// SPB = 2 (more than 512 slabs, one partial per slab - config 3): two slabs per workgroup, one system wave and one streaming
+// wave each, so that 1024 slabs still fit the device in one round (two workgroups per CU).
+template <int RP, int SPB>
 __global__ __launch_bounds__(256) void k_A_finish_rows_wide(float *__restrict__ BtB, const double *__restrict__ CtC, int I,
                                                             int r, float scale, float l2, int constant,
                                                             const float *__restrict__ rho_max, float *__restrict__ rhoA,
@@ -1267,19 +1269,28 @@ __global__ __launch_bounds__(256) void k_A_finish_rows_wide(float *__restrict__ 
                                                             const double *__restrict__ seg_rhs,
                                                             const double *__restrict__ seg_btb,
                                                             float *__restrict__ rhsA_out, AFuse F) {
-    __shared__ double part[3][32];
+    __shared__ double part[SPB][3][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x;
-    if (wave != 0) {
-        double a0, a1;
-        m_coldot(F, slab_seg_ptr[i] + wave - 1, slab_seg_ptr[i + 1], 3, lane, a0, a1);
-        if (lane < 16) part[wave - 1][lane] = a0, part[wave - 1][16 + lane] = a1;
-        __syncthreads();  // pairs with the barrier of wave 0 behind its Gauss-Jordan (a_finish_rows_slab)
+    constexpr int WPS = 4 / SPB;                  // waves per slab: one system wave + WPS - 1 streaming waves
+    const int sl = wave / WPS, role = wave % WPS;  // role 0: the system wave
+    const int i = blockIdx.x * SPB + sl;
+    if (role != 0) {
+        double a0 = 0.0, a1 = 0.0;
+        if (i < I) m_coldot(F, slab_seg_ptr[i] + role - 1, slab_seg_ptr[i + 1], WPS - 1, lane, a0, a1);
+        if (lane < 16) {
+            part[sl][role - 1][lane] = a0, part[sl][role - 1][16 + lane] = a1;
+            if (SPB == 2) part[sl][1][lane] = part[sl][1][16 + lane] = part[sl][2][lane] = part[sl][2][16 + lane] = 0.0;
+        }
+        __syncthreads();  // pairs with the barrier of the system wave behind its Gauss-Jordan (a_finish_rows_slab)
+        return;
+    }
+    if (i >= I) {  // the odd slab out of a two-slab workgroup
+        __syncthreads();
         return;
     }
     a_finish_rows_slab<RP>(i, lane, BtB, CtC, r, scale, l2, constant, rho_max, rhoA, LinvA, A, regs, inner, fused_inner, e1,
                            diag_row, next_B, l2_B, n_regs_B, rhoB, LinvB, slab_seg_ptr, seg_rhs, seg_btb, rhsA_out, F,
-                           &part[0][0]);
+                           &part[sl][0][0]);
 }
 
 // rho_i of the A-phase alone (needed before the systems when the feasibility penalty is constant)
@@ -1712,10 +1723,17 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     if (!rows_kernel) {
         DISPATCH_RP_T(c, k_A_finish, grid, block, MCL_AF_ARGS);
     } else if (c->a_rhs_wide) {
-        const dim3 gw((unsigned)c->I);
-        if (c->RP == 8) hipLaunchKernelGGL((k_A_finish_rows_wide<8>), gw, block, 0, c->stream, MCL_AF_ARGS, F);
-        else if (c->RP == 16) hipLaunchKernelGGL((k_A_finish_rows_wide<16>), gw, block, 0, c->stream, MCL_AF_ARGS, F);
-        else hipLaunchKernelGGL((k_A_finish_rows_wide<32>), gw, block, 0, c->stream, MCL_AF_ARGS, F);
+        if (c->a_rhs_pairs) {  // two slabs per workgroup (one partial per slab, many slabs)
+            const dim3 gp((unsigned)((c->I + 1) / 2));
+            if (c->RP == 8) hipLaunchKernelGGL((k_A_finish_rows_wide<8, 2>), gp, block, 0, c->stream, MCL_AF_ARGS, F);
+            else if (c->RP == 16) hipLaunchKernelGGL((k_A_finish_rows_wide<16, 2>), gp, block, 0, c->stream, MCL_AF_ARGS, F);
+            else hipLaunchKernelGGL((k_A_finish_rows_wide<32, 2>), gp, block, 0, c->stream, MCL_AF_ARGS, F);
+        } else {
+            const dim3 gw((unsigned)c->I);
+            if (c->RP == 8) hipLaunchKernelGGL((k_A_finish_rows_wide<8, 1>), gw, block, 0, c->stream, MCL_AF_ARGS, F);
+            else if (c->RP == 16) hipLaunchKernelGGL((k_A_finish_rows_wide<16, 1>), gw, block, 0, c->stream, MCL_AF_ARGS, F);
+            else hipLaunchKernelGGL((k_A_finish_rows_wide<32, 1>), gw, block, 0, c->stream, MCL_AF_ARGS, F);
+        }
     } else if (c->RP == 8) {
         hipLaunchKernelGGL((k_A_finish_rows<8>), grid, block, 0, c->stream, MCL_AF_ARGS, F);
     } else if (c->RP == 16) {

@@ -802,6 +802,7 @@ int mcl_A_begin(mcl_context *c) {
     c->seg_from_sweep = false;
     c->a_rhs_from_M = false;
     c->a_rhs_wide = false;
+    c->a_rhs_pairs = false;
     if (c->mseg_valid && !c->opt.constant_A && mcl_mode_is_row_separable(c, 0)) {
         // the sweep left M_i = X_i^T B_i per bseg: rhs_i = coldot(M_i, C), no pass over X
         if (int rc = ensure_cfrag_sweep(c)) return rc;
@@ -814,6 +815,9 @@ int mcl_A_begin(mcl_context *c) {
         // (with one partial per slab only while all the workgroups are resident at once - two per CU: beyond 512 slabs a
         // second round of workgroups would cost more than the overlap returns, config 3: +4 us)
         c->a_rhs_wide = fusable && c->n_parts <= 8 * c->I && (c->n_parts > c->I || c->I <= 512) && !c->sw.no_a_wide;
+        // ... up to 1024 slabs two slabs share a workgroup: one system wave and one streaming wave each
+        c->a_rhs_pairs = fusable && !c->a_rhs_wide && c->n_parts <= c->I && c->I <= 1024 && !c->sw.no_a_wide;
+        if (c->a_rhs_pairs) c->a_rhs_wide = true;
         c->a_rhs_from_M = fusable && (c->n_parts <= c->I || c->a_rhs_wide);
         if (!c->a_rhs_from_M)
             if (int rc = mcl_launch_A_rhs_from_M(c)) return rc;

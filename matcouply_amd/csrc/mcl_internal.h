@@ -165,6 +165,7 @@ struct mcl_context {
     // launch fusion of the A-phase finish (admm.hip: AFuse)
     bool a_rhs_from_M = false;       // k_A_finish_rows forms rhs_i from the sweep's M_bseg itself
     bool a_rhs_wide = false;         // ... with one workgroup (four waves) per slab: k_A_finish_rows_wide
+    bool a_rhs_pairs = false;        // ... or two slabs per workgroup (one system + one streaming wave each)
 
     double *colsq = nullptr;    // [max(I,1), r]   per-slab column sums of squares (L2Ball)
     double *uni_f64 = nullptr;  // unimodal regression scratch: 8 fp64 arrays of (rows + slabs) * r
