@@ -869,7 +869,7 @@ static int launch_sweep_v(mcl_context *c) {
                        c->sw.sweep_dbg, c->sweep_cycles, c->bseg_part)
     bool launched = false;
     if constexpr (KS == 1 && NB == 1 && VEC) {  // the instrumented twin exists for the config-2/3 variants only
-        if (c->sw.sweep_dbg != 0) {
+        if (c->sw.sweep_dbg != 0 && c->n_parts == n) {  // (the twin has no grouped flush: a plan with grouped partials keeps GRP)
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<KS, NB, NREG, DEPTH, NW, VEC, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) == hipSuccess) {
                 MCL_SWEEP_LAUNCH(true, false);
