@@ -343,6 +343,7 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     c->RP = mcl_pad_rank(rank);
     c->NB = (rank + 15) / 16;
     if (c->NB == 3) c->NB = 4;
+    c->sweep_kc = (K <= 128 && c->NB == 1 && !c->sw.no_sweep_half) ? 2 : 4 * (int)((K + 255) / 256);
     c->h_slab_of_row.resize((size_t)N);
     c->h_tile_slab.clear(), c->h_tile_row0.clear(), c->h_tile_nrows.clear();
     c->h_seg_slab.clear(), c->h_seg_row0.clear(), c->h_seg_nrows.clear();

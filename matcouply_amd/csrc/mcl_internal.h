@@ -130,6 +130,7 @@ struct mcl_context {
     int *slab_part_ptr = nullptr;   // int32[I+1] first partial of every slab
     std::vector<int> h_bseg_part, h_slab_part_ptr;
     int n_parts = 0;
+    int sweep_kc = 4;               // 64-column chunks of the sweep's tiles / partial images (mcl_sweep_KC)
     int *wave_bseg_ptr = nullptr;  // int32[n_bseg_waves+1] first bseg of every wave of the sweep
     std::vector<int> h_wave_bseg_ptr;
     int n_bseg_waves = 0;

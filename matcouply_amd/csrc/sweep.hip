@@ -825,7 +825,8 @@ __global__ __launch_bounds__(256) void k_A_rhs_from_M(const float *__restrict__ 
 // row accesses of X; other K are zero-padded through the C fragments), Kpad * NB <= 512 (accumulator registers).
 int mcl_sweep_KS(const mcl_context *c) { return (int)((c->K + 255) / 256); }
 // 64-column chunks of a tile row / of the M partials: 2 for the half-width kernels (K <= 128, rank <= 16), else 4 per 256
-int mcl_sweep_KC(const mcl_context *c) { return (c->K <= 128 && c->NB == 1 && !c->sw.no_sweep_half) ? 2 : 4 * mcl_sweep_KS(c); }
+// (decided once per problem, mcl_set_problem: the partial buffers are sized with it)
+int mcl_sweep_KC(const mcl_context *c) { return c->sweep_kc; }
 
 bool mcl_sweep_shape_ok(const mcl_context *c) {
     if (c->sw.no_sweep) return false;
