@@ -31,6 +31,8 @@ CASES = {
     "k36_r4_none": ([90, 200, 64], 36, 4, [[NN], [], [NN]], (False, False)),
     # K <= 128: the half-width kernels (two rows per wave load), with padded columns and a short second row pair
     "k100_r8_nn": ([150, 400, 260, 97], 100, 8, [[NN], [NN], [NN]], (False, False)),
+    # more than 512 slabs with one partial each: the A-phase finish pairs two slabs per workgroup; the odd slab out
+    "pairs_515_slabs": ([64] * 515, 64, 8, [[NN], [NN], [NN]], (False, False)),
     "k36_r4_nn": ([90, 200, 64, 33], 36, 4, [[NN], [{"kind": "l1", "reg_strength": 0.02, "non_negativity": True}], [NN]], (False, False)),
     "k508_r16_nn": ([130, 222, 97], 508, 16, [[NN], [NN], [NN]], (False, False)),
     # ranks that are not a multiple of 4: scalar row accesses of B / aux / dual
