@@ -7,6 +7,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmatcouply_hip.so")
 SOURCES = ["contract.hip", "admm.hip", "generic.hip", "sweep.hip", "reconstruct.hip", "api.hip"]
+# per-file compiler options.  sweep.hip: let small MFMA results live in VGPRs - by default the register allocator parks the
+# 4-register accumulators of the inner loop / X C product in AGPRs and copies them back for every VALU use (468
+# v_accvgpr_* instructions in the config-3 kernel, 129 with the option; no scratch either way)
+EXTRA_FLAGS = {"sweep.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _stale():
@@ -26,7 +30,8 @@ def build_library(force=False, verbose=True):
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(src, []) + [
+            "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

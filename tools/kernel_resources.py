@@ -16,8 +16,11 @@ def demangle(names):
 
 
 def resources(src):
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", "/dev/null",
-           "-Rpass-analysis=kernel-resource-usage"]
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from matcouply_amd._build import EXTRA_FLAGS  # the per-file options the library is built with
+
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(os.path.basename(src), []) + [
+        "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
     err = subprocess.run(cmd, capture_output=True, text=True).stderr
     rows, cur = [], None
     for line in err.splitlines():
