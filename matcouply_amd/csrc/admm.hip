@@ -968,6 +968,12 @@ static __device__ __forceinline__ double lead_sum(double v) {
 struct AFuse {
     const float *Mpart, *Cfrag;
     int MS, NBm;
+    // the C-phase finish over several workgroups (k_C_finish_multi) leaves C^T C as ctc_parts partial 16 x 16 fp64 blocks:
+    // the finish sums them (fixed order) and slab 0 writes the totals out for everybody else
+    int ctc_parts;
+    const double *CtCpart;
+    double *CtC64_out;
+    float *CtC_out;
 };
 
 // sum_k M[k][c] C[k][c] over the bsegs sgA, sgA + step, ... < sgB, both operands in C-fragment order (element
@@ -1045,10 +1051,36 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
     }
     // all global loads up front
     double ctc[RL], btbv[RL];
+    if (F.ctc_parts > 0) {
+        for (int pb = 0; pb < F.ctc_parts; pb += 4) {  // four partial blocks per trip: independent clamped loads, added in order
+            double v[4][RL];
 #pragma unroll
-    for (int j = 0; j < RL; ++j) {
-        ctc[j] = CtC[drow[j] * r + c];
-        btbv[j] = 0.0;
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < RL; ++j) v[u][j] = F.CtCpart[(long)min(pb + u, F.ctc_parts - 1) * 256 + drow[j] * 16 + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (pb + u < F.ctc_parts) {
+#pragma unroll
+                    for (int j = 0; j < RL; ++j) ctc[j] = (pb + u == 0) ? v[u][j] : ctc[j] + v[u][j];
+                }
+        }
+        if (i == 0) {
+#pragma unroll
+            for (int j = 0; j < RL; ++j)
+                if (dok[j]) {
+                    F.CtC64_out[drow[j] * r + c] = ctc[j];
+                    F.CtC_out[drow[j] * r + c] = (float)ctc[j];
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < RL; ++j) btbv[j] = 0.0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {
+            ctc[j] = CtC[drow[j] * r + c];
+            btbv[j] = 0.0;
+        }
     }
     double rhs_pre = 0.0;
     float z[MCL_MAX_REGS], u[MCL_MAX_REGS], on[MCL_MAX_REGS];
@@ -1668,11 +1700,163 @@ static int launch_C_fused_t(mcl_context *c) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The C-side finish over ceil(K / 64) workgroups (rank <= 16, penalised C, K >= 128).  In the single workgroup of
+// k_C_finish_fused the 16-row tiles of C queue four deep on every SIMD (9 k of its 23.5 k cycles at K = 256) and C^T C, the
+// fragment image and the barriers see all K rows; here a workgroup owns 64 rows = one 16-row tile per wave = one 64-column
+// chunk of the fragment image.  Every workgroup builds and inverts the (identical) r x r system itself - same inputs,
+// same instructions, same bits - so nothing crosses workgroups inside the launch: C^T C leaves as one partial 16 x 16
+// fp64 block per workgroup, which the A-phase finish sums in fixed order (AFuse::ctc_parts; ensure_ctc folds them for
+// any other consumer).
+// ---------------------------------------------------------------------------------------------------------
+template <int NREG, bool VEC>
+__global__ __launch_bounds__(256) void k_C_finish_multi(const double *__restrict__ GR, int K, int r, float scale, float l2,
+                                                        float *__restrict__ rhoC, float *__restrict__ LinvC,
+                                                        float *__restrict__ C, RegSet regs, int inner,
+                                                        double *__restrict__ CtCpart, float *__restrict__ Cfrag, int KC,
+                                                        double *__restrict__ diag_row) {
+    __shared__ float Ls[256];
+    __shared__ float Cs[64 * 16];
+    __shared__ double dsm[4][DIAG_COLS];
+    __shared__ double slots[4][256];
+    __shared__ float rho_s;
+    constexpr int RP = 16, RL = GJRows<RP>::RL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b0 = 64 * blockIdx.x;
+    const long row0 = b0 + 16 * wave;
+    const int nrows = max(0, min(16, K - (int)row0));
+    RowBlock<1, NREG, VEC> pre;
+    if (nrows > 0) pre.load(lane, row0 + ((lane & 15) < nrows ? (lane & 15) : 0), r, nullptr, GR + (long)r * r, regs);
+    if (wave == 0) {  // the system, as in k_C_finish_fused
+        const int cc = lane % RP, g = lane / RP;
+        const bool act = cc < r;
+        const int cl = act ? cc : 0;
+        double gv[RL];
+        double tr = 0.0;
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {
+            const int d = g * RL + j;
+            gv[j] = GR[(d < r ? d : r - 1) * r + cl];
+        }
+#pragma unroll
+        for (int j = 0; j < RL; ++j)
+            if (act && g * RL + j == cc) tr = gv[j];
+        tr = wave_sum(tr);
+        const float rho = (float)(0.5 * tr * scale);
+        const double shift = (double)rho * NREG + (double)l2;
+        double col[RL];
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {
+            const int d = g * RL + j;
+            double v = (d == cc) ? 1.0 : 0.0;
+            if (act && d < r) v = gv[j] + (d == cc ? shift : 0.0);
+            col[j] = v;
+        }
+        gj_inverse_rows<RP>(col, r, lane);
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {
+            const int d = g * RL + j;
+            if (act && d < r) {
+                Ls[d * r + cc] = (float)col[j];
+                if (blockIdx.x == 0) LinvC[d * r + cc] = (float)col[j];
+            }
+        }
+        if (lane == 0) {
+            rho_s = rho;
+            if (blockIdx.x == 0) rhoC[0] = rho;
+        }
+    }
+    __syncthreads();
+    double dg[DIAG_COLS];
+    // (the LDS copy is indexed by the GLOBAL row like C itself: its base is shifted back by the workgroup's first row)
+    rows_fused_tile<1, NREG, VEC>(lane, row0, nrows, rho_s, Ls, nullptr, nullptr, C, Cs - (long)b0 * r, regs, r, inner, dg,
+                                  GR + (long)r * r, &pre);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 2 + NREG; ++k) dsm[wave][k] = dg[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 + NREG)  // one diagnostics row per workgroup
+        diag_row[(long)blockIdx.x * DIAG_COLS + threadIdx.x] =
+            (dsm[0][threadIdx.x] + dsm[1][threadIdx.x]) + (dsm[2][threadIdx.x] + dsm[3][threadIdx.x]);
+    // partial C^T C of the workgroup's rows on the fp64 MFMA (fp32 x fp32 products are exact in fp64)
+    {
+        typedef double f64x4 __attribute__((ext_vector_type(4)));
+        const int rsub = lane >> 4, c16 = lane & 15;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int rl = 4 * (4 * gq + wave) + rsub;  // groups of 4 rows, interleaved over the waves
+            const double y = (b0 + rl < K && c16 < r) ? (double)Cs[rl * r + c16] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) slots[wave][(rsub + 4 * v) * 16 + c16] = acc[v];
+        __syncthreads();
+        const int e = threadIdx.x;
+        CtCpart[(long)blockIdx.x * 256 + e] = (slots[0][e] + slots[1][e]) + (slots[2][e] + slots[3][e]);
+    }
+    // the workgroup's chunk of the fragment image of C (see k_build_cfrag; NB = 1): 1024 floats; the last workgroup also
+    // clears the chunks past K
+    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+        const int m = idx & 3, ln = (idx >> 2) & 63, kq = idx >> 8;
+        const int kl = 16 * kq + 4 * (ln >> 4) + m, col = ln & 15;
+        Cfrag[(long)blockIdx.x * 1024 + idx] = (b0 + kl < K && col < r) ? Cs[kl * r + col] : 0.f;
+    }
+    if (blockIdx.x == gridDim.x - 1)
+        for (long idx = (long)gridDim.x * 1024 + threadIdx.x; idx < (long)KC * 1024; idx += 256) Cfrag[idx] = 0.f;
+}
+
+// C^T C from the partial blocks of k_C_finish_multi, for the consumers other than the A-phase finish
+__global__ __launch_bounds__(256) void k_ctc_fold(const double *__restrict__ CtCpart, int parts, int r, float *__restrict__ CtC,
+                                                  double *__restrict__ CtC64) {
+    const int e = threadIdx.x, a = e >> 4, b = e & 15;
+    double t = 0.0;
+    for (int p = 0; p < parts; ++p) t = (p == 0) ? CtCpart[e] : t + CtCpart[(long)p * 256 + e];
+    if (a < r && b < r) {
+        CtC64[a * r + b] = t;
+        CtC[a * r + b] = (float)t;
+    }
+}
+
+int mcl_launch_ctc_fold(mcl_context *c) {
+    hipLaunchKernelGGL(k_ctc_fold, dim3(1), dim3(256), 0, c->stream, c->CtCpart, c->ctc_parts, c->r, c->CtC, c->CtC64);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    c->ctc_parts = 0;
+    return 0;
+}
+
+template <int NREG>
+static int launch_C_multi_t(mcl_context *c) {
+    const RegSet &rs = c->regs[2];
+    bool vec = (c->r % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->C) & 15) == 0) && ((c->r * c->r) % 4 == 0);
+    for (int k = 0; k < rs.n; ++k)
+        vec = vec && ((reinterpret_cast<uintptr_t>(rs.aux[k]) & 15) == 0) && ((reinterpret_cast<uintptr_t>(rs.dual[k]) & 15) == 0);
+    const int nblk = (int)((c->K + 63) / 64);
+#define MCL_CM(VEC_)                                                                                                   \
+    hipLaunchKernelGGL((k_C_finish_multi<NREG, VEC_>), dim3(nblk), dim3(256), 0, c->stream, c->GR, (int)c->K, c->r,       \
+                       (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[2], c->rhoC, c->LinvC, c->C, rs, \
+                       c->opt.inner_n_iter_max, c->CtCpart, c->Cfrag, mcl_cfrag_chunks(c), c->diagC_tile)
+    if (vec) MCL_CM(true);
+    else MCL_CM(false);
+#undef MCL_CM
+    MCL_CHECK_HIP(c, hipGetLastError());
+    c->diag_rows[2] = nblk;
+    c->ctc_parts = nblk;
+    return 0;
+}
+
 // Single-workgroup C-side finish; returns -1 if the shape has no instantiation (caller uses the separate kernels)
 int mcl_launch_C_finish_fused(mcl_context *c) {
     if (c->K > 1024 || c->sw.no_fused_c) return -1;
     if ((size_t)(c->r * c->r + c->K * c->r) * sizeof(float) > 150 * 1024) return -1;
     const int n = c->regs[2].n;
+    c->ctc_parts = 0;
+    // rank <= 16 with penalties on C and at least two 64-row chunks: one workgroup per chunk (k_C_finish_multi); the
+    // fragment image is then the one of the sweep / X C kernels with NB = 1
+    if (c->r <= 16 && n >= 1 && n <= 2 && c->K >= 128 && c->NB == 1 && !c->sw.no_multi_c &&
+        mcl_cfrag_chunks(c) >= (int)((c->K + 63) / 64))
+        return n == 1 ? launch_C_multi_t<1>(c) : launch_C_multi_t<2>(c);
     if (c->r <= 16) {
         switch (n) {
             case 0: return launch_C_fused_t<1, 0>(c);
@@ -1714,11 +1898,14 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
         (const double *)c->seg_rhs, (const double *)((seg && c->seg_from_sweep) ? c->part_btb : c->seg_btb), c->rhsA
     // what the row-split kernel absorbs: rhs_i from the sweep's M_bseg
     AFuse F{};
+    F.ctc_parts = c->ctc_parts, F.CtCpart = c->CtCpart, F.CtC64_out = c->CtC64, F.CtC_out = c->CtC;
     if (c->a_rhs_from_M) {
         F.Mpart = c->Mpart, F.Cfrag = c->CfragS, F.NBm = c->NB;
         F.MS = mcl_sweep_KC(c) * 64 * 16 * c->NB;
     }
     const bool rows_kernel = !(c->RP == 64 || c->RP == 4 || c->sw.a_finish_cols);
+    if (!rows_kernel && c->ctc_parts > 0)
+        if (int rc = mcl_launch_ctc_fold(c)) return rc;
     // ranks 5..32: rows of every system split over the lane groups (all 64 lanes busy); 64 columns fill the wave anyway
     if (!rows_kernel) {
         DISPATCH_RP_T(c, k_A_finish, grid, block, MCL_AF_ARGS);
@@ -1743,6 +1930,7 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     }
 #undef MCL_AF_ARGS
     MCL_CHECK_HIP(c, hipGetLastError());
+    c->ctc_parts = 0;  // the rows kernels wrote the totals
     c->b_systems_valid = (next_B != 0);
     return 0;
 }

@@ -77,6 +77,7 @@ int64_t plan(mcl_context *c, char *base) {
     if (c->sweep_planned) c->CfragS = c->Cfrag;
     c->CtC = b.take<float>(r * r);
     c->CtC64 = b.take<double>(r * r);
+    c->CtCpart = b.take<double>(16 * 256);
     c->rhoB = b.take<float>(I);
     c->LinvB = b.take<float>(I * r * r);
     c->LinvB64 = (c->regs[1].n == 0) ? b.take<double>(I * r * r) : nullptr;
@@ -149,7 +150,7 @@ void read_switches(mcl_switches &w) {
     w.no_fused_gram = flag("MCL_NO_FUSED_GRAM"), w.no_fused_c = flag("MCL_NO_FUSED_C");
     w.a_finish_cols = flag("MCL_A_FINISH_COLS"), w.xc_norow = flag("MCL_XC_NOROW");
     w.unimodal_v3 = flag("MCL_UNIMODAL_V3"), w.stats_reduce = flag("MCL_STATS_REDUCE");
-    w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_a_wide = flag("MCL_NO_A_WIDE"), w.no_bseg_groups = flag("MCL_NO_BSEG_GROUPS"), w.no_sweep_half = flag("MCL_NO_SWEEP_HALF"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1");
+    w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_a_wide = flag("MCL_NO_A_WIDE"), w.no_bseg_groups = flag("MCL_NO_BSEG_GROUPS"), w.no_sweep_half = flag("MCL_NO_SWEEP_HALF"), w.no_multi_c = flag("MCL_NO_MULTI_C"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1");
     w.seg_rows = num("MCL_SEG_ROWS", 0), w.bseg_rows = num("MCL_BSEG_ROWS", 0);
     w.xc_waves = num("MCL_XC_WAVES", 0), w.xt_waves = num("MCL_XT_WAVES", 0), w.sweep_waves = num("MCL_SWEEP_WAVES", 0);
     w.xc_dbg = num("MCL_XC_DBG", 0), w.xt_dbg = num("MCL_XT_DBG", 0), w.xt_depth = num("MCL_XT_DEPTH", 0);
@@ -206,6 +207,9 @@ int ensure_ctc(mcl_context *c) {
     if (!c->ctc_valid) {
         if (int rc = mcl_launch_ctc(c)) return rc;
         c->ctc_valid = true;
+        c->ctc_parts = 0;
+    } else if (c->ctc_parts > 0) {  // current, but still in the partial blocks of k_C_finish_multi
+        if (int rc = mcl_launch_ctc_fold(c)) return rc;
     }
     return 0;
 }
@@ -796,7 +800,11 @@ int mcl_update_C_finish(mcl_context *c) {
 // ---- A-phase -------------------------------------------------------------------------------------------
 int mcl_A_begin(mcl_context *c) {
     if (int rc = ready(c)) return rc;
-    if (int rc = ensure_ctc(c)) return rc;
+    // C^T C still in the partial blocks of k_C_finish_multi: the rows kernels of the A-phase finish sum them themselves (and
+    // write the totals); anything else - the constant-rho pre-pass, the column-layout finish - gets them folded first
+    const bool rows_finish = !(c->RP == 64 || c->RP == 4 || c->sw.a_finish_cols) && !c->opt.constant_A;
+    if (!(c->ctc_valid && c->ctc_parts > 0 && rows_finish))
+        if (int rc = ensure_ctc(c)) return rc;
     // When X C has to be recomputed anyway (C changed), the per-slab reductions ride in its epilogue; the
     // constant-rho pre-pass (k_A_rho) needs the assembled per-slab Gram, so it keeps the separate kernel.
     c->use_seg_gram = false;
@@ -1004,7 +1012,10 @@ float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {
         case 3: p = c->rhoB, n = c->I; break;
         case 4: p = c->rhoA, n = c->I; break;
         case 5: p = c->rhoC, n = 1; break;
-        case 6: p = c->CtC, n = (int64_t)c->r * c->r; break;
+        case 6:
+            if (c->ctc_valid && c->ctc_parts > 0) (void)mcl_launch_ctc_fold(c);
+            p = c->CtC, n = (int64_t)c->r * c->r;
+            break;
         case 7: p = c->LinvB, n = c->I * c->r * c->r; break;
         case 9: p = reinterpret_cast<float *>(c->pf2_acc), n = c->pf2_acc ? 2 * c->I * ((int64_t)c->r * c->r + 1) : 0; break;
         case 10: p = reinterpret_cast<float *>(c->pf2_S), n = c->pf2_S ? 2 * c->I * (int64_t)c->r * c->r : 0; break;

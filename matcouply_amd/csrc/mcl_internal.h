@@ -57,7 +57,7 @@ struct mcl_switches {
     bool no_sweep = false, no_pass_chain = false, no_pf2_delta_fusion = false, ns_plain = false, pf2_jacobi = false;
     bool no_stack_fusion = false, no_solve_stats = false, no_next_b = false, no_fused_gram = false, no_fused_c = false;
     bool a_finish_cols = false, xc_norow = false, unimodal_v3 = false, stats_reduce = false;
-    bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_sweep_half = false, no_diag_defer = false, xc_depth1 = false;
+    bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_sweep_half = false, no_multi_c = false, no_diag_defer = false, xc_depth1 = false;
     int seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
     int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
 };
@@ -184,6 +184,8 @@ struct mcl_context {
     // validity of cached by-products
     bool xc_valid = false;      // XC == X @ C for the current C
     bool ctc_valid = false;     // CtC == C^T C for the current C
+    int ctc_parts = 0;          // > 0: ... as that many partial blocks in CtCpart, not yet folded (k_C_finish_multi)
+    double *CtCpart = nullptr;  // [16, 16, 16] fp64
     bool cfrag_valid = false;   // Cfrag is the fragment image of the current C
     bool e1_valid = false;      // e1/rhsA/BtB consistent with the current factors (A-phase just ran)
     bool diag_valid[3] = {false, false, false};  // per-mode diag tables consistent with factors/aux
@@ -273,6 +275,7 @@ int mcl_launch_A_rhs_from_M(mcl_context *c);     // seg_rhs[bseg] = coldot(M_bse
 
 // ---- launchers implemented in admm.hip ---------------------------------------------------------------
 int mcl_launch_ctc(mcl_context *c);
+int mcl_launch_ctc_fold(mcl_context *c);
 int mcl_launch_B_rho(mcl_context *c);
 int mcl_launch_B_systems(mcl_context *c);
 int mcl_launch_B_solve_f64(mcl_context *c);                      // penalty-free B: B_i = ((X_i C) o a_i) L_i^-1 in fp64
