@@ -116,8 +116,6 @@ static __device__ __forceinline__ void gj_inverse_rows(double (&col)[GJRows<RP>:
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
         if (p < r) {  // wave-uniform
-            constexpr int dummy = 0;
-            (void)dummy;
             const int pg = p / RL, pj = p % RL;
             const double pivot = readlane_f64(col[pj], pg * RP + p);
             double cp[RL];
@@ -1116,8 +1114,8 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
         }
     }
     if (rhs_lds != nullptr) {
-        // k_A_finish_rows_wide: the other three waves of the workgroup stream the slab's partials of M while this wave builds
-        // and inverts the system; their column sums are picked up behind the workgroup barrier after the Gauss-Jordan
+        // k_A_finish_rows_wide: the slab's other wave(s) stream its partials of M while this wave builds and inverts the
+        // system; their column sums are picked up behind the workgroup barrier after the Gauss-Jordan
     } else if (F.Mpart != nullptr) {
         // rhs_i[c] = sum_k M_i[k][c] C[k][c] over the slab's bsegs; the column's sum is fetched into the lanes that own it
         double acc0, acc1;
