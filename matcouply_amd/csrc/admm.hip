@@ -1699,7 +1699,7 @@ static int launch_C_fused_t(mcl_context *c) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The C-side finish over ceil(K / 64) workgroups (rank <= 16, penalised C, K >= 128).  In the single workgroup of
+// The C-side finish over ceil(K / 64) workgroups (rank <= 16, K >= 128).  In the single workgroup of
 // k_C_finish_fused the 16-row tiles of C queue four deep on every SIMD (9 k of its 23.5 k cycles at K = 256) and C^T C, the
 // fragment image and the barriers see all K rows; here a workgroup owns 64 rows = one 16-row tile per wave = one 64-column
 // chunk of the fragment image.  Every workgroup builds and inverts the (identical) r x r system itself - same inputs,
@@ -1718,13 +1718,15 @@ __global__ __launch_bounds__(256) void k_C_finish_multi(const double *__restrict
     __shared__ double dsm[4][DIAG_COLS];
     __shared__ double slots[4][256];
     __shared__ float rho_s;
+    __shared__ double Ls64[NREG == 0 ? 256 : 1];  // penalty-free C: the solve itself runs in fp64 (as in k_C_finish_fused)
     constexpr int RP = 16, RL = GJRows<RP>::RL;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b0 = 64 * blockIdx.x;
     const long row0 = b0 + 16 * wave;
     const int nrows = max(0, min(16, K - (int)row0));
     RowBlock<1, NREG, VEC> pre;
-    if (nrows > 0) pre.load(lane, row0 + ((lane & 15) < nrows ? (lane & 15) : 0), r, nullptr, GR + (long)r * r, regs);
+    if (NREG > 0 && nrows > 0)
+        pre.load(lane, row0 + ((lane & 15) < nrows ? (lane & 15) : 0), r, nullptr, GR + (long)r * r, regs);
     if (wave == 0) {  // the system, as in k_C_finish_fused
         const int cc = lane % RP, g = lane / RP;
         const bool act = cc < r;
@@ -1756,6 +1758,7 @@ __global__ __launch_bounds__(256) void k_C_finish_multi(const double *__restrict
             const int d = g * RL + j;
             if (act && d < r) {
                 Ls[d * r + cc] = (float)col[j];
+                if (NREG == 0) Ls64[d * r + cc] = col[j];
                 if (blockIdx.x == 0) LinvC[d * r + cc] = (float)col[j];
             }
         }
@@ -1767,8 +1770,29 @@ __global__ __launch_bounds__(256) void k_C_finish_multi(const double *__restrict
     __syncthreads();
     double dg[DIAG_COLS];
     // (the LDS copy is indexed by the GLOBAL row like C itself: its base is shifted back by the workgroup's first row)
-    rows_fused_tile<1, NREG, VEC>(lane, row0, nrows, rho_s, Ls, nullptr, nullptr, C, Cs - (long)b0 * r, regs, r, inner, dg,
-                                  GR + (long)r * r, &pre);
+    float *Csg = Cs - (long)b0 * r;
+    if (NREG == 0) {
+        // C = R G^-1 in fp64 (un-shifted normal equations: every rounding of the product is amplified by cond(G))
+        const double *R = GR + (long)r * r;
+        double nf = 0.0, na = 0.0;
+        if (inner > 0)
+            for (int e = lane; e < nrows * r; e += 64) {
+                const int rl = e / r, cidx = e - rl * r;
+                const long j = row0 + rl;
+                double acc = 0.0;
+                for (int d = 0; d < r; ++d) acc = fma(R[j * r + d], Ls64[d * r + cidx], acc);
+                const float f = (float)acc;
+                C[j * r + cidx] = f;
+                Csg[j * r + cidx] = f;
+                nf += (double)f * (double)f;
+                na += fabs((double)f);
+            }
+        dg[0] = wave_sum(nf);
+        dg[1] = wave_sum(na);
+    } else {
+        rows_fused_tile<1, NREG, VEC>(lane, row0, nrows, rho_s, Ls, nullptr, nullptr, C, Csg, regs, r, inner, dg,
+                                      GR + (long)r * r, &pre);
+    }
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 2 + NREG; ++k) dsm[wave][k] = dg[k];
@@ -1850,11 +1874,11 @@ int mcl_launch_C_finish_fused(mcl_context *c) {
     if ((size_t)(c->r * c->r + c->K * c->r) * sizeof(float) > 150 * 1024) return -1;
     const int n = c->regs[2].n;
     c->ctc_parts = 0;
-    // rank <= 16 with penalties on C and at least two 64-row chunks: one workgroup per chunk (k_C_finish_multi); the
+    // rank <= 16 and at least two 64-row chunks: one workgroup per chunk (k_C_finish_multi); the
     // fragment image is then the one of the sweep / X C kernels with NB = 1
-    if (c->r <= 16 && n >= 1 && n <= 2 && c->K >= 128 && c->NB == 1 && !c->sw.no_multi_c &&
+    if (c->r <= 16 && n <= 2 && c->K >= 128 && c->NB == 1 && !c->sw.no_multi_c &&
         mcl_cfrag_chunks(c) >= (int)((c->K + 63) / 64))
-        return n == 1 ? launch_C_multi_t<1>(c) : launch_C_multi_t<2>(c);
+        return n == 0 ? launch_C_multi_t<0>(c) : (n == 1 ? launch_C_multi_t<1>(c) : launch_C_multi_t<2>(c));
     if (c->r <= 16) {
         switch (n) {
             case 0: return launch_C_fused_t<1, 0>(c);
