@@ -444,16 +444,31 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
                                c->sw.sweep_dbg == 0;
         c->h_bseg_part.assign((size_t)nbs, 0);
         int parts = 0;
+        // encoding of bseg_part: bits 0-27 the partial, bit 28 "this workgroup runs the cooperative flush", bits 29-30 log2 of
+        // the group size of the wave (groups: all four bsegs of the workgroup, or an aligned pair of them, in one slab)
         for (int b0 = 0; b0 < nbs; b0 += 4) {
-            const bool g4 = can_group && b0 + 3 < nbs && c->h_bseg_slab[(size_t)b0] == c->h_bseg_slab[(size_t)b0 + 3];
-            for (int b = b0; b < std::min(b0 + 4, nbs); ++b) c->h_bseg_part[(size_t)b] = g4 ? (parts | (1 << 30)) : parts++;
-            if (g4) ++parts;
+            const bool full = can_group && b0 + 3 < nbs;
+            auto same = [&](int x, int y) { return c->h_bseg_slab[(size_t)x] == c->h_bseg_slab[(size_t)y]; };
+            const bool g4 = full && same(b0, b0 + 3);
+            const bool p0 = full && !g4 && same(b0, b0 + 1), p1 = full && !g4 && same(b0 + 2, b0 + 3);
+            const int coop = (g4 || p0 || p1) ? (1 << 28) : 0;
+            if (g4) {
+                for (int b = b0; b < b0 + 4; ++b) c->h_bseg_part[(size_t)b] = parts | coop | (2 << 29);
+                ++parts;
+            } else {
+                for (int h = 0; h < 2; ++h) {
+                    const bool pair = h == 0 ? p0 : p1;
+                    for (int b = b0 + 2 * h; b < std::min(b0 + 2 * h + 2, nbs); ++b)
+                        c->h_bseg_part[(size_t)b] = pair ? (parts | coop | (1 << 29)) : ((parts++) | coop);
+                    if (pair) ++parts;
+                }
+            }
         }
         c->n_parts = parts;
         c->h_slab_part_ptr.assign((size_t)I + 1, parts);
         for (int64_t i = I - 1; i >= 0; --i) {
             const int b = c->h_slab_bseg_ptr[(size_t)i];
-            c->h_slab_part_ptr[(size_t)i] = (b < c->h_slab_bseg_ptr[(size_t)i + 1]) ? (c->h_bseg_part[(size_t)b] & 0x3fffffff)
+            c->h_slab_part_ptr[(size_t)i] = (b < c->h_slab_bseg_ptr[(size_t)i + 1]) ? (c->h_bseg_part[(size_t)b] & 0x0fffffff)
                                                                                     : c->h_slab_part_ptr[(size_t)i + 1];
         }
     }

@@ -529,14 +529,19 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
 
         // ---- flush this bseg straight from the accumulators (fragment order: 1 KB per store instruction).
         // The partial a bseg goes to is the planner's (mcl_set_problem): normally its own; GRP - short bsegs, every wave of
-        // the workgroup holding ONE bseg of the SAME slab (bit 30 of bs_part, workgroup-uniform) - the four waves first add
-        // their accumulators through the LDS tiles (no longer read by anybody) in the fixed order ((w0 + w1) + w2) + w3 and
-        // flush ONE partial: a quarter of the partial traffic of the sweep, of k_reduce_frag and of the A-phase on the
-        // per-rank shards of a multi-GPU run and on config 2, where a bseg is 64 rows
+        // the workgroup holding ONE bseg, and all four (or the two of an aligned pair) of the SAME slab - the waves of a
+        // group first add their accumulators through the LDS tiles (no longer read by anybody) in the fixed order
+        // ((w0 + w1) + w2) + w3 and flush ONE partial: a quarter (half) of the partial traffic of the sweep, of k_reduce_frag
+        // and of the A-phase on the per-rank shards of a multi-GPU run and on config 2, where a bseg is 64 rows
         {
             const int pinfo = __builtin_amdgcn_readfirstlane(bs_part[bs]);
-            const int part = pinfo & 0x3fffffff;
-            const bool grouped = GRP && (pinfo >> 30) != 0;
+            const int part = pinfo & 0x0fffffff;
+            // bit 28: the workgroup runs the cooperative flush (workgroup-uniform); bits 29-30: this wave's group is a pair /
+            // all four waves (waves g0 .. g0 + gs - 1 hold bsegs of one slab; a wave outside any group flushes on its own
+            // but keeps the workgroup's barriers company)
+            const bool coop = GRP && ((pinfo >> 28) & 1) != 0;
+            const int gs = GRP ? (1 << ((pinfo >> 29) & 3)) : 1;
+            const int g0 = wave & ~(gs - 1);
             float *mp = Mpart + (long)part * MS;
             float *gp = GRpart + (long)part * (W * W + W);  // [weighted Gram | a_i]: k_reduce_frag weights M_part itself
             const float *arow = A + (long)slab * r;
@@ -550,46 +555,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
 #pragma unroll
                 for (int b = 0; b < NB; ++b) gsum[a][b] = accG[a][b];
             bool writer = true;  // this wave writes the Gram / weights of the partial
-            if (grouped) {
-                static_assert(!GRP || NI % NW == 0, "fragments split evenly over the waves");
-#pragma unroll
-                for (int kb = 0; kb < KC; ++kb)
-#pragma unroll
-                    for (int w = 0; w < 4; ++w)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            const f32x4 val = {accM[kb][0][nb][w], accM[kb][1][nb][w], accM[kb][2][nb][w], accM[kb][3][nb][w]};
-                            *reinterpret_cast<f32x4 *>(L + ((((kb * 4 + w) * NB + nb) * 64 + lane) << 2)) = val;
-                        }
-                __syncthreads();
-#pragma unroll
-                for (int ii = 0; ii < NI / NW; ++ii) {
-                    const int e = ((wave * (NI / NW) + ii) * 64 + lane) << 2;
-                    f32x4 t = *reinterpret_cast<const f32x4 *>(lds_dyn + e);
-#pragma unroll
-                    for (int wv = 1; wv < NW; ++wv) t += *reinterpret_cast<const f32x4 *>(lds_dyn + wv * (16 * KW) + e);
-                    *reinterpret_cast<f32x4 *>(mp + e) = t;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int a = 0; a < NB; ++a)
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) *reinterpret_cast<f32x4 *>(L + (((a * NB + b) * 64 + lane) << 2)) = accG[a][b];
-                __syncthreads();
-                writer = wave == 0;
-                if (writer) {
-#pragma unroll
-                    for (int a = 0; a < NB; ++a)
-#pragma unroll
-                        for (int b = 0; b < NB; ++b) {
-                            f32x4 t = *reinterpret_cast<const f32x4 *>(lds_dyn + (((a * NB + b) * 64 + lane) << 2));
-#pragma unroll
-                            for (int wv = 1; wv < NW; ++wv)
-                                t += *reinterpret_cast<const f32x4 *>(lds_dyn + wv * (16 * KW) + (((a * NB + b) * 64 + lane) << 2));
-                            gsum[a][b] = t;
-                        }
-                }
-            } else {
+            auto flush_own = [&]() {
 #pragma unroll
                 for (int kb = 0; kb < KC; ++kb)
 #pragma unroll
@@ -600,6 +566,54 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                             const int e = ((((kb * 4 + w) * NB + nb) * 64 + lane) << 2);
                             *reinterpret_cast<f32x4 *>(mp + e) = val;
                         }
+            };
+            if (coop) {
+                static_assert(!GRP || NI % NW == 0, "fragments split evenly over the waves");
+                if (gs > 1) {
+#pragma unroll
+                    for (int kb = 0; kb < KC; ++kb)
+#pragma unroll
+                        for (int w = 0; w < 4; ++w)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) {
+                                const f32x4 val = {accM[kb][0][nb][w], accM[kb][1][nb][w], accM[kb][2][nb][w], accM[kb][3][nb][w]};
+                                *reinterpret_cast<f32x4 *>(L + ((((kb * 4 + w) * NB + nb) * 64 + lane) << 2)) = val;
+                            }
+                } else {
+                    flush_own();
+                }
+                __syncthreads();
+                if (gs > 1) {
+                    const int per = NI / gs;  // fragments this wave sums: the group's tiles in the fixed order g0, g0 + 1, ...
+                    for (int ii = 0; ii < per; ++ii) {
+                        const int e = (((wave - g0) * per + ii) * 64 + lane) << 2;
+                        f32x4 t = *reinterpret_cast<const f32x4 *>(lds_dyn + g0 * (16 * KW) + e);
+                        for (int wv = 1; wv < gs; ++wv) t += *reinterpret_cast<const f32x4 *>(lds_dyn + (g0 + wv) * (16 * KW) + e);
+                        *reinterpret_cast<f32x4 *>(mp + e) = t;
+                    }
+                }
+                __syncthreads();
+                if (gs > 1) {
+#pragma unroll
+                    for (int a = 0; a < NB; ++a)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) *reinterpret_cast<f32x4 *>(L + (((a * NB + b) * 64 + lane) << 2)) = accG[a][b];
+                }
+                __syncthreads();
+                writer = wave == g0;
+                if (writer && gs > 1) {
+#pragma unroll
+                    for (int a = 0; a < NB; ++a)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            const int eo = ((a * NB + b) * 64 + lane) << 2;
+                            f32x4 t = *reinterpret_cast<const f32x4 *>(lds_dyn + g0 * (16 * KW) + eo);
+                            for (int wv = 1; wv < gs; ++wv) t += *reinterpret_cast<const f32x4 *>(lds_dyn + (g0 + wv) * (16 * KW) + eo);
+                            gsum[a][b] = t;
+                        }
+                }
+            } else {
+                flush_own();
             }
             if (writer) {
                 if (q == 0) {
