@@ -38,7 +38,7 @@ static __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.
 // ---------------------------------------------------------------------------------------------------------
 // MODE 0: R slice of blockIdx.y, and G in the blocks with blockIdx.y == 0.  Rank > 32 (NB = 4) has no registers for both
 // accumulator sets with their fp64 shadows: MODE 1 (R only) and MODE 2 (G only, one launch with gridDim.y = 1, X untouched).
-template <int KB, int NB, int VEC, int DEPTH, int MODE>
+template <int KB, int NB, int VEC, int DEPTH, int MODE, bool XNT = false>  // XNT: non-temporal loads of X (X >> last-level cache)
 __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X, const float *__restrict__ B,
                                                      const float *__restrict__ A, const int *__restrict__ seg_slab,
                                                      const int *__restrict__ seg_row0, const int *__restrict__ seg_rows,
@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
 #pragma unroll
             for (int kb = 0; kb < (DO_R ? KB : 0); ++kb) {
                 if (VEC == 4) {
-                    fx[d][kb] = *reinterpret_cast<const f32x4 *>(X + j * K + kcol[kb]);
+                    fx[d][kb] = XNT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(X + j * K + kcol[kb]))
+                                    : *reinterpret_cast<const f32x4 *>(X + j * K + kcol[kb]);
                 } else {
                     f32x4 v;
 #pragma unroll
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256) void k_contract_xc(const float *__restrict__ X
 // k_slab_gram pass (a 2 S_B re-read and a launch).
 // CREG: K == 256 and NB == 1: the 64 C-fragment registers stay resident.
 // ---------------------------------------------------------------------------------------------------------
-template <int NB, bool CREG, int GRAM>
+template <int NB, bool CREG, int GRAM, bool XNT = false>
 __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict__ X, const float *__restrict__ Cfrag,
                                                          float *__restrict__ XC, const float *__restrict__ B,
                                                          const int *__restrict__ seg_row0,
@@ -473,7 +474,8 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const long j = row0 + min(16 * blk + t, nrows - 1);
-            xr[t] = *reinterpret_cast<const f32x4 *>(X + j * K + 256 * sc + 4 * lane);
+            xr[t] = XNT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(X + j * K + 256 * sc + 4 * lane))
+                        : *reinterpret_cast<const f32x4 *>(X + j * K + 256 * sc + 4 * lane);
         }
         if (GRAM && sc == 0) {  // unconditional clamped loads; masked at use
 #pragma unroll
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(256) void k_contract_xc_row(const float *__restrict
 // The flat walk: `cur` is the block being multiplied, `pre` the one being requested (two blocks ahead); past the wave's last
 // block `pre` keeps pointing at the last valid rows (unconditional clamped loads, nothing stored).
 // ---------------------------------------------------------------------------------------------------------
-template <int GRAM, int D>
+template <int GRAM, int D, bool XNT = false>
 __global__ __launch_bounds__(256) void k_contract_xc_256(const float *__restrict__ X, const float *__restrict__ Cfrag,
                                                          float *__restrict__ XC, const float *__restrict__ B,
                                                          const int *__restrict__ seg_row0,
@@ -711,7 +713,8 @@ __global__ __launch_bounds__(256) void k_contract_xc_256(const float *__restrict
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const long j = c.row0 + min(16 * c.blk + t, c.nrows - 1);
-            xr[d][t] = *reinterpret_cast<const f32x4 *>(X + j * K + 4 * lane);
+            xr[d][t] = XNT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(X + j * K + 4 * lane))
+                           : *reinterpret_cast<const f32x4 *>(X + j * K + 4 * lane);
         }
         if (GRAM) {
 #pragma unroll
@@ -921,10 +924,15 @@ static int launch_xt(mcl_context *c) {
     dbg = c->sw.xt_dbg;
     if (c->sw.xt_depth > 0) depth = c->sw.xt_depth;
     constexpr int RMODE = (NB == 4) ? 1 : 0;
-#define MCL_XT(VEC_, DEPTH_, MODE_, GRID_)                                                                            \
-    hipLaunchKernelGGL((k_contract_xt<KB, NB, VEC_, DEPTH_, MODE_>), GRID_, dim3(256), 0, c->stream, c->X, c->B, c->A, \
+#define MCL_XT_(VEC_, DEPTH_, MODE_, GRID_, NT_)                                                                      \
+    hipLaunchKernelGGL((k_contract_xt<KB, NB, VEC_, DEPTH_, MODE_, NT_>), GRID_, dim3(256), 0, c->stream, c->X, c->B, c->A, \
                        c->segs.slab, c->segs.row0, c->segs.nrows, c->wave_seg_ptr, c->n_seg_waves, (int)c->K, c->r, c->partials, \
                        E, dbg)
+#define MCL_XT(VEC_, DEPTH_, MODE_, GRID_)                                                                            \
+    do {                                                                                                              \
+        if (c->x_streams && (VEC_) == 4 && (MODE_) != 2) MCL_XT_(VEC_, DEPTH_, MODE_, GRID_, true);                   \
+        else MCL_XT_(VEC_, DEPTH_, MODE_, GRID_, false);                                                              \
+    } while (0)
     if (vec) {
         if (depth == 2) MCL_XT(4, 2, RMODE, grid);
         else MCL_XT(4, 4, RMODE, grid);
@@ -933,6 +941,7 @@ static int launch_xt(mcl_context *c) {
     }
     if constexpr (NB == 4) MCL_XT(1, 2, 2, dim3(nb, 1));  // G of the same row ranges into the same partial slabs
 #undef MCL_XT
+#undef MCL_XT_
     c->n_part = nb;
     char buf[96];
     snprintf(buf, sizeof buf, "k_contract_xt<KB=%d,NB=%d,VEC=%d>", KB, NB, vec ? 4 : 1);
@@ -1000,20 +1009,31 @@ static int launch_xc(mcl_context *c) {
         // 0: X C only; 1: + per-segment rhs / Gram in fp32 chains (penalised A); 2: in fp64 (penalty-free A)
         int gram = !c->xc_with_gram ? 0 : (c->regs[0].n == 0 ? 2 : 1);
         if (NB == 4 && gram == 2) gram = 0;  // rank > 32 has no registers for the fp64 Gram tiles: k_slab_gram follows
-#define MCL_XCR(CREG_, GRAM_)                                                                                        \
-    hipLaunchKernelGGL((k_contract_xc_row<NB, CREG_, GRAM_>), dim3(g), dim3(256), sm, c->stream, c->X, c->Cfrag,     \
+#define MCL_XCR_(CREG_, GRAM_, NT_)                                                                                  \
+    hipLaunchKernelGGL((k_contract_xc_row<NB, CREG_, GRAM_, NT_>), dim3(g), dim3(256), sm, c->stream, c->X, c->Cfrag, \
                        c->XC, c->B, c->segs.row0, c->segs.nrows, c->wave_seg_ptr, c->n_seg_waves, (int)c->K, c->r, c->seg_rhs, \
                        c->seg_btb)
+#define MCL_XCR(CREG_, GRAM_)                                                                                        \
+    do {                                                                                                              \
+        if (c->x_streams) MCL_XCR_(CREG_, GRAM_, true);                                                               \
+        else MCL_XCR_(CREG_, GRAM_, false);                                                                           \
+    } while (0)
         if (n_segs > 0) {
             if constexpr (NB == 1) {  // resident C fragments: K = 256, rank <= 16 only
                 if (creg && !c->sw.xc_depth1) {  // two blocks of X in flight per wave
-#define MCL_XC256(GRAM_)                                                                                              \
-    hipLaunchKernelGGL((k_contract_xc_256<GRAM_, 2>), dim3(g), dim3(256), sm, c->stream, c->X, c->Cfrag, c->XC, c->B,    \
+#define MCL_XC256_(GRAM_, NT_)                                                                                        \
+    hipLaunchKernelGGL((k_contract_xc_256<GRAM_, 2, NT_>), dim3(g), dim3(256), sm, c->stream, c->X, c->Cfrag, c->XC, c->B, \
                        c->segs.row0, c->segs.nrows, c->wave_seg_ptr, c->n_seg_waves, c->r, c->seg_rhs, c->seg_btb)
+#define MCL_XC256(GRAM_)                                                                                              \
+    do {                                                                                                              \
+        if (c->x_streams) MCL_XC256_(GRAM_, true);                                                                    \
+        else MCL_XC256_(GRAM_, false);                                                                                \
+    } while (0)
                     if (gram == 2) MCL_XC256(2);
                     else if (gram == 1) MCL_XC256(1);
                     else MCL_XC256(0);
 #undef MCL_XC256
+#undef MCL_XC256_
                 } else if (creg) {
                     if (gram == 2) MCL_XCR(true, 2);
                     else if (gram == 1) MCL_XCR(true, 1);
@@ -1031,6 +1051,7 @@ static int launch_xc(mcl_context *c) {
             }
         }
 #undef MCL_XCR
+#undef MCL_XCR_
         c->xc_did_gram = gram != 0;
         char buf[96];
         if (creg && !c->sw.xc_depth1) snprintf(buf, sizeof buf, "k_contract_xc_256<DEPTH=2,GRAM=%d>", gram);

@@ -57,7 +57,7 @@ struct mcl_switches {
     bool no_sweep = false, no_pass_chain = false, no_pf2_delta_fusion = false, ns_plain = false, pf2_jacobi = false;
     bool no_stack_fusion = false, no_solve_stats = false, no_next_b = false, no_fused_gram = false, no_fused_c = false;
     bool a_finish_cols = false, xc_norow = false, unimodal_v3 = false, stats_reduce = false;
-    bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_sweep_half = false, no_multi_c = false, no_diag_defer = false, xc_depth1 = false;
+    bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_x_nt = false, no_sweep_half = false, no_multi_c = false, no_diag_defer = false, xc_depth1 = false;
     int seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
     int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
 };
@@ -130,6 +130,7 @@ struct mcl_context {
     int *slab_part_ptr = nullptr;   // int32[I+1] first partial of every slab
     std::vector<int> h_bseg_part, h_slab_part_ptr;
     int n_parts = 0;
+    bool x_streams = false;         // X is larger than the last-level cache (256 MB): the X kernels load it non-temporally
     int sweep_kc = 4;               // 64-column chunks of the sweep's tiles / partial images (mcl_sweep_KC)
     int *wave_bseg_ptr = nullptr;  // int32[n_bseg_waves+1] first bseg of every wave of the sweep
     std::vector<int> h_wave_bseg_ptr;

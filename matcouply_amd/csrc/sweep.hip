@@ -52,7 +52,7 @@ static __device__ __forceinline__ long uniform_off(long v) {
 // DBG: the MCL_SWEEP_DBG experiments (phase elimination, per-section cycle counters: tools/run_dbg.sh, sweep_cycles.py)
 // are compiled into a second instantiation of the config-2/3 variants only; the production kernels carry none of it
 // (the counters alone cost 12 registers in kernels that sit at the 512-register limit).
-template <int KS, int NB, int NREG, int DEPTH, int NW, bool VEC, bool DBG = false, bool GRP = false>
+template <int KS, int NB, int NREG, int DEPTH, int NW, bool VEC, bool DBG = false, bool GRP = false, bool XNT = false>
 __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, const float *__restrict__ Cfrag,
                                                const float *__restrict__ A, const float *__restrict__ rhoB,
                                                const float *__restrict__ LinvB, float *__restrict__ Bout, RegSet regs,
@@ -205,6 +205,11 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
             // Stage block `blk` of this wave into ring slot d.  Every load is unconditional (rows clamped into the
             // wave's range, scalar arithmetic): a branch around loads makes the compiler's counted s_waitcnt vmcnt(N)
             // collapse to the pessimistic merge of both paths and drains the prefetch at every block.
+            // XNT: X is far larger than the last-level cache (256 MB) and read once per iteration - its loads carry the
+            // non-temporal hint, so the stream does not evict B / aux / dual (100 MB at config 3), the partials and the C image
+            // from the cache between the kernels of an iteration (config 3: k_sweep 161 -> 137 us on the same box).  Problems
+            // that fit the cache (per-rank shards, config 2) keep ordinary loads: with the hint they ran 3-5 % slower
+            auto ldx = [](const f32x4 *p) -> f32x4 { return XNT ? __builtin_nontemporal_load(p) : *p; };
             auto issue_x = [&](auto dc, int blk) {  // 16 rows x K columns, one 1 KB row segment per wave load
                 constexpr int d = decltype(dc)::value;
                 // scalar addressing: ONE 64-bit product per block, then a 32-bit row offset per row (row clamped into
@@ -218,15 +223,15 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
 #pragma unroll
                     for (int t = 0; t < XL; ++t) {
                         const unsigned up = (2 * t + 1 <= tmax) ? (unsigned)K : 0u;  // wave-uniform
-                        xr[d][0][t] = *reinterpret_cast<const f32x4 *>(X + uniform_off(blk_off + (long)(min(2 * t, tmax) * K)) +
-                                                                       (xcol[0] + (hi ? up : 0u)));
+                        xr[d][0][t] = ldx(reinterpret_cast<const f32x4 *>(X + uniform_off(blk_off + (long)(min(2 * t, tmax) * K)) +
+                                                                          (xcol[0] + (hi ? up : 0u))));
                     }
                 } else {
 #pragma unroll
                     for (int sc = 0; sc < KSA; ++sc)
 #pragma unroll
                         for (int t = 0; t < 16; ++t)
-                            xr[d][sc][t] = *reinterpret_cast<const f32x4 *>(X + uniform_off(blk_off + (long)(min(t, tmax) * K)) + xcol[sc]);
+                            xr[d][sc][t] = ldx(reinterpret_cast<const f32x4 *>(X + uniform_off(blk_off + (long)(min(t, tmax) * K)) + xcol[sc]));
                 }
             };
             // aux / dual rows go straight into the registers the inner loop works on.  They are issued AFTER the slot's
@@ -877,8 +882,8 @@ static int launch_sweep_v(mcl_context *c) {
     // tables (mcl_diagnostics_deferred) may still be waiting for the coming C-phase reduction kernel
     c->diagB_parity ^= 1;
     c->diagB_tile = c->diagB_bufs[c->diagB_parity];
-#define MCL_SWEEP_LAUNCH(DBG_, GRP_)                                                                                   \
-    hipLaunchKernelGGL((k_sweep<KS, NB, NREG, DEPTH, NW, VEC, DBG_, GRP_>), dim3(grid), dim3(64 * NW), sm, c->stream, c->X,    \
+#define MCL_SWEEP_LAUNCH(DBG_, GRP_, NT_)                                                                              \
+    hipLaunchKernelGGL((k_sweep<KS, NB, NREG, DEPTH, NW, VEC, DBG_, GRP_, NT_>), dim3(grid), dim3(64 * NW), sm, c->stream, c->X,    \
                        c->CfragS, c->A, c->rhoB, c->LinvB, c->B, c->regs[1], c->bsegs.slab, c->bsegs.row0, c->bsegs.nrows, \
                        c->wave_bseg_ptr, n_waves, (int)c->K, c->r, c->opt.inner_n_iter_max, c->Mpart, c->part_btb, c->GRpart, c->diagB_tile, \
                        c->sw.sweep_dbg, c->sweep_cycles, c->bseg_part)
@@ -887,7 +892,7 @@ static int launch_sweep_v(mcl_context *c) {
         if (c->sw.sweep_dbg != 0 && c->n_parts == n) {  // (the twin has no grouped flush: a plan with grouped partials keeps GRP)
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<KS, NB, NREG, DEPTH, NW, VEC, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) == hipSuccess) {
-                MCL_SWEEP_LAUNCH(true, false);
+                MCL_SWEEP_LAUNCH(true, false, false);
                 launched = true;
             }
         }
@@ -899,7 +904,7 @@ static int launch_sweep_v(mcl_context *c) {
                 (void)hipGetLastError();
                 return -1;
             }
-            MCL_SWEEP_LAUNCH(false, true);
+            MCL_SWEEP_LAUNCH(false, true, false);
             launched = true;
         }
     }
@@ -908,7 +913,16 @@ static int launch_sweep_v(mcl_context *c) {
             c->err = "k_sweep: grouped partials planned for a kernel without the grouped flush";
             return 1;
         }
-        MCL_SWEEP_LAUNCH(false, false);
+        if (c->x_streams) {  // X does not fit the last-level cache: non-temporal loads of X
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<KS, NB, NREG, DEPTH, NW, VEC, false, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
+                (void)hipGetLastError();
+                return -1;
+            }
+            MCL_SWEEP_LAUNCH(false, false, true);
+        } else {
+            MCL_SWEEP_LAUNCH(false, false, false);
+        }
     }
 #undef MCL_SWEEP_LAUNCH
     MCL_CHECK_HIP(c, hipGetLastError());
