@@ -721,6 +721,19 @@ struct UniRec {
     float lev;
     int len;
 };
+// the per-position arrays of the column regressions (prefix errors, block records) are written once and read once, a column
+// batch apart - at config-5 scale gigabytes each: streamed past the caches (non-temporal)
+static __device__ __forceinline__ void st_rec_nt(UniRec *p, UniRec rc) {
+    long long bits;
+    __builtin_memcpy(&bits, &rc, 8);
+    __builtin_nontemporal_store(bits, reinterpret_cast<long long *>(p));
+}
+static __device__ __forceinline__ UniRec ld_rec_nt(const UniRec *p) {
+    const long long bits = __builtin_nontemporal_load(reinterpret_cast<const long long *>(p));
+    UniRec rc;
+    __builtin_memcpy(&rc, &bits, 8);
+    return rc;
+}
 
 static __device__ __forceinline__ void ur4_push(UniRing4 &st, int lane, double sy, int cw, double q, double *__restrict__ gsy,
                                                 double *__restrict__ gq, int *__restrict__ gcw, long base, long rs, int col) {
@@ -877,10 +890,10 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                 if (i0 + j < n) {
                     const double er = step(vb[j], i0 + j == 0);
                     ep += rs;
-                    *ep = er;
+                    __builtin_nontemporal_store(er, ep);
                     UniRec rc;
                     rc.lev = levf, rc.len = (int)ccw;
-                    *rp = rc;
+                    st_rec_nt(rp, rc);
                     rp += rs;
                 }
             }
@@ -901,7 +914,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
         for (int j = 0; j < UB; ++j) {
             const long o = (long)min(j, n - 1) * rs;
             fb[j] = fp[-o], ub[j] = up[-o];
-            eb_n[j] = (MODE == 0) ? ep[-o] : 0.0;
+            eb_n[j] = (MODE == 0) ? __builtin_nontemporal_load(ep - o) : 0.0;
         }
         for (int i0 = 0; i0 < n; i0 += UB) {
             double vb[UB], eb_l[UB];
@@ -911,7 +924,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
             for (int j = 0; j < UB; ++j) {
                 const long o = (long)min(i0 + UB + j, n - 1) * rs;
                 fb[j] = fp[-o], ub[j] = up[-o];
-                if (MODE == 0) eb_n[j] = ep[-o];
+                if (MODE == 0) eb_n[j] = __builtin_nontemporal_load(ep - o);
             }
 #pragma unroll
             for (int j = 0; j < UB; ++j) {
@@ -920,7 +933,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                     const double er = step(vb[j], i == 0);
                     UniRec rc;
                     rc.lev = levf, rc.len = (int)ccw;
-                    *rp = rc;
+                    st_rec_nt(rp, rc);
                     rp -= rs;
                     if (MODE == 0) {
                         const double tot = eb_l[j] + er;
@@ -1010,13 +1023,13 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
         const int jtop = wave_max_i(split) - 1;
         UniRec rn[EB];
 #pragma unroll
-        for (int u = 0; u < EB; ++u) rn[u] = rp[(long)min(max(jtop - u, 0), nm1) * rs];
+        for (int u = 0; u < EB; ++u) rn[u] = ld_rec_nt(rp + (long)min(max(jtop - u, 0), nm1) * rs);
         for (int j0 = jtop; j0 >= 0; j0 -= EB) {
             UniRec rb[EB];
 #pragma unroll
             for (int u = 0; u < EB; ++u) rb[u] = rn[u];
 #pragma unroll
-            for (int u = 0; u < EB; ++u) rn[u] = rp[(long)min(max(j0 - EB - u, 0), nm1) * rs];
+            for (int u = 0; u < EB; ++u) rn[u] = ld_rec_nt(rp + (long)min(max(j0 - EB - u, 0), nm1) * rs);
 #pragma unroll
             for (int u = 0; u < EB; ++u) {  // branch-free (a branch around the stores would turn the counted waits on
                 const int j = j0 - u;       // the next batch's loads into waits for every store of this one)
@@ -1040,14 +1053,14 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
         UniRec rn[EB];
         if (jbot < jend) {
 #pragma unroll
-            for (int u = 0; u < EB; ++u) rn[u] = rp[(long)min(jbot + u, nm1) * rs];
+            for (int u = 0; u < EB; ++u) rn[u] = ld_rec_nt(rp + (long)min(jbot + u, nm1) * rs);
         }
         for (int j0 = jbot; j0 < jend; j0 += EB) {
             UniRec rb[EB];
 #pragma unroll
             for (int u = 0; u < EB; ++u) rb[u] = rn[u];
 #pragma unroll
-            for (int u = 0; u < EB; ++u) rn[u] = rp[(long)min(j0 + EB + u, nm1) * rs];
+            for (int u = 0; u < EB; ++u) rn[u] = ld_rec_nt(rp + (long)min(j0 + EB + u, nm1) * rs);
 #pragma unroll
             for (int u = 0; u < EB; ++u) {
                 const int j = j0 + u;
