@@ -150,7 +150,7 @@ void read_switches(mcl_switches &w) {
     w.no_fused_gram = flag("MCL_NO_FUSED_GRAM"), w.no_fused_c = flag("MCL_NO_FUSED_C");
     w.a_finish_cols = flag("MCL_A_FINISH_COLS"), w.xc_norow = flag("MCL_XC_NOROW");
     w.unimodal_v3 = flag("MCL_UNIMODAL_V3"), w.stats_reduce = flag("MCL_STATS_REDUCE");
-    w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_a_wide = flag("MCL_NO_A_WIDE"), w.no_bseg_groups = flag("MCL_NO_BSEG_GROUPS"), w.no_sweep_half = flag("MCL_NO_SWEEP_HALF"), w.no_x_nt = flag("MCL_NO_X_NT"), w.no_multi_c = flag("MCL_NO_MULTI_C"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1");
+    w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_a_wide = flag("MCL_NO_A_WIDE"), w.no_bseg_groups = flag("MCL_NO_BSEG_GROUPS"), w.no_sweep_half = flag("MCL_NO_SWEEP_HALF"), w.no_x_nt = flag("MCL_NO_X_NT"), w.x_nt_mb = num("MCL_X_NT_MB", 0), w.no_multi_c = flag("MCL_NO_MULTI_C"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1");
     w.seg_rows = num("MCL_SEG_ROWS", 0), w.bseg_rows = num("MCL_BSEG_ROWS", 0);
     w.xc_waves = num("MCL_XC_WAVES", 0), w.xt_waves = num("MCL_XT_WAVES", 0), w.sweep_waves = num("MCL_SWEEP_WAVES", 0);
     w.xc_dbg = num("MCL_XC_DBG", 0), w.xt_dbg = num("MCL_XT_DBG", 0), w.xt_depth = num("MCL_XT_DEPTH", 0);
@@ -348,7 +348,7 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     c->NB = (rank + 15) / 16;
     if (c->NB == 3) c->NB = 4;
     c->sweep_kc = (K <= 128 && c->NB == 1 && !c->sw.no_sweep_half) ? 2 : 4 * (int)((K + 255) / 256);
-    c->x_streams = !c->sw.no_x_nt && (double)N * (double)K * 4.0 > 256.0 * 1048576.0;
+    c->x_streams = !c->sw.no_x_nt && (double)N * (double)K * 4.0 > (c->sw.x_nt_mb > 0 ? c->sw.x_nt_mb : 256) * 1048576.0;
     c->h_slab_of_row.resize((size_t)N);
     c->h_tile_slab.clear(), c->h_tile_row0.clear(), c->h_tile_nrows.clear();
     c->h_seg_slab.clear(), c->h_seg_row0.clear(), c->h_seg_nrows.clear();
