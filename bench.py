@@ -64,6 +64,7 @@ CONFIGS["c3r"] = dict(CONFIGS["c3"], J="ragged", desc="config 3 with the ragged 
 CONFIGS["k512"] = dict(CONFIGS["c3"], I=512, J=512, K=512, desc="K=512 variant of config 3 (same bytes of X): I=512 J_i=512 K=512 rank=16")
 CONFIGS["r32"] = dict(CONFIGS["c3"], r=32, desc="rank-32 variant of config 3: I=1024 J_i=512 K=256 rank=32")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix rate (v_mfma_f32_16x16x4_f32: 256 flop/cycle/CU)
 
 
 def make_shard(cfg, rank, world, device, seed=0):
@@ -228,13 +229,43 @@ def cpu_baseline(cfg, budget_s=15.0):
                        f"os.cpu_count() = {os.cpu_count()}); value scaled by {I_s}/{I}")
 
 
+def spawn_ranks(n):
+    """Start `n` ranks of this script under torch.distributed.run as child processes; returns their exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:  # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)  # stderr passes through
+    lines = []
+    for line in proc.stdout:
+        lines.append(line)
+    rc = proc.wait()
+    json_lines = [l for l in lines if l.startswith("{")]
+    for l in lines:
+        if not l.startswith("{"):
+            sys.stderr.write(l)  # anything else the ranks printed is not part of the contract line
+    if json_lines:
+        sys.stdout.write(json_lines[-1])
+        sys.stdout.flush()
+    return rc if rc else (0 if json_lines else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--regions", type=int, default=25, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--settle-ms", type=float, default=100.0,
+                    help="un-timed settling after --warmup: keep stepping for at least this long AND until two consecutive "
+                         "probe regions of --steps steps agree within 2 %% (clock ramp of a fresh device); 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -242,6 +273,12 @@ def main():
     # RCCL shares device buffers between the ranks of a node through dmabuf IPC; the legacy IPC mode is not supported by the
     # host driver of this pool (hipIpcGetMemHandle: invalid argument) - keep the setting the image exports
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has not touched the GPU
+        # (no torch import yet) and never will: the N ranks are CHILD processes of torch.distributed.run, rank 0's JSON
+        # line is forwarded and the children's exit code is ours.  (No exec: replacing a process is not allowed on the
+        # GPU boxes once anything has initialised the device, and a child keeps the parent free to report failures.)
+        return spawn_ranks(args.gpus)
     import torch
     import torch.distributed as dist
 
@@ -250,8 +287,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus} (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus disagree "
+                         f"(one rank per GPU; without a launcher `python bench.py --gpus N` starts its own ranks)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # MCL_BENCH_SHARE_GPU=1 (+ MCL_BENCH_BACKEND=gloo): all ranks use device 0 - a functional check of the sharded path
@@ -272,7 +309,8 @@ def main():
     from matcouply_amd._engine import DIAG_LEN
 
     n_regions = max(1, args.regions)
-    ring = torch.zeros((args.warmup + n_regions * args.steps, DIAG_LEN), dtype=torch.float64, device=device)
+    ring = torch.zeros((max(1, n_regions * args.steps), DIAG_LEN), dtype=torch.float64, device=device)
+    scratch = torch.zeros((max(1, args.warmup, args.steps), DIAG_LEN), dtype=torch.float64, device=device)  # un-timed steps
     n_coll = [0]  # collectives issued by this rank (counted on the host)
 
     def all_reduce(t, **kw):
@@ -300,7 +338,7 @@ def main():
                 eng.B_prox_finish(k)
         eng.B_end()
 
-    def step(it):
+    def step(slot):
         update_B()
         gr = eng.update_C_local()
         if world > 1:
@@ -311,7 +349,7 @@ def main():
         eng.update_A()
         # deferred: the reduction of the diagnostics tables rides on the next step's C-phase reduction kernel (what
         # mcl_iterate - the fixed-count loop behind cmf_aoadmm - does between its iterations); flushed at the region end
-        eng.diagnostics_deferred(include_replicated=(rank == 0), out=ring[it])
+        eng.diagnostics_deferred(include_replicated=(rank == 0), out=slot)
 
     def sync():
         if world > 1:
@@ -319,9 +357,34 @@ def main():
         torch.cuda.synchronize()
 
     for it in range(args.warmup):
-        step(it)
+        step(scratch[it])
     eng.flush_diagnostics()
     sync()
+    # Settling (un-timed, on top of --warmup): a fresh device ramps its clocks over the first ~100 ms of work - with 5
+    # warm-up steps (0.8 ms at config 3) the first timed regions of round 2 fell monotonically by 10 %.  Keep stepping in
+    # probe regions of --steps steps until >= --settle-ms have passed AND two consecutive probes agree within 2 %
+    # (bounded: 50 probes / 3 s).  Every rank takes the same decision (the probe time is the MAX over ranks).
+    settle = dict(ms=0.0, probes=0, settled=None)
+    if args.settle_ms > 0 and args.steps > 0:
+        prev, total = None, 0.0
+        for probe in range(50):
+            sync()
+            t0 = time.perf_counter()
+            for it in range(args.steps):
+                step(scratch[it])
+            eng.flush_diagnostics()
+            sync()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            total += dt
+            agree = prev is not None and abs(dt - prev) <= 0.02 * max(dt, prev)
+            prev = dt
+            settle = dict(ms=round(1e3 * total, 2), probes=probe + 1, settled=bool(agree))
+            if (1e3 * total >= args.settle_ms and agree) or total > 3.0:
+                break
     # HIP events inside the library around every `stride`-th launch of the timed region: an event pair opens ~5 us
     # dispatch gaps before and after the kernel (11 us per step when every launch is bracketed - measured), so the
     # timed loop samples ~10 launches instead of taxing all of them
@@ -330,11 +393,11 @@ def main():
     region_s = []
     coll_before = n_coll[0]
     for reg in range(n_regions):
-        first = args.warmup + reg * args.steps
+        first = reg * args.steps
         sync()
         t0 = time.perf_counter()
         for it in range(args.steps):
-            step(first + it)
+            step(ring[first + it])
         eng.flush_diagnostics()
         if world > 1:
             all_reduce(ring[first:first + args.steps])
@@ -380,7 +443,7 @@ def main():
     def pmc_traffic(kernel_variant):
         """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), if the
         profile was taken on this configuration; counters are collected in separate runs, never inside this one."""
-        for rnd in ("r2", "r1"):
+        for rnd in ("r3", "r2", "r1"):
             path = os.path.join(REPO, "profiles", f"{rnd}_{args.config}_pmc_traffic.json")
             if os.path.exists(path):
                 break
@@ -397,6 +460,22 @@ def main():
                 return int(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
         return None
 
+    def mfma_block(slot, avg_ms):
+        """The kernel's second limiter: fp32 MFMA flops it ISSUES per launch (padded rank / K as the tiles are) over the same
+        HIP-event time, against the dense fp32 matrix peak.  At config 3 the analytic count (10.47 GFLOP) equals
+        SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 of profiles/r2_c3_sq_counters.json; fp32 MFMA and VALU work do not overlap on a
+        SIMD (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so the sweep sits at the SUM of this and its VALU / LDS / wait time."""
+        RPk = 16 * ((r + 15) // 16)
+        Kp = 128 if (slot == 3 and K <= 128 and RPk == 16) else 256 * ((K + 255) // 256) if slot == 3 else 64 * ((K + 63) // 64)
+        n_inner = 5
+        flops = {0: 2.0 * N_loc * Kp * RPk + (2.0 * N_loc * RPk * RPk if xc_fused else 0.0),
+                 1: 2.0 * N_loc * Kp * RPk + 2.0 * N_loc * RPk * RPk,
+                 2: 2.0 * N_loc * RPk * RPk * n_inner,
+                 3: 4.0 * N_loc * Kp * RPk + 2.0 * N_loc * RPk * RPk * (n_inner + 2)}[slot]
+        tf = flops / (avg_ms * 1e-3) / 1e12
+        return dict(achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                    flops_per_launch=int(flops), counted="issued fp32 MFMA flops (analytic, padded tiles)")
+
     roofline = None
     if prof:
         avg_ms, slot, n = max(prof)
@@ -410,9 +489,10 @@ def main():
                         kernel_role=names[slot], avg_us=round(avg_ms * 1e3, 2), launches_timed=n,
                         launches_in_timed_regions=n_regions * args.steps, event_stride=prof_stride,
                         algorithmic_bytes_per_launch=int(alg_bytes[slot]),
+                        mfma=mfma_block(slot, avg_ms),
                         all_kernels_avg_us={names[s]: round(a * 1e3, 2) for a, s, _ in prof})
 
-    final = ring[args.warmup + n_regions * args.steps - 1].cpu().numpy() if args.steps else None
+    final = ring[n_regions * args.steps - 1].cpu().numpy() if args.steps else None
     if rank == 0:
         its = args.steps / elapsed
         S_X_tot, S_B_tot = 4.0 * N_tot * K, 4.0 * N_tot * r
@@ -429,6 +509,12 @@ def main():
             "hbm_gbps_algorithmic": round(bytes_iter * its / 1e9, 1),
             "roofline": roofline,
             "timed_regions": n_regions, "region_ms": [round(1e3 * v, 4) for v in region_s], "region_stat": "median",
+            "region_ms_stats": {"min": round(1e3 * float(np.min(region_s)), 4), "median": round(1e3 * elapsed, 4),
+                                "q25": round(1e3 * float(np.percentile(region_s, 25)), 4),
+                                "q75": round(1e3 * float(np.percentile(region_s, 75)), 4),
+                                "max": round(1e3 * float(np.max(region_s)), 4)},
+            "settling": dict(settle, target_ms=args.settle_ms, rule="un-timed probe regions until >= target_ms and two "
+                                                                    "consecutive probes within 2 %"),
         }
         if world > 1:
             out["collectives_per_step"] = round(coll_per_step, 2)
@@ -439,11 +525,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_budget)
         elif world > 1:
-            out["cpu_baseline"] = None
+            # the CPU leg is timed on rank 0 at N = 1 only (task contract); the N > 1 lines point at it
+            out["cpu_baseline"] = {"value": None, "unit": "outer-iters/s", "cores": None, "kind": "port",
+                                   "sample": "not timed at N > 1: see the cpu_baseline of the N = 1 line of the same workload"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

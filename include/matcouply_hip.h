@@ -26,6 +26,12 @@ extern "C" {
 
 typedef struct mcl_context mcl_context;
 
+/* ABI version = what mcl_version() of a matching library returns.  History: 100 first release (fp32 [G | R]);
+ * 200 mcl_c_normal_equations returns fp64 (the buffer a multi-GPU host all-reduces changed its element size);
+ * 300 this header (mcl_run and the stop-rule structs, the communication-buffer and event entry points).
+ * A host MUST compare mcl_version() with the MCL_ABI_VERSION it was built against before any other call. */
+#define MCL_ABI_VERSION 300
+
 #define MCL_MAX_REGS 4   /* penalties per mode */
 #define MCL_MAX_RANK 64
 
@@ -115,6 +121,39 @@ int mcl_flush_diagnostics(mcl_context *ctx);
  * MCL_DIAG_LEN doubles are appended per iteration (device memory, n * MCL_DIAG_LEN doubles). */
 int mcl_iterate(mcl_context *ctx, int32_t n_iter, int32_t update_A, int32_t update_B, int32_t update_C,
                 double *diag_ring);
+
+/* The outer loop WITH its stopping rule on one device (decomposition.py:945-1053): the reduction of the diagnostics and
+ * the stopping test (feasibility gaps :996, relative / absolute loss criterion :1037-1053, quirks Q8-Q10 of SURVEY.md
+ * Appendix C kept) run in a kernel at the end of every iteration; the host enqueues up to max_run_ahead iterations
+ * ahead of the verdicts it has seen and never waits for one.  Every kernel that writes a factor or an ADMM variable tests
+ * the device-side stop flag first, so when the call returns the factors and ADMM variables are EXACTLY those of the
+ * stopping iteration, however far the host had run ahead.
+ *   rule          Python truthiness is kept: a tolerance of 0 means "not set" (None / 0 / False of the reference);
+ *   diag_ring     device fp64 [n_iter_max, MCL_DIAG_LEN]: row `it` = the mcl_diagnostics vector after iteration `it`;
+ *   verdict_ring  device fp64 [n_iter_max, 4]: {relative reconstruction error, regularised loss, worst feasibility gap,
+ *                 flags: bit 0 feasible, bit 1 error / loss evaluated (Q10), bits 2.. stop code}; rows beyond the stopping
+ *                 iteration are not written;
+ *   status        int32[4] in PINNED host memory (hipHostMalloc / a registered buffer): written by the device.
+ * Unlike every other entry point this one synchronises the stream before it returns (it reports the verdict). */
+typedef struct {
+    double tol;                 /* relative loss criterion, decomposition.py:1039; 0 = not set */
+    double absolute_tol;        /* decomposition.py:1040; only looked at when tol is set (Q8); tests the newest loss (Q9) */
+    double feasibility_tol;     /* decomposition.py:996; 0 = not set: the feasibility criterion then never holds */
+    double initial_loss;        /* losses[0]: regularised loss of the initial state (decomposition.py:916-921) */
+    double penalty_weight[3][MCL_MAX_REGS]; /* loss += weight * sum |factor|: reg_strength of an L1Penalty, else 0 */
+    int32_t evaluate_loss_always; /* return_errors of the reference: the loss is evaluated on infeasible iterates too (Q10) */
+    int32_t max_run_ahead;      /* iterations the host may enqueue beyond the newest verdict it has seen; <= 0: 8 */
+} mcl_stop_rule;
+#define MCL_STOP_RELATIVE 1     /* "FEASIBILITY GAP CRITERION AND RELATIVE LOSS CRITERION SATISFIED" */
+#define MCL_STOP_ABSOLUTE 2     /* "FEASIBILITY GAP CRITERION AND ABSOLUTE LOSS CRITERION SATISFIED" */
+typedef struct {
+    volatile int32_t stopped;         /* 1 once a criterion has fired */
+    volatile int32_t stop_iteration;  /* 0-based outer iteration it fired on (n_iter of the reference = this + 1) */
+    volatile int32_t code;            /* MCL_STOP_RELATIVE / MCL_STOP_ABSOLUTE */
+    volatile int32_t progress;        /* iterations whose verdict has been evaluated so far */
+} mcl_run_status;
+int mcl_run(mcl_context *ctx, int32_t n_iter_max, int32_t update_A, int32_t update_B, int32_t update_C,
+            const mcl_stop_rule *rule, double *diag_ring, double *verdict_ring, mcl_run_status *status);
 
 /* ---- step calls (constant feasibility penalty / PARAFAC2 / EXTERNAL penalties on several devices) ---- */
 /* B-phase prologue: CtC, rhs_i, rho_i; returns pointer to this rank's max rho (device fp32[1]) for a MAX all-reduce */

@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmatcouply_hip.so")
 
+MCL_ABI_VERSION = 300  # include/matcouply_hip.h; checked against mcl_version() when the library is loaded
 MCL_MAX_REGS = 4
 MCL_MAX_RANK = 64
 DIAG_NORM_SQ, DIAG_INNER, DIAG_MODEL_SQ, DIAG_X_SQ, DIAG_REG = 0, 3, 4, 5, 8
@@ -28,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "mcl_set_factors", "mcl_set_penalties", "mcl_workspace_bytes", "mcl_set_workspace", "mcl_update_B",
     "mcl_update_C_local", "mcl_c_normal_equations", "mcl_update_C_finish", "mcl_update_A", "mcl_diagnostics",
     "mcl_diagnostics_deferred", "mcl_flush_diagnostics",
-    "mcl_iterate", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
+    "mcl_iterate", "mcl_run", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_B_end", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
     "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
     "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_set_stride", "mcl_profile_read",
@@ -47,6 +48,16 @@ class Options(ctypes.Structure):
                 ("inner_n_iter_max", ctypes.c_int32), ("constant_A", ctypes.c_int32), ("constant_B", ctypes.c_int32),
                 ("reserved", ctypes.c_int32)]
 
+
+class StopRule(ctypes.Structure):
+    """mcl_stop_rule of include/matcouply_hip.h (a tolerance of 0 = not set, like None / 0 in the reference)"""
+    _fields_ = [("tol", ctypes.c_double), ("absolute_tol", ctypes.c_double), ("feasibility_tol", ctypes.c_double),
+                ("initial_loss", ctypes.c_double), ("penalty_weight", (ctypes.c_double * MCL_MAX_REGS) * 3),
+                ("evaluate_loss_always", ctypes.c_int32), ("max_run_ahead", ctypes.c_int32)]
+
+
+STOP_RELATIVE, STOP_ABSOLUTE = 1, 2
+VERDICT_FEASIBLE, VERDICT_LOSS_EVALUATED = 1, 2  # flag bits of a verdict row; the stop code sits above them (>> 2)
 
 _lib = None
 
@@ -82,6 +93,7 @@ def load_library():
         "mcl_diagnostics_deferred": (ctypes.c_int, [P, P, I32]),
         "mcl_flush_diagnostics": (ctypes.c_int, [P]),
         "mcl_iterate": (ctypes.c_int, [P, I32, I32, I32, I32, P]),
+        "mcl_run": (ctypes.c_int, [P, I32, I32, I32, I32, ctypes.POINTER(StopRule), P, P, P]),
         "mcl_B_begin": (ctypes.c_int, [P]),
         "mcl_B_rho_max": (P, [P]),
         "mcl_B_factor": (ctypes.c_int, [P]),
@@ -111,6 +123,9 @@ def load_library():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.mcl_version() != MCL_ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} reports ABI version {lib.mcl_version()}, this binding was written against "
+                           f"{MCL_ABI_VERSION} (include/matcouply_hip.h): rebuild the library (`python matcouply_amd/_build.py --force`)")
     _lib = lib
     return lib
 
@@ -278,6 +293,31 @@ class HipEngine:
     def iterate(self, n_iter, update_A=True, update_B=True, update_C=True, diag_ring=None):
         ptr = diag_ring.data_ptr() if diag_ring is not None else None
         self._check(self.lib.mcl_iterate(self._h, int(n_iter), int(update_A), int(update_B), int(update_C), ptr))
+
+    def run(self, n_iter_max, tol, absolute_tol, feasibility_tol, initial_loss, penalty_weight, evaluate_loss_always,
+            update_A=True, update_B=True, update_C=True, max_run_ahead=0):
+        """Up to `n_iter_max` outer iterations with the reference's stopping rule evaluated ON THE DEVICE (mcl_run).
+        Tolerances: None / 0 = not set.  Returns (n_iter, code, diag [n_iter, DIAG_LEN], verdict [n_iter, 4]) with the
+        two rings as NumPy arrays; code 0 = iteration budget exhausted, STOP_RELATIVE / STOP_ABSOLUTE otherwise."""
+        torch = self._torch
+        n = int(n_iter_max)
+        rule = StopRule()
+        rule.tol, rule.absolute_tol = float(tol or 0.0), float(absolute_tol or 0.0)
+        rule.feasibility_tol, rule.initial_loss = float(feasibility_tol or 0.0), float(initial_loss)
+        for m in range(3):
+            for k in range(MCL_MAX_REGS):
+                rule.penalty_weight[m][k] = float(penalty_weight[m][k]) if k < len(penalty_weight[m]) else 0.0
+        rule.evaluate_loss_always, rule.max_run_ahead = int(bool(evaluate_loss_always)), int(max_run_ahead)
+        ring = torch.zeros((max(n, 1), DIAG_LEN), dtype=torch.float64, device=self.device)
+        verdict = torch.zeros((max(n, 1), 4), dtype=torch.float64, device=self.device)
+        if getattr(self, "_status", None) is None:
+            self._status = torch.zeros(4, dtype=torch.int32).pin_memory()  # written by the verdict kernel
+        status = self._status
+        self._check(self.lib.mcl_run(self._h, n, int(update_A), int(update_B), int(update_C), ctypes.byref(rule),
+                                     ring.data_ptr(), verdict.data_ptr(), status.data_ptr()))
+        stopped, stop_it, code, _ = (int(v) for v in status)  # mcl_run has synchronised the stream
+        n_done = stop_it + 1 if stopped else max(n, 0)
+        return n_done, (code if stopped else 0), ring[:n_done].cpu().numpy(), verdict[:n_done].cpu().numpy()
 
     # -- step calls -----------------------------------------------------------------------------------
     def B_begin(self):

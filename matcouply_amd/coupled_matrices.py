@@ -140,8 +140,18 @@ def _validate_cmf(cmf):
 
 
 def _on_device(A, B_is, C):
-    """factors held as torch tensors on a HIP device: the dense converters then run in the native kernel"""
-    return all(is_torch(t) and t.is_cuda for t in [A, C] + list(B_is))
+    """factors the native reconstruction kernel can take as they are: float32 torch tensors on a HIP device, outside any
+    autograd graph, rank within the kernel's limit.  Everything else (float64 factors, factors that require grad, larger
+    ranks) goes through the generic array expression below, which keeps dtype and gradients like the reference's"""
+    from . import _engine
+
+    ts = [A, C] + list(B_is)
+    if not all(is_torch(t) and t.is_cuda for t in ts):
+        return False
+    import torch
+
+    return (all(t.dtype == torch.float32 and not t.requires_grad for t in ts)
+            and 1 <= int(C.shape[1]) <= _engine.MCL_MAX_RANK)
 
 
 def _device_matrices(weights, A, B_is, C):

@@ -260,7 +260,9 @@ template <int RP>
 __global__ __launch_bounds__(256) void k_B_solve_f64(const int *__restrict__ tile_slab, const int *__restrict__ tile_row0,
                                                      const int *__restrict__ tile_nrows, int n_tiles,
                                                      const double *__restrict__ XC, const float *__restrict__ A,
-                                                     const double *__restrict__ Linv64, int r, float *__restrict__ B) {
+                                                     const double *__restrict__ Linv64, int r, float *__restrict__ B,
+                                                     const int *__restrict__ gate) {
+    MCL_GATE(gate);
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= n_tiles) return;
@@ -320,7 +322,8 @@ __global__ __launch_bounds__(64) void k_C_prepare(const double *__restrict__ GR,
 // Penalty-free C (decomposition.py:328-331 with an empty penalty list): C = R G^-1 is a plain least-squares solve whose
 // normal equations are not shifted, so the product is taken in fp64 from the fp64 [G | R] and rounded once.
 __global__ __launch_bounds__(256) void k_C_solve_f64(const double *__restrict__ R, const double *__restrict__ Linv, int K,
-                                                     int r, float *__restrict__ C) {
+                                                     int r, float *__restrict__ C, const int *__restrict__ gate) {
+    MCL_GATE(gate);
     extern __shared__ double Ls[];
     for (int e = threadIdx.x; e < r * r; e += 256) Ls[e] = Linv[e];
     __syncthreads();
@@ -539,6 +542,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const int *__restrict__ tile
                                                     const float *__restrict__ rho_arr, const float *__restrict__ Linv,
                                                     float *__restrict__ F, RegSet regs, int r, int inner,
                                                     double *__restrict__ diag_tile) {
+    MCL_GATE(regs.gate);
     __shared__ double dsm[4][DIAG_COLS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile_raw = blockIdx.x * 4 + wave;
@@ -573,6 +577,7 @@ __global__ __launch_bounds__(1024) void k_C_finish_fused(const double *__restric
                                                          float *__restrict__ CtC, double *__restrict__ CtC64,
                                                          float *__restrict__ Cfrag, int KC, int NBc,
                                                          double *__restrict__ diag_row, int rows_per_wave) {
+    MCL_GATE(regs.gate);
     extern __shared__ float smc[];
     __shared__ double dsm[16][DIAG_COLS];
     __shared__ float rho_s;
@@ -759,6 +764,7 @@ __global__ __launch_bounds__(256) void k_A_finish(float *__restrict__ BtB, const
                                                   float *__restrict__ LinvB, const int *__restrict__ slab_seg_ptr,
                                                   const double *__restrict__ seg_rhs, const double *__restrict__ seg_btb,
                                                   float *__restrict__ rhsA_out) {
+    MCL_GATE(regs.gate);
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= I) return;
@@ -1273,6 +1279,7 @@ __global__ __launch_bounds__(256) void k_A_finish_rows(float *__restrict__ BtB, 
                                                        const double *__restrict__ seg_rhs,
                                                        const double *__restrict__ seg_btb, float *__restrict__ rhsA_out,
                                                        AFuse F) {
+    MCL_GATE(regs.gate);
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= I) return;
@@ -1299,6 +1306,7 @@ __global__ __launch_bounds__(256) void k_A_finish_rows_wide(float *__restrict__ 
                                                             const double *__restrict__ seg_rhs,
                                                             const double *__restrict__ seg_btb,
                                                             float *__restrict__ rhsA_out, AFuse F) {
+    MCL_GATE(regs.gate);
     __shared__ double part[SPB][3][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int WPS = 4 / SPB;                  // waves per slab: one system wave + WPS - 1 streaming waves
@@ -1341,6 +1349,7 @@ __global__ __launch_bounds__(64) void k_A_e1(const float *__restrict__ rhsA, con
                                              const float *__restrict__ CtC, int btb_is_q, const float *__restrict__ A,
                                              RegSet regs, int r, double *__restrict__ e1,
                                              double *__restrict__ diag_row) {
+    MCL_GATE(regs.gate);
     const int i = blockIdx.x, lane = threadIdx.x;
     const bool act = lane < r;
     const int c = act ? lane : 0;
@@ -1453,12 +1462,114 @@ __global__ __launch_bounds__(256) void k_diag_final(DiagTables T, int include_re
     }
 }
 
+// ---- device-side stopping rule (mcl_run) ---------------------------------------------------------------------------
+// The reduction of the diagnostics tables of k_diag_final, and in the LAST block to finish (ticket) the stopping test of
+// the reference's outer loop (decomposition.py:990-1053) on the reduced vector: feasibility gaps (:404-417, :996),
+// relative reconstruction error (:1013-1014), regularised loss (:1016-1023), relative / absolute loss criterion
+// (:1037-1053) with the quirks kept (Q8: the absolute criterion only counts when `tol` is set; Q9: it tests the newest
+// loss; Q10: no loss on an infeasible iterate unless the caller records errors, so "previous loss" means the previous
+// COMPUTED one).  A hit sets the gate flag every state-writing kernel of the iterations enqueued behind this one tests
+// (MCL_GATE), and is reported - like every iteration's progress - through four int32 in pinned host memory.
+struct StopRuleDev {
+    double tol, abs_tol, feas_tol;
+    double l2[3];
+    double w[3][MCL_MAX_REGS];
+    int has_tol, has_feas, loss_always, it;
+};
+
+__global__ __launch_bounds__(256) void k_diag_verdict(DiagTables T, double *__restrict__ out, StopRuleDev R,
+                                                      int *__restrict__ gate, double *__restrict__ state,
+                                                      double *__restrict__ verdict_row, int *__restrict__ status_host) {
+    __shared__ double sm[4];
+    __shared__ int last;
+    if (*gate != 0) return;  // an earlier iteration has stopped the run: nothing is evaluated any more
+    const int b = blockIdx.x;
+    if (b < 3 * DIAG_COLS) {
+        const int t = b / DIAG_COLS, col = b - t * DIAG_COLS;
+        const double s = (T.rows[t] > 0) ? block_colsum(T.tab[t], T.rows[t], DIAG_COLS, col, sm) : 0.0;
+        if (threadIdx.x == 0) {
+            if (col == 0) {
+                out[MCL_DIAG_NORM_SQ + t] = s;
+            } else if (col == 1) {
+                for (int k = 0; k < MCL_MAX_REGS; ++k)
+                    out[MCL_DIAG_REG + (t * MCL_MAX_REGS + k) * 2 + 1] = (k < T.nreg[t]) ? s : 0.0;
+            } else {
+                const int k = col - 2;
+                out[MCL_DIAG_REG + (t * MCL_MAX_REGS + k) * 2] = (k < T.nreg[t]) ? s : 0.0;
+            }
+        }
+    } else if (b < 3 * DIAG_COLS + 2) {
+        const int col = b - 3 * DIAG_COLS;
+        const double s = (T.I > 0) ? block_colsum(T.e1, T.I, 2, col, sm) : 0.0;
+        if (threadIdx.x == 0) out[col == 0 ? MCL_DIAG_INNER : MCL_DIAG_MODEL_SQ] = s;
+    } else if (threadIdx.x == 0) {
+        out[MCL_DIAG_X_SQ] = T.xsq[0];
+        out[6] = 0.0;
+        out[7] = 0.0;
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();  // this block's entries of `out` are visible device-wide before its ticket
+        const int ticket = atomicAdd(gate + 3, 1);
+        last = ticket == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    __threadfence();
+    gate[3] = 0;  // ticket counter ready for the next launch (stream order)
+    auto ld = [&](int i) { return __hip_atomic_load(out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // feasibility gaps ||aux - factor|| / ||factor||, worst over all penalties of all modes (vacuously feasible without any)
+    double worst = -__builtin_inf();
+    for (int m = 0; m < 3; ++m) {
+        const double fn = sqrt(ld(MCL_DIAG_NORM_SQ + m));
+        for (int k = 0; k < T.nreg[m]; ++k) {
+            const double gap = sqrt(ld(MCL_DIAG_REG + (m * MCL_MAX_REGS + k) * 2)) / fn;
+            worst = (gap > worst || gap != gap) ? gap : worst;  // a NaN gap is never feasible
+        }
+    }
+    const bool feasible = R.has_feas && (worst < R.feas_tol);
+    int code = 0, computed = 0;
+    double rec = 0.0, loss = 0.0;
+    if (feasible || R.loss_always) {
+        const double xsq = ld(MCL_DIAG_X_SQ), inner = ld(MCL_DIAG_INNER), model = ld(MCL_DIAG_MODEL_SQ);
+        rec = sqrt(fmax(0.0, xsq - 2.0 * inner + model)) / sqrt(xsq);
+        double reg = 0.0;
+        for (int m = 0; m < 3; ++m) {
+            for (int k = 0; k < T.nreg[m]; ++k)
+                if (R.w[m][k] != 0.0) reg += R.w[m][k] * ld(MCL_DIAG_REG + (m * MCL_MAX_REGS + k) * 2 + 1);
+            if (R.l2[m] != 0.0) reg += 0.5 * R.l2[m] * ld(MCL_DIAG_NORM_SQ + m);
+        }
+        loss = 0.5 * (rec * rec) + reg;
+        computed = 1;
+        if (R.has_tol) {
+            const double prev = state[0];
+            const bool rel = fabs(prev - loss) < R.tol * prev;
+            const bool absc = loss < R.abs_tol;
+            if (feasible && rel) code = 1;
+            else if (feasible && absc) code = 2;
+        }
+        state[0] = loss;
+    }
+    verdict_row[0] = rec, verdict_row[1] = loss, verdict_row[2] = worst;
+    verdict_row[3] = (double)((feasible ? 1 : 0) | (computed << 1) | (code << 2));
+    if (code) {
+        gate[1] = R.it, gate[2] = code;
+        __threadfence();
+        gate[0] = 1;
+        status_host[1] = R.it, status_host[2] = code;
+        __threadfence_system();
+        status_host[0] = 1;
+    }
+    status_host[3] = R.it + 1;  // progress: the host keeps its run-ahead bounded by this
+    __threadfence_system();
+}
+
 // Per-tile diagnostics of a packed factor from memory (generic path / initial state):
 // ||F||^2, sum|F|, ||Z_k - F||^2 with Z_k = aux_k or P Delta (PARAFAC2; product on the MFMA).  Tile layout of rows_mfma.h.
 template <int NBR, bool VEC>
 __global__ __launch_bounds__(256) void k_rows_diag(const int *__restrict__ tile_row0, const int *__restrict__ tile_nrows,
                                                    int n_tiles, const float *__restrict__ F, RegSet regs, int r,
                                                    double *__restrict__ diag_tile) {
+    MCL_GATE(regs.gate);
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= n_tiles) return;
@@ -1580,7 +1691,7 @@ int mcl_launch_B_solve_f64(mcl_context *c) {
     }
     dim3 grid((unsigned)((c->tilesB.n_tiles + 3) / 4)), block(256);
     DISPATCH_RP_T(c, k_B_solve_f64, grid, block, c->tilesB.slab, c->tilesB.row0, c->tilesB.nrows, c->tilesB.n_tiles, c->XC64,
-                  c->A, c->LinvB64, c->r, c->B);
+                  c->A, c->LinvB64, c->r, c->B, c->gate_active);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
@@ -1596,7 +1707,7 @@ int mcl_launch_C_prepare(mcl_context *c) {
 int mcl_launch_C_solve_f64(mcl_context *c) {
     const long n = (long)c->K * c->r;
     hipLaunchKernelGGL(k_C_solve_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), sizeof(double) * c->r * c->r, c->stream,
-                       c->GR + (long)c->r * c->r, c->LinvC64, (int)c->K, c->r, c->C);
+                       c->GR + (long)c->r * c->r, c->LinvC64, (int)c->K, c->r, c->C, c->gate_active);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
@@ -1713,6 +1824,7 @@ __global__ __launch_bounds__(256) void k_C_finish_multi(const double *__restrict
                                                         float *__restrict__ C, RegSet regs, int inner,
                                                         double *__restrict__ CtCpart, float *__restrict__ Cfrag, int KC,
                                                         double *__restrict__ diag_row) {
+    MCL_GATE(regs.gate);
     __shared__ float Ls[256];
     __shared__ float Cs[64 * 16];
     __shared__ double dsm[4][DIAG_COLS];
@@ -2014,6 +2126,22 @@ DiagTables mcl_diag_tables(const mcl_context *c, bool a_from_rows) {
 
 int mcl_launch_diag_tables(mcl_context *c, const DiagTables &T, double *out, int include_replicated) {
     hipLaunchKernelGGL(k_diag_final, dim3(3 * DIAG_COLS + 3), dim3(256), 0, c->stream, T, include_replicated, out);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int mcl_launch_diag_verdict(mcl_context *c, double *out, const mcl_stop_rule *rule, int it, double *verdict_row,
+                            int *status_dev) {
+    StopRuleDev R{};
+    R.tol = rule->tol, R.abs_tol = rule->absolute_tol, R.feas_tol = rule->feasibility_tol;
+    R.has_tol = rule->tol != 0.0, R.has_feas = rule->feasibility_tol != 0.0;  // Python truthiness of the keyword values
+    R.loss_always = rule->evaluate_loss_always != 0, R.it = it;
+    for (int m = 0; m < 3; ++m) {
+        R.l2[m] = c->opt.l2_penalty[m];
+        for (int k = 0; k < MCL_MAX_REGS; ++k) R.w[m][k] = rule->penalty_weight[m][k];
+    }
+    hipLaunchKernelGGL(k_diag_verdict, dim3(3 * DIAG_COLS + 3), dim3(256), 0, c->stream, mcl_diag_tables(c, true), out, R,
+                       c->gate, c->stop_state, verdict_row, status_dev);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

@@ -107,6 +107,8 @@ int64_t plan(mcl_context *c, char *base) {
     c->diag_sums = b.take<double>(3 * DIAG_COLS + 2);
     c->xsq_part = b.take<double>(1024);
     c->x_sq = b.take<double>(1);
+    c->gate = b.take<int>(4);
+    c->stop_state = b.take<double>(4);
 
     // generic (non row-separable) path scratch
     const int64_t maxrows = std::max<int64_t>(N, std::max<int64_t>(I, K));
@@ -184,7 +186,19 @@ int flush_B_finish(mcl_context *c) {
 int flush_diag(mcl_context *c) {
     if (!c->diag_pending) return 0;
     c->diag_pending = false;
+    c->diag_crossed_sweep = false;
     return mcl_launch_diag_tables(c, c->diag_pending_T, c->diag_pending_out, c->diag_pending_incl);
+}
+
+// Entry points that REPLACE what a deferred reduction refers to (workspace, problem, factors, penalty buffers) or end the
+// context: the reduction is issued first, while the tables it recorded are still the old, valid ones - the header's
+// contract is that `out` is written when any other entry point has been called.
+int settle_deferred(mcl_context *c) {
+    if (!c->diag_pending) return 0;
+    if (c->has_problem && c->has_factors && c->has_workspace) return flush_diag(c);
+    c->diag_pending = false;  // cannot happen (a deferral needs a complete context); never reduce through stale pointers
+    c->diag_crossed_sweep = false;
+    return 0;
 }
 
 int ready(mcl_context *c) {
@@ -281,7 +295,7 @@ int generic_inner_loop(mcl_context *c, int mode) {
 
 extern "C" {
 
-int mcl_version(void) { return 100; }
+int mcl_version(void) { return MCL_ABI_VERSION; }
 
 const char *mcl_last_error(const mcl_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -325,6 +339,7 @@ int mcl_create(mcl_context **out, int device, void *hip_stream) {
 
 void mcl_destroy(mcl_context *ctx) {
     if (!ctx) return;
+    (void)settle_deferred(ctx);  // a deferred diagnostics vector is still delivered
     for (int s = 0; s < 4; ++s)
         for (hipEvent_t e : ctx->prof_ev[s]) (void)hipEventDestroy(e);
     delete ctx;
@@ -334,6 +349,7 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     if (!c) return 1;
     if (I < 0 || K < 1) return fail(c, "mcl_set_problem: need I >= 0 and K >= 1");
     if (rank < 1 || rank > MCL_MAX_RANK) return fail(c, "mcl_set_problem: rank must be in [1, 64]");
+    if (int rc = settle_deferred(c)) return rc;
     c->b_finish_pending = false;  // a deferred row pass of the step API refers to the buffers being replaced
     if (!row_ptr || row_ptr[0] != 0) return fail(c, "mcl_set_problem: row_ptr[0] must be 0");
     for (int64_t i = 0; i < I; ++i)
@@ -503,6 +519,7 @@ int mcl_set_factors(mcl_context *c, float *A, float *B, float *C) {
     if (!c) return 1;
     if (!c->has_problem) return fail(c, "mcl_set_factors: call mcl_set_problem first");
     if ((c->I > 0 && !A) || (c->N > 0 && !B) || !C) return fail(c, "mcl_set_factors: NULL factor pointer");
+    if (int rc = settle_deferred(c)) return rc;
     c->b_finish_pending = false;  // a deferred row pass of the step API refers to the buffers being replaced
     c->A = A, c->B = B, c->C = C;
     c->has_factors = true;
@@ -518,6 +535,7 @@ int mcl_set_penalties(mcl_context *c, int32_t mode, int32_t n, const mcl_penalty
     if (!c) return 1;
     if (mode < 0 || mode > 2) return fail(c, "mcl_set_penalties: mode must be 0, 1 or 2");
     if (n < 0 || n > MCL_MAX_REGS) return fail(c, "mcl_set_penalties: at most 4 penalties per mode");
+    if (int rc = settle_deferred(c)) return rc;
     c->b_finish_pending = false;  // a deferred row pass of the step API refers to the buffers being replaced
     RegSet rs{};
     rs.n = n;
@@ -558,8 +576,12 @@ int64_t mcl_workspace_bytes(mcl_context *c) {
 int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
     if (!c) return 1;
     if (!c->has_problem) return fail(c, "mcl_set_workspace: call mcl_set_problem first");
+    if (int rc = settle_deferred(c)) return rc;  // reduces the tables of the OLD workspace before it is re-planned / zeroed
     const int64_t need = plan(c, nullptr);
-    if (!workspace || bytes < need) return fail(c, "mcl_set_workspace: workspace too small");
+    if (!workspace || bytes < need) {
+        if (c->has_workspace) plan(c, c->ws);  // a refused call leaves the installed workspace as it was
+        return fail(c, "mcl_set_workspace: workspace too small");
+    }
     c->b_finish_pending = false;  // a deferred row pass of the step API refers to the buffers being replaced
     if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(c, "mcl_set_workspace: workspace must be 256-byte aligned");
     c->ws = static_cast<char *>(workspace);
@@ -706,9 +728,12 @@ int mcl_B_prox_finish(mcl_context *c, int32_t k) {
 }
 
 int mcl_update_B(mcl_context *c) {
-    if (c && c->diag_pending && ready_noflush(c) == 0 && !c->b_finish_pending && mcl_sweep_eligible(c)) {
-        // a deferred diagnostics reduction survives the sweep (which writes the OTHER mode-1 table) and rides on the
-        // C-phase reduction that follows it
+    if (c && c->diag_pending && !c->diag_crossed_sweep && ready_noflush(c) == 0 && !c->b_finish_pending &&
+        mcl_sweep_eligible(c)) {
+        // a deferred diagnostics reduction survives ONE sweep (which writes the OTHER mode-1 table) and rides on the
+        // C-phase reduction that follows it; a second sweep would flip the table parity back and overwrite the table the
+        // deferral recorded, so a deferral that has already crossed a sweep is issued first (the else branch)
+        c->diag_crossed_sweep = true;
     } else if (int rc = ready(c)) {
         return rc;
     }
@@ -947,10 +972,8 @@ int mcl_C_end(mcl_context *c) {
 }
 
 // ---- diagnostics ---------------------------------------------------------------------------------------
-int mcl_diagnostics(mcl_context *c, double *out, int32_t include_replicated) {
-    if (int rc = ready(c)) return rc;
-    if (!out) return fail(c, "mcl_diagnostics: out is NULL");
-
+// every table the diagnostics vector is reduced from is made current (what mcl_diagnostics does before its reduction)
+static int mcl_prepare_diag_tables(mcl_context *c) {
     if (!c->xsq_valid) {
         if (int rc = mcl_launch_x_sq(c)) return rc;
         c->xsq_valid = true;
@@ -972,6 +995,13 @@ int mcl_diagnostics(mcl_context *c, double *out, int32_t include_replicated) {
         if (int rc = mcl_launch_A_e1(c, !c->e1_from_raw_gram)) return rc;
     }
     c->diag_valid[0] = true;
+    return 0;
+}
+
+int mcl_diagnostics(mcl_context *c, double *out, int32_t include_replicated) {
+    if (int rc = ready(c)) return rc;
+    if (!out) return fail(c, "mcl_diagnostics: out is NULL");
+    if (int rc = mcl_prepare_diag_tables(c)) return rc;
     return mcl_launch_diag_final(c, out, include_replicated, true);
 }
 
@@ -1015,6 +1045,75 @@ int mcl_iterate(mcl_context *c, int32_t n_iter, int32_t update_A, int32_t update
         }
     }
     return flush_diag(c);
+}
+
+// Everything the context caches about the factors (validity flags of by-products, pending deferrals): forgotten.  After a
+// gated run that stopped early the scratch buffers hold a mixture of the stopping iteration's by-products and recomputed
+// ones, the host-side flags describe iterations that did not happen - the factors and ADMM variables are exact.
+static void forget_byproducts(mcl_context *c) {
+    c->b_finish_pending = false;
+    c->diag_pending = c->diag_crossed_sweep = false;
+    c->step_fuse = c->step_stats = false;
+    c->b_systems_valid = false;
+    c->cfrag_valid = false;
+    c->xc_valid = c->ctc_valid = c->e1_valid = false;
+    c->ctc_parts = 0;
+    c->mseg_valid = c->grpart_valid = false;
+    c->diag_valid[0] = c->diag_valid[1] = c->diag_valid[2] = false;
+}
+
+int mcl_run(mcl_context *c, int32_t n_iter_max, int32_t update_A, int32_t update_B, int32_t update_C,
+            const mcl_stop_rule *rule, double *diag_ring, double *verdict_ring, mcl_run_status *status) {
+    if (!c) return 1;
+    if (!rule || !status) return fail(c, "mcl_run: rule and status must not be NULL (fixed iteration counts: mcl_iterate)");
+    if (n_iter_max > 0 && (!diag_ring || !verdict_ring)) return fail(c, "mcl_run: diag_ring / verdict_ring is NULL");
+    if (int rc = ready(c)) return rc;
+    int *status_dev = nullptr;
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&status_dev), (void *)status, 0) != hipSuccess || !status_dev) {
+        (void)hipGetLastError();
+        return fail(c, "mcl_run: status must live in pinned (page-locked, device-mapped) host memory");
+    }
+    status->stopped = 0, status->stop_iteration = -1, status->code = 0, status->progress = 0;
+    if (n_iter_max <= 0) return 0;
+    const int ahead = rule->max_run_ahead > 0 ? rule->max_run_ahead : 8;
+    c->h_stop_init[0] = rule->initial_loss;
+    MCL_CHECK_HIP(c, hipMemsetAsync(c->gate, 0, 4 * sizeof(int), c->stream));
+    MCL_CHECK_HIP(c, hipMemcpyAsync(c->stop_state, c->h_stop_init, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    auto set_gate = [&](const int *g) {
+        c->gate_active = g;
+        for (int m = 0; m < 3; ++m) c->regs[m].gate = g;
+    };
+    set_gate(c->gate);
+    int rc = 0, enqueued = 0;
+    for (int it = 0; it < n_iter_max && rc == 0; ++it) {
+        // bounded run-ahead: wait (without synchronising the stream) until the device is at most `ahead` verdicts behind
+        long spins = 0;
+        while (!status->stopped && it - status->progress >= ahead) {
+            if ((++spins & 0x3fff) == 0 && hipStreamQuery(c->stream) == hipSuccess && it - status->progress >= ahead &&
+                !status->stopped) {
+                rc = fail(c, "mcl_run: the stream drained without the verdict kernel reporting progress");
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+        if (rc || status->stopped) break;
+        if (update_B) rc = mcl_update_B(c);
+        if (rc == 0 && update_C) {
+            rc = mcl_update_C_local(c);
+            if (rc == 0) rc = mcl_update_C_finish(c);
+        }
+        if (rc == 0 && update_A) rc = mcl_update_A(c);
+        if (rc == 0) rc = mcl_prepare_diag_tables(c);
+        if (rc == 0)
+            rc = mcl_launch_diag_verdict(c, diag_ring + (int64_t)it * MCL_DIAG_LEN, rule, it,
+                                         verdict_ring + (int64_t)it * 4, status_dev);
+        enqueued = it + 1;
+    }
+    set_gate(nullptr);
+    const hipError_t e = hipStreamSynchronize(c->stream);  // the call reports the verdict: the one entry point that waits
+    if (e != hipSuccess && rc == 0) rc = fail(c, std::string("mcl_run: hipStreamSynchronize: ") + hipGetErrorString(e));
+    if (status->stopped && enqueued > status->stop_iteration + 1) forget_byproducts(c);
+    return rc;
 }
 
 float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {

@@ -30,10 +30,12 @@ struct ModeView {
     int n_slabs;
     const float *rho;      // [n_slabs]
     float *F;              // factor [rows, r]
+    const int *gate;       // stop flag of a gated run (mcl_run with a stopping rule), else NULL: see MCL_GATE
 };
 
 static ModeView view_of(mcl_context *c, int mode) {
     ModeView v{};
+    v.gate = c->gate_active;
     const TileMap &tm = (mode == 1) ? c->tilesB : (mode == 2 ? c->tilesC : c->tilesA);
     v.tile_slab = tm.slab, v.tile_row0 = tm.row0, v.tile_nrows = tm.nrows, v.n_tiles = tm.n_tiles;
     if (mode == 1) {
@@ -51,6 +53,7 @@ static ModeView view_of(mcl_context *c, int mode) {
 // wave-uniform r x r matrix (L^-1, Delta, T_i) run on the fp32 MFMA.
 // ---------------------------------------------------------------------------------------------------------
 #define TILE_PROLOGUE()                                                                                      \
+    MCL_GATE(mv.gate);                                                                                       \
     const int lane = threadIdx.x & 63;                                                                       \
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);                                                    \
     if (tile >= mv.n_tiles) return;                                                                          \
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(256) void k_rows_solve_stats(ModeView mv, const flo
 __global__ __launch_bounds__(256) void k_stats_reduce(const int *__restrict__ slab_tile_ptr, const double *__restrict__ stat_gram,
                                                       const double *__restrict__ stat_colsq, RegSet regs, int r, int W,
                                                       int n_slabs, double *__restrict__ S, double *__restrict__ colsq) {
+    MCL_GATE(regs.gate);
     const int slab = blockIdx.x;
     const int t0 = slab_tile_ptr[slab], t1 = slab_tile_ptr[slab + 1];
     int kpf2 = -1;
@@ -297,6 +301,7 @@ __global__ __launch_bounds__(256) void k_stats_reduce(const int *__restrict__ sl
 __global__ __launch_bounds__(64) void k_A_rows_solve(const float *__restrict__ rhsA, const float *__restrict__ rhoA,
                                                      const float *__restrict__ LinvA, float *__restrict__ A,
                                                      RegSet regs, int r) {
+    MCL_GATE(regs.gate);
     __shared__ float tS[MCL_MAX_RANK];
     const int i = blockIdx.x, lane = threadIdx.x;
     const bool act = lane < r;
@@ -407,6 +412,7 @@ __global__ __launch_bounds__(256) void k_rows_l2ball(ModeView mv, RegSet regs, i
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_slab_tv(const int *__restrict__ ext, int n_slabs, const float *__restrict__ F,
                                                 const float *__restrict__ rho_arr, RegSet regs, int kreg, int r) {
+    MCL_GATE(regs.gate);
     const long t = (long)blockIdx.x * 64 + threadIdx.x;
     if (t >= (long)n_slabs * r) return;
     const int slab = (int)(t / r), col = (int)(t - (long)slab * r);
@@ -552,6 +558,7 @@ static __device__ __forceinline__ bool ur3_pop(UniRing3 &st, int lane, double &s
 __global__ __launch_bounds__(64) void k_slab_unimodal_v3(const int *__restrict__ ext, int n_slabs, float *__restrict__ F,
                                                          RegSet regs, int k, int r, double *__restrict__ errL,
                                                          double *__restrict__ ssy, double *__restrict__ ssw) {
+    MCL_GATE(regs.gate);
     __shared__ double ring[2][RC3 * 64];
     const int lane = threadIdx.x;
     const long t = (long)blockIdx.x * 64 + threadIdx.x;
@@ -803,6 +810,7 @@ static __device__ __forceinline__ int wave_min_i(int v) {
 template <int MODE>
 __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const int *__restrict__ ext, int n_slabs, float *__restrict__ F,
                                                          RegSet regs, int k, int r, UniScratch sc) {
+    MCL_GATE(regs.gate);
     __shared__ double ring_d[2][MODE == 2 ? 1 : RC4 * 64];
     __shared__ int ring_i[MODE == 2 ? 1 : RC4 * 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;  // MODE 2: four waves work on the same 64 columns
@@ -1297,6 +1305,7 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
                                                        float *__restrict__ T, double *__restrict__ acc_out,
                                                        int *__restrict__ status, TileStats ts, RegSet regs,
                                                        float *__restrict__ xmin_est, int scaled) {
+    MCL_GATE(regs.gate);
     __shared__ double Ssm[TILES ? 256 * NB * NB : 1];
     __shared__ float Dsm[256 * NB * NB];
     // rank <= 16: the Jacobi route of a slab this iteration cannot handle runs right here (8 KB of LDS; saves the launch of
@@ -1617,7 +1626,9 @@ __global__ __launch_bounds__(256) void k_pf2_sum(const double *__restrict__ acc,
 // k_pf2_sum + k_pf2_delta in one launch (single-process runs: no all-reduce between them).  Workgroup e sums element e
 // and the weight total with the same order and roundings as the two kernels.
 __global__ __launch_bounds__(256) void k_pf2_sum_delta(const double *__restrict__ acc, int n_slabs, int n2,
-                                                       float *__restrict__ red, float *__restrict__ Delta) {
+                                                       float *__restrict__ red, float *__restrict__ Delta,
+                                                       const int *__restrict__ gate) {
+    MCL_GATE(gate);
     __shared__ double sm[2][4];
     const int e = blockIdx.x, n_el = n2 + 1;
     double s = 0.0, w = 0.0;
@@ -1637,7 +1648,8 @@ __global__ __launch_bounds__(256) void k_pf2_sum_delta(const double *__restrict_
         Delta[e] = re / rw;
     }
 }
-__global__ void k_pf2_delta(const float *__restrict__ red, int r, float *__restrict__ Delta) {
+__global__ void k_pf2_delta(const float *__restrict__ red, int r, float *__restrict__ Delta, const int *__restrict__ gate) {
+    MCL_GATE(gate);
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < r * r) Delta[e] = red[e] / red[r * r];
 }
@@ -2160,7 +2172,7 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                 DISPATCH_ROWS(c, vec, k_pf2_apply, grid, block, mv, (const float *)rs.dual[k], (const float *)c->pf2_T, rs.aux[k], r);
             if (c->pf2_delta_fused)  // single-process inner loop: Delta follows at once, no all-reduce in between
                 hipLaunchKernelGGL(k_pf2_sum_delta, dim3((unsigned)n2), dim3(256), 0, c->stream, c->pf2_acc, (int)c->I, n2,
-                                   c->pf2_red, rs.aux2[k]);
+                                   c->pf2_red, rs.aux2[k], c->gate_active);
             else
                 hipLaunchKernelGGL(k_pf2_sum, dim3((unsigned)(n2 + 1)), dim3(256), 0, c->stream, c->pf2_acc, (int)c->I,
                                    n2 + 1, c->pf2_red);
@@ -2182,7 +2194,7 @@ int mcl_launch_generic_prox_finish(mcl_context *c, int mode, int k) {
     const int n2 = c->r * c->r;
     if (!c->pf2_delta_fused)
         hipLaunchKernelGGL(k_pf2_delta, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->pf2_red, c->r,
-                           rs.aux2[k]);
+                           rs.aux2[k], c->gate_active);
     if (c->stack_fused) {  // the dual update rides in the fused finish pass
         MCL_CHECK_HIP(c, hipGetLastError());
         return 0;

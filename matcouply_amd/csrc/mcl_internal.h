@@ -30,7 +30,17 @@ struct RegSet {
     float *aux[MCL_MAX_REGS];
     float *dual[MCL_MAX_REGS];
     float *aux2[MCL_MAX_REGS];
+    const int *gate;  // stop flag of a gated run (mcl_run with a stopping rule), else NULL: see MCL_GATE
 };
+
+// Gated runs (mcl_run with a stopping rule): the host enqueues outer iterations AHEAD of the device-side verdict.  Every
+// kernel that writes a factor or an ADMM variable starts with this test of the stop flag the verdict kernel sets, so the
+// iterations enqueued behind the stopping one leave the state exactly as the stopping iteration left it (kernels that only
+// write scratch run on unchanged inputs; the host invalidates every cached by-product after an early stop).
+#define MCL_GATE(p)                                   \
+    do {                                              \
+        if ((p) != nullptr && *(p) != 0) return;      \
+    } while (0)
 
 // The per-row / per-tile fp64 diagnostic tables of the three modes and what else the MCL_DIAG_LEN vector is made of
 // (k_diag_final, and the spare workgroup of k_reduce_frag that takes over a DEFERRED reduction: admm.hip / sweep.hip).
@@ -160,7 +170,13 @@ struct mcl_context {
     // tables of iteration t stay intact while the sweep of t + 1 writes its own
     double *diagB_bufs[2] = {nullptr, nullptr};
     int diagB_parity = 0;
+    // gated runs (mcl_run): device state of the stopping rule
+    int *gate = nullptr;               // int32[4]: {stopped, stop_it, code, ticket of the verdict launch}
+    const int *gate_active = nullptr;  // == gate while a gated run is enqueueing (copied into ModeView / RegSet), else NULL
+    double *stop_state = nullptr;      // fp64[4]: {last computed loss, ...}
+    double h_stop_init[1] = {0.0};     // host source of the asynchronous upload of the initial loss (must outlive it)
     bool diag_pending = false;
+    bool diag_crossed_sweep = false;  // the pending deferral has already survived one sweep (it may not survive a second)
     DiagTables diag_pending_T{};
     double *diag_pending_out = nullptr;
     int diag_pending_incl = 1;
@@ -295,6 +311,8 @@ int mcl_launch_rows_diag(mcl_context *c, int mode);
 int mcl_launch_diag_final(mcl_context *c, double *out, int include_replicated, bool a_from_rows);
 DiagTables mcl_diag_tables(const mcl_context *c, bool a_from_rows);  // the tables as they stand now
 int mcl_launch_diag_tables(mcl_context *c, const DiagTables &T, double *out, int include_replicated);
+int mcl_launch_diag_verdict(mcl_context *c, double *out, const mcl_stop_rule *rule, int it, double *verdict_row,
+                            int *status_dev);  // table reduction + the stopping test of mcl_run
 int mcl_launch_x_sq(mcl_context *c);
 bool mcl_mode_is_row_separable(const mcl_context *c, int mode);
 bool mcl_stack_can_fuse(const mcl_context *c, int mode);          // generic.hip

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
                                                double *__restrict__ part_btb, float *__restrict__ GRpart,
                                                double *__restrict__ diag_block, int dbg_rt,
                                                long long *__restrict__ cyc_out, const int *__restrict__ bs_part) {
+    MCL_GATE(regs.gate);
     const int dbg = DBG ? dbg_rt : 0;
     // KS = 0: the half-width form for K <= 128 (config 2) - tile rows of 128 floats, a wave load / LDS store covers TWO
     // rows (lanes 0..31 row 2t, lanes 32..63 row 2t + 1): half the MFMAs, LDS traffic and partial bytes of the 256-wide form
@@ -978,6 +979,7 @@ int mcl_launch_reduce_weighted(mcl_context *c) {
     if (c->diag_pending) {  // a deferred diagnostics reduction takes a spare workgroup of this launch
         piggy.T = c->diag_pending_T, piggy.out = c->diag_pending_out, piggy.include_replicated = c->diag_pending_incl;
         c->diag_pending = false;
+        c->diag_crossed_sweep = false;
     }
     const int blocks = (MS + W * W + el - 1) / el + (piggy.out ? MCL_PIGGY_BLOCKS : 0);
     if (el == 64)

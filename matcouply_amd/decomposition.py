@@ -873,6 +873,11 @@ def cmf_aoadmm(
     if host_value and world > 1:
         raise NotImplementedError("TotalVariationPenalty is not supported with group= (its penalty value is summed on the host)")
     lazy_diag = (not (tol or absolute_tol)) and world > 1 and not verbose and n_iter_max > 0
+    # stopping rule on the device (mcl_run): single device, every penalty native, silent.  (tol set with absolute_tol=None is
+    # a TypeError in the reference's comparison - the host loop below raises it the same way.)
+    device_stop = (bool(tol or absolute_tol) and world == 1 and not verbose and n_iter_max > 0 and not any(has_ext)
+                   and not host_value and not (tol and absolute_tol is None) and hasattr(eng, "run"))
+    final_gaps_known = False
     if lazy_diag:
         # sharded, fixed iteration count: nothing depends on the diagnostics inside the loop, so their partial sums stay
         # on the device and are all-reduced once for all iterations (one collective per iteration remains: [G | R])
@@ -894,6 +899,32 @@ def cmf_aoadmm(
                 feasibility_gaps.append(gaps)
                 rec_errors.append(rec_error)
                 losses.append(0.5 * rec_error ** 2 + reg)
+    elif device_stop:
+        # a stopping rule is active (the DEFAULT call: tol=1e-8, absolute_tol=1e-10, feasibility_tol=1e-4): the rule is
+        # evaluated by a kernel at the end of every iteration (mcl_run), the host enqueues ahead of the verdicts and never
+        # blocks on one; state-writing kernels behind a stopping iteration see the device-side flag and do nothing, so
+        # the factors returned are exactly those of the stopping iteration.  Chunked so that the rings stay small.
+        weights = [[(reg.reg_strength if isinstance(reg, penalties.L1Penalty) else 0.0) for reg in regs[m]] for m in range(3)]
+        done, code, chunk = 0, 0, 4096
+        while done < n_iter_max and not code:
+            n_now = min(chunk, n_iter_max - done)
+            n_ran, code, ring_h, verdict_h = eng.run(
+                n_now, tol, absolute_tol, feasibility_tol, initial_loss=losses[-1], penalty_weight=weights,
+                evaluate_loss_always=return_errors, update_A=update_A, update_B=update_B_is, update_C=update_C)
+            for row, (v_rec, v_loss, _, v_flags) in zip(ring_h, verdict_h):
+                _, gaps, _ = read_diag(row)
+                feasibility_gaps.append(gaps)
+                flags = int(v_flags)
+                feasibility_criterion = bool(flags & _engine.VERDICT_FEASIBLE) if feasibility_tol else feasibility_tol
+                if flags & _engine.VERDICT_LOSS_EVALUATED:  # not on infeasible iterates unless errors are recorded (Q10)
+                    rec_errors.append(float(v_rec))
+                    losses.append(float(v_loss))
+            done += n_ran
+        it = done - 1
+        if code:
+            satisfied_stopping_condition = True
+            message = _StopRule.RELATIVE if code == _engine.STOP_RELATIVE else _StopRule.ABSOLUTE
+        final_gaps_known = True
     elif fast_path:
         # fixed iteration count: the whole outer loop runs natively, diagnostics stay on the device until the end
         ring = None
@@ -938,7 +969,10 @@ def cmf_aoadmm(
         else:
             progress.exhausted()
 
-    if feasibility_tol and return_errors:
+    if feasibility_tol and return_errors and final_gaps_known:
+        # the reference re-evaluates the gaps of the final state here: the state the last verdict was taken on
+        feasibility_criterion = _check_feasibility(feasibility_gaps[-1], feasibility_tol)
+    elif feasibility_tol and return_errors:
         _, final_gaps, _ = diagnostics()
         feasibility_criterion = _check_feasibility(final_gaps, feasibility_tol)
     elif not feasibility_tol:

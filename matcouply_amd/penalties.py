@@ -133,7 +133,6 @@ class ADMMPenalty(metaclass=InheritableDocstrings):
     def penalty(self, x):  # pragma: nocover
         """Value of the penalty at `x` (a factor matrix, or the list of matrices of a multi-matrix mode); it is added to
         the regularised loss the stopping rule looks at.  Hard constraints return 0."""
-        """Compute the penalty for the given factor matrix or list of factor matrices."""
         raise NotImplementedError
 
     # -- aux <-> matrix helpers (penalties.py:268-343) --------------------------------------------------------

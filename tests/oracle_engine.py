@@ -257,6 +257,51 @@ class OracleEngine:
             if diag_ring is not None:
                 self.diagnostics(out=diag_ring[it])
 
+    def run(self, n_iter_max, tol, absolute_tol, feasibility_tol, initial_loss, penalty_weight, evaluate_loss_always,
+            update_A=True, update_B=True, update_C=True, max_run_ahead=0):
+        """mcl_run of the C ABI (include/matcouply_hip.h) restated on the host: same verdict arithmetic, same rings"""
+        tol, absolute_tol, feasibility_tol = float(tol or 0.0), float(absolute_tol or 0.0), float(feasibility_tol or 0.0)
+        prev, rows, verdicts, code = float(initial_loss), [], [], 0
+        for it in range(int(n_iter_max)):
+            self.iterate(1, update_A=update_A, update_B=update_B, update_C=update_C)
+            d = self.diagnostics().numpy().copy()
+            worst = -np.inf
+            for m in range(3):
+                fn = np.sqrt(d[_engine.DIAG_NORM_SQ + m])
+                for k in range(len(self.regs[m])):
+                    with np.errstate(invalid="ignore", divide="ignore"):
+                        gap = np.sqrt(d[_engine.DIAG_REG + (m * _engine.MCL_MAX_REGS + k) * 2]) / fn
+                    worst = gap if (gap > worst or gap != gap) else worst
+            feasible = bool(feasibility_tol != 0.0 and worst < feasibility_tol)
+            rec = loss = 0.0
+            computed = feasible or bool(evaluate_loss_always)
+            if computed:
+                xsq, inner, model = d[_engine.DIAG_X_SQ], d[_engine.DIAG_INNER], d[_engine.DIAG_MODEL_SQ]
+                rec = np.sqrt(max(0.0, xsq - 2.0 * inner + model)) / np.sqrt(xsq)
+                reg = 0.0
+                for m in range(3):
+                    for k in range(len(self.regs[m])):
+                        w = penalty_weight[m][k] if k < len(penalty_weight[m]) else 0.0
+                        if w:
+                            reg += w * d[_engine.DIAG_REG + (m * _engine.MCL_MAX_REGS + k) * 2 + 1]
+                    if self.l2[m]:
+                        reg += 0.5 * self.l2[m] * d[_engine.DIAG_NORM_SQ + m]
+                loss = 0.5 * (rec * rec) + reg
+                if tol != 0.0:
+                    with np.errstate(invalid="ignore"):
+                        rel = abs(prev - loss) < tol * prev
+                    if feasible and rel:
+                        code = _engine.STOP_RELATIVE
+                    elif feasible and loss < absolute_tol:
+                        code = _engine.STOP_ABSOLUTE
+                prev = loss
+            rows.append(d)
+            verdicts.append([rec, loss, worst, float(int(feasible) | (int(computed) << 1) | (code << 2))])
+            if code:
+                break
+        n = len(rows)
+        return (n, code, np.asarray(rows).reshape(n, _engine.DIAG_LEN), np.asarray(verdicts, dtype=np.float64).reshape(n, 4))
+
     def diagnostics_deferred(self, include_replicated=True, out=None):
         return self.diagnostics(include_replicated=include_replicated, out=out)  # the checker has nothing to defer
 

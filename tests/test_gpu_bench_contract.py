@@ -29,16 +29,42 @@ def test_single_rank_line():
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"]
     assert len(d["region_ms"]) == 3 and abs(d["ms_per_step"] * d["steps"] - sorted(d["region_ms"])[1]) < 1e-3
+    assert d["region_ms_stats"]["min"] <= d["region_ms_stats"]["median"] <= d["region_ms_stats"]["max"]
+    assert d["settling"]["probes"] >= 2 and d["settling"]["ms"] >= 100.0
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None or str(r["traffic_source"]).startswith("static: profiles/")
+    m = r["mfma"]
+    assert m["unit"] == "TFLOP/s" and m["peak"] == 157.3 and 0 < m["frac"] < 1 and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
-    # a --gpus value that does not match the launch is refused instead of silently re-labelled
+    # a --gpus value that does not match an EXISTING launch is refused instead of silently re-labelled
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                         capture_output=True, text=True, timeout=300)
+                         env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
+def test_gpus_2_without_a_launcher_spawns_its_own_ranks():
+    """the driver's command form: `python bench.py --gpus N ...` with no torch.distributed.run around it;
+    two ranks share this box's one GPU over gloo"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MCL_BENCH_SHARE_GPU="1", MCL_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--config", "c3_8th", "--steps", "4",
+                          "--warmup", "2", "--regions", "2", "--settle-ms", "20"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]  # ONE JSON line on stdout, nothing else
+    d = json.loads(lines[0])
+    assert all(k in d for k in REQUIRED), sorted(set(REQUIRED) - set(d))
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["replicated_C_bit_identical"] is True
+    assert d["collectives_per_step"] == 1.0
+    assert d["cpu_baseline"]["value"] is None and "N = 1" in d["cpu_baseline"]["sample"]
+    # a failing rank turns into a non-zero exit code of the launcher (here: an unknown process-group backend)
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--config", "c3_8th"], env=dict(env, MCL_BENCH_BACKEND="no_such_backend"),
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
 
 
 @pytest.mark.parametrize("config", ["c3_8th", "c4"])
@@ -47,11 +73,11 @@ def test_two_ranks_sharing_the_gpu(config):
     port = str(29400 + (os.getpid() + len(config)) % 200)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.join(REPO, "bench.py"), "--gpus", "2", "--config", config, "--steps", "4",
-           "--warmup", "2", "--regions", "2"]
+           "--warmup", "2", "--regions", "2", "--settle-ms", "20"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"] is None
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"]["value"] is None
     assert d["replicated_C_bit_identical"] is True
     assert d["collectives_per_step"] == (6.0 if config == "c4" else 1.0)  # [G | R] (+ PARAFAC2 per inner iteration)
     assert 0 < d["final_rel_rec_error"] < 1

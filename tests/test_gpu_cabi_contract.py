@@ -104,3 +104,73 @@ def test_deferred_diagnostics_equal_immediate_ones():
     torch.cuda.synchronize()
     np.testing.assert_allclose(ring.cpu().numpy(), a, rtol=1e-13, atol=1e-300)
     eng.close()
+
+
+def _sweep_problem():
+    from oracle import aoadmm_oracle as orc
+
+    nn = {"kind": "nn"}
+    regs = [[nn], [nn], [{"kind": "l1", "reg_strength": 0.05, "non_negativity": True}]]
+    J = np.full(12, 96)
+    X, row_ptr = orc.synthetic_problem(len(J), J, 64, 8, seed=5, dtype=np.float64)  # sweep-eligible shape
+    return orc, regs, X.astype(np.float32).astype(np.float64), row_ptr
+
+
+@pytest.mark.parametrize("how", ["set_workspace", "destroy", "set_factors"])
+def test_deferred_diagnostics_survive_a_setter_or_destroy(how):
+    """a pending deferred reduction must be issued by ANY other entry point - also by the setters
+    that replace what it refers to and by mcl_destroy - while the old workspace is still the valid one."""
+    import torch
+    from matcouply_amd._engine import DIAG_LEN
+
+    orc, regs, X, row_ptr = _sweep_problem()
+    st = orc.random_state_for(X, row_ptr, 8, regs, seed=6)
+    eng = engine_from_oracle_state(st)
+    eng.update_B(); eng.update_C_local(); eng.update_C_finish(); eng.update_A()
+    want = eng.diagnostics().cpu().numpy()
+    out = torch.full((DIAG_LEN,), float("nan"), dtype=torch.float64, device="cuda")
+    eng.diagnostics_deferred(out=out)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out).all())  # really deferred
+    if how == "set_workspace":
+        nbytes = eng.lib.mcl_workspace_bytes(eng._h)
+        ws2 = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device="cuda")
+        off = (-ws2.data_ptr()) % 256
+        eng._check(eng.lib.mcl_set_workspace(eng._h, ws2.data_ptr() + off, nbytes))
+        old, eng.workspace = eng.workspace, ws2
+        old.zero_()  # the old workspace may be re-used by the host at once
+    elif how == "set_factors":
+        eng._check(eng.lib.mcl_set_factors(eng._h, eng.A.data_ptr(), eng.B.data_ptr(), eng.C.data_ptr()))
+    else:
+        eng.close()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-13, atol=1e-300)
+    eng.close()
+
+
+def test_a_deferral_crosses_at_most_one_sweep():
+    """two mcl_update_B in a row with a deferral pending - the second sweep would overwrite the mode-1
+    table the deferral recorded; the vector must still describe the iterate at the time of the deferring call."""
+    import torch
+    from matcouply_amd._engine import DIAG_LEN
+
+    orc, regs, X, row_ptr = _sweep_problem()
+    st = orc.random_state_for(X, row_ptr, 8, regs, seed=6)
+    eng = engine_from_oracle_state(st)
+    eng.update_B(); eng.update_C_local(); eng.update_C_finish(); eng.update_A()
+    assert eng.kernel_variant(3).startswith("k_sweep<")
+    want = eng.diagnostics().cpu().numpy()
+    out = torch.full((DIAG_LEN,), float("nan"), dtype=torch.float64, device="cuda")
+    eng.diagnostics_deferred(out=out)
+    eng.update_B()
+    eng.update_B()  # no C-phase in between
+    eng.update_C_local(); eng.update_C_finish()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-13, atol=1e-300)
+    eng.close()
+
+
+def test_library_reports_the_header_abi_version():
+    from matcouply_amd import _engine
+
+    assert _engine.load_library().mcl_version() == _engine.MCL_ABI_VERSION == 300

@@ -56,6 +56,23 @@ def test_no_gpu_fails_loudly():
         dec.cmf_aoadmm(X, 3, n_iter_max=1)
 
 
+def test_bench_launcher_starts_its_own_ranks_and_reports_their_failure():
+    """`python bench.py --gpus 2` without torch.distributed.run around it (the driver's command form) becomes the launcher:
+    here, without a GPU, both ranks refuse loudly and the launcher's exit code is theirs (the GPU run: -m gpu suite)"""
+    import subprocess
+    import sys
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert "needs an MI355X" in out.stderr and "WORLD_SIZE" not in out.stderr.split("Traceback")[0][:200]
+
+
 def test_simulated_data_matches_reference():
     c1 = load_npz("c1_data.npz")
     X, cmf = get_simple_simulated_data(noise_level=0.2, random_state=1)

@@ -38,23 +38,30 @@ def xc():
 def xca():  # the X C pass as the A-phase issues it (fused per-segment Gram epilogue)
     eng.update_C_finish(); eng.A_begin()
 
+def engine_with(**switches):
+    """The wave geometry (MCL_SEG_ROWS, MCL_X?_WAVES) is fixed by mcl_set_problem: one engine per setting, created AFTER the
+    switches are in the environment, and the switches are removed again so that they do not leak into the next engine."""
+    os.environ.update({k: str(v) for k, v in switches.items()})
+    try:
+        e = bench.make_engine(cfg, X, row_ptr, I_loc, 0, dev)
+    finally:
+        for k in switches:
+            os.environ.pop(k, None)
+    e.update_B(); e.update_C_local(); e.update_C_finish(); e.update_A()
+    return e
+
+
 for seg in os.environ.get("SEGS", "256").split(","):
-    os.environ["MCL_SEG_ROWS"] = seg
-    eng = bench.make_engine(cfg, X, row_ptr, I_loc, 0, dev)  # segment length is fixed when the problem is set
-    eng.update_B(); eng.update_C_local(); eng.update_C_finish(); eng.update_A()
     for waves in (1024, 2048, 4096):
-        os.environ.update(MCL_XT_WAVES=str(waves), MCL_XC_WAVES=str(waves))
-        eng.reload_switches()
+        eng = engine_with(MCL_SEG_ROWS=seg, MCL_XT_WAVES=waves, MCL_XC_WAVES=waves)
         print(f"seg={seg} waves={waves}: xt {prof(xt, 1):.1f} us   xc+gram {prof(xca, 0):.1f} us  [{eng.kernel_variant(0)}]", flush=True)
-os.environ.pop("MCL_SEG_ROWS", None)
+        eng.close()
 for waves in (512, 1024, 2048):
-    os.environ.update(MCL_XT_WAVES=str(waves))
-    eng.reload_switches()
+    eng = engine_with(MCL_XT_WAVES=waves)
     print(f"xt kernel (events) waves={waves}: {prof(xt, 1):.1f} us")
+    eng.close()
 for norow in ("", "1"):
     for waves in (512, 1024, 2048, 4096):
-        if norow: os.environ["MCL_XC_NOROW"] = "1"
-        else: os.environ.pop("MCL_XC_NOROW", None)
-        os.environ.update(MCL_XC_WAVES=str(waves))
-        eng.reload_switches()
+        eng = engine_with(MCL_XC_WAVES=waves, **({"MCL_XC_NOROW": 1} if norow else {}))
         print(f"xc kernel (events) norow={norow or 0} waves={waves}: {prof(xc, 0):.1f} us  [{eng.kernel_variant(0)}]")
+        eng.close()
