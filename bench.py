@@ -63,6 +63,10 @@ CONFIGS["c3_4th"] = dict(CONFIGS["c3"], I=256, desc="one quarter of config 3 (th
 CONFIGS["c3r"] = dict(CONFIGS["c3"], J="ragged", desc="config 3 with the ragged slabs of config 4: I=1024 J_i in [128,1024] K=256 rank=16")
 CONFIGS["k512"] = dict(CONFIGS["c3"], I=512, J=512, K=512, desc="K=512 variant of config 3 (same bytes of X): I=512 J_i=512 K=512 rank=16")
 CONFIGS["r32"] = dict(CONFIGS["c3"], r=32, desc="rank-32 variant of config 3: I=1024 J_i=512 K=256 rank=32")
+# the same penalty stacks as keyword arguments of the public API (the `api` block of the JSON line)
+CONFIGS["c2"]["api_kwargs"] = dict(non_negative=True)
+CONFIGS["c3"]["api_kwargs"] = dict(non_negative=True, l1_penalty={2: 0.1})
+CONFIGS["c4"]["api_kwargs"] = dict(parafac2=True, l2_norm_bound={1: 1.0})
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix rate (v_mfma_f32_16x16x4_f32: 256 flop/cycle/CU)
 
@@ -256,6 +260,39 @@ def spawn_ranks(n):
     return rc if rc else (0 if json_lines else 1)
 
 
+def api_block(cfg, X, row_ptr, n_short=100, n_long=400):
+    """Outer iterations / s of the PUBLIC call - `cmf_aoadmm(PackedMatrices, rank, ...)` - on the resident data, with
+    `tol=None` (fixed iteration count: mcl_iterate) and with the DEFAULT tolerances (tol=1e-8, absolute_tol=1e-10,
+    feasibility_tol=1e-4: the stopping rule evaluated on the device, mcl_run).  Every call pays the set-up of the
+    reference's API (host RNG of the initial factors and ADMM variables, upload, context): the rate is therefore taken
+    from the DIFFERENCE of a long and a short call, (n_long - n_short) / (t_long - t_short)."""
+    import torch
+    from matcouply_amd import decomposition as dec
+
+    kw = cfg.get("api_kwargs")
+    if kw is None:
+        return None
+    packed = dec.PackedMatrices(X, row_ptr)
+
+    def call(n, **tols):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, diag = dec.cmf_aoadmm(packed, cfg["r"], n_iter_max=n, random_state=0, return_errors=True, **kw, **tols)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, diag.n_iter
+
+    out = {"call": "cmf_aoadmm(PackedMatrices, rank=%d, %s, return_errors=True, random_state=0)" % (
+        cfg["r"], ", ".join(f"{k}={v}" for k, v in kw.items())), "n_iter_max": [n_short, n_long]}
+    call(3, tol=None, absolute_tol=None)  # first call: library / allocator warm-up
+    for name, tols in (("tol_none", dict(tol=None, absolute_tol=None)), ("default_tol", dict())):
+        (t1, n1), (t2, n2) = call(n_short, **tols), call(n_long, **tols)
+        rate = (n2 - n1) / (t2 - t1) if n2 > n1 and t2 > t1 else n2 / t2
+        out[name] = {"iters_per_s": round(rate, 1), "seconds": [round(t1, 4), round(t2, 4)], "n_iter": [n1, n2],
+                     "from": "difference of the two calls" if n2 > n1 else "whole call (stopped early)"}
+    out["default_over_tol_none"] = round(out["default_tol"]["iters_per_s"] / out["tol_none"]["iters_per_s"], 4)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -267,6 +304,7 @@ def main():
                     help="un-timed settling after --warmup: keep stepping for at least this long AND until two consecutive "
                          "probe regions of --steps steps agree within 2 %% (clock ramp of a fresh device); 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the `api` block (timing of the public cmf_aoadmm call)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -363,11 +401,11 @@ def main():
     # Settling (un-timed, on top of --warmup): a fresh device ramps its clocks over the first ~100 ms of work - with 5
     # warm-up steps (0.8 ms at config 3) the first timed regions of round 2 fell monotonically by 10 %.  Keep stepping in
     # probe regions of --steps steps until >= --settle-ms have passed AND two consecutive probes agree within 2 %
-    # (bounded: 50 probes / 3 s).  Every rank takes the same decision (the probe time is the MAX over ranks).
+    # (bounded by 3 s).  Every rank takes the same decision (the probe time is the MAX over ranks).
     settle = dict(ms=0.0, probes=0, settled=None)
     if args.settle_ms > 0 and args.steps > 0:
         prev, total = None, 0.0
-        for probe in range(50):
+        for probe in range(1000000):
             sync()
             t0 = time.perf_counter()
             for it in range(args.steps):
@@ -522,6 +560,8 @@ def main():
         if final is not None:
             xsq, inner, model = final[5], final[3], final[4]
             out["final_rel_rec_error"] = round(float(np.sqrt(max(0.0, xsq - 2 * inner + model) / xsq)), 6)
+        if world == 1 and not args.no_api:
+            out["api"] = api_block(cfg, X, row_ptr)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_budget)
         elif world > 1:

@@ -978,6 +978,7 @@ struct AFuse {
     const double *CtCpart;
     double *CtC64_out;
     float *CtC_out;
+    double *LinvB64;  // fp64 copy of the next B-phase's inverses (fp64 row passes of PARAFAC2 stacks: mcl_rows64), or NULL
 };
 
 // sum_k M[k][c] C[k][c] over the bsegs sgA, sgA + step, ... < sgB, both operands in C-fragment order (element
@@ -1262,7 +1263,10 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
         gj_inverse_rows<RP>(col, r, in_range ? lane : cc);
 #pragma unroll
         for (int j = 0; j < RL; ++j)
-            if (dok[j]) LinvB[((long)i * r + drow[j]) * r + c] = (float)col[j];
+            if (dok[j]) {
+                LinvB[((long)i * r + drow[j]) * r + c] = (float)col[j];
+                if (F.LinvB64 != nullptr) F.LinvB64[((long)i * r + drow[j]) * r + c] = col[j];
+            }
         if (lane == 0) rhoB[i] = rb;
     }
 }
@@ -2021,7 +2025,10 @@ int mcl_launch_A_rho(mcl_context *c) {
 int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     if (c->I == 0) return 0;
     // also prepare the next B-phase's systems when that is exact: fused inner loop, per-slab rho for B
-    const int next_B = (fused_inner && !c->opt.constant_B && c->regs[1].n > 0 && !c->sw.no_next_b) ? 1 : 0;
+    const bool rows_kernel = !(c->RP == 64 || c->RP == 4 || c->sw.a_finish_cols);
+    // (a B-phase with fp64 row passes also needs the fp64 inverses: only the row-split kernels write them)
+    const int next_B = (fused_inner && !c->opt.constant_B && c->regs[1].n > 0 && !c->sw.no_next_b &&
+                        (rows_kernel || !mcl_rows64(c))) ? 1 : 0;
     const bool seg = c->use_seg_gram;
     dim3 grid((unsigned)((c->I + 3) / 4)), block(256);
 #define MCL_AF_ARGS                                                                                                   \
@@ -2037,7 +2044,7 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
         F.Mpart = c->Mpart, F.Cfrag = c->CfragS, F.NBm = c->NB;
         F.MS = mcl_sweep_KC(c) * 64 * 16 * c->NB;
     }
-    const bool rows_kernel = !(c->RP == 64 || c->RP == 4 || c->sw.a_finish_cols);
+    F.LinvB64 = mcl_rows64(c) ? c->LinvB64 : nullptr;
     if (!rows_kernel && c->ctc_parts > 0)
         if (int rc = mcl_launch_ctc_fold(c)) return rc;
     // ranks 5..32: rows of every system split over the lane groups (all 64 lanes busy); 64 columns fill the wave anyway

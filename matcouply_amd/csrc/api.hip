@@ -80,7 +80,8 @@ int64_t plan(mcl_context *c, char *base) {
     c->CtCpart = b.take<double>(16 * 256);
     c->rhoB = b.take<float>(I);
     c->LinvB = b.take<float>(I * r * r);
-    c->LinvB64 = (c->regs[1].n == 0) ? b.take<double>(I * r * r) : nullptr;
+    c->rows64 = c->NB == 1 && has_kind(c, MCL_PEN_PARAFAC2) && !c->sw.no_rows64;
+    c->LinvB64 = (c->regs[1].n == 0 || c->rows64) ? b.take<double>(I * r * r) : nullptr;
     c->XC64 = (c->regs[1].n == 0) ? b.take<double>(N * r) : nullptr;
     c->rho_max = b.take<float>(2);
     c->partials = b.take<double>((int64_t)mcl_contract_n_partials(c) * E);
@@ -127,14 +128,19 @@ int64_t plan(mcl_context *c, char *base) {
     if (has_kind(c, MCL_PEN_PARAFAC2)) {
         c->pf2_S = b.take<double>(I * r * r);
         c->pf2_T = b.take<float>(I * r * r);
+        c->pf2_T64 = c->rows64 ? b.take<double>(I * r * r) : nullptr;
         c->pf2_acc = b.take<double>(I * (r * r + 1));
         c->pf2_red = b.take<float>(r * r + 1);
         c->pf2_status = b.take<int>(I);
+#ifdef MCL_NS_STAMPS
+        c->pf2_xmin = b.take<float>(I + 16 * I + 64);  // + 8 int64 stamps per slab (tools/ns_stamps.py)
+#else
         c->pf2_xmin = b.take<float>(I);  // zeroed with the workspace: "no estimate yet"
+#endif
     } else {
         c->pf2_status = nullptr;
         c->pf2_xmin = nullptr;
-        c->pf2_S = nullptr, c->pf2_T = nullptr, c->pf2_acc = nullptr, c->pf2_red = nullptr;
+        c->pf2_S = nullptr, c->pf2_T = nullptr, c->pf2_acc = nullptr, c->pf2_red = nullptr, c->pf2_T64 = nullptr;
     }
     return (b.off + 255) & ~int64_t(255);
 }
@@ -152,6 +158,7 @@ void read_switches(mcl_switches &w) {
     w.no_fused_gram = flag("MCL_NO_FUSED_GRAM"), w.no_fused_c = flag("MCL_NO_FUSED_C");
     w.a_finish_cols = flag("MCL_A_FINISH_COLS"), w.xc_norow = flag("MCL_XC_NOROW");
     w.unimodal_v3 = flag("MCL_UNIMODAL_V3"), w.stats_reduce = flag("MCL_STATS_REDUCE");
+    w.no_rows64 = flag("MCL_NO_ROWS64");
     w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_a_wide = flag("MCL_NO_A_WIDE"), w.no_bseg_groups = flag("MCL_NO_BSEG_GROUPS"), w.no_sweep_half = flag("MCL_NO_SWEEP_HALF"), w.no_x_nt = flag("MCL_NO_X_NT"), w.x_nt_mb = num("MCL_X_NT_MB", 0), w.no_multi_c = flag("MCL_NO_MULTI_C"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1");
     w.seg_rows = num("MCL_SEG_ROWS", 0), w.bseg_rows = num("MCL_BSEG_ROWS", 0);
     w.xc_waves = num("MCL_XC_WAVES", 0), w.xt_waves = num("MCL_XT_WAVES", 0), w.sweep_waves = num("MCL_SWEEP_WAVES", 0);
@@ -1136,6 +1143,9 @@ float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {
         case 10: p = reinterpret_cast<float *>(c->pf2_S), n = c->pf2_S ? 2 * c->I * (int64_t)c->r * c->r : 0; break;
         case 11: p = reinterpret_cast<float *>(c->sweep_cycles), n = c->sweep_cycles ? (int64_t)2048 * 6 * 2 : 0; break;
         case 8: p = reinterpret_cast<float *>(c->pf2_status), n = c->pf2_status ? c->I : 0; break;  // int32 bits
+#ifdef MCL_NS_STAMPS
+        case 18: p = c->pf2_xmin, n = c->pf2_xmin ? 17 * c->I : 0; break;
+#endif
         // the planner's work-unit tables (int32 bits): segments of the X passes, bsegs of the sweep, and the first
         // unit of every wave (mcl_set_problem)
         case 12: p = reinterpret_cast<float *>(c->segs.row0), n = c->segs.n_tiles; break;

@@ -757,10 +757,13 @@ __global__ __launch_bounds__(256) void k_contract_xc_256(const float *__restrict
         for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4 *>(L + t * 256 + ((lane ^ t) << 2)) = xr[d][t];
         issue(dc, pre);  // the slot is free again: its next block (two ahead) goes out now
         advance(pre);
-        f32x4 acc4[4];
+        // EIGHT fp32 accumulation chains per output (32 columns = 8 MFMAs each; round 2: four of 16), summed as a tree in
+        // fp64 and rounded once: the 256-term dot products of X C are the second largest rounding of config 4's B-phase
+        // (tools/pf2_rounding_study.py), and that configuration's penalty-free A / C systems amplify it
+        f32x4 acc8[4][2];
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
-            acc4[kc] = zero4();
+            acc8[kc][0] = zero4(), acc8[kc][1] = zero4();
             f32x4 fr[4];
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq)
@@ -768,9 +771,15 @@ __global__ __launch_bounds__(256) void k_contract_xc_256(const float *__restrict
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc4[kc] = MFMA16(fr[kq][m], creg[kc][kq][m], acc4[kc]);
+                for (int m = 0; m < 4; ++m) acc8[kc][kq >> 1] = MFMA16(fr[kq][m], creg[kc][kq][m], acc8[kc][kq >> 1]);
         }
-        const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+        f32x4 acc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double s01 = ((double)acc8[0][0][v] + (double)acc8[0][1][v]) + ((double)acc8[1][0][v] + (double)acc8[1][1][v]);
+            const double s23 = ((double)acc8[2][0][v] + (double)acc8[2][1][v]) + ((double)acc8[3][0][v] + (double)acc8[3][1][v]);
+            acc[v] = (float)(s01 + s23);
+        }
         if (!live) return;  // the dummy half of an odd trip: nothing stored (wave-uniform)
         float bv[4];
 #pragma unroll

@@ -6,6 +6,7 @@
 // treated as a single slab (tile maps tilesA / tilesC, extents ext_A / ext_C).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "mcl_internal.h"
 #include "rows_mfma.h"
@@ -19,6 +20,17 @@ static __device__ __forceinline__ float prox_elem_g(int kind, int nonneg, float 
         case MCL_PEN_L1:
             if (nonneg) return fmaxf(y - thr, 0.f);
             return copysignf(fmaxf(fabsf(y) - thr, 0.f), y);
+        default: return y;
+    }
+}
+
+static __device__ __forceinline__ double prox_elem_g(int kind, int nonneg, double p0, double p1, double thr, double y) {
+    switch (kind) {
+        case MCL_PEN_NN: return fmax(y, 0.0);
+        case MCL_PEN_BOX: return fmin(fmax(y, p0), p1);
+        case MCL_PEN_L1:
+            if (nonneg) return fmax(y - thr, 0.0);
+            return copysign(fmax(fabs(y) - thr, 0.0), y);
         default: return y;
     }
 }
@@ -127,16 +139,24 @@ __global__ __launch_bounds__(256) void k_rows_solve(ModeView mv, const float *__
 //   L2 ball :  per-tile column sums of squares of (F + U) (optionally clamped at 0), fp64
 // k_stats_reduce sums the tiles of every slab in fixed order.  Saves the two extra reads of F and the duals that
 // k_pf2_gram and k_slab_colsq need.
-template <int NBR, bool VEC>
+// R64 (rank <= 16 with a PARAFAC2 member, see mcl_rows64): the same pass with every product and sum in fp64 registers
+// around the fp32 loads and stores - L^-1 from its fp64 copy, the statistics of Y = F + U from the exact fp64 sum of the
+// two STORED (fp32) values.  tools/pf2_rounding_study.py: the fp32 accumulation chains of the r x r products, the fp32
+// image of T_i and the rounded sum F + U carry two thirds of the B-phase error of BASELINE config 4 against the fp64
+// reference (7e-7 per phase, amplified to 1e-5 in A by the penalty-free A / C systems of that configuration).
+template <int NBR, bool VEC, bool R64 = false>
 __global__ __launch_bounds__(256) void k_rows_solve_stats(ModeView mv, const float *__restrict__ rhs_src,
                                                           const float *__restrict__ Arows, const float *__restrict__ Linv,
                                                           RegSet regs, int r, double *__restrict__ stat_gram,
-                                                          double *__restrict__ stat_colsq) {
+                                                          double *__restrict__ stat_colsq,
+                                                          const double *__restrict__ Linv64 = nullptr) {
     typedef double f64x4s __attribute__((ext_vector_type(4)));
+    typedef RowArith<R64> RA;
     TILE_PROLOGUE();
     const float rho = mv.rho[slab];
-    RowMat<NBR> L, D;
-    L.load(Linv + (long)slab * r * r, r, lane);
+    typename RA::template Mat<NBR> L, D;
+    if constexpr (R64) L.load(Linv64 + (long)slab * r * r, r, lane);
+    else L.load(Linv + (long)slab * r * r, r, lane);
     int kpf2 = -1;
     for (int k = 0; k < regs.n; ++k)
         if (regs.kind[k] == MCL_PEN_PARAFAC2) kpf2 = k;
@@ -149,7 +169,7 @@ __global__ __launch_bounds__(256) void k_rows_solve_stats(ModeView mv, const flo
             const int col = 16 * h + 4 * g + v;
             av[h][v] = (Arows != nullptr && col < r) ? Arows[(long)slab * r + col] : 1.f;
         }
-    float bsel[4];
+    typename std::conditional<R64, double, float>::type bsel[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) bsel[v] = (row16 == 4 * g + v) ? 1.f : 0.f;
     f64x4s accS[NBR][NBR];
@@ -170,7 +190,7 @@ __global__ __launch_bounds__(256) void k_rows_solve_stats(ModeView mv, const flo
         f32x4 t[NBR], f[NBR], ukeep[MCL_MAX_REGS][NBR];
 #pragma unroll
         for (int h = 0; h < NBR; ++h) {
-            t[h] = row_ld4<VEC>(rhs_src, j, 16 * h + 4 * g, ok, r);
+            t[h] = (row_ld4<VEC>(rhs_src, j, 16 * h + 4 * g, ok, r));
 #pragma unroll
             for (int v = 0; v < 4; ++v) t[h][v] *= av[h][v];
         }
@@ -179,7 +199,7 @@ __global__ __launch_bounds__(256) void k_rows_solve_stats(ModeView mv, const flo
             if (k < regs.n) {
                 f32x4 z[NBR];
 #pragma unroll
-                for (int h = 0; h < NBR; ++h) z[h] = row_ld4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r);
+                for (int h = 0; h < NBR; ++h) z[h] = (row_ld4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r));
                 if (k == kpf2) {
                     f32x4 pz[NBR];
                     D.apply(z, pz);
@@ -188,7 +208,7 @@ __global__ __launch_bounds__(256) void k_rows_solve_stats(ModeView mv, const flo
                 }
 #pragma unroll
                 for (int h = 0; h < NBR; ++h) {
-                    ukeep[k][h] = row_ld4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r);
+                    ukeep[k][h] = (row_ld4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r));
 #pragma unroll
                     for (int v = 0; v < 4; ++v) t[h][v] = fmaf(rho, z[h][v] - ukeep[k][h][v], t[h][v]);
                 }
@@ -215,14 +235,25 @@ __global__ __launch_bounds__(256) void k_rows_solve_stats(ModeView mv, const flo
                     double yt[NBR][4];
 #pragma unroll
                     for (int nb = 0; nb < NBR; ++nb) {
-                        f32x4 tr = {0.f, 0.f, 0.f, 0.f};
+                        if constexpr (R64) {  // exact fp64 sum, transposed by the fp64 MFMA: lane (q, i16) reg w = Y[q + 4w][16nb + i16]
+                            f64x4s tr = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const float y = ok ? f[nb][v] + ukeep[k][nb][v] : 0.f;
-                            tr = MFMA16(y, bsel[v], tr);  // COL layout: lane (q, i16) reg w = Y[4q + w][16nb + i16]
+                            for (int v = 0; v < 4; ++v) {
+                                const double y = ok ? (double)f[nb][v] + (double)ukeep[k][nb][v] : 0.0;
+                                tr = __builtin_amdgcn_mfma_f64_16x16x4f64(y, bsel[v], tr, 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) yt[nb][w] = tr[w];
+                        } else {
+                            f32x4 tr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const float y = ok ? f[nb][v] + ukeep[k][nb][v] : 0.f;
+                                tr = MFMA16(y, bsel[v], tr);  // COL layout: lane (q, i16) reg w = Y[4q + w][16nb + i16]
+                            }
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) yt[nb][w] = (double)tr[w];
                         }
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) yt[nb][w] = (double)tr[w];
                     }
 #pragma unroll
                     for (int w = 0; w < 4; ++w)
@@ -1144,7 +1175,8 @@ __global__ __launch_bounds__(256) void k_pf2_gram(const int *__restrict__ ext, c
 // One slab through the Jacobi route (one wave; `smd` = 4 r^2 + r doubles of LDS, `Ssrc` = the slab's S in any address
 // space).  Called by the stand-alone kernel below and by k_pf2_algebra_ns for the slabs it cannot handle.
 static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const float *__restrict__ Delta, double rh, int r,
-                                       int slab, int lane, float *__restrict__ T, double *__restrict__ acc_out) {
+                                       int slab, int lane, float *__restrict__ T, double *__restrict__ acc_out,
+                                       double *__restrict__ T64 = nullptr) {
     double *Sm = smd, *G = smd + r * r, *V = G + r * r, *lam = V + r * r, *D = lam + r;  // D: Delta in fp64 [r*r]
     const int n2 = r * r;
     for (int e = lane; e < n2; e += 64) {
@@ -1241,18 +1273,20 @@ static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const fl
         for (int k = 0; k < r; ++k) sum += V[k * r + a] * Sm[k * r + b];
         acc_out[(long)slab * (n2 + 1) + e] = rh * sum;
         T[(long)slab * n2 + e] = (float)V[e];
+        if (T64 != nullptr) T64[(long)slab * n2 + e] = V[e];
     }
     if (lane == 0) acc_out[(long)slab * (n2 + 1) + n2] = rh;
 }
 
 __global__ __launch_bounds__(64) void k_pf2_algebra(const double *__restrict__ S, const float *__restrict__ Delta,
                                                     const float *__restrict__ rho, int r, float *__restrict__ T,
-                                                    double *__restrict__ acc_out, const int *__restrict__ status) {
+                                                    double *__restrict__ acc_out, const int *__restrict__ status,
+                                                    double *__restrict__ T64) {
     extern __shared__ double smd[];
     if (status != nullptr && status[blockIdx.x] <= 0) return;  // already done by the Newton-Schulz kernel (-iterations)
     if (status != nullptr && status[blockIdx.x] == 77) return;  // debugging hook
     const int slab = blockIdx.x;
-    pf2_jacobi_slab(smd, S + (long)slab * r * r, Delta, (double)rho[slab], r, slab, threadIdx.x, T, acc_out);
+    pf2_jacobi_slab(smd, S + (long)slab * r * r, Delta, (double)rho[slab], r, slab, threadIdx.x, T, acc_out, T64);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1299,12 +1333,19 @@ struct TileStats {
     double *colsq;
     int W, n_slabs;
 };
+// -DMCL_NS_STAMPS (tools/ns_stamps.py; never in the shipped library): s_memtime stamps of the kernel's sections per slab -
+// [0] entry, [1] statistics summed, [2] G formed, [3] iteration done, [4] exit, [5] steps - in the scratch of pf2_acc's tail
+#ifdef MCL_NS_STAMPS
+#define NS_STAMP(i) do { if (lane == 0) stamps[(long)slab * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define NS_STAMP(i) do { } while (0)
+#endif
 template <int NB, bool TILES>
 __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, const float *__restrict__ Delta,
                                                        const float *__restrict__ rho, const int *__restrict__ ext, int r,
                                                        float *__restrict__ T, double *__restrict__ acc_out,
                                                        int *__restrict__ status, TileStats ts, RegSet regs,
-                                                       float *__restrict__ xmin_est, int scaled) {
+                                                       float *__restrict__ xmin_est, int scaled, double *__restrict__ T64) {
     MCL_GATE(regs.gate);
     __shared__ double Ssm[TILES ? 256 * NB * NB : 1];
     __shared__ float Dsm[256 * NB * NB];
@@ -1317,6 +1358,10 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
     const int q = lane >> 4, c16 = lane & 15;
     const int n2 = r * r;
     const double *Ss = S + (long)slab * n2;
+#ifdef MCL_NS_STAMPS
+    long long *stamps = reinterpret_cast<long long *>(xmin_est + gridDim.x);  // the plan reserves 8 int64 per slab behind pf2_xmin
+#endif
+    NS_STAMP(0);
     // everything this wave needs besides the statistics is requested up front, so its latency overlaps the tile loop:
     // the slab's extent and weight, and Delta (staged in LDS; every product below reads it from there)
     const int slab_rows = ext[slab + 1] - ext[slab];
@@ -1334,7 +1379,8 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
         const long WW = (long)ts.W * ts.W;
         // the order of k_stats_reduce (even tile offsets -> s0, odd -> s1, ascending), tiles fetched TB at a time with
         // independent clamped loads (one memory latency per batch instead of one per tile)
-        constexpr int EPL = 4 * NB * NB, TB = NB == 1 ? 8 : 2;  // elements per lane (n2 <= 256 NB^2); register budget
+        constexpr int EPL = 4 * NB * NB, TB = NB == 1 ? 16 : 2;  // elements per lane (n2 <= 256 NB^2); register budget
+        // (rank <= 16: a slab of <= 1024 rows is ONE batch - one memory round trip instead of two in front of the chain)
         double s0[EPL], s1[EPL];
         long off[EPL];
 #pragma unroll
@@ -1385,6 +1431,7 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
         }
     }
     __syncthreads();
+    NS_STAMP(1);
     auto Sat = [&](int i, int j) -> double {
         if (TILES) return (i < r && j < r) ? Ssm[i * r + j] : 0.0;
         return (i < r && j < r) ? Ss[i * r + j] : 0.0;
@@ -1393,7 +1440,7 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
     const double *Sany = TILES ? static_cast<const double *>(Ssm) : Ss;
     if (slab_rows < r) {  // fewer rows than columns: rank-deficient by construction
         if (lane == 0) status[slab] = 1;
-        if (INK) pf2_jacobi_slab(Jsm, Sany, Delta, rh, r, slab, lane, T, acc_out);
+        if (INK) pf2_jacobi_slab(Jsm, Sany, Delta, rh, r, slab, lane, T, acc_out, T64);
         return;
     }
     // U1 = S Delta^T   (A = S, symmetric: A[i][k] = S[k][i];  B[k][n] = Delta[n][k])
@@ -1440,9 +1487,10 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
     tr = wave_sum_d(tr);
     if (!(tr > 0.0)) {
         if (lane == 0) status[slab] = 1;
-        if (INK) pf2_jacobi_slab(Jsm, Sany, Delta, rh, r, slab, lane, T, acc_out);
+        if (INK) pf2_jacobi_slab(Jsm, Sany, Delta, rh, r, slab, lane, T, acc_out, T64);
         return;
     }
+    NS_STAMP(2);
     // Newton-Schulz for the inverse square root of G / tr (padding rows/cols >= r carry the identity)
     SymTiles<NB> Y, Yt, Z, Zt, P, Pt, Tm, Tmt, N1, N2, N3, N4;
     const double inv_s = 1.0 / tr;
@@ -1467,42 +1515,52 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
     // the minimax coefficients of that cubic on [lo, hi] (equi-oscillation at lo, sqrt(s/3), hi; (1.5, 0.5) when lo = hi = 1),
     // which roughly doubles the growth of the small eigenvalues per step (2.6 x instead of 1.5 x) and so halves the
     // iteration count.  hi = 1 holds by the trace scaling; lo starts from the estimate 1 / ||Z||_F left by the previous
-    // call for this slab (the matrices change slowly between inner iterations; 1e-2 when there is none) and, like hi, is
-    // tightened by the certified bound |1 - eig| <= ||I - Z Y||_F.  An eigenvalue below the assumed lo still grows by a
-    // every step (the cubic is increasing there), so a wrong estimate costs iterations, not convergence.
-    double xlo = 1.0, xhi = 1.0;
+    // call for this slab (the matrices change slowly between inner iterations; 1e-2 when there is none).  An eigenvalue
+    // below the assumed lo still grows by a every step (the cubic is increasing there) and nothing exceeds 1 + e, so a wrong
+    // estimate costs iterations, not convergence.
+    // Round 3: the interval is PREDICTED ([1 - e, 1 + e] after every step, e from the coefficients) instead of measured: the
+    // coefficient chain - three square roots and a division, formerly in fp64 behind the wave reduction of ||I - Z Y||^2,
+    // 1.4 k of a step's 3.0 k cycles - is a handful of fp32 instructions that do not depend on this step's product, and
+    // the residual is only reduced once the prediction says the end is near (e < 0.01).  Below e = 1e-3 the step is the
+    // plain Newton-Schulz one with EXACT coefficients (a - b = 1 is what fixes x = 1; fp32 coefficients would leave the
+    // fixed point at 1 + 1e-7), where the minimax scaling has nothing left to gain.
+    float flo = 1.f, fhi = 1.f;
     if (scaled) {
         const float est = xmin_est[slab];
-        xlo = est > 0.f ? fmin(0.5 * (double)est, 1.0) : 1e-2;
+        flo = est > 0.f ? fminf(0.5f * est, 1.f) : 1e-2f;
     }
     for (int it = 0; it < 100; ++it) {
         it_used = it;
+        double ca = 1.5, cb = 0.5;
+        const bool watch = !scaled || (1.f - flo) < 1e-2f;  // the end is near: measure the residual from here on
+        if (scaled && (1.f - flo) >= 1e-3f) {
+            const float ss = fhi * fhi + fhi * flo + flo * flo, sq = __builtin_sqrtf(ss * (1.f / 3.f));
+            const float fb = 2.f / ((2.f / 3.f) * ss * sq + flo * fhi * (flo + fhi));
+            const float fa = fb * ss;
+            const float e = (2.f / 3.f) * fa * sq - 1.f;
+            ca = (double)fa, cb = (double)fb;
+            flo = 1.f - e, fhi = 1.f + e;
+        } else if (scaled) {
+            const float e = 1.f - flo;
+            flo = 1.f - 1.5f * e * e, fhi = 1.f;  // plain Newton-Schulz: x -> x (3 - x^2) / 2 <= 1, error 1.5 e^2
+        }
         mm_t<NB>(Zt, Y, P);   // P  = Z Y
         mm_t<NB>(Y, Zt, Pt);  // Pt = Y^T Z^T = P^T
-        double res = 0.0;
+        double res = 1.0;
+        if (watch) {
+            res = 0.0;
 #pragma unroll
-        for (int a = 0; a < NB; ++a)
+            for (int a = 0; a < NB; ++a)
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+                for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int row = 16 * a + q + 4 * v, col = 16 * b + c16;
-                    const double id = (row == col) ? 1.0 : 0.0;
-                    const double d = id - P.t[a][b][v];
-                    res += d * d;
-                }
-        res = wave_sum_d(res);
-        double ca = 1.5, cb = 0.5;
-        if (scaled) {
-            const double rn = sqrt(res);
-            if (rn < 1.0) xlo = fmax(xlo, sqrt(1.0 - rn));
-            xhi = fmin(xhi, sqrt(1.0 + rn));
-            xlo = fmin(xlo, xhi);
-            const double ss = xhi * xhi + xhi * xlo + xlo * xlo, sq = sqrt(ss * (1.0 / 3.0));
-            cb = 2.0 / ((2.0 / 3.0) * ss * sq + xlo * xhi * (xlo + xhi));
-            ca = cb * ss;
-            const double e = (2.0 / 3.0) * ca * sq - 1.0;
-            xlo = 1.0 - e, xhi = 1.0 + e;
+                    for (int v = 0; v < 4; ++v) {
+                        const int row = 16 * a + q + 4 * v, col = 16 * b + c16;
+                        const double id = (row == col) ? 1.0 : 0.0;
+                        const double d = id - P.t[a][b][v];
+                        res += d * d;
+                    }
+            res = wave_sum_d(res);
         }
 #pragma unroll
         for (int a = 0; a < NB; ++a)
@@ -1517,11 +1575,17 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
                 }
         // converged: ||I - Z Y||_F < 1e-12 sqrt(r), or stagnation at the fp64 round-off floor of an ill-conditioned G
         // (the floor grows with cond(G); 1e-8 in ||I - ZY|| still leaves W accurate far beyond the fp32 data)
-        if (res < 1e-24 * r || (res < 1e-16 && res > 0.25 * prev)) {
-            converged = true;
-            break;
+        if (watch) {
+            if (res < 1e-24 * r || (res < 1e-16 && res > 0.25 * prev)) {
+                converged = true;
+                break;
+            }
+            prev = res;
+            // a lower bound that was too optimistic (an eigenvalue below the assumed lo): the prediction is ahead of the
+            // iterate - fall back to measuring, i.e. keep the predicted interval no tighter than the certified one
+            // (|1 - x^2| <= ||I - Z Y||_F for every eigenvalue x^2 of Z Y, so x >= 1 - ||I - Z Y||_F)
+            if (scaled) flo = fminf(flo, res < 1.0 ? 1.f - __builtin_sqrtf((float)res) : 0.1f);
         }
-        prev = res;
         mm_t<NB>(Yt, Tm, N1);   // Y  <- Y T
         mm_t<NB>(Tm, Yt, N2);   // Yt <- T^T Y^T
         mm_t<NB>(Tmt, Z, N3);   // Z  <- T Z
@@ -1533,9 +1597,13 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
     }
     if (!converged) {
         if (lane == 0) status[slab] = 1;
-        if (INK) pf2_jacobi_slab(Jsm, Sany, Delta, rh, r, slab, lane, T, acc_out);
+        if (INK) pf2_jacobi_slab(Jsm, Sany, Delta, rh, r, slab, lane, T, acc_out, T64);
         return;
     }
+    NS_STAMP(3);
+#ifdef MCL_NS_STAMPS
+    if (lane == 0) stamps[(long)slab * 8 + 5] = it_used;
+#endif
     if (lane == 0) status[slab] = -it_used;  // <= 0: converged (number of Newton-Schulz iterations, for diagnostics)
     if (scaled) {  // 1 / ||Z||_F <= 1 / ||Z||_2 = sqrt(eig_min(G / tr)): the next call's starting estimate for this slab
         double zn = 0.0;
@@ -1565,7 +1633,10 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int row = 16 * a + q + 4 * v, col = 16 * b + c16;
-                if (row < r && col < r) T[(long)slab * n2 + row * r + col] = (float)acc[v];
+                if (row < r && col < r) {
+                    T[(long)slab * n2 + row * r + col] = (float)acc[v];
+                    if (T64 != nullptr) T64[(long)slab * n2 + row * r + col] = acc[v];  // fp64 row passes (mcl_rows64)
+                }
             }
         }
 #pragma unroll
@@ -1585,6 +1656,7 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
             }
         }
     if (lane == 0) acc_out[(long)slab * (n2 + 1) + n2] = rh;
+    NS_STAMP(4);
 }
 
 // P = Y T_slab
@@ -1705,10 +1777,12 @@ __global__ __launch_bounds__(256) void k_rows_dual(ModeView mv, RegSet regs, int
 // P = (F + U) T_i stays in registers for its dual update.  Replaces k_pf2_apply + k_rows_pf2_dual + k_rows_l2ball
 // (+ k_rows_prox_rowsep), i.e. three to four passes over the B-sized arrays per inner iteration.
 // ---------------------------------------------------------------------------------------------------------
-template <int NBR, bool VEC>
+template <int NBR, bool VEC, bool R64 = false>
 __global__ __launch_bounds__(256) void k_rows_finish_fused(ModeView mv, RegSet regs, int r, const float *__restrict__ T,
                                                            const double *__restrict__ colsq,
-                                                           double *__restrict__ diag_tile, int want_diag) {
+                                                           double *__restrict__ diag_tile, int want_diag,
+                                                           const double *__restrict__ T64 = nullptr) {
+    typedef RowArith<R64> RA;  // R64: the r x r products on the fp64 MFMA, exact Y = F + U (see k_rows_solve_stats)
     TILE_PROLOGUE();
     double nf = 0.0, na = 0.0, gap[MCL_MAX_REGS];  // per-tile diagnostics (same sums as k_rows_diag)
 #pragma unroll
@@ -1717,9 +1791,10 @@ __global__ __launch_bounds__(256) void k_rows_finish_fused(ModeView mv, RegSet r
     int kpf2 = -1;
     for (int k = 0; k < regs.n; ++k)
         if (regs.kind[k] == MCL_PEN_PARAFAC2) kpf2 = k;
-    RowMat<NBR> Ts, D;
+    typename RA::template Mat<NBR> Ts, D;
     if (kpf2 >= 0) {
-        Ts.load(T + (long)slab * r * r, r, lane);
+        if constexpr (R64) Ts.load(T64 + (long)slab * r * r, r, lane);
+        else Ts.load(T + (long)slab * r * r, r, lane);
         D.load(regs.aux2[kpf2], r, lane);
     }
     FOR_ROW_BLOCKS() {
@@ -1728,7 +1803,7 @@ __global__ __launch_bounds__(256) void k_rows_finish_fused(ModeView mv, RegSet r
         f32x4 f[NBR];
 #pragma unroll
         for (int h = 0; h < NBR; ++h) {
-            f[h] = row_ld4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r);  // zeros for padding rows / columns
+            f[h] = (row_ld4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r));  // zeros for padding rows / columns
             if (want_diag) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -1743,15 +1818,17 @@ __global__ __launch_bounds__(256) void k_rows_finish_fused(ModeView mv, RegSet r
             const int kind = regs.kind[k];
             f32x4 u[NBR], z[NBR], zg[NBR];  // zg: what the feasibility gap is measured against (P Delta for PARAFAC2)
 #pragma unroll
-            for (int h = 0; h < NBR; ++h) u[h] = row_ld4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r);
+            for (int h = 0; h < NBR; ++h) u[h] = (row_ld4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r));
             if (kind == MCL_PEN_PARAFAC2) {
-                f32x4 y[NBR], pd[NBR];
+                typename RA::Y y[NBR], pw[NBR];
+                f32x4 pd[NBR];
 #pragma unroll
-                for (int h = 0; h < NBR; ++h) y[h] = f[h] + u[h];
-                Ts.apply(y, z);   // P = Y T_i      (the aux variable)
-                D.apply(z, pd);   // P Delta        (what the dual is measured against)
+                for (int h = 0; h < NBR; ++h) y[h] = RA::ysum(f[h], u[h]);
+                Ts.apply(y, pw);   // P = Y T_i      (the aux variable)
+                D.apply(pw, pd);   // P Delta        (what the dual is measured against)
 #pragma unroll
                 for (int h = 0; h < NBR; ++h) {
+                    z[h] = RA::narrow(pw[h]);
                     zg[h] = pd[h];
 #pragma unroll
                     for (int v = 0; v < 4; ++v) u[h][v] = f[h][v] - (pd[h][v] - u[h][v]);
@@ -1759,7 +1836,7 @@ __global__ __launch_bounds__(256) void k_rows_finish_fused(ModeView mv, RegSet r
             } else if (kind == MCL_PEN_UNIMODAL) {  // aux rows already written by the column regressions
 #pragma unroll
                 for (int h = 0; h < NBR; ++h) {
-                    z[h] = row_ld4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r);
+                    z[h] = (row_ld4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r));
 #pragma unroll
                     for (int v = 0; v < 4; ++v) u[h][v] = f[h][v] - (z[h][v] - u[h][v]);
                 }
@@ -1824,24 +1901,29 @@ __global__ __launch_bounds__(256) void k_rows_finish_fused(ModeView mv, RegSet r
 // no later step of the inner loop reads them (PARAFAC2's Delta and T_i carry its state); the LAST inner iteration ends
 // with the plain k_rows_finish_fused, which writes them and the diagnostics.
 // ---------------------------------------------------------------------------------------------------------
-template <int NBR, bool VEC>
+template <int NBR, bool VEC, bool R64 = false>
 __global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, const float *__restrict__ rhs_src,
                                                                  const float *__restrict__ Arows,
                                                                  const float *__restrict__ Linv, RegSet regs, int r,
                                                                  const float *__restrict__ T,
                                                                  const double *__restrict__ colsq,
                                                                  double *__restrict__ stat_gram,
-                                                                 double *__restrict__ stat_colsq) {
+                                                                 double *__restrict__ stat_colsq,
+                                                                 const double *__restrict__ Linv64 = nullptr,
+                                                                 const double *__restrict__ T64 = nullptr) {
     typedef double f64x4s __attribute__((ext_vector_type(4)));
+    typedef RowArith<R64> RA;  // R64: the r x r products on the fp64 MFMA, exact Y = F + U (see k_rows_solve_stats)
     TILE_PROLOGUE();
     const float rho = mv.rho[slab];
     int kpf2 = -1;
     for (int k = 0; k < regs.n; ++k)
         if (regs.kind[k] == MCL_PEN_PARAFAC2) kpf2 = k;
-    RowMat<NBR> L, Ts, D;
-    L.load(Linv + (long)slab * r * r, r, lane);
+    typename RA::template Mat<NBR> L, Ts, D;
+    if constexpr (R64) L.load(Linv64 + (long)slab * r * r, r, lane);
+    else L.load(Linv + (long)slab * r * r, r, lane);
     if (kpf2 >= 0) {
-        Ts.load(T + (long)slab * r * r, r, lane);
+        if constexpr (R64) Ts.load(T64 + (long)slab * r * r, r, lane);
+        else Ts.load(T + (long)slab * r * r, r, lane);
         D.load(regs.aux2[kpf2], r, lane);
     }
     float av[NBR][4];
@@ -1870,7 +1952,7 @@ __global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, co
                 l2s[h][v] = bound / fmaxf(nrm, bound);
             }
         }
-    float bsel[4];
+    typename std::conditional<R64, double, float>::type bsel[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) bsel[v] = (row16 == 4 * g + v) ? 1.f : 0.f;
     f64x4s accS[NBR][NBR];
@@ -1889,8 +1971,8 @@ __global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, co
         f32x4 f[NBR], t[NBR], upf[NBR], ul2[NBR];  // new duals of the PARAFAC2 / L2-ball penalty (statistics below)
 #pragma unroll
         for (int h = 0; h < NBR; ++h) {
-            f[h] = row_ld4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r);  // zeros for padding rows / columns
-            t[h] = row_ld4<VEC>(rhs_src, j, 16 * h + 4 * g, ok, r);
+            f[h] = (row_ld4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r));  // zeros for padding rows / columns
+            t[h] = (row_ld4<VEC>(rhs_src, j, 16 * h + 4 * g, ok, r));
 #pragma unroll
             for (int v = 0; v < 4; ++v) t[h][v] *= av[h][v];
         }
@@ -1901,16 +1983,16 @@ __global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, co
             const int kind = regs.kind[k];
             f32x4 u[NBR], zg[NBR];
 #pragma unroll
-            for (int h = 0; h < NBR; ++h) u[h] = row_ld4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r);
+            for (int h = 0; h < NBR; ++h) u[h] = (row_ld4<VEC>(regs.dual[k], j, 16 * h + 4 * g, ok, r));
             if (kind == MCL_PEN_PARAFAC2) {
-                f32x4 y[NBR], pz[NBR];
+                typename RA::Y y[NBR], pz[NBR];
 #pragma unroll
-                for (int h = 0; h < NBR; ++h) y[h] = f[h] + u[h];
+                for (int h = 0; h < NBR; ++h) y[h] = RA::ysum(f[h], u[h]);
                 Ts.apply(y, pz);   // P = Y T_i
                 D.apply(pz, zg);   // P Delta
             } else if (kind == MCL_PEN_UNIMODAL) {  // aux rows written by the column regressions
 #pragma unroll
-                for (int h = 0; h < NBR; ++h) zg[h] = row_ld4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r);
+                for (int h = 0; h < NBR; ++h) zg[h] = (row_ld4<VEC>(regs.aux[k], j, 16 * h + 4 * g, ok, r));
             } else if (kind == MCL_PEN_L2BALL) {
 #pragma unroll
                 for (int h = 0; h < NBR; ++h)
@@ -1959,14 +2041,25 @@ __global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, co
             double yt[NBR][4];
 #pragma unroll
             for (int nb = 0; nb < NBR; ++nb) {
-                f32x4 tr = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (R64) {  // exact fp64 sum, transposed by the fp64 MFMA: lane (q, i16) reg w = Y[q + 4w][16nb + i16]
+                    f64x4s tr = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float y = ok ? fn[nb][v] + upf[nb][v] : 0.f;
-                    tr = MFMA16(y, bsel[v], tr);  // COL layout: lane (q, i16) reg w = Y[4q + w][16nb + i16]
+                    for (int v = 0; v < 4; ++v) {
+                        const double y = ok ? (double)fn[nb][v] + (double)upf[nb][v] : 0.0;
+                        tr = __builtin_amdgcn_mfma_f64_16x16x4f64(y, bsel[v], tr, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) yt[nb][w] = tr[w];
+                } else {
+                    f32x4 tr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float y = ok ? fn[nb][v] + upf[nb][v] : 0.f;
+                        tr = MFMA16(y, bsel[v], tr);  // COL layout: lane (q, i16) reg w = Y[4q + w][16nb + i16]
+                    }
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) yt[nb][w] = (double)tr[w];
                 }
-#pragma unroll
-                for (int w = 0; w < 4; ++w) yt[nb][w] = (double)tr[w];
             }
 #pragma unroll
             for (int w = 0; w < 4; ++w)
@@ -2006,6 +2099,10 @@ __global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, co
 // =========================================================================================================
 // host launchers
 // =========================================================================================================
+// fp64 row algebra for the B-mode passes of a fused stack with a PARAFAC2 member, rank <= 16 (the kernels above with
+// R64 = true): decided by the plan (it owns the fp64 copies of L_i^-1 and T_i); see k_rows_solve_stats
+bool mcl_rows64(const mcl_context *c) { return c->rows64 && c->LinvB64 != nullptr && c->pf2_T64 != nullptr; }
+
 static bool rows_vec_ok(const mcl_context *c, const ModeView &mv, const RegSet &rs, const float *extra) {
     bool vec = (c->r % 4 == 0) && ((reinterpret_cast<uintptr_t>(mv.F) & 15) == 0) &&
                ((reinterpret_cast<uintptr_t>(extra) & 15) == 0);
@@ -2155,7 +2252,7 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
 #define MCL_NS(NB_, TILES_)                                                                                          \
     hipLaunchKernelGGL((k_pf2_algebra_ns<NB_, TILES_>), dim3((unsigned)c->I), dim3(64), 0, c->stream, c->pf2_S,       \
                        rs.aux2[k], c->rhoB, mv.ext, r, c->pf2_T, c->pf2_acc, c->pf2_status, ts, rs, c->pf2_xmin,     \
-                       c->sw.ns_plain ? 0 : 1)
+                       c->sw.ns_plain ? 0 : 1, c->pf2_T64)
                 if (c->NB == 1) {
                     if (tiles) MCL_NS(1, true);
                     else MCL_NS(1, false);
@@ -2167,7 +2264,7 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
             }
             if (status == nullptr || c->NB != 1)  // rank <= 16: the Newton-Schulz kernel runs the Jacobi route itself
                 hipLaunchKernelGGL(k_pf2_algebra, dim3((unsigned)c->I), dim3(64), sm, c->stream, c->pf2_S, rs.aux2[k],
-                                   c->rhoB, r, c->pf2_T, c->pf2_acc, status);
+                                   c->rhoB, r, c->pf2_T, c->pf2_acc, status, c->pf2_T64);
             if (!c->stack_fused)  // the fused finish pass applies T_i itself
                 DISPATCH_ROWS(c, vec, k_pf2_apply, grid, block, mv, (const float *)rs.dual[k], (const float *)c->pf2_T, rs.aux[k], r);
             if (c->pf2_delta_fused)  // single-process inner loop: Delta follows at once, no all-reduce in between
@@ -2228,8 +2325,17 @@ int mcl_launch_rows_finish_fused(mcl_context *c, int mode, bool want_diag) {
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
     const bool vec = rows_vec_ok(c, mv, rs, nullptr);
     double *diag = (mode == 1) ? c->diagB_tile : c->diagC_tile;
-    DISPATCH_ROWS(c, vec, k_rows_finish_fused, grid, block, mv, rs, c->r, (const float *)c->pf2_T, (const double *)c->colsq,
-                  diag, want_diag ? 1 : 0);
+    if (mode == 1 && mcl_rows64(c)) {  // rank <= 16 with a PARAFAC2 member: fp64 row algebra
+        if (vec)
+            hipLaunchKernelGGL((k_rows_finish_fused<1, true, true>), grid, block, 0, c->stream, mv, rs, c->r, (const float *)c->pf2_T,
+                               (const double *)c->colsq, diag, want_diag ? 1 : 0, (const double *)c->pf2_T64);
+        else
+            hipLaunchKernelGGL((k_rows_finish_fused<1, false, true>), grid, block, 0, c->stream, mv, rs, c->r, (const float *)c->pf2_T,
+                               (const double *)c->colsq, diag, want_diag ? 1 : 0, (const double *)c->pf2_T64);
+    } else {
+        DISPATCH_ROWS(c, vec, k_rows_finish_fused, grid, block, mv, rs, c->r, (const float *)c->pf2_T, (const double *)c->colsq,
+                      diag, want_diag ? 1 : 0, (const double *)nullptr);
+    }
     MCL_CHECK_HIP(c, hipGetLastError());
     if (want_diag) c->diag_rows[mode] = mv.n_tiles;  // one row per tile, as k_rows_diag writes them
     return 0;
@@ -2253,16 +2359,20 @@ int mcl_launch_rows_finish_solve_stats(mcl_context *c) {
     const float *rhs = c->XC;
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
     const bool vec = rows_vec_ok(c, mv, c->regs[1], rhs);
-#define MCL_FSS(NBR_, VEC_)                                                                                          \
-    hipLaunchKernelGGL((k_rows_finish_solve_stats<NBR_, VEC_>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, \
-                       (const float *)c->LinvB, c->regs[1], c->r, (const float *)c->pf2_T, (const double *)c->colsq,   \
-                       c->stat_gram, c->stat_colsq)
-    if (c->NB == 1) {
-        if (vec) MCL_FSS(1, true);
-        else MCL_FSS(1, false);
+#define MCL_FSS(NBR_, VEC_, R64_)                                                                                    \
+    hipLaunchKernelGGL((k_rows_finish_solve_stats<NBR_, VEC_, R64_>), grid, block, 0, c->stream, mv, rhs,              \
+                       (const float *)c->A, (const float *)c->LinvB, c->regs[1], c->r, (const float *)c->pf2_T,        \
+                       (const double *)c->colsq, c->stat_gram, c->stat_colsq, (const double *)c->LinvB64,              \
+                       (const double *)c->pf2_T64)
+    if (mcl_rows64(c)) {
+        if (vec) MCL_FSS(1, true, true);
+        else MCL_FSS(1, false, true);
+    } else if (c->NB == 1) {
+        if (vec) MCL_FSS(1, true, false);
+        else MCL_FSS(1, false, false);
     } else {
-        if (vec) MCL_FSS(2, true);
-        else MCL_FSS(2, false);
+        if (vec) MCL_FSS(2, true, false);
+        else MCL_FSS(2, false, false);
     }
 #undef MCL_FSS
     if (!mcl_stats_reduce_in_algebra(c))
@@ -2279,13 +2389,20 @@ int mcl_launch_rows_solve_stats(mcl_context *c) {
     const float *rhs = c->XC;
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
     const bool vec = rows_vec_ok(c, mv, c->regs[1], rhs);
-    if (c->NB == 1) {
-        if (vec) hipLaunchKernelGGL((k_rows_solve_stats<1, true>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, (const float *)c->LinvB, c->regs[1], c->r, c->stat_gram, c->stat_colsq);
-        else hipLaunchKernelGGL((k_rows_solve_stats<1, false>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, (const float *)c->LinvB, c->regs[1], c->r, c->stat_gram, c->stat_colsq);
+#define MCL_SS(NBR_, VEC_, R64_)                                                                                     \
+    hipLaunchKernelGGL((k_rows_solve_stats<NBR_, VEC_, R64_>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, \
+                       (const float *)c->LinvB, c->regs[1], c->r, c->stat_gram, c->stat_colsq, (const double *)c->LinvB64)
+    if (mcl_rows64(c)) {
+        if (vec) MCL_SS(1, true, true);
+        else MCL_SS(1, false, true);
+    } else if (c->NB == 1) {
+        if (vec) MCL_SS(1, true, false);
+        else MCL_SS(1, false, false);
     } else {
-        if (vec) hipLaunchKernelGGL((k_rows_solve_stats<2, true>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, (const float *)c->LinvB, c->regs[1], c->r, c->stat_gram, c->stat_colsq);
-        else hipLaunchKernelGGL((k_rows_solve_stats<2, false>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, (const float *)c->LinvB, c->regs[1], c->r, c->stat_gram, c->stat_colsq);
+        if (vec) MCL_SS(2, true, false);
+        else MCL_SS(2, false, false);
     }
+#undef MCL_SS
     if (!mcl_stats_reduce_in_algebra(c))
         hipLaunchKernelGGL(k_stats_reduce, dim3((unsigned)c->I), dim3(256), 0, c->stream, (const int *)c->slab_tile_ptr,
                            (const double *)c->stat_gram, (const double *)c->stat_colsq, c->regs[1], c->r, 16 * c->NB,

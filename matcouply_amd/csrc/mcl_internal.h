@@ -67,6 +67,7 @@ struct mcl_switches {
     bool no_sweep = false, no_pass_chain = false, no_pf2_delta_fusion = false, ns_plain = false, pf2_jacobi = false;
     bool no_stack_fusion = false, no_solve_stats = false, no_next_b = false, no_fused_gram = false, no_fused_c = false;
     bool a_finish_cols = false, xc_norow = false, unimodal_v3 = false, stats_reduce = false;
+    bool no_rows64 = false;
     bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_x_nt = false, no_sweep_half = false, no_multi_c = false, no_diag_defer = false, xc_depth1 = false;
     int x_nt_mb = 0, seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
     int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
@@ -190,6 +191,8 @@ struct mcl_context {
     int *uni_i32 = nullptr;     //                              2 int32 arrays of rows * r
     double *pf2_S = nullptr;    // [I, r, r]  Y_i^T Y_i (fp64)
     float *pf2_T = nullptr;     // [I, r, r]  P_i = Y_i T_i
+    double *pf2_T64 = nullptr;  // [I, r, r]  the same before its rounding (fp64 row passes: rows64)
+    bool rows64 = false;        // rank <= 16 and a PARAFAC2 member on mode 1: the fused B-mode row passes compute in fp64
     double *pf2_acc = nullptr;  // [I, r*r + 1] per-slab rho_i P_i^T Y_i | rho_i
     float *pf2_xmin = nullptr;  // [I] 1 / ||(G_i / tr)^-1/2||_F of the last Newton-Schulz run: starting estimate of the next
     int *pf2_status = nullptr;  // [I] 0: Newton-Schulz converged, 1: redo with the Jacobi kernel
@@ -316,6 +319,7 @@ int mcl_launch_diag_verdict(mcl_context *c, double *out, const mcl_stop_rule *ru
 int mcl_launch_x_sq(mcl_context *c);
 bool mcl_mode_is_row_separable(const mcl_context *c, int mode);
 bool mcl_stack_can_fuse(const mcl_context *c, int mode);          // generic.hip
+bool mcl_rows64(const mcl_context *c);                            // generic.hip
 int mcl_launch_rows_finish_fused(mcl_context *c, int mode, bool want_diag);  // generic.hip
 bool mcl_stats_can_ride_in_solve(const mcl_context *c, int mode);  // generic.hip
 bool mcl_stats_reduce_in_algebra(const mcl_context *c);            // generic.hip

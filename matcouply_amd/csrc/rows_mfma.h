@@ -123,3 +123,79 @@ static __device__ __forceinline__ void row_st4(float *__restrict__ base, long j,
             if (ok && col + q < r) base[j * r + col + q] = v[q];
     }
 }
+
+// ---- the same row algebra in fp64 (PARAFAC2 stacks of rank <= 16, generic.hip) ----------------------------------------
+// v_mfma_f64_16x16x4_f64 has the operand layouts of the fp32 instruction (A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15])
+// but ANOTHER result layout: lane l, register v holds D[i = (l >> 4) + 4 v][j = l & 15].  For the transposed problem
+// out^T = M^T t^T the row index i of D is an output COLUMN, so loading the A operand with the columns of M permuted by
+// colmap(i) = 4 (i & 3) + (i >> 2) makes register v of lane (row, g) the output column 4 g + v again: input and output
+// fragments coincide exactly as in the fp32 form, and products chain without any cross-lane traffic.
+typedef double rd64x4 __attribute__((ext_vector_type(4)));
+
+template <int NBR>
+struct RowMat64 {
+    double m[NBR][NBR][4];  // m[h'][h][kq] = M[16h + 4g + kq][16h' + colmap(row16)]
+    template <typename SRC>
+    __device__ __forceinline__ void load(const SRC *M, int r, int lane) {
+        const int row16 = lane & 15, g = lane >> 4;
+        const int cm = 4 * (row16 & 3) + (row16 >> 2);
+#pragma unroll
+        for (int hp = 0; hp < NBR; ++hp)
+#pragma unroll
+            for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) {
+                    const int k = 16 * h + 4 * g + kq, c = 16 * hp + cm;
+                    m[hp][h][kq] = (k < r && c < r) ? (double)M[k * r + c] : 0.0;
+                }
+    }
+    __device__ __forceinline__ void apply(const rd64x4 (&t)[NBR], rd64x4 (&out)[NBR]) const {
+#pragma unroll
+        for (int hp = 0; hp < NBR; ++hp) {
+            rd64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int h = 0; h < NBR; ++h)
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m[hp][h][kq], t[h][kq], acc, 0, 0, 0);
+            out[hp] = acc;
+        }
+    }
+    // fp32 rows in and / or out: exact widening, ONE rounding of the result
+    __device__ __forceinline__ void apply(const rd64x4 (&t)[NBR], f32x4 (&out)[NBR]) const {
+        rd64x4 o[NBR];
+        apply(t, o);
+#pragma unroll
+        for (int h = 0; h < NBR; ++h) out[h] = f32x4{(float)o[h][0], (float)o[h][1], (float)o[h][2], (float)o[h][3]};
+    }
+    __device__ __forceinline__ void apply(const f32x4 (&t)[NBR], f32x4 (&out)[NBR]) const {
+        rd64x4 w[NBR];
+#pragma unroll
+        for (int h = 0; h < NBR; ++h) w[h] = rd64x4{(double)t[h][0], (double)t[h][1], (double)t[h][2], (double)t[h][3]};
+        apply(w, out);
+    }
+};
+
+// Row arithmetic of a kernel.  R64 = false: everything in fp32.  R64 = true (PARAFAC2 stacks of rank <= 16): the vectors
+// stay fp32 - they are what is stored - but every r x r product runs on the fp64 MFMA with fp64 matrices, the polar input
+// Y = F + U is the EXACT fp64 sum of the two stored values, and P = Y T_i stays in fp64 until P Delta has been formed.  Each
+// product's result is rounded once, where it is stored anyway.
+template <bool R64>
+struct RowArith;
+template <>
+struct RowArith<false> {
+    typedef f32x4 Y;
+    template <int NBR>
+    using Mat = RowMat<NBR>;
+    static __device__ __forceinline__ Y ysum(f32x4 f, f32x4 u) { return f + u; }
+    static __device__ __forceinline__ f32x4 narrow(Y v) { return v; }
+};
+template <>
+struct RowArith<true> {
+    typedef rd64x4 Y;
+    template <int NBR>
+    using Mat = RowMat64<NBR>;
+    static __device__ __forceinline__ Y ysum(f32x4 f, f32x4 u) {
+        return Y{(double)f[0] + (double)u[0], (double)f[1] + (double)u[1], (double)f[2] + (double)u[2], (double)f[3] + (double)u[3]};
+    }
+    static __device__ __forceinline__ f32x4 narrow(Y v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+};
