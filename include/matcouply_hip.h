@@ -211,8 +211,14 @@ int mcl_profile_enable(mcl_context *ctx, int32_t capacity);
 int mcl_profile_set_stride(mcl_context *ctx, int32_t stride);
 int mcl_profile_read(mcl_context *ctx, int32_t which, double *total_ms, int32_t *count);
 /* The MCL_* environment switches (A/B experiments, debug paths; tools/README.md) are read once in mcl_create();
- * this re-reads them for an existing context (tests that compare kernel forms on one problem). */
+ * this re-reads them for an existing context (tests that compare kernel forms on one problem).
+ * PRODUCTION NOTE: the parity statements of this library hold for a CLEAN environment - several
+ * switches select other kernel forms or other summation orders (MCL_SEG_ROWS, MCL_XC_WAVES, MCL_NO_ROWS64, MCL_NO_SWEEP, ...)
+ * and move results at the 1e-6 level.  mcl_active_switches() returns the space-separated names of the MCL_* switches the
+ * context found in its environment ("" = clean); a host should refuse, or at least log, a non-empty answer
+ * (matcouply_amd.cmf_aoadmm issues a RuntimeWarning). */
 int mcl_reload_switches(mcl_context *ctx);
+const char *mcl_active_switches(const mcl_context *ctx);
 
 #ifdef __cplusplus
 }

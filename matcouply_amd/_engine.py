@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_B_end", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
     "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
     "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_set_stride", "mcl_profile_read",
-    "mcl_reload_switches", "mcl_cmf_to_packed",
+    "mcl_reload_switches", "mcl_active_switches", "mcl_cmf_to_packed",
 ]
 
 
@@ -117,6 +117,7 @@ def load_library():
         "mcl_profile_set_stride": (ctypes.c_int, [P, I32]),
         "mcl_profile_read": (ctypes.c_int, [P, I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I32)]),
         "mcl_reload_switches": (ctypes.c_int, [P]),
+        "mcl_active_switches": (ctypes.c_char_p, [P]),
         "mcl_cmf_to_packed": (ctypes.c_int, [P, P, P, P, P, I64, I64, I32, P, P]),
     }
     for name, (res, args) in sig.items():
@@ -223,6 +224,12 @@ class HipEngine:
         nbytes = self.lib.mcl_workspace_bytes(self._h)
         if nbytes < 0:
             raise EngineError("mcl_workspace_bytes failed")
+        active = self.lib.mcl_active_switches(self._h).decode()
+        if active:
+            import warnings
+
+            warnings.warn(f"libmatcouply_hip: MCL_* switches in the environment ({active}) select non-default kernel forms; the "
+                          "parity statements of DESIGN.md hold for a clean environment", RuntimeWarning, stacklevel=3)
         self.workspace = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.device)
         self._ws_off = (-self.workspace.data_ptr()) % 256
         self._check(self.lib.mcl_set_workspace(self._h, self.workspace.data_ptr() + self._ws_off, nbytes))

@@ -166,6 +166,21 @@ void read_switches(mcl_switches &w) {
     w.sweep_dbg = num("MCL_SWEEP_DBG", 0), w.reduce_el = num("MCL_REDUCE_EL", 0), w.uni_split = num("MCL_UNI_SPLIT", -1);
 }
 
+// names of the MCL_* switches present in the environment (what mcl_active_switches reports)
+std::string switches_in_env() {
+    static const char *names[] = {
+        "MCL_NO_SWEEP", "MCL_NO_PASS_CHAIN", "MCL_NO_PF2_DELTA_FUSION", "MCL_NS_PLAIN", "MCL_PF2_JACOBI", "MCL_NO_STACK_FUSION",
+        "MCL_NO_SOLVE_STATS", "MCL_NO_NEXT_B", "MCL_NO_FUSED_GRAM", "MCL_NO_FUSED_C", "MCL_A_FINISH_COLS", "MCL_XC_NOROW",
+        "MCL_UNIMODAL_V3", "MCL_STATS_REDUCE", "MCL_NO_ROWS64", "MCL_NO_A_FUSION", "MCL_NO_A_WIDE", "MCL_NO_BSEG_GROUPS",
+        "MCL_NO_SWEEP_HALF", "MCL_NO_X_NT", "MCL_X_NT_MB", "MCL_NO_MULTI_C", "MCL_NO_DIAG_DEFER", "MCL_XC_DEPTH1", "MCL_SEG_ROWS",
+        "MCL_BSEG_ROWS", "MCL_XC_WAVES", "MCL_XT_WAVES", "MCL_SWEEP_WAVES", "MCL_XC_DBG", "MCL_XT_DBG", "MCL_XT_DEPTH",
+        "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT"};
+    std::string out;
+    for (const char *n : names)
+        if (getenv(n) != nullptr) out += (out.empty() ? "" : " ") + std::string(n);
+    return out;
+}
+
 int fail(mcl_context *c, const std::string &msg) {
     c->err = msg;
     return 1;
@@ -340,6 +355,7 @@ int mcl_create(mcl_context **out, int device, void *hip_stream) {
     c->opt.feasibility_penalty_scale = 1.0;
     c->opt.inner_n_iter_max = 5;
     read_switches(c->sw);
+    c->active_switches = switches_in_env();
     *out = c;
     return 0;
 }
@@ -1204,8 +1220,11 @@ int mcl_profile_read(mcl_context *c, int32_t which, double *total_ms, int32_t *c
 int mcl_reload_switches(mcl_context *c) {
     if (!c) return 1;
     read_switches(c->sw);
+    c->active_switches = switches_in_env();
     return 0;
 }
+
+const char *mcl_active_switches(const mcl_context *c) { return c ? c->active_switches.c_str() : ""; }
 
 const char *mcl_kernel_variant(mcl_context *c, int32_t which) {
     if (!c || which < 0 || which > 3) return "";

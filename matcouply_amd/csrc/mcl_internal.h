@@ -76,6 +76,7 @@ struct mcl_switches {
 struct mcl_context {
     int device = 0;
     mcl_switches sw;
+    std::string active_switches;  // names of the MCL_* switches found in the environment when they were last read
     hipStream_t stream = nullptr;
     std::string err;
 

@@ -520,6 +520,19 @@ def _default_engine_factory(**kw):
     return _engine.HipEngine(**kw)
 
 
+_DIRECT_COMMS = {}
+
+
+def _direct_comm(group):
+    """the cached direct RCCL communicator of a process group (None: use torch.distributed), see _rccl.py"""
+    key = id(group)
+    if key not in _DIRECT_COMMS:
+        from . import _rccl
+
+        _DIRECT_COMMS[key] = (group, _rccl.DirectComm.try_create(group))  # the group is kept alive with its communicator
+    return _DIRECT_COMMS[key][1]
+
+
 # ------------------------------------------------------------------------------------------------------------
 # the solver
 # ------------------------------------------------------------------------------------------------------------
@@ -559,6 +572,7 @@ def cmf_aoadmm(
     verbose=False,
     *,
     group=None,
+    gather_A=False,
     _byproducts=None,
 ):
     r"""Fit a regularized coupled matrix factorization model with AO-ADMM on an MI355X.
@@ -573,6 +587,18 @@ def cmf_aoadmm(
     initialisations.  ``inner_tol`` > 0 is supported on a slower step path (see below in the code).  Penalties without a native kernel (user
     subclasses of ``matcouply_amd.penalties.ADMMPenalty``) are evaluated through their own Python methods on device
     tensors between the native solve and dual-update steps.
+
+    Sharded runs (``group=``, keyword-only, not in the reference): every rank of the ``torch.distributed`` process group
+    passes ITS matrices (see :func:`partition_slabs`) and gets back its rows of ``A``, its ``B_i`` and the replicated ``C``;
+    ``gather_A=True`` all-gathers the rows of ``A`` once at the end (rank order, i.e. the original order for contiguous
+    partitions): the factorization returned stays the rank's own, the whole ``A`` rides along as ``cmf.A_all`` with this
+    rank's rows at ``cmf.rows_of_rank`` (the ADMM variables of mode 0 stay rank-local).  Per outer iteration
+    the ranks exchange the fp64 normal equations ``[G | R]`` of the C-phase, the diagnostic sums while a stopping rule is
+    active, one ``r*r + 1`` reduction per inner iteration with PARAFAC2 and a scalar MAX per phase with a constant
+    feasibility penalty.  NOT supported with ``group=`` (``NotImplementedError``): ``TotalVariationPenalty`` on any mode,
+    host-evaluated (user-defined / overridden) penalties on mode 1, matrix penalties on mode 0 other than the L2 ball
+    (PARAFAC2 is mode 1 only; the L2 ball on A needs ``constant_feasibility_penalty``, as in the reference).  None of these
+    occurs in the BASELINE configurations.
 
     >>> import numpy as np, matcouply_amd
     >>> len(matcouply_amd.decomposition._listify({1: 0.5}, "l1_penalty"))
@@ -663,21 +689,32 @@ def cmf_aoadmm(
         rank_id = dist.get_rank(group)
     else:
         rank_id = 0
-    needs_B_steps = world > 1 and (constant_B or any(r.kind == _engine.PEN_PARAFAC2 for r in native[1]))
-    needs_A_steps = world > 1 and constant_A
+    # the sharded code path (step calls with the reductions in between): taken with more than one rank - and, for
+    # rehearsals of that path on a single-GPU box, with a one-rank group when MCL_FORCE_SHARDED_PATH=1
+    sharded = world > 1 or (group is not None and os.environ.get("MCL_FORCE_SHARDED_PATH") == "1")
+    needs_B_steps = sharded and (constant_B or any(r.kind == _engine.PEN_PARAFAC2 for r in native[1]))
+    needs_A_steps = sharded and constant_A
     # mode 0 under sharding: the rows of A live on different ranks.  Row-separable penalties need nothing; an L2 ball
     # (the README case: l2_norm_bound on A with a constant feasibility penalty) needs the r column sums of squares of
     # A + U all-reduced in every inner iteration; other matrix penalties are not supported.
-    sharded_ball_A = world > 1 and any(r.kind == _engine.PEN_L2BALL for r in native[0])
-    if world > 1 and not all(r.kind in (_engine.PEN_NN, _engine.PEN_BOX, _engine.PEN_L1, _engine.PEN_L2BALL)
+    sharded_ball_A = sharded and any(r.kind == _engine.PEN_L2BALL for r in native[0])
+    if sharded and not all(r.kind in (_engine.PEN_NN, _engine.PEN_BOX, _engine.PEN_L1, _engine.PEN_L2BALL)
                              for r in native[0]):
         raise NotImplementedError("this matrix penalty on mode 0 couples rows that live on different ranks; "
                                   "not supported with group=")
     if sharded_ball_A and not constant_A:
         raise NotImplementedError("an L2 ball on mode 0 needs constant_feasibility_penalty (as in the reference)")
 
+    # RCCL groups: the collectives go straight onto the engine's stream through a communicator of the engine's own
+    # (_rccl.DirectComm: no stream hand-over); any other backend (gloo in the CPU tests), or a failed self-test: torch's
+    direct = _direct_comm(group) if (sharded and sub is None) else None
+
     def all_reduce(t, op="sum"):
-        if world > 1:
+        if not sharded:
+            return
+        if direct is not None and is_torch(t) and t.is_cuda and t.dtype in (torch.float32, torch.float64) and t.is_contiguous():
+            direct.all_reduce(t, op)
+        elif sharded:
             dist.all_reduce(t, op=(dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM), group=group)
 
     has_ext = [any(r.kind == _engine.PEN_EXTERNAL for r in native[m]) for m in range(3)]
@@ -737,7 +774,7 @@ def cmf_aoadmm(
             eng.B_solve()
             for k, reg in enumerate(native[1]):
                 if reg.kind == _engine.PEN_EXTERNAL:
-                    if world > 1:
+                    if sharded:
                         raise NotImplementedError("host-evaluated penalties on mode 1 are not supported with group=")
                     host_prox_B(k)
                     continue
@@ -868,14 +905,14 @@ def cmf_aoadmm(
 
     it = -1  # Needed if n_iter_max <= 0
     host_value = any(r.kind == _engine.PEN_TV for m in range(3) for r in native[m])  # penalty value needs a host call
-    fast_path = ((not (tol or absolute_tol)) and world == 1 and not verbose and n_iter_max > 0 and not any(has_ext)
+    fast_path = ((not (tol or absolute_tol)) and not sharded and not verbose and n_iter_max > 0 and not any(has_ext)
                  and not host_value)
-    if host_value and world > 1:
+    if host_value and sharded:
         raise NotImplementedError("TotalVariationPenalty is not supported with group= (its penalty value is summed on the host)")
-    lazy_diag = (not (tol or absolute_tol)) and world > 1 and not verbose and n_iter_max > 0
+    lazy_diag = (not (tol or absolute_tol)) and sharded and not verbose and n_iter_max > 0
     # stopping rule on the device (mcl_run): single device, every penalty native, silent.  (tol set with absolute_tol=None is
     # a TypeError in the reference's comparison - the host loop below raises it the same way.)
-    device_stop = (bool(tol or absolute_tol) and world == 1 and not verbose and n_iter_max > 0 and not any(has_ext)
+    device_stop = (bool(tol or absolute_tol) and not sharded and not verbose and n_iter_max > 0 and not any(has_ext)
                    and not host_value and not (tol and absolute_tol is None) and hasattr(eng, "run"))
     final_gaps_known = False
     if lazy_diag:
@@ -980,6 +1017,22 @@ def cmf_aoadmm(
 
     # ---- results back in the caller's array type ------------------------------------------------------------------
     cmf = CoupledMatrixFactorization((None, (out(eng.A), out.split(eng.B, row_ptr), out(eng.C))))
+    if gather_A and group is not None:
+        # the one all-gather of a sharded run: ranks hold different numbers of matrices, so the rows are
+        # padded to the largest share for the collective and trimmed afterwards.  The factorization returned stays this
+        # rank's (its rows of A, its B_i); the whole A rides along as `cmf.A_all`, this rank's rows being
+        # `cmf.A_all[cmf.rows_of_rank[0]:cmf.rows_of_rank[1]]`.
+        n_loc = torch.tensor([eng.A.shape[0]], dtype=torch.int64, device=eng.A.device)
+        counts = [torch.zeros_like(n_loc) for _ in range(world)]
+        dist.all_gather(counts, n_loc, group=group)
+        counts = [int(c.item()) for c in counts]
+        padded = torch.zeros((max(counts), eng.A.shape[1]), dtype=eng.A.dtype, device=eng.A.device)
+        padded[: eng.A.shape[0]] = eng.A
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded, group=group)
+        cmf.A_all = out(torch.cat([p[:c] for p, c in zip(parts, counts)], 0))
+        lo = sum(counts[:rank_id])
+        cmf.rows_of_rank = (lo, lo + counts[rank_id])
     result = [cmf]
     if return_admm_vars:
         auxes, duals = [[], [], []], [[], [], []]
@@ -1103,6 +1156,7 @@ def parafac2_aoadmm(
     verbose=False,
     *,
     group=None,
+    gather_A=False,
 ):
     """Alias for cmf_aoadmm with the PARAFAC2 constraint on mode 1 (reference decomposition.py:1103-1179)."""
     return cmf_aoadmm(
@@ -1114,4 +1168,4 @@ def parafac2_aoadmm(
         init_params=init_params, random_state=random_state, tol=tol, absolute_tol=absolute_tol,
         feasibility_tol=feasibility_tol, inner_tol=inner_tol, inner_n_iter_max=inner_n_iter_max, update_A=update_A,
         update_B_is=update_B_is, update_C=update_C, return_errors=return_errors, return_admm_vars=return_admm_vars,
-        verbose=verbose, group=group)
+        verbose=verbose, group=group, gather_A=gather_A)

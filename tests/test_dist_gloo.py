@@ -106,7 +106,8 @@ def _run_with_checker(dec, case, lo, hi, group):
     w, (A0, B0, C0) = init
     cmf, diag = dec.cmf_aoadmm(mats[lo:hi], r, init=(None, (A0[lo:hi].copy(), [b.copy() for b in B0[lo:hi]], C0.copy())),
                                regs=_build(regs_spec, lo, hi), n_iter_max=6, tol=None, absolute_tol=None,
-                               return_errors=True, constant_feasibility_penalty=const, group=group)
+                               return_errors=True, constant_feasibility_penalty=const, group=group,
+                               gather_A=group is not None)
     return cmf, diag
 
 
@@ -117,7 +118,7 @@ def _worker(rank, world, port, case, q):
     bounds = [0, 4, 6]  # uneven split of the 6 slabs
     cmf, diag = _run(case, bounds[rank], bounds[rank + 1], dist.group.WORLD)
     q.put((rank, cmf[1][0], np.concatenate(cmf[1][1]), cmf[1][2], diag.rec_errors, diag.regularized_loss,
-           [[list(map(float, g)) for g in it] for it in diag.feasibility_gaps]))
+           [[list(map(float, g)) for g in it] for it in diag.feasibility_gaps], np.asarray(cmf.A_all), cmf.rows_of_rank))
     dist.destroy_process_group()
 
 
@@ -136,6 +137,11 @@ def test_two_rank_sharded_run_equals_single_process(case):
         p.join(timeout=60)
         assert p.exitcode == 0
     A = np.concatenate([res[1] for res in results])
+    # gather_A=True: every rank also holds the WHOLE A (one all-gather at the end), its own rows at rows_of_rank
+    for rk, res in enumerate(results):
+        np.testing.assert_array_equal(res[7], A)
+        assert res[8] == ((0, 4), (4, 6))[rk]
+        np.testing.assert_array_equal(res[7][res[8][0]:res[8][1]], res[1])
     B = np.concatenate([res[2] for res in results])
     np.testing.assert_allclose(A, ref_cmf[1][0], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(B, np.concatenate(ref_cmf[1][1]), rtol=1e-9, atol=1e-12)

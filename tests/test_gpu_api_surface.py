@@ -144,6 +144,7 @@ def test_two_ranks_sharing_the_gpu_equal_single_process(tmp_path, stack):
     assert max(err.values()) < 1e-5, err
 
 
+
 @pytest.mark.parametrize("stack", ["pf2", "pf2_ball"])
 def test_parafac2_polar_factor_routes_agree(stack):
     """PARAFAC2's polar factors (penalties.py:1224-1250) through both native routes - Newton-Schulz on the fp64 MFMA and the
@@ -260,6 +261,14 @@ mats = [X[row_ptr[i]:row_ptr[i+1]] for i in range(6)]
 kw = dict(non_negative={0: True}, parafac2=True, l2_norm_bound={1: 1.0}, l1_penalty={2: 0.05}, n_iter_max=5, tol=None,
           absolute_tol=None, return_errors=True, constant_feasibility_penalty=True, random_state=0)
 cmf_g, diag_g = dec.cmf_aoadmm(mats, 4, group=dist.group.WORLD, **kw)   # step path: every reduction goes through RCCL
+direct = dec._direct_comm(dist.group.WORLD)                              # ... called directly on the engine's stream
+print("RCCL_DIRECT " + json.dumps(dict(available=direct is not None, calls=(direct.calls if direct is not None else 0))), flush=True)
+os.environ["MCL_NO_DIRECT_RCCL"] = "1"                                  # the same through torch.distributed's own stream
+dec._DIRECT_COMMS.clear()
+cmf_t, diag_t = dec.cmf_aoadmm(mats, 4, group=dist.group.WORLD, **kw)
+assert dec._direct_comm(dist.group.WORLD) is None
+print("RCCL_PATHS_EQUAL " + json.dumps(bool(np.array_equal(cmf_t[1][0], cmf_g[1][0]) and np.array_equal(cmf_t[1][2], cmf_g[1][2]))), flush=True)
+os.environ.pop("MCL_FORCE_SHARDED_PATH")
 cmf_1, diag_1 = dec.cmf_aoadmm(mats, 4, **kw)                           # single-call path
 err = dict(A=float(np.linalg.norm(cmf_g[1][0] - cmf_1[1][0]) / np.linalg.norm(cmf_1[1][0])),
            C=float(np.linalg.norm(cmf_g[1][2] - cmf_1[1][2]) / np.linalg.norm(cmf_1[1][2])),
@@ -278,7 +287,8 @@ def test_step_path_over_rccl_on_one_rank(tmp_path):
     script = tmp_path / "rccl_one.py"
     script.write_text(RCCL_ONE_RANK)
     port = str(29300 + os.getpid() % 300)
-    env = dict(os.environ, REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MCL_FORCE_SHARDED_PATH="1")  # a one-rank group takes the step path with every reduction in it
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", port, str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
@@ -288,3 +298,8 @@ def test_step_path_over_rccl_on_one_rank(tmp_path):
 
     err = json.loads(line[0].split(" ", 1)[1])
     assert max(err.values()) < 1e-5, err
+    # the collectives went through the engine's own communicator (RCCL on the engine's stream), and give the bits of the
+    # torch.distributed path
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("RCCL_DIRECT")][0].split(" ", 1)[1])
+    assert d["available"] and d["calls"] > 20, d
+    assert json.loads([l for l in out.stdout.splitlines() if l.startswith("RCCL_PATHS_EQUAL")][0].split(" ", 1)[1]) is True

@@ -109,18 +109,43 @@ def test_golden_trajectories(fname):
     print(fname, "20 it vs reference:", {k: f"{v:.1e}" for k, v in e.items()})
     if max(e.values()) < 3e-6:  # measured: <= 7e-7 on six of the seven trajectories
         return
-    # Above that, the loss must be a LOCALISED event of a discontinuous projection, not a diffuse loss of digits: the
-    # unimodal regression of the full stack (traj_c5_full) re-pools a column differently when two candidate level sets
-    # are closer than fp32 rounding (tools/traj_growth.py: B error 3e-6 at iteration 12, 2.3e-5 at 16, 82 % of it in one
-    # (slab, column) pair and 99 % in three of 45).  Bound 5e-5, and >= 90 % of the squared error in <= 3 columns.
+    # Above that the free-running trajectory has met a DISCONTINUITY of the reference's own map: the unimodal regression of
+    # the full stack (traj_c5_full) pools a column differently when two candidate level sets are closer than the distance
+    # the two trajectories have drifted apart by then (tools/traj_growth.py: B error 3e-6 at iteration 12, 2e-5 at 16, 98 % of
+    # it in three of 45 (slab, column) pairs).  That is not held to a looser tolerance: it is PINNED as an equivalence -
+    # from the engine's OWN state before every one of the 20 iterations, the reference arithmetic (oracle, fp64) takes the
+    # step the engine took, to the flat 1e-5 bar on every factor and every ADMM variable.  Whatever split the engine chose,
+    # the reference chooses on the same input; the trajectories differ only in which side of a tie their inputs fell.
     assert any(d["kind"] == "unimodal" for d in spec["regs"][1]), (fname, e)
-    assert max(e.values()) < 5e-5, e
-    Bg, rp = np.concatenate(cmf[1][1]), st.row_ptr
-    err = np.array([[np.sum((Bg[rp[i]:rp[i + 1], c] - arrs["B"][rp[i]:rp[i + 1], c]) ** 2) for c in range(Bg.shape[1])]
-                    for i in range(len(rp) - 1)]).ravel()
-    share = np.sort(err)[::-1][:3].sum() / err.sum()
-    print(fname, f"share of the squared B error in the worst 3 of {err.size} (slab, column) pairs: {share:.3f}")
-    assert share > 0.9, share
+    _assert_stepwise_equivalence(_traj_state(arrs, spec), spec["n_iter_max"], fname)
+
+
+def _state_from_gpu(st, cmf, admm):
+    """a fresh OracleState holding the engine's factors and ADMM variables (fp32 values, exactly, as fp64)"""
+    from oracle import aoadmm_oracle as orc
+
+    aux, dual = [[], [], []], [[], [], []]
+    for m in range(3):
+        for d, z, u in zip(st.regs[m], admm.auxes[m], admm.duals[m]):
+            if d["kind"] == "parafac2":
+                aux[m].append((np.concatenate(z[0]), np.asarray(z[1])))
+            else:
+                aux[m].append(np.concatenate(z) if m == 1 else np.asarray(z))
+            dual[m].append(np.concatenate(u) if m == 1 else np.asarray(u))
+    return orc.OracleState(st.X, st.row_ptr, cmf[1][0], np.concatenate(cmf[1][1]), cmf[1][2], st.regs, aux, dual, l2=st.l2,
+                           inner_n_iter_max=st.inner, feasibility_penalty_scale=st.scale, constant_A=st.constant_A,
+                           constant_B=st.constant_B)
+
+
+def _assert_stepwise_equivalence(st, n_iter, label):
+    worst = {}
+    for it in range(n_iter):
+        cmf, admm, diag, res = _run_both(st, 1)        # engine and oracle, one iteration each, from the SAME state
+        errs = _compare(cmf, admm, diag, st, res, 1e-5)  # `st` now holds the oracle's result
+        for k, v in errs.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+        st = _state_from_gpu(st, cmf, admm)              # ... and both continue from the ENGINE's state
+    print(label, f"re-synchronised one-step parity over {n_iter} iterations, worst:", {k: f"{v:.1e}" for k, v in worst.items()})
 
 
 def test_seeded_keyword_run_on_gpu():
