@@ -187,6 +187,15 @@ int mcl_C_begin(mcl_context *ctx);           /* rho, L^-1 from the reduced norma
 int mcl_C_solve(mcl_context *ctx);           /* decomposition.py:328-331 */
 int mcl_C_end(mcl_context *ctx);             /* invalidates everything derived from C */
 
+/* ---- ordering against other streams (a host that runs its collectives on a communication stream of its own) ------------ */
+/* The library enqueues everything on the stream of mcl_create().  A host whose collective library wants its own stream
+ * chains it with two events per collective:  mcl_update_C_local -> mcl_record_event(ctx, e1) -> [comm stream: wait e1,
+ * all-reduce mcl_c_normal_equations() in place, record e2] -> mcl_wait_event(ctx, e2) -> mcl_update_C_finish.
+ * (A host that can enqueue its collective on the engine's stream itself - RCCL takes any stream - needs neither: that
+ * is what matcouply_amd/_rccl.py does, and it saves the ~8 us of the hand-over.)  `hip_event`: a hipEvent_t. */
+int mcl_record_event(mcl_context *ctx, void *hip_event);
+int mcl_wait_event(mcl_context *ctx, void *hip_event);
+
 /* ---- the step after the solver: dense reconstruction (replaces cmf_to_matrices, coupled_matrices.py:365-497) ---------- */
 /* M_i = (B_i diag(weights o a_i)) C^T for all matrices, packed along rows like X.  Stateless (no context): A [I, r],
  * B packed [N, r], C [K, r], weights [r] or NULL, slab_of_row int32 [N] (matrix index of every packed row), out [N, K] -

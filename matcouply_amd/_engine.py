@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_B_end", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
     "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
     "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_set_stride", "mcl_profile_read",
-    "mcl_reload_switches", "mcl_active_switches", "mcl_cmf_to_packed",
+    "mcl_reload_switches", "mcl_active_switches", "mcl_record_event", "mcl_wait_event", "mcl_cmf_to_packed",
 ]
 
 
@@ -118,6 +118,8 @@ def load_library():
         "mcl_profile_read": (ctypes.c_int, [P, I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I32)]),
         "mcl_reload_switches": (ctypes.c_int, [P]),
         "mcl_active_switches": (ctypes.c_char_p, [P]),
+        "mcl_record_event": (ctypes.c_int, [P, P]),
+        "mcl_wait_event": (ctypes.c_int, [P, P]),
         "mcl_cmf_to_packed": (ctypes.c_int, [P, P, P, P, P, I64, I64, I32, P, P]),
     }
     for name, (res, args) in sig.items():
@@ -380,6 +382,13 @@ class HipEngine:
 
     def C_end(self):
         self._check(self.lib.mcl_C_end(self._h))
+
+    def record_event(self, event):
+        """record a torch.cuda.Event on the engine's stream (for a host that reduces on a communication stream of its own)"""
+        self._check(self.lib.mcl_record_event(self._h, ctypes.c_void_p(event.cuda_event)))
+
+    def wait_event(self, event):
+        self._check(self.lib.mcl_wait_event(self._h, ctypes.c_void_p(event.cuda_event)))
 
     def rho(self, mode):
         """device fp32 feasibility penalties of the current phase: mode 0 -> [I], 1 -> [I], 2 -> [1]"""

@@ -158,7 +158,7 @@ void read_switches(mcl_switches &w) {
     w.no_fused_gram = flag("MCL_NO_FUSED_GRAM"), w.no_fused_c = flag("MCL_NO_FUSED_C");
     w.a_finish_cols = flag("MCL_A_FINISH_COLS"), w.xc_norow = flag("MCL_XC_NOROW");
     w.unimodal_v3 = flag("MCL_UNIMODAL_V3"), w.stats_reduce = flag("MCL_STATS_REDUCE");
-    w.no_rows64 = flag("MCL_NO_ROWS64");
+    w.no_rows64 = flag("MCL_NO_ROWS64"), w.no_uni_coop = flag("MCL_NO_UNI_COOP");
     w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_a_wide = flag("MCL_NO_A_WIDE"), w.no_bseg_groups = flag("MCL_NO_BSEG_GROUPS"), w.no_sweep_half = flag("MCL_NO_SWEEP_HALF"), w.no_x_nt = flag("MCL_NO_X_NT"), w.x_nt_mb = num("MCL_X_NT_MB", 0), w.no_multi_c = flag("MCL_NO_MULTI_C"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1");
     w.seg_rows = num("MCL_SEG_ROWS", 0), w.bseg_rows = num("MCL_BSEG_ROWS", 0);
     w.xc_waves = num("MCL_XC_WAVES", 0), w.xt_waves = num("MCL_XT_WAVES", 0), w.sweep_waves = num("MCL_SWEEP_WAVES", 0);
@@ -171,7 +171,7 @@ std::string switches_in_env() {
     static const char *names[] = {
         "MCL_NO_SWEEP", "MCL_NO_PASS_CHAIN", "MCL_NO_PF2_DELTA_FUSION", "MCL_NS_PLAIN", "MCL_PF2_JACOBI", "MCL_NO_STACK_FUSION",
         "MCL_NO_SOLVE_STATS", "MCL_NO_NEXT_B", "MCL_NO_FUSED_GRAM", "MCL_NO_FUSED_C", "MCL_A_FINISH_COLS", "MCL_XC_NOROW",
-        "MCL_UNIMODAL_V3", "MCL_STATS_REDUCE", "MCL_NO_ROWS64", "MCL_NO_A_FUSION", "MCL_NO_A_WIDE", "MCL_NO_BSEG_GROUPS",
+        "MCL_UNIMODAL_V3", "MCL_STATS_REDUCE", "MCL_NO_ROWS64", "MCL_NO_UNI_COOP", "MCL_NO_A_FUSION", "MCL_NO_A_WIDE", "MCL_NO_BSEG_GROUPS",
         "MCL_NO_SWEEP_HALF", "MCL_NO_X_NT", "MCL_X_NT_MB", "MCL_NO_MULTI_C", "MCL_NO_DIAG_DEFER", "MCL_XC_DEPTH1", "MCL_SEG_ROWS",
         "MCL_BSEG_ROWS", "MCL_XC_WAVES", "MCL_XT_WAVES", "MCL_SWEEP_WAVES", "MCL_XC_DBG", "MCL_XT_DBG", "MCL_XT_DEPTH",
         "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT"};
@@ -1137,6 +1137,19 @@ int mcl_run(mcl_context *c, int32_t n_iter_max, int32_t update_A, int32_t update
     if (e != hipSuccess && rc == 0) rc = fail(c, std::string("mcl_run: hipStreamSynchronize: ") + hipGetErrorString(e));
     if (status->stopped && enqueued > status->stop_iteration + 1) forget_byproducts(c);
     return rc;
+}
+
+int mcl_record_event(mcl_context *c, void *hip_event) {
+    if (!c || !hip_event) return 1;
+    if (int rc = ready(c)) return rc;  // pending deferred work belongs in front of the event
+    MCL_CHECK_HIP(c, hipEventRecord(reinterpret_cast<hipEvent_t>(hip_event), c->stream));
+    return 0;
+}
+
+int mcl_wait_event(mcl_context *c, void *hip_event) {
+    if (!c || !hip_event) return 1;
+    MCL_CHECK_HIP(c, hipStreamWaitEvent(c->stream, reinterpret_cast<hipEvent_t>(hip_event), 0));
+    return 0;
 }
 
 float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {

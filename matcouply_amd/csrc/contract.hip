@@ -46,15 +46,21 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
                                                      double *__restrict__ part, int part_stride, int dbg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rsub = lane >> 4, c16 = lane & 15;
-    const int kbase = blockIdx.y * (64 * KB);
-    const int w = blockIdx.x * 4 + wave;
+    // The K-slice is the FASTEST grid index (round 3): the slices of one row range are dispatched back to back - onto
+    // the 8 XCDs - so the rows of B (and the a_i) they all need are fetched from HBM once and served to the other slices
+    // from the memory-side cache, and the 4 KB rows of X at K = 1024 are read as a whole at nearly the same time.  Before,
+    // with the row range fastest, every slice was a pass of its own over all the rows: config 5 fetched B eight times
+    // (86.2 GB for 68.7 GB of X, profiles/r2_c5_pmc_traffic.json).
+    const int bslice = blockIdx.x, brow = blockIdx.y;
+    const int kbase = bslice * (64 * KB);
+    const int w = brow * 4 + wave;
     // the wave's segments: a contiguous range with (nearly) the same number of 16-row blocks in every wave
     // (mcl_set_problem balances ragged slabs); waves past the end have an empty range
     const int s0 = wave_seg_ptr[min(w, n_waves)];
     const int s1 = wave_seg_ptr[min(w + 1, n_waves)];
     constexpr bool DO_R = MODE != 2;
     constexpr int NG_ = (MODE == 1) ? 1 : NB;  // extent of the G accumulator arrays
-    const bool doG = (MODE == 2) || (MODE == 0 && blockIdx.y == 0);
+    const bool doG = (MODE == 2) || (MODE == 0 && bslice == 0);
 
     int kcol[KB];
 #pragma unroll
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
         }
         __syncthreads();
     }
-    double *out = part + (long)blockIdx.x * part_stride;
+    double *out = part + (long)brow * part_stride;
     for (int e = threadIdx.x; e < LR; e += 256) {
         const int kl = e / W, n = e - kl * W;
         const int k = kbase + kl;
@@ -926,7 +932,7 @@ static int launch_xt(mcl_context *c) {
         c->n_part = 1;
         return 0;
     }
-    dim3 grid(nb, (unsigned)((c->K + 64 * KB - 1) / (64 * KB)));
+    dim3 grid((unsigned)((c->K + 64 * KB - 1) / (64 * KB)), nb);  // (K-slices, row ranges): see the kernel
     const bool vec = (c->K % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->X) & 15) == 0);
     ProfScope prof(c, 1);
     int dbg = 0, depth = 4;
@@ -948,7 +954,7 @@ static int launch_xt(mcl_context *c) {
     } else {
         MCL_XT(1, 2, RMODE, grid);
     }
-    if constexpr (NB == 4) MCL_XT(1, 2, 2, dim3(nb, 1));  // G of the same row ranges into the same partial slabs
+    if constexpr (NB == 4) MCL_XT(1, 2, 2, dim3(1, nb));  // G of the same row ranges into the same partial slabs
 #undef MCL_XT
 #undef MCL_XT_
     c->n_part = nb;

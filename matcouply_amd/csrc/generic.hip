@@ -528,6 +528,7 @@ __global__ __launch_bounds__(64) void k_slab_tv(const int *__restrict__ ext, int
 struct UniScratch {
     double *lvL, *lvR, *eL, *eR, *sy, *sy2, *sw, *cum2;
     int *stL, *stR;
+    int coop;  // cooperative ring refill (ur4_refill_coop); 0: MCL_NO_UNI_COOP (A/B switch)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -748,10 +749,10 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v3(const int *__restrict__
 //   * ring entries are 20 bytes and the ring holds 8: 10 KB of LDS per wave, 16 waves per CU.
 // The records of the right-to-left sweep are stored at the position they belong to, so both emit loops index rows.
 // ---------------------------------------------------------------------------------------------------------
-#define RC4 8
+#define RC4 8  // ring entries of the throughput form (MODE 0); the latency form (MODE 1: one wave per SIMD) has LDS for 16
 struct UniRing4 {
-    double *sy, *q;  // LDS [RC4][64]
-    int *cw;         // LDS [RC4][64]
+    double *sy, *q;  // LDS [RC][64]
+    int *cw;         // LDS [RC][64]
     int h, cnt;      // ring index of its top entry, number of entries in the ring
     long mem_n;      // entries spilled to global memory
 };
@@ -773,18 +774,30 @@ static __device__ __forceinline__ UniRec ld_rec_nt(const UniRec *p) {
     return rc;
 }
 
-static __device__ __forceinline__ void ur4_push(UniRing4 &st, int lane, double sy, int cw, double q, double *__restrict__ gsy,
-                                                double *__restrict__ gq, int *__restrict__ gcw, long base, long rs, int col) {
-    if (st.cnt == RC4) {  // spill the bottom entry of the ring
-        const int b = ((st.h - RC4 + 1) & (RC4 - 1)) * 64 + lane;
+// The top NRF entries of the spill area, prefetched into registers (see ur4_refill_coop): n of them are valid copies of the
+// spill indices [mem_n - n, mem_n).
+template <int NRF>
+struct UniPrefetch {
+    double sy[NRF], q[NRF];
+    int cw[NRF];
+    int n;
+};
+
+template <int RC, int NRF>
+static __device__ __forceinline__ void ur4_push(UniRing4 &st, UniPrefetch<NRF> &pf, int lane, double sy, int cw, double q,
+                                                double *__restrict__ gsy, double *__restrict__ gq, int *__restrict__ gcw,
+                                                long base, long rs, int col) {
+    if (st.cnt == RC) {  // spill the bottom entry of the ring
+        const int b = ((st.h - RC + 1) & (RC - 1)) * 64 + lane;
         const long idx = (base + st.mem_n) * rs + col;
         gsy[idx] = st.sy[b];
         gq[idx] = st.q[b];
         gcw[idx] = st.cw[b];
         st.mem_n += 1;
-        st.cnt = RC4 - 1;
+        st.cnt = RC - 1;
+        pf.n = 0;  // the prefetched entries are no longer the top of the spill area
     }
-    st.h = (st.h + 1) & (RC4 - 1);
+    st.h = (st.h + 1) & (RC - 1);
     const int t = st.h * 64 + lane;
     st.sy[t] = sy;
     st.q[t] = q;
@@ -792,29 +805,106 @@ static __device__ __forceinline__ void ur4_push(UniRing4 &st, int lane, double s
     st.cnt += 1;
 }
 
-static __device__ __forceinline__ bool ur4_pop(UniRing4 &st, int lane, double &sy, int &cw, double &q, const double *__restrict__ gsy,
-                                               const double *__restrict__ gq, const int *__restrict__ gcw, long base, long rs,
-                                               int col) {
+// prefetched entries -> ring, below its bottom entry (needs room for pf.n entries)
+template <int RC, int NRF>
+static __device__ __forceinline__ void ur4_take_prefetched(UniRing4 &st, UniPrefetch<NRF> &pf, int lane) {
+#pragma unroll
+    for (int i = 0; i < NRF; ++i) {
+        if (i < pf.n) {
+            const int t = ((st.h - st.cnt - i) & (RC - 1)) * 64 + lane;
+            st.sy[t] = pf.sy[i], st.q[t] = pf.q[i], st.cw[t] = pf.cw[i];
+        }
+    }
+    st.mem_n -= pf.n;
+    st.cnt += pf.n;
+    pf.n = 0;
+}
+
+// request the next entries of the spill area (top first); nothing waits for them here
+template <int NRF>
+static __device__ __forceinline__ void ur4_prefetch(const UniRing4 &st, UniPrefetch<NRF> &pf, const double *__restrict__ gsy,
+                                                    const double *__restrict__ gq, const int *__restrict__ gcw, long base,
+                                                    long rs, int col) {
+#pragma unroll
+    for (int i = 0; i < NRF; ++i) {  // unconditional clamped loads
+        const long idx = (base + (st.mem_n > i ? st.mem_n - 1 - i : 0)) * rs + col;
+        pf.sy[i] = gsy[idx], pf.q[i] = gq[idx], pf.cw[i] = gcw[idx];
+    }
+    pf.n = st.mem_n < (long)NRF ? (int)st.mem_n : NRF;
+}
+
+template <int RC, int NRF>
+static __device__ __forceinline__ bool ur4_pop(UniRing4 &st, UniPrefetch<NRF> &pf, int lane, double &sy, int &cw, double &q,
+                                               const double *__restrict__ gsy, const double *__restrict__ gq,
+                                               const int *__restrict__ gcw, long base, long rs, int col) {
     if (st.cnt == 0) {
         if (st.mem_n == 0) return false;
-        const int nref = st.mem_n >= RC4 / 2 ? RC4 / 2 : (int)st.mem_n;  // refill (independent loads, one latency)
-        for (int i = 0; i < nref; ++i) {
-            const long idx = (base + st.mem_n - 1 - i) * rs + col;
-            const int t = ((st.h - i) & (RC4 - 1)) * 64 + lane;
-            st.sy[t] = gsy[idx];
-            st.q[t] = gq[idx];
-            st.cw[t] = gcw[idx];
+        if (pf.n > 0) {
+            ur4_take_prefetched<RC, NRF>(st, pf, lane);
+        } else {
+            const int nref = st.mem_n >= RC / 2 ? RC / 2 : (int)st.mem_n;  // refill (independent loads, one latency)
+            for (int i = 0; i < nref; ++i) {
+                const long idx = (base + st.mem_n - 1 - i) * rs + col;
+                const int t = ((st.h - i) & (RC - 1)) * 64 + lane;
+                st.sy[t] = gsy[idx];
+                st.q[t] = gq[idx];
+                st.cw[t] = gcw[idx];
+            }
+            st.mem_n -= nref;
+            st.cnt = nref;
         }
-        st.mem_n -= nref;
-        st.cnt = nref;
     }
     const int tp = st.h * 64 + lane;
     sy = st.sy[tp];
     q = st.q[tp];
     cw = st.cw[tp];
-    st.h = (st.h - 1) & (RC4 - 1);
+    st.h = (st.h - 1) & (RC - 1);
     st.cnt -= 1;
     return true;
+}
+
+// Cooperative, prefetched refill (round 3).  On smooth, nearly unimodal columns - what the iterates of a converging run
+// look like - the stack is as deep as the rising flank is long (one block per element; config 5 at outer iteration 25:
+// median depth 157, maximum 870, tools/uni_depth.py), the ring spills hundreds of entries, and the falling flank pops
+// them back one per step: every lane then ran dry every RC / 2 steps at its own phase, so nearly EVERY step of the wave
+// waited a memory round trip for one lane or another (the regressions of config 5 took 8-11 ms per call on the noise-like
+// iterates of the first outer iterations and 21-26 ms from iteration ~20 on, same kernel; 1.7 -> 4.5 ms on the 1/8 shard).
+// Now, once per element step: if ANY lane is about to run dry, every lane with spilled entries and room tops its ring
+// up - from the NRF entries it PREFETCHED into registers at its previous refill (no wait: they were requested several
+// steps ago), or with a blocking load when a spill has invalidated them - and requests the next NRF.  The lanes fall
+// into step, and on a falling flank no refill waits for memory at all.
+template <int RC, int NRF>
+static __device__ __forceinline__ void ur4_refill_coop(UniRing4 &st, UniPrefetch<NRF> &pf, int lane,
+                                                       const double *__restrict__ gsy, const double *__restrict__ gq,
+                                                       const int *__restrict__ gcw, long base, long rs, int col) {
+    if (__builtin_amdgcn_ballot_w64(st.cnt <= 1 && st.mem_n > 0) == 0) return;  // wave-uniform
+    const int room = RC - 2 - st.cnt;
+    if (pf.n > 0) {
+        if (room >= pf.n) {
+            ur4_take_prefetched<RC, NRF>(st, pf, lane);
+            ur4_prefetch<NRF>(st, pf, gsy, gq, gcw, base, rs, col);
+        }
+    } else if (st.mem_n > 0 && room > 0) {
+        const int want = room < NRF ? room : NRF;
+        const int nref = st.mem_n < (long)want ? (int)st.mem_n : want;
+        double vsy[NRF], vq[NRF];
+        int vcw[NRF];
+#pragma unroll
+        for (int i = 0; i < NRF; ++i) {  // independent clamped loads: one latency
+            const long idx = (base + (st.mem_n > i ? st.mem_n - 1 - i : 0)) * rs + col;
+            vsy[i] = gsy[idx], vq[i] = gq[idx], vcw[i] = gcw[idx];
+        }
+#pragma unroll
+        for (int i = 0; i < NRF; ++i) {
+            if (i < nref) {
+                const int t = ((st.h - st.cnt - i) & (RC - 1)) * 64 + lane;  // below the ring's bottom entry
+                st.sy[t] = vsy[i], st.q[t] = vq[i], st.cw[t] = vcw[i];
+            }
+        }
+        st.mem_n -= nref;
+        st.cnt += nref;
+        ur4_prefetch<NRF>(st, pf, gsy, gq, gcw, base, rs, col);
+    }
 }
 
 // 1 / w for a positive integer-valued w: hardware estimate + two Newton steps (<= 1 ulp)
@@ -842,8 +932,11 @@ template <int MODE>
 __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const int *__restrict__ ext, int n_slabs, float *__restrict__ F,
                                                          RegSet regs, int k, int r, UniScratch sc) {
     MCL_GATE(regs.gate);
-    __shared__ double ring_d[2][MODE == 2 ? 1 : RC4 * 64];
-    __shared__ int ring_i[MODE == 2 ? 1 : RC4 * 64];
+    // ring entries per lane: 8 in the throughput form (10 KB per wave, 16 waves per CU); the latency form runs at most two
+    // waves per SIMD and takes 16 (20 KB per wave) with refills of 8 - half as many spills and refills on deep stacks
+    constexpr int RC = 16, NRF = 8;
+    __shared__ double ring_d[2][MODE == 2 ? 1 : RC * 64];
+    __shared__ int ring_i[MODE == 2 ? 1 : RC * 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;  // MODE 2: four waves work on the same 64 columns
     const bool do_L = MODE == 0 || (MODE == 1 && (blockIdx.x & 1) == 0);
     const bool do_R = MODE == 0 || (MODE == 1 && (blockIdx.x & 1) == 1);
@@ -864,22 +957,25 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
     const long eb = (long)s + slab;  // n + 1 error entries per slab
 
     UniRing4 st;
+    UniPrefetch<NRF> pf;
     st.sy = ring_d[0], st.q = ring_d[1], st.cw = ring_i;
+    static_assert((RC & (RC - 1)) == 0, "ring indices wrap by masking");
     double csy, ccw, curQ, cum2;  // block being built (count kept as a double), Q including it, sum of y^2
     double tsy, tcw, tQ;          // cached top of the stack below it
     bool has_top;
     float levf;
     auto reset = [&]() {
-        st.h = 0, st.cnt = 0, st.mem_n = 0;
+        st.h = 0, st.cnt = 0, st.mem_n = 0, pf.n = 0;
         cum2 = 0.0, csy = 0.0, ccw = 1.0, curQ = 0.0;
         tsy = 0.0, tcw = 1.0, tQ = 0.0;
         has_top = false, levf = 0.f;
     };
     // one element: returns the prefix error; leaves (levf, ccw) = record of the block ending at this element
     auto step = [&](double v, bool first) -> double {
+        if (sc.coop) ur4_refill_coop<RC, NRF>(st, pf, lane, gsy, gq, gcw, s, rs, col);
         cum2 += v * v;
         if (!first) {  // the finished block becomes the cached top; the previous top moves into the ring
-            if (has_top) ur4_push(st, lane, tsy, (int)tcw, tQ, gsy, gq, gcw, s, rs, col);
+            if (has_top) ur4_push<RC, NRF>(st, pf, lane, tsy, (int)tcw, tQ, gsy, gq, gcw, s, rs, col);
             tsy = csy, tcw = ccw, tQ = curQ;
             has_top = true;
         }
@@ -889,7 +985,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
             csy += tsy;
             ccw += tcw;
             int icw;
-            has_top = ur4_pop(st, lane, tsy, icw, tQ, gsy, gq, gcw, s, rs, col);
+            has_top = ur4_pop<RC, NRF>(st, pf, lane, tsy, icw, tQ, gsy, gq, gcw, s, rs, col);
             tcw = (double)icw;
         }
         // a block with a negative mean is clamped to level 0 and contributes q = 0; every block below it has a smaller
@@ -2154,6 +2250,7 @@ static UniScratch uni_scratch(mcl_context *c) {
     s.lvL = d, s.lvR = d + n1, s.eL = d + 2 * n1, s.eR = d + 3 * n1;
     s.sy = d + 4 * n1, s.sy2 = d + 5 * n1, s.sw = d + 6 * n1, s.cum2 = d + 7 * n1;
     s.stL = c->uni_i32, s.stR = c->uni_i32 + maxrows * c->r;
+    s.coop = c->sw.no_uni_coop ? 0 : 1;
     return s;
 }
 

@@ -174,3 +174,36 @@ def test_library_reports_the_header_abi_version():
     from matcouply_amd import _engine
 
     assert _engine.load_library().mcl_version() == _engine.MCL_ABI_VERSION == 300
+
+
+def test_events_order_a_side_stream_collective():
+    """mcl_record_event / mcl_wait_event: the C-phase reduction handed to ANOTHER stream (where a host's collective library
+    runs) and back - the finish must see what the side stream wrote into [G | R]."""
+    import torch
+
+    orc, regs, X, row_ptr = _sweep_problem()
+    results = []
+    for side in (False, True):
+        st = orc.random_state_for(X, row_ptr, 8, regs, seed=6)
+        eng = engine_from_oracle_state(st)
+        comm = torch.cuda.Stream()
+        for _ in range(3):
+            eng.update_B()
+            gr = eng.update_C_local()
+            if side:  # the "collective": a scaling by 1 + 2^-20 on the communication stream, in place
+                e1, e2 = torch.cuda.Event(), torch.cuda.Event()
+                e1.record()  # lazily creates the event; the engine then records it on ITS stream
+                eng.record_event(e1)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(e1)
+                    torch.cuda._sleep(2000000)  # the side stream is slow: the finish has to wait for it
+                    gr.mul_(1.0 + 2.0 ** -20)
+                    e2.record(comm)
+                eng.wait_event(e2)
+            else:
+                gr.mul_(1.0 + 2.0 ** -20)
+            eng.update_C_finish(); eng.update_A()
+        torch.cuda.synchronize()
+        results.append(to_np(eng.C))
+        eng.close()
+    assert np.array_equal(results[0], results[1])

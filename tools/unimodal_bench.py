@@ -71,12 +71,13 @@ def main():
         return e0.elapsed_time(e1)
 
     ts = [run() for _ in range(args.reps)]
-    tag = ",".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("MCL_UNI")) or "default"
+    tag = ",".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("MCL_UNI") or k == "MCL_NO_UNI_COOP") or "default"
     print(f"unimodal prox + dual [{tag}] I={args.I} J={args.J} r={args.r} data={args.data}: "
           + " ".join(f"{t:.2f}" for t in ts) + " ms", flush=True)
     if args.check:
         ref = aux.clone()
-        saved = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith("MCL_UNI")}
+        saved = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith("MCL_UNI") or k == "MCL_NO_UNI_COOP"}
+        eng.reload_switches()
         run()
         ndiff = int((ref != aux).sum())
         md = float((ref - aux).abs().max())
