@@ -43,15 +43,19 @@ __global__ __launch_bounds__(256) void k_contract_xt(const float *__restrict__ X
                                                      const float *__restrict__ A, const int *__restrict__ seg_slab,
                                                      const int *__restrict__ seg_row0, const int *__restrict__ seg_rows,
                                                      const int *__restrict__ wave_seg_ptr, int n_waves, int K, int r,
-                                                     double *__restrict__ part, int part_stride, int dbg) {
+                                                     double *__restrict__ part, int part_stride, int dbg, int n_slices,
+                                                     int n_rowblocks) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rsub = lane >> 4, c16 = lane & 15;
-    // The K-slice is the FASTEST grid index (round 3): the slices of one row range are dispatched back to back - onto
-    // the 8 XCDs - so the rows of B (and the a_i) they all need are fetched from HBM once and served to the other slices
-    // from the memory-side cache, and the 4 KB rows of X at K = 1024 are read as a whole at nearly the same time.  Before,
-    // with the row range fastest, every slice was a pass of its own over all the rows: config 5 fetched B eight times
-    // (86.2 GB for 68.7 GB of X, profiles/r2_c5_pmc_traffic.json).
-    const int bslice = blockIdx.x, brow = blockIdx.y;
+    // XCD-aware mapping (round 3).  The K-slices of one row range all need the same rows of B (and a_i); with the row
+    // range as the fastest grid index (round 2) every slice was a pass of its own over all the rows and config 5 fetched
+    // B eight times (86.2 GB for 68.7 GB of X, profiles/r2_c5_pmc_traffic.json).  Workgroup ids go round-robin over the
+    // 8 XCDs, each with its own L2: id = 8 m + x runs on XCD x.  Here x = row range mod 8 and the slices are
+    // consecutive m, so the `n_slices` workgroups of a row range sit on ONE XCD, are dispatched back to back and share
+    // their rows of B through that XCD's L2; the 4 KB rows of X at K = 1024 are read as a whole at about the same time.
+    const int xcd = blockIdx.x & 7, m = blockIdx.x >> 3;
+    const int bslice = m % n_slices, brow = (m / n_slices) * 8 + xcd;
+    if (brow >= n_rowblocks) return;
     const int kbase = bslice * (64 * KB);
     const int w = brow * 4 + wave;
     // the wave's segments: a contiguous range with (nearly) the same number of 16-row blocks in every wave
@@ -932,7 +936,8 @@ static int launch_xt(mcl_context *c) {
         c->n_part = 1;
         return 0;
     }
-    dim3 grid((unsigned)((c->K + 64 * KB - 1) / (64 * KB)), nb);  // (K-slices, row ranges): see the kernel
+    const int n_slices = (int)((c->K + 64 * KB - 1) / (64 * KB));
+    dim3 grid((unsigned)(((nb + 7) / 8) * 8 * n_slices));  // 1-D: (row range mod 8 = XCD, slice, row range div 8), see the kernel
     const bool vec = (c->K % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->X) & 15) == 0);
     ProfScope prof(c, 1);
     int dbg = 0, depth = 4;
@@ -942,7 +947,7 @@ static int launch_xt(mcl_context *c) {
 #define MCL_XT_(VEC_, DEPTH_, MODE_, GRID_, NT_)                                                                      \
     hipLaunchKernelGGL((k_contract_xt<KB, NB, VEC_, DEPTH_, MODE_, NT_>), GRID_, dim3(256), 0, c->stream, c->X, c->B, c->A, \
                        c->segs.slab, c->segs.row0, c->segs.nrows, c->wave_seg_ptr, c->n_seg_waves, (int)c->K, c->r, c->partials, \
-                       E, dbg)
+                       E, dbg, ((GRID_).x / (((nb + 7) / 8) * 8)), nb)
 #define MCL_XT(VEC_, DEPTH_, MODE_, GRID_)                                                                            \
     do {                                                                                                              \
         if (c->x_streams && (VEC_) == 4 && (MODE_) != 2) MCL_XT_(VEC_, DEPTH_, MODE_, GRID_, true);                   \
@@ -954,7 +959,7 @@ static int launch_xt(mcl_context *c) {
     } else {
         MCL_XT(1, 2, RMODE, grid);
     }
-    if constexpr (NB == 4) MCL_XT(1, 2, 2, dim3(1, nb));  // G of the same row ranges into the same partial slabs
+    if constexpr (NB == 4) MCL_XT(1, 2, 2, dim3((unsigned)(((nb + 7) / 8) * 8)));  // G of the same row ranges into the same partial slabs
 #undef MCL_XT
 #undef MCL_XT_
     c->n_part = nb;

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void k_rows_solve_stats(ModeView mv, const flo
                                                           const double *__restrict__ Linv64 = nullptr) {
     typedef double f64x4s __attribute__((ext_vector_type(4)));
     typedef RowArith<R64> RA;
+    __shared__ double ytile[R64 ? 4 * 16 * 17 : 1];  // R64: one padded 16 x 16 fp64 tile per wave (row -> column layout of Y)
     TILE_PROLOGUE();
     const float rho = mv.rho[slab];
     typename RA::template Mat<NBR> L, D;
@@ -235,15 +236,15 @@ __global__ __launch_bounds__(256) void k_rows_solve_stats(ModeView mv, const flo
                     double yt[NBR][4];
 #pragma unroll
                     for (int nb = 0; nb < NBR; ++nb) {
-                        if constexpr (R64) {  // exact fp64 sum, transposed by the fp64 MFMA: lane (q, i16) reg w = Y[q + 4w][16nb + i16]
-                            f64x4s tr = {0.0, 0.0, 0.0, 0.0};
+                        if constexpr (R64) {  // exact fp64 sum, transposed through the wave's LDS tile (the fp64 matrix pipe
+                            // is the scarce unit of these passes: 44 TFLOP/s at best, tools/mfma64_rate.hip):
+                            // lane (q, i16) reg w = Y[q + 4w][16nb + i16]
+                            double *yl = ytile + (threadIdx.x >> 6) * (16 * 17);
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) {
-                                const double y = ok ? (double)f[nb][v] + (double)ukeep[k][nb][v] : 0.0;
-                                tr = __builtin_amdgcn_mfma_f64_16x16x4f64(y, bsel[v], tr, 0, 0, 0);
-                            }
+                            for (int v = 0; v < 4; ++v)
+                                yl[row16 * 17 + 4 * g + v] = ok ? (double)f[nb][v] + (double)ukeep[k][nb][v] : 0.0;
 #pragma unroll
-                            for (int w = 0; w < 4; ++w) yt[nb][w] = tr[w];
+                            for (int w = 0; w < 4; ++w) yt[nb][w] = yl[(g + 4 * w) * 17 + row16];
                         } else {
                             f32x4 tr = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -2009,6 +2010,7 @@ __global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, co
                                                                  const double *__restrict__ T64 = nullptr) {
     typedef double f64x4s __attribute__((ext_vector_type(4)));
     typedef RowArith<R64> RA;  // R64: the r x r products on the fp64 MFMA, exact Y = F + U (see k_rows_solve_stats)
+    __shared__ double ytile[R64 ? 4 * 16 * 17 : 1];  // R64: one padded 16 x 16 fp64 tile per wave (row -> column layout of Y)
     TILE_PROLOGUE();
     const float rho = mv.rho[slab];
     int kpf2 = -1;
@@ -2137,15 +2139,12 @@ __global__ __launch_bounds__(256) void k_rows_finish_solve_stats(ModeView mv, co
             double yt[NBR][4];
 #pragma unroll
             for (int nb = 0; nb < NBR; ++nb) {
-                if constexpr (R64) {  // exact fp64 sum, transposed by the fp64 MFMA: lane (q, i16) reg w = Y[q + 4w][16nb + i16]
-                    f64x4s tr = {0.0, 0.0, 0.0, 0.0};
+                if constexpr (R64) {  // exact fp64 sum, transposed through the wave's LDS tile: lane (q, i16) reg w = Y[q + 4w][16nb + i16]
+                    double *yl = ytile + (threadIdx.x >> 6) * (16 * 17);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const double y = ok ? (double)fn[nb][v] + (double)upf[nb][v] : 0.0;
-                        tr = __builtin_amdgcn_mfma_f64_16x16x4f64(y, bsel[v], tr, 0, 0, 0);
-                    }
+                    for (int v = 0; v < 4; ++v) yl[row16 * 17 + 4 * g + v] = ok ? (double)fn[nb][v] + (double)upf[nb][v] : 0.0;
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) yt[nb][w] = tr[w];
+                    for (int w = 0; w < 4; ++w) yt[nb][w] = yl[(g + 4 * w) * 17 + row16];
                 } else {
                     f32x4 tr = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
