@@ -53,22 +53,48 @@ def _load():
 class DirectComm:
     """RCCL communicator over the ranks of a torch.distributed process group; collectives on torch's CURRENT stream."""
 
+    INIT_TIMEOUT_S = 90.0  # ncclCommInitRank is a collective bootstrap: bounded, so that a start-up problem costs time, not the run
+
     def __init__(self, group):
+        import threading
+
         import torch
         import torch.distributed as dist
 
         self._torch, self.lib = torch, _load()
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.calls = 0
+        self._comm = ctypes.c_void_p()
         uid = _UniqueId()
         if self.rank == 0:
             self._check(self.lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev_index = torch.cuda.current_device()
+        dev = torch.device("cuda", dev_index)
         t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(dev)
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
-        self._comm = ctypes.c_void_p()
-        self._check(self.lib.ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
-        self.calls = 0
+        # the bootstrap runs in a worker thread so that it can be abandoned: a rank that does not get its communicator in
+        # time reports failure, try_create() then makes every rank fall back to torch.distributed together
+        result = {}
+
+        def init():
+            try:
+                torch.cuda.set_device(dev_index)
+                comm = ctypes.c_void_p()
+                result["rc"] = self.lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank)
+                result["comm"] = comm
+            except Exception as e:  # pragma: no cover
+                result["error"] = e
+
+        th = threading.Thread(target=init, daemon=True)
+        th.start()
+        th.join(self.INIT_TIMEOUT_S)
+        if th.is_alive():
+            raise TimeoutError(f"ncclCommInitRank did not return within {self.INIT_TIMEOUT_S:.0f} s")
+        if "error" in result:
+            raise result["error"]
+        self._check(result["rc"], "ncclCommInitRank")
+        self._comm = result["comm"]
 
     def _check(self, rc, what):
         if rc != 0:
@@ -109,10 +135,31 @@ class DirectComm:
                 return None
         except Exception:
             return None
-        comm, ok = None, 1.0
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def agreed(ok):
+            """every rank takes the same decision: MIN over the ranks of the local verdict (a torch.distributed collective
+            that EVERY rank reaches, whatever happened to it before)"""
+            try:
+                flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                return float(flag.item()) >= 1.0
+            except Exception:
+                return False
+
+        # 1) the communicator (bounded bootstrap); no other collective until every rank has reported
+        comm = None
         try:
             comm = cls(group)
-            dev = torch.device("cuda", torch.cuda.current_device())
+        except Exception:
+            comm = None
+        if not agreed(comm is not None):
+            if comm is not None:
+                comm._comm = ctypes.c_void_p()  # peers may never have joined: abandon it rather than destroy it collectively
+            return None
+        # 2) self-test against torch.distributed's result, again agreed by all
+        ok = True
+        try:
             g = torch.Generator(device=dev)
             g.manual_seed(1234 + comm.rank)
             a = torch.rand(4099, dtype=torch.float64, generator=g, device=dev)
@@ -124,19 +171,11 @@ class DirectComm:
             comm.all_reduce(b, "max")
             torch.cuda.synchronize()
             # same ring / tree, same order of the sums inside RCCL: equal to rounding at worst, usually to the bit
-            if not (torch.allclose(a, a_ref, rtol=1e-13, atol=0.0) and torch.equal(b, b_ref)):
-                ok = 0.0
+            ok = bool(torch.allclose(a, a_ref, rtol=1e-13, atol=0.0) and torch.equal(b, b_ref))
         except Exception:
-            ok = 0.0
-        try:  # every rank takes the same decision
-            flag = torch.tensor([ok], dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-            ok = float(flag.item())
-        except Exception:
-            ok = 0.0
-        if ok < 1.0:
-            if comm is not None:
-                comm.close()
+            ok = False
+        if not agreed(ok):
+            comm.close()
             return None
         comm.calls = 0
         return comm
