@@ -1421,6 +1421,28 @@ static __device__ __forceinline__ void mm_t(const SymTiles<NB> &A, const SymTile
         }
 }
 
+// At = A^T for a matrix in D layout, through a wave-private LDS area of (16 NB) x (16 NB + 1) doubles (the kernel runs ONE wave
+// per workgroup; LDS operations of a wave complete in order, so consecutive transposes need no barrier).  Round 3: the
+// Newton-Schulz iteration used to carry every iterate WITH its transpose and advance both by matrix products (6 per step);
+// the fp64 matrix pipe is what bounds the kernel (one v_mfma_f64_16x16x4_f64 per 143 cycles and wave, 44 TFLOP/s for the
+// whole part: tools/mfma64_rate.hip), so the transposes now cost 8 NB^2 LDS operations instead of 4 NB^3 MFMAs each.
+template <int NB>
+static __device__ __forceinline__ void tr_lds(const SymTiles<NB> &A, SymTiles<NB> &At, double *W, int q, int c16) {
+    constexpr int LD = 16 * NB + 1;
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) W[(16 * a + q + 4 * v) * LD + 16 * b + c16] = A.t[a][b][v];
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) At.t[a][b][v] = W[(16 * b + c16) * LD + 16 * a + q + 4 * v];
+}
+
 // TILES: the per-tile statistics of the solve pass (k_rows_solve_stats / k_rows_finish_solve_stats) are summed HERE, in
 // k_stats_reduce's order - S_i goes to LDS (and to S for the Jacobi fallback), the L2-ball column sums to colsq - which
 // saves the separate reduction launch in front of this kernel in every inner iteration.
@@ -1438,23 +1460,47 @@ struct TileStats {
 #define NS_STAMP(i) do { } while (0)
 #endif
 template <int NB, bool TILES>
-__global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, const float *__restrict__ Delta,
+__global__ __launch_bounds__((TILES && NB == 1) ? 128 : 64) void k_pf2_algebra_ns(double *__restrict__ S, const float *__restrict__ Delta,
                                                        const float *__restrict__ rho, const int *__restrict__ ext, int r,
                                                        float *__restrict__ T, double *__restrict__ acc_out,
                                                        int *__restrict__ status, TileStats ts, RegSet regs,
                                                        float *__restrict__ xmin_est, int scaled, double *__restrict__ T64) {
     MCL_GATE(regs.gate);
-    __shared__ double Ssm[TILES ? 256 * NB * NB : 1];
+    // S_i while the system is formed (TILES), then the scratch of the LDS transposes (the epilogue re-reads S_i from memory)
+    __shared__ double Ssm[(16 * NB) * (16 * NB + 1)];
     __shared__ float Dsm[256 * NB * NB];
     // rank <= 16: the Jacobi route of a slab this iteration cannot handle runs right here (8 KB of LDS; saves the launch of
     // the stand-alone kernel in every inner iteration); rank 32 would need 33 KB and lose a wave per CU, so those slabs are
     // left to k_pf2_algebra (status = 1)
     constexpr bool INK = NB == 1;
     __shared__ double Jsm[INK ? 4 * 256 + 16 : 1];
-    const int slab = blockIdx.x, lane = threadIdx.x;
+    const int slab = blockIdx.x, lane = threadIdx.x & 63;
     const int q = lane >> 4, c16 = lane & 15;
     const int n2 = r * r;
     const double *Ss = S + (long)slab * n2;
+    // The L2-ball column sums of the slab's tiles, in k_stats_reduce's order: two more memory round trips.  Rank <= 16 (one
+    // slab per SIMD at config 4: the chain's latency is the kernel's duration): a SECOND wave takes them and is done; rank 32
+    // (register-bound at two waves per SIMD: a second wave would halve the resident slabs) keeps them in front of the chain.
+    constexpr bool COLSQ_WAVE = TILES && NB == 1;
+    if (TILES && (COLSQ_WAVE ? threadIdx.x >= 64 : true)) {
+        const int t0 = ts.slab_tile_ptr[slab], t1 = ts.slab_tile_ptr[slab + 1];
+        for (int k = 0; k < regs.n; ++k) {
+            if (regs.kind[k] != MCL_PEN_L2BALL) continue;
+            for (int col = lane; col < r; col += 64) {
+                double sq = 0.0;
+                for (int tb = t0; tb < t1; tb += 8) {  // ascending order, 8 loads in flight
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = ts.stat_colsq[((long)min(tb + u, t1 - 1) * MCL_MAX_REGS + k) * r + col];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (tb + u < t1) sq += v[u];
+                }
+                ts.colsq[((long)k * ts.n_slabs + slab) * r + col] = sq;
+            }
+        }
+        if (COLSQ_WAVE) return;
+    }
 #ifdef MCL_NS_STAMPS
     long long *stamps = reinterpret_cast<long long *>(xmin_est + gridDim.x);  // the plan reserves 8 int64 per slab behind pf2_xmin
 #endif
@@ -1511,21 +1557,6 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
                 S[(long)slab * n2 + e] = s0[m] + s1[m];
             }
         }
-        for (int k = 0; k < regs.n; ++k) {
-            if (regs.kind[k] != MCL_PEN_L2BALL) continue;
-            for (int col = lane; col < r; col += 64) {
-                double sq = 0.0;
-                for (int tb = t0; tb < t1; tb += 8) {  // ascending order as in k_stats_reduce, 8 loads in flight
-                    double v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = ts.stat_colsq[((long)min(tb + u, t1 - 1) * MCL_MAX_REGS + k) * r + col];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (tb + u < t1) sq += v[u];
-                }
-                ts.colsq[((long)k * ts.n_slabs + slab) * r + col] = sq;
-            }
-        }
     }
     __syncthreads();
     NS_STAMP(1);
@@ -1564,17 +1595,15 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
     for (int a = 0; a < NB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acct = {0.0, 0.0, 0.0, 0.0};
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     const int k = 16 * kb + q + 4 * st;
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Dat(16 * a + c16, k), U1.t[kb][b][st], acc, 0, 0, 0);
-                    acct = __builtin_amdgcn_mfma_f64_16x16x4f64(U1.t[kb][a][st], Dat(16 * b + c16, k), acct, 0, 0, 0);
                 }
             G.t[a][b] = acc;
-            Gt.t[a][b] = acct;
             if (a == b) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
@@ -1582,9 +1611,10 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
             }
         }
     tr = wave_sum_d(tr);
+    tr_lds<NB>(G, Gt, Ssm, q, c16);  // G^T (S_i has been consumed by U1: its LDS copy is free; the fallbacks below read memory)
     if (!(tr > 0.0)) {
         if (lane == 0) status[slab] = 1;
-        if (INK) pf2_jacobi_slab(Jsm, Sany, Delta, rh, r, slab, lane, T, acc_out, T64);
+        if (INK) pf2_jacobi_slab(Jsm, Ss, Delta, rh, r, slab, lane, T, acc_out, T64);
         return;
     }
     NS_STAMP(2);
@@ -1641,8 +1671,8 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
             const float e = 1.f - flo;
             flo = 1.f - 1.5f * e * e, fhi = 1.f;  // plain Newton-Schulz: x -> x (3 - x^2) / 2 <= 1, error 1.5 e^2
         }
-        mm_t<NB>(Zt, Y, P);   // P  = Z Y
-        mm_t<NB>(Y, Zt, Pt);  // Pt = Y^T Z^T = P^T
+        mm_t<NB>(Zt, Y, P);             // P  = Z Y
+        tr_lds<NB>(P, Pt, Ssm, q, c16);  // Pt = P^T
         double res = 1.0;
         if (watch) {
             res = 0.0;
@@ -1683,10 +1713,10 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
             // (|1 - x^2| <= ||I - Z Y||_F for every eigenvalue x^2 of Z Y, so x >= 1 - ||I - Z Y||_F)
             if (scaled) flo = fminf(flo, res < 1.0 ? 1.f - __builtin_sqrtf((float)res) : 0.1f);
         }
-        mm_t<NB>(Yt, Tm, N1);   // Y  <- Y T
-        mm_t<NB>(Tm, Yt, N2);   // Yt <- T^T Y^T
-        mm_t<NB>(Tmt, Z, N3);   // Z  <- T Z
-        mm_t<NB>(Z, Tmt, N4);   // Zt <- Z^T T^T
+        mm_t<NB>(Yt, Tm, N1);            // Y  <- Y T
+        mm_t<NB>(Tmt, Z, N3);            // Z  <- T Z
+        tr_lds<NB>(N1, N2, Ssm, q, c16);  // Yt <- Y^T
+        tr_lds<NB>(N3, N4, Ssm, q, c16);  // Zt <- Z^T
         Y = N1;
         Yt = N2;
         Z = N3;
@@ -1694,7 +1724,7 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
     }
     if (!converged) {
         if (lane == 0) status[slab] = 1;
-        if (INK) pf2_jacobi_slab(Jsm, Sany, Delta, rh, r, slab, lane, T, acc_out, T64);
+        if (INK) pf2_jacobi_slab(Jsm, Ss, Delta, rh, r, slab, lane, T, acc_out, T64);  // (the LDS copy of S is gone: from memory)
         return;
     }
     NS_STAMP(3);
@@ -1713,6 +1743,9 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
         zn = wave_sum_d(zn);
         if (lane == 0) xmin_est[slab] = (float)(1.0 / sqrt(zn));
     }
+    // S_i for the epilogue: from memory (this wave wrote it above when it summed the tiles; its LDS copy has been the scratch of
+    // the transposes since)
+    auto Smem = [&](int i, int j) -> double { return (i < r && j < r) ? Ss[i * r + j] : 0.0; };
     const double wscale = 1.0 / sqrt(tr);  // W = Z / sqrt(tr)
     // T = Delta^T W  (A[i][k] = Delta[k][i];  B = W in D layout), then acc = rho T^T S (A = T^T: A[i][k] = T[k][i] = D layout of T)
     SymTiles<NB> Tt;
@@ -1745,7 +1778,7 @@ __global__ __launch_bounds__(64) void k_pf2_algebra_ns(double *__restrict__ S, c
             for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
                 for (int st = 0; st < 4; ++st)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Tt.t[kb][a][st], Sat(16 * kb + q + 4 * st, 16 * b + c16), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Tt.t[kb][a][st], Smem(16 * kb + q + 4 * st, 16 * b + c16), acc, 0, 0, 0);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int row = 16 * a + q + 4 * v, col = 16 * b + c16;
@@ -2346,7 +2379,7 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                 TileStats ts{c->slab_tile_ptr, c->stat_gram, c->stat_colsq, c->colsq, 16 * c->NB, (int)c->I};
                 const bool tiles = c->stats_in_solve && mcl_stats_reduce_in_algebra(c);
 #define MCL_NS(NB_, TILES_)                                                                                          \
-    hipLaunchKernelGGL((k_pf2_algebra_ns<NB_, TILES_>), dim3((unsigned)c->I), dim3(64), 0, c->stream, c->pf2_S,       \
+    hipLaunchKernelGGL((k_pf2_algebra_ns<NB_, TILES_>), dim3((unsigned)c->I), dim3(((TILES_) && (NB_) == 1) ? 128 : 64), 0, c->stream, c->pf2_S, \
                        rs.aux2[k], c->rhoB, mv.ext, r, c->pf2_T, c->pf2_acc, c->pf2_status, ts, rs, c->pf2_xmin,     \
                        c->sw.ns_plain ? 0 : 1, c->pf2_T64)
                 if (c->NB == 1) {
