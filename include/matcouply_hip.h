@@ -155,6 +155,17 @@ typedef struct {
 int mcl_run(mcl_context *ctx, int32_t n_iter_max, int32_t update_A, int32_t update_B, int32_t update_C,
             const mcl_stop_rule *rule, double *diag_ring, double *verdict_ring, mcl_run_status *status);
 
+/* The same rule for a host that drives the iterations itself - the sharded loop, whose diagnostics vector only exists after an
+ * all-reduce over the ranks:  mcl_gate_begin -> per iteration { phase / step calls with their reductions, mcl_diagnostics(ctx,
+ * vec, rank == 0) -> [SUM all-reduce of vec] -> mcl_verdict(ctx, vec, it, row) } -> (synchronise, read `status`) -> mcl_gate_end.
+ * Between begin and end every state-writing kernel tests the stop flag, so iterations enqueued behind a hit do nothing
+ * (their collectives still run: every rank must enqueue the SAME number of iterations before it looks at `status` - e.g.
+ * fixed chunks with a synchronisation in between; the ranks reach identical verdicts because they evaluate identical bits).
+ * mcl_gate_end(ctx, 1) after an early stop makes the context forget its cached by-products. */
+int mcl_gate_begin(mcl_context *ctx, const mcl_stop_rule *rule, mcl_run_status *status);
+int mcl_verdict(mcl_context *ctx, const double *diag_vec, int32_t iteration, double *verdict_row);
+int mcl_gate_end(mcl_context *ctx, int32_t stopped_early);
+
 /* ---- step calls (constant feasibility penalty / PARAFAC2 / EXTERNAL penalties on several devices) ---- */
 /* B-phase prologue: CtC, rhs_i, rho_i; returns pointer to this rank's max rho (device fp32[1]) for a MAX all-reduce */
 int mcl_B_begin(mcl_context *ctx);

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "mcl_set_factors", "mcl_set_penalties", "mcl_workspace_bytes", "mcl_set_workspace", "mcl_update_B",
     "mcl_update_C_local", "mcl_c_normal_equations", "mcl_update_C_finish", "mcl_update_A", "mcl_diagnostics",
     "mcl_diagnostics_deferred", "mcl_flush_diagnostics",
-    "mcl_iterate", "mcl_run", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
+    "mcl_iterate", "mcl_run", "mcl_gate_begin", "mcl_verdict", "mcl_gate_end", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_B_end", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
     "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
     "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_set_stride", "mcl_profile_read",
@@ -94,6 +94,9 @@ def load_library():
         "mcl_flush_diagnostics": (ctypes.c_int, [P]),
         "mcl_iterate": (ctypes.c_int, [P, I32, I32, I32, I32, P]),
         "mcl_run": (ctypes.c_int, [P, I32, I32, I32, I32, ctypes.POINTER(StopRule), P, P, P]),
+        "mcl_gate_begin": (ctypes.c_int, [P, ctypes.POINTER(StopRule), P]),
+        "mcl_verdict": (ctypes.c_int, [P, P, I32, P]),
+        "mcl_gate_end": (ctypes.c_int, [P, I32]),
         "mcl_B_begin": (ctypes.c_int, [P]),
         "mcl_B_rho_max": (P, [P]),
         "mcl_B_factor": (ctypes.c_int, [P]),
@@ -303,13 +306,7 @@ class HipEngine:
         ptr = diag_ring.data_ptr() if diag_ring is not None else None
         self._check(self.lib.mcl_iterate(self._h, int(n_iter), int(update_A), int(update_B), int(update_C), ptr))
 
-    def run(self, n_iter_max, tol, absolute_tol, feasibility_tol, initial_loss, penalty_weight, evaluate_loss_always,
-            update_A=True, update_B=True, update_C=True, max_run_ahead=0):
-        """Up to `n_iter_max` outer iterations with the reference's stopping rule evaluated ON THE DEVICE (mcl_run).
-        Tolerances: None / 0 = not set.  Returns (n_iter, code, diag [n_iter, DIAG_LEN], verdict [n_iter, 4]) with the
-        two rings as NumPy arrays; code 0 = iteration budget exhausted, STOP_RELATIVE / STOP_ABSOLUTE otherwise."""
-        torch = self._torch
-        n = int(n_iter_max)
+    def _stop_rule(self, tol, absolute_tol, feasibility_tol, initial_loss, penalty_weight, evaluate_loss_always, max_run_ahead=0):
         rule = StopRule()
         rule.tol, rule.absolute_tol = float(tol or 0.0), float(absolute_tol or 0.0)
         rule.feasibility_tol, rule.initial_loss = float(feasibility_tol or 0.0), float(initial_loss)
@@ -317,11 +314,41 @@ class HipEngine:
             for k in range(MCL_MAX_REGS):
                 rule.penalty_weight[m][k] = float(penalty_weight[m][k]) if k < len(penalty_weight[m]) else 0.0
         rule.evaluate_loss_always, rule.max_run_ahead = int(bool(evaluate_loss_always)), int(max_run_ahead)
+        return rule
+
+    def _pinned_status(self):
+        if getattr(self, "_status", None) is None:
+            self._status = self._torch.zeros(4, dtype=self._torch.int32).pin_memory()  # written by the verdict kernel
+        return self._status
+
+    # the pieces of run() for a host that drives the iterations itself (sharded loop: reductions between the calls)
+    def gate_begin(self, tol, absolute_tol, feasibility_tol, initial_loss, penalty_weight, evaluate_loss_always):
+        rule = self._stop_rule(tol, absolute_tol, feasibility_tol, initial_loss, penalty_weight, evaluate_loss_always)
+        self._check(self.lib.mcl_gate_begin(self._h, ctypes.byref(rule), self._pinned_status().data_ptr()))
+
+    def verdict(self, vec, iteration, row):
+        """the stopping test on the (all-reduced) diagnostics vector `vec` of iteration `iteration`; writes `row` (4 doubles)"""
+        self._check(self.lib.mcl_verdict(self._h, vec.data_ptr(), int(iteration), row.data_ptr()))
+
+    def gate_status(self):
+        """(stopped, stop_iteration, code) - meaningful once the stream has been synchronised"""
+        s = self._pinned_status()
+        return bool(int(s[0])), int(s[1]), int(s[2])
+
+    def gate_end(self, stopped_early):
+        self._check(self.lib.mcl_gate_end(self._h, int(bool(stopped_early))))
+
+    def run(self, n_iter_max, tol, absolute_tol, feasibility_tol, initial_loss, penalty_weight, evaluate_loss_always,
+            update_A=True, update_B=True, update_C=True, max_run_ahead=0):
+        """Up to `n_iter_max` outer iterations with the reference's stopping rule evaluated ON THE DEVICE (mcl_run).
+        Tolerances: None / 0 = not set.  Returns (n_iter, code, diag [n_iter, DIAG_LEN], verdict [n_iter, 4]) with the
+        two rings as NumPy arrays; code 0 = iteration budget exhausted, STOP_RELATIVE / STOP_ABSOLUTE otherwise."""
+        torch = self._torch
+        n = int(n_iter_max)
+        rule = self._stop_rule(tol, absolute_tol, feasibility_tol, initial_loss, penalty_weight, evaluate_loss_always, max_run_ahead)
         ring = torch.zeros((max(n, 1), DIAG_LEN), dtype=torch.float64, device=self.device)
         verdict = torch.zeros((max(n, 1), 4), dtype=torch.float64, device=self.device)
-        if getattr(self, "_status", None) is None:
-            self._status = torch.zeros(4, dtype=torch.int32).pin_memory()  # written by the verdict kernel
-        status = self._status
+        status = self._pinned_status()
         self._check(self.lib.mcl_run(self._h, n, int(update_A), int(update_B), int(update_C), ctypes.byref(rule),
                                      ring.data_ptr(), verdict.data_ptr(), status.data_ptr()))
         stopped, stop_it, code, _ = (int(v) for v in status)  # mcl_run has synchronised the stream

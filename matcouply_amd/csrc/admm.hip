@@ -1481,6 +1481,56 @@ struct StopRuleDev {
     int has_tol, has_feas, loss_always, it;
 };
 
+// one thread: the stopping test on a complete diagnostics vector (read with device-scope loads: other workgroups wrote it)
+static __device__ void verdict_eval(const double *out, const int *nreg, const StopRuleDev &R, int *gate, double *state,
+                                    double *verdict_row, int *status_host) {
+    auto ld = [&](int i) { return __hip_atomic_load(out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // feasibility gaps ||aux - factor|| / ||factor||, worst over all penalties of all modes (vacuously feasible without any)
+    double worst = -__builtin_inf();
+    for (int m = 0; m < 3; ++m) {
+        const double fn = sqrt(ld(MCL_DIAG_NORM_SQ + m));
+        for (int k = 0; k < nreg[m]; ++k) {
+            const double gap = sqrt(ld(MCL_DIAG_REG + (m * MCL_MAX_REGS + k) * 2)) / fn;
+            worst = (gap > worst || gap != gap) ? gap : worst;  // a NaN gap is never feasible
+        }
+    }
+    const bool feasible = R.has_feas && (worst < R.feas_tol);
+    int code = 0, computed = 0;
+    double rec = 0.0, loss = 0.0;
+    if (feasible || R.loss_always) {
+        const double xsq = ld(MCL_DIAG_X_SQ), inner = ld(MCL_DIAG_INNER), model = ld(MCL_DIAG_MODEL_SQ);
+        rec = sqrt(fmax(0.0, xsq - 2.0 * inner + model)) / sqrt(xsq);
+        double reg = 0.0;
+        for (int m = 0; m < 3; ++m) {
+            for (int k = 0; k < nreg[m]; ++k)
+                if (R.w[m][k] != 0.0) reg += R.w[m][k] * ld(MCL_DIAG_REG + (m * MCL_MAX_REGS + k) * 2 + 1);
+            if (R.l2[m] != 0.0) reg += 0.5 * R.l2[m] * ld(MCL_DIAG_NORM_SQ + m);
+        }
+        loss = 0.5 * (rec * rec) + reg;
+        computed = 1;
+        if (R.has_tol) {
+            const double prev = state[0];
+            const bool rel = fabs(prev - loss) < R.tol * prev;
+            const bool absc = loss < R.abs_tol;
+            if (feasible && rel) code = 1;
+            else if (feasible && absc) code = 2;
+        }
+        state[0] = loss;
+    }
+    verdict_row[0] = rec, verdict_row[1] = loss, verdict_row[2] = worst;
+    verdict_row[3] = (double)((feasible ? 1 : 0) | (computed << 1) | (code << 2));
+    if (code) {
+        gate[1] = R.it, gate[2] = code;
+        __threadfence();
+        gate[0] = 1;
+        status_host[1] = R.it, status_host[2] = code;
+        __threadfence_system();
+        status_host[0] = 1;
+    }
+    status_host[3] = R.it + 1;  // progress: the host keeps its run-ahead bounded by this
+    __threadfence_system();
+}
+
 __global__ __launch_bounds__(256) void k_diag_verdict(DiagTables T, double *__restrict__ out, StopRuleDev R,
                                                       int *__restrict__ gate, double *__restrict__ state,
                                                       double *__restrict__ verdict_row, int *__restrict__ status_host) {
@@ -1520,51 +1570,17 @@ __global__ __launch_bounds__(256) void k_diag_verdict(DiagTables T, double *__re
     if (!last || threadIdx.x != 0) return;
     __threadfence();
     gate[3] = 0;  // ticket counter ready for the next launch (stream order)
-    auto ld = [&](int i) { return __hip_atomic_load(out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    // feasibility gaps ||aux - factor|| / ||factor||, worst over all penalties of all modes (vacuously feasible without any)
-    double worst = -__builtin_inf();
-    for (int m = 0; m < 3; ++m) {
-        const double fn = sqrt(ld(MCL_DIAG_NORM_SQ + m));
-        for (int k = 0; k < T.nreg[m]; ++k) {
-            const double gap = sqrt(ld(MCL_DIAG_REG + (m * MCL_MAX_REGS + k) * 2)) / fn;
-            worst = (gap > worst || gap != gap) ? gap : worst;  // a NaN gap is never feasible
-        }
-    }
-    const bool feasible = R.has_feas && (worst < R.feas_tol);
-    int code = 0, computed = 0;
-    double rec = 0.0, loss = 0.0;
-    if (feasible || R.loss_always) {
-        const double xsq = ld(MCL_DIAG_X_SQ), inner = ld(MCL_DIAG_INNER), model = ld(MCL_DIAG_MODEL_SQ);
-        rec = sqrt(fmax(0.0, xsq - 2.0 * inner + model)) / sqrt(xsq);
-        double reg = 0.0;
-        for (int m = 0; m < 3; ++m) {
-            for (int k = 0; k < T.nreg[m]; ++k)
-                if (R.w[m][k] != 0.0) reg += R.w[m][k] * ld(MCL_DIAG_REG + (m * MCL_MAX_REGS + k) * 2 + 1);
-            if (R.l2[m] != 0.0) reg += 0.5 * R.l2[m] * ld(MCL_DIAG_NORM_SQ + m);
-        }
-        loss = 0.5 * (rec * rec) + reg;
-        computed = 1;
-        if (R.has_tol) {
-            const double prev = state[0];
-            const bool rel = fabs(prev - loss) < R.tol * prev;
-            const bool absc = loss < R.abs_tol;
-            if (feasible && rel) code = 1;
-            else if (feasible && absc) code = 2;
-        }
-        state[0] = loss;
-    }
-    verdict_row[0] = rec, verdict_row[1] = loss, verdict_row[2] = worst;
-    verdict_row[3] = (double)((feasible ? 1 : 0) | (computed << 1) | (code << 2));
-    if (code) {
-        gate[1] = R.it, gate[2] = code;
-        __threadfence();
-        gate[0] = 1;
-        status_host[1] = R.it, status_host[2] = code;
-        __threadfence_system();
-        status_host[0] = 1;
-    }
-    status_host[3] = R.it + 1;  // progress: the host keeps its run-ahead bounded by this
-    __threadfence_system();
+    verdict_eval(out, T.nreg, R, gate, state, verdict_row, status_host);
+}
+
+// The same test on a vector that is already complete - the sharded loop: every rank reduces its tables (mcl_diagnostics),
+// the host all-reduces the vectors, then every rank evaluates the rule on the SAME bits and reaches the same verdict.
+__global__ __launch_bounds__(64) void k_verdict(const double *__restrict__ vec, StopRuleDev R, int n0, int n1, int n2,
+                                                int *__restrict__ gate, double *__restrict__ state,
+                                                double *__restrict__ verdict_row, int *__restrict__ status_host) {
+    if (*gate != 0 || threadIdx.x != 0) return;
+    const int nreg[3] = {n0, n1, n2};
+    verdict_eval(vec, nreg, R, gate, state, verdict_row, status_host);
 }
 
 // Per-tile diagnostics of a packed factor from memory (generic path / initial state):
@@ -2137,8 +2153,7 @@ int mcl_launch_diag_tables(mcl_context *c, const DiagTables &T, double *out, int
     return 0;
 }
 
-int mcl_launch_diag_verdict(mcl_context *c, double *out, const mcl_stop_rule *rule, int it, double *verdict_row,
-                            int *status_dev) {
+static StopRuleDev rule_dev(const mcl_context *c, const mcl_stop_rule *rule, int it) {
     StopRuleDev R{};
     R.tol = rule->tol, R.abs_tol = rule->absolute_tol, R.feas_tol = rule->feasibility_tol;
     R.has_tol = rule->tol != 0.0, R.has_feas = rule->feasibility_tol != 0.0;  // Python truthiness of the keyword values
@@ -2147,6 +2162,20 @@ int mcl_launch_diag_verdict(mcl_context *c, double *out, const mcl_stop_rule *ru
         R.l2[m] = c->opt.l2_penalty[m];
         for (int k = 0; k < MCL_MAX_REGS; ++k) R.w[m][k] = rule->penalty_weight[m][k];
     }
+    return R;
+}
+
+int mcl_launch_verdict(mcl_context *c, const double *vec, const mcl_stop_rule *rule, int it, double *verdict_row,
+                       int *status_dev) {
+    hipLaunchKernelGGL(k_verdict, dim3(1), dim3(64), 0, c->stream, vec, rule_dev(c, rule, it), c->regs[0].n, c->regs[1].n,
+                       c->regs[2].n, c->gate, c->stop_state, verdict_row, status_dev);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int mcl_launch_diag_verdict(mcl_context *c, double *out, const mcl_stop_rule *rule, int it, double *verdict_row,
+                            int *status_dev) {
+    const StopRuleDev R = rule_dev(c, rule, it);
     hipLaunchKernelGGL(k_diag_verdict, dim3(3 * DIAG_COLS + 3), dim3(256), 0, c->stream, mcl_diag_tables(c, true), out, R,
                        c->gate, c->stop_state, verdict_row, status_dev);
     MCL_CHECK_HIP(c, hipGetLastError());

@@ -1152,6 +1152,43 @@ int mcl_wait_event(mcl_context *c, void *hip_event) {
     return 0;
 }
 
+// ---- the pieces of mcl_run for a host that drives the iterations itself (the sharded loop: reductions between the calls) ----
+int mcl_gate_begin(mcl_context *c, const mcl_stop_rule *rule, mcl_run_status *status) {
+    if (!c) return 1;
+    if (!rule || !status) return fail(c, "mcl_gate_begin: rule and status must not be NULL");
+    if (int rc = ready(c)) return rc;
+    int *status_dev = nullptr;
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&status_dev), (void *)status, 0) != hipSuccess || !status_dev) {
+        (void)hipGetLastError();
+        return fail(c, "mcl_gate_begin: status must live in pinned (page-locked, device-mapped) host memory");
+    }
+    status->stopped = 0, status->stop_iteration = -1, status->code = 0, status->progress = 0;
+    c->run_rule = *rule;
+    c->run_status_dev = status_dev;
+    c->h_stop_init[0] = rule->initial_loss;
+    MCL_CHECK_HIP(c, hipMemsetAsync(c->gate, 0, 4 * sizeof(int), c->stream));
+    MCL_CHECK_HIP(c, hipMemcpyAsync(c->stop_state, c->h_stop_init, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->gate_active = c->gate;
+    for (int m = 0; m < 3; ++m) c->regs[m].gate = c->gate;
+    return 0;
+}
+
+int mcl_verdict(mcl_context *c, const double *diag_vec, int32_t iteration, double *verdict_row) {
+    if (!c) return 1;
+    if (!c->gate_active || !c->run_status_dev) return fail(c, "mcl_verdict: call mcl_gate_begin first");
+    if (!diag_vec || !verdict_row) return fail(c, "mcl_verdict: NULL vector");
+    return mcl_launch_verdict(c, diag_vec, &c->run_rule, iteration, verdict_row, c->run_status_dev);
+}
+
+int mcl_gate_end(mcl_context *c, int32_t stopped_early) {
+    if (!c) return 1;
+    c->gate_active = nullptr;
+    c->run_status_dev = nullptr;
+    for (int m = 0; m < 3; ++m) c->regs[m].gate = nullptr;
+    if (stopped_early) forget_byproducts(c);
+    return 0;
+}
+
 float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {
     if (!c || !c->has_workspace) return nullptr;
     float *p = nullptr;

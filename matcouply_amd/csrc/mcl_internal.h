@@ -177,6 +177,8 @@ struct mcl_context {
     const int *gate_active = nullptr;  // == gate while a gated run is enqueueing (copied into ModeView / RegSet), else NULL
     double *stop_state = nullptr;      // fp64[4]: {last computed loss, ...}
     double h_stop_init[1] = {0.0};     // host source of the asynchronous upload of the initial loss (must outlive it)
+    mcl_stop_rule run_rule{};          // mcl_gate_begin .. mcl_gate_end: the rule mcl_verdict evaluates
+    int *run_status_dev = nullptr;     // ... and the device view of the host's pinned status words
     bool diag_pending = false;
     bool diag_crossed_sweep = false;  // the pending deferral has already survived one sweep (it may not survive a second)
     DiagTables diag_pending_T{};
@@ -317,6 +319,8 @@ DiagTables mcl_diag_tables(const mcl_context *c, bool a_from_rows);  // the tabl
 int mcl_launch_diag_tables(mcl_context *c, const DiagTables &T, double *out, int include_replicated);
 int mcl_launch_diag_verdict(mcl_context *c, double *out, const mcl_stop_rule *rule, int it, double *verdict_row,
                             int *status_dev);  // table reduction + the stopping test of mcl_run
+int mcl_launch_verdict(mcl_context *c, const double *vec, const mcl_stop_rule *rule, int it, double *verdict_row,
+                       int *status_dev);  // the stopping test on an already reduced vector (sharded loop)
 int mcl_launch_x_sq(mcl_context *c);
 bool mcl_mode_is_row_separable(const mcl_context *c, int mode);
 bool mcl_stack_can_fuse(const mcl_context *c, int mode);          // generic.hip

@@ -914,6 +914,12 @@ def cmf_aoadmm(
     # a TypeError in the reference's comparison - the host loop below raises it the same way.)
     device_stop = (bool(tol or absolute_tol) and not sharded and not verbose and n_iter_max > 0 and not any(has_ext)
                    and not host_value and not (tol and absolute_tol is None) and hasattr(eng, "run"))
+    # ... and the same rule under sharding (mcl_gate_begin / mcl_verdict): the phases are stepped with their reductions, the
+    # diagnostics vector is all-reduced and every rank evaluates the rule on the same bits.  Every rank must enqueue the same
+    # number of iterations (their collectives pair up), so the loop runs in fixed chunks with one synchronisation each.
+    sharded_stop = (bool(tol or absolute_tol) and sharded and not verbose and n_iter_max > 0 and not any(has_ext)
+                    and not host_value and not sharded_ball_A and not (tol and absolute_tol is None)
+                    and hasattr(eng, "gate_begin"))
     final_gaps_known = False
     if lazy_diag:
         # sharded, fixed iteration count: nothing depends on the diagnostics inside the loop, so their partial sums stay
@@ -936,6 +942,50 @@ def cmf_aoadmm(
                 feasibility_gaps.append(gaps)
                 rec_errors.append(rec_error)
                 losses.append(0.5 * rec_error ** 2 + reg)
+    elif sharded_stop:
+        weights = [[(reg.reg_strength if isinstance(reg, penalties.L1Penalty) else 0.0) for reg in regs[m]] for m in range(3)]
+        eng.gate_begin(tol, absolute_tol, feasibility_tol, initial_loss=losses[-1], penalty_weight=weights,
+                       evaluate_loss_always=return_errors)
+        chunk, done, code, stop_it = 8, 0, 0, -1
+        ring = torch.zeros((n_iter_max if n_iter_max <= 4096 else 4096, _engine.DIAG_LEN), dtype=torch.float64, device=device)
+        verdict = torch.zeros((ring.shape[0], 4), dtype=torch.float64, device=device)
+        while done < n_iter_max and not code:
+            n_now = min(chunk, n_iter_max - done)
+            base = done % ring.shape[0]
+            if base + n_now > ring.shape[0]:
+                base = 0
+            for j in range(n_now):
+                if update_B_is:
+                    do_update_B()
+                if update_C:
+                    do_update_C()
+                if update_A:
+                    do_update_A()
+                eng.diagnostics(include_replicated=(rank_id == 0), out=ring[base + j])
+                all_reduce(ring[base + j])
+                eng.verdict(ring[base + j], done + j, verdict[base + j])
+            if is_torch(ring) and ring.is_cuda:
+                torch.cuda.synchronize(device)
+            stopped, stop_it, code = eng.gate_status()
+            n_ran = (stop_it - done + 1) if stopped else n_now
+            ring_h, verdict_h = ring[base:base + n_ran].cpu().numpy(), verdict[base:base + n_ran].cpu().numpy()
+            for row, (v_rec, v_loss, _, v_flags) in zip(ring_h, verdict_h):
+                _, gaps, _ = read_diag(row)
+                feasibility_gaps.append(gaps)
+                flags = int(v_flags)
+                feasibility_criterion = bool(flags & _engine.VERDICT_FEASIBLE) if feasibility_tol else feasibility_tol
+                if flags & _engine.VERDICT_LOSS_EVALUATED:
+                    rec_errors.append(float(v_rec))
+                    losses.append(float(v_loss))
+            done += n_ran
+            if not stopped:
+                code = 0
+        eng.gate_end(bool(code))
+        it = done - 1
+        if code:
+            satisfied_stopping_condition = True
+            message = _StopRule.RELATIVE if code == _engine.STOP_RELATIVE else _StopRule.ABSOLUTE
+        final_gaps_known = True
     elif device_stop:
         # a stopping rule is active (the DEFAULT call: tol=1e-8, absolute_tol=1e-10, feasibility_tol=1e-4): the rule is
         # evaluated by a kernel at the end of every iteration (mcl_run), the host enqueues ahead of the verdicts and never

@@ -302,6 +302,73 @@ class OracleEngine:
         n = len(rows)
         return (n, code, np.asarray(rows).reshape(n, _engine.DIAG_LEN), np.asarray(verdicts, dtype=np.float64).reshape(n, 4))
 
+    # ---- mcl_gate_begin / mcl_verdict / mcl_gate_end restated: after a hit every later state-writing call is a no-op ---------
+    def gate_begin(self, tol, absolute_tol, feasibility_tol, initial_loss, penalty_weight, evaluate_loss_always):
+        self._gate = dict(tol=float(tol or 0.0), abs=float(absolute_tol or 0.0), feas=float(feasibility_tol or 0.0),
+                          prev=float(initial_loss), w=penalty_weight, always=bool(evaluate_loss_always), stopped=False,
+                          stop_it=-1, code=0)
+        if not getattr(type(self), "_gated", False):
+            # wrap every state-writing method once: with the gate closed they do nothing (the kernels' MCL_GATE)
+            def gated(fn):
+                def inner(self, *a, **kw):
+                    g = getattr(self, "_gate", None)
+                    if g is not None and g["stopped"]:
+                        return self.GR if fn.__name__ == "update_C_local" else None
+                    return fn(self, *a, **kw)
+                inner.__name__ = fn.__name__
+                return inner
+            for name in ("B_begin", "B_factor", "B_solve", "B_prox_local", "B_prox_finish", "B_end", "update_B", "update_C_local",
+                         "update_C_finish", "A_begin", "A_finish", "A_factor", "A_solve", "A_end", "update_A"):
+                setattr(type(self), name, gated(getattr(type(self), name)))
+            type(self)._gated = True
+
+    def verdict(self, vec, iteration, row):
+        g = self._gate
+        if g["stopped"]:
+            return
+        d = vec.numpy()
+        worst = -np.inf
+        for m in range(3):
+            fn = np.sqrt(d[_engine.DIAG_NORM_SQ + m])
+            for k in range(len(self.regs[m])):
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    gap = np.sqrt(d[_engine.DIAG_REG + (m * _engine.MCL_MAX_REGS + k) * 2]) / fn
+                worst = gap if (gap > worst or gap != gap) else worst
+        feasible = bool(g["feas"] != 0.0 and worst < g["feas"])
+        rec = loss = 0.0
+        code = 0
+        computed = feasible or g["always"]
+        if computed:
+            xsq, inner, model = d[_engine.DIAG_X_SQ], d[_engine.DIAG_INNER], d[_engine.DIAG_MODEL_SQ]
+            rec = np.sqrt(max(0.0, xsq - 2.0 * inner + model)) / np.sqrt(xsq)
+            reg = 0.0
+            for m in range(3):
+                for k in range(len(self.regs[m])):
+                    w = g["w"][m][k] if k < len(g["w"][m]) else 0.0
+                    if w:
+                        reg += w * d[_engine.DIAG_REG + (m * _engine.MCL_MAX_REGS + k) * 2 + 1]
+                if self.l2[m]:
+                    reg += 0.5 * self.l2[m] * d[_engine.DIAG_NORM_SQ + m]
+            loss = 0.5 * (rec * rec) + reg
+            if g["tol"] != 0.0:
+                with np.errstate(invalid="ignore"):
+                    rel = abs(g["prev"] - loss) < g["tol"] * g["prev"]
+                if feasible and rel:
+                    code = _engine.STOP_RELATIVE
+                elif feasible and loss < g["abs"]:
+                    code = _engine.STOP_ABSOLUTE
+            g["prev"] = loss
+        row[...] = torch.tensor([rec, loss, worst, float(int(feasible) | (int(computed) << 1) | (code << 2))], dtype=torch.float64)
+        if code:
+            g.update(stopped=True, stop_it=int(iteration), code=code)
+
+    def gate_status(self):
+        g = self._gate
+        return g["stopped"], g["stop_it"], g["code"]
+
+    def gate_end(self, stopped_early):
+        self._gate = None
+
     def diagnostics_deferred(self, include_replicated=True, out=None):
         return self.diagnostics(include_replicated=include_replicated, out=out)  # the checker has nothing to defer
 

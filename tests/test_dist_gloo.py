@@ -13,6 +13,15 @@ import torch.multiprocessing as mp
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# keyword overrides of the runs below (set per test; the default is a fixed iteration count)
+RUN_KW = dict(n_iter_max=6, tol=None, absolute_tol=None)
+STOP_RULES = {
+    # stops on the relative criterion somewhere inside the budget (every iterate counts as feasible)
+    "relative": dict(n_iter_max=40, tol=2e-2, absolute_tol=1e-12, feasibility_tol=float("inf")),
+    # never feasible: runs to the budget; the loss is evaluated all the same (return_errors)
+    "budget": dict(n_iter_max=11, tol=1e-3, absolute_tol=1e-12, feasibility_tol=1e-30),
+}
+
 CASES = {
     "c3_nn_l1C": dict(non_negative=True, l1_penalty={2: 0.1}),
     "pf2_ball_constant": dict(parafac2=True, l2_norm_bound={1: 1.0}, non_negative={0: True},
@@ -105,8 +114,8 @@ def _run_with_checker(dec, case, lo, hi, group):
     const = kw.get("constant_feasibility_penalty", False)
     w, (A0, B0, C0) = init
     cmf, diag = dec.cmf_aoadmm(mats[lo:hi], r, init=(None, (A0[lo:hi].copy(), [b.copy() for b in B0[lo:hi]], C0.copy())),
-                               regs=_build(regs_spec, lo, hi), n_iter_max=6, tol=None, absolute_tol=None,
-                               return_errors=True, constant_feasibility_penalty=const, group=group,
+                               regs=_build(regs_spec, lo, hi), return_errors=True, constant_feasibility_penalty=const, group=group,
+                               **(json.loads(os.environ["MCL_TEST_RUN_KW"]) if os.environ.get("MCL_TEST_RUN_KW") else RUN_KW),
                                gather_A=group is not None)
     return cmf, diag
 
@@ -118,7 +127,8 @@ def _worker(rank, world, port, case, q):
     bounds = [0, 4, 6]  # uneven split of the 6 slabs
     cmf, diag = _run(case, bounds[rank], bounds[rank + 1], dist.group.WORLD)
     q.put((rank, cmf[1][0], np.concatenate(cmf[1][1]), cmf[1][2], diag.rec_errors, diag.regularized_loss,
-           [[list(map(float, g)) for g in it] for it in diag.feasibility_gaps], np.asarray(cmf.A_all), cmf.rows_of_rank))
+           [[list(map(float, g)) for g in it] for it in diag.feasibility_gaps], np.asarray(cmf.A_all), cmf.rows_of_rank,
+           (diag.n_iter, diag.message, diag.satisfied_stopping_condition, bool(diag.satisfied_feasibility_condition))))
     dist.destroy_process_group()
 
 
@@ -154,6 +164,40 @@ def test_two_rank_sharded_run_equals_single_process(case):
             for g, rg in zip(got_it, ref_it):
                 np.testing.assert_allclose(g, rg, rtol=1e-8, atol=1e-12)
     np.testing.assert_array_equal(results[0][3], results[1][3])
+
+
+@pytest.mark.parametrize("rule", sorted(STOP_RULES))
+def test_two_rank_sharded_run_with_a_stopping_rule(rule, monkeypatch):
+    """the stopping rule under sharding (mcl_gate_begin / mcl_verdict, here restated by the checker engine): the phases are
+    stepped with their reductions, the diagnostics vector is all-reduced, every rank evaluates the rule on the same bits and
+    the loop runs in fixed chunks - same stopping iteration, message, lists and factors as the single-process call"""
+    sys.path.insert(0, REPO)
+    kw = STOP_RULES[rule]
+    monkeypatch.setenv("MCL_TEST_RUN_KW", json.dumps(kw))  # (the workers are spawned processes: passed through the environment)
+    case = "pf2_ball_constant"
+    ref_cmf, ref_diag = _run(case, 0, 6, None)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 17) % 2000)
+    procs = [ctx.Process(target=_worker, args=(rk, 2, port, case, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if rule == "relative":
+        assert ref_diag.message.startswith("FEASIBILITY GAP CRITERION AND RELATIVE") and 1 <= ref_diag.n_iter < kw["n_iter_max"]
+    else:
+        assert ref_diag.n_iter == kw["n_iter_max"] and not ref_diag.satisfied_stopping_condition
+    want = (ref_diag.n_iter, ref_diag.message, ref_diag.satisfied_stopping_condition, bool(ref_diag.satisfied_feasibility_condition))
+    for res in results:
+        assert res[9] == want
+        np.testing.assert_allclose(res[4], ref_diag.rec_errors, rtol=1e-9)
+        np.testing.assert_allclose(res[5], ref_diag.regularized_loss, rtol=1e-9)
+        np.testing.assert_allclose(res[3], ref_cmf[1][2], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.concatenate([res[1] for res in results]), ref_cmf[1][0], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.concatenate([res[2] for res in results]), np.concatenate(ref_cmf[1][1]), rtol=1e-9, atol=1e-12)
 
 
 def test_partition_slabs_balances_rows():

@@ -99,6 +99,10 @@ P0 = [np.eye(j, 4) for j in J]; D0 = mk((4, 4)); dualP = [mk((j, 4)) for j in J]
 auxL, dualL = [mk((j, 4)) for j in J], [mk((j, 4)) for j in J]
 auxU, dualU = [mk((j, 4)) for j in J], [mk((j, 4)) for j in J]
 README_STACK = os.environ.get("STACK") == "readme"  # README.rst:66-91 of the reference: L2 ball on A, unimodal B_i
+# STACK = "pf2_stop": the PARAFAC2 stack WITH a stopping rule - under sharding it is evaluated on the device too
+# (mcl_gate_begin / mcl_verdict on the all-reduced vector; chunks of 8 iterations, gated kernels behind a hit)
+STOP = dict(n_iter_max=60, tol=2e-2, absolute_tol=1e-12, feasibility_tol=float("inf")) if os.environ.get("STACK") == "pf2_stop" \
+    else dict(n_iter_max=5, tol=None, absolute_tol=None)
 def run(lo, hi, group):
     regs = [[pen.NonNegativity(aux_init=auxA[lo:hi].copy(), dual_init=dualA[lo:hi].copy())],
             [pen.Parafac2(aux_init=([p.copy() for p in P0[lo:hi]], D0.copy()), dual_init=[d.copy() for d in dualP[lo:hi]]),
@@ -109,8 +113,7 @@ def run(lo, hi, group):
         regs[1].insert(1, pen.Unimodality(non_negativity=True, aux_init=[a.copy() for a in auxU[lo:hi]],
                                           dual_init=[d.copy() for d in dualU[lo:hi]]))
     return dec.cmf_aoadmm(mats[lo:hi], 4, init=(None, (A0[lo:hi].copy(), [b.copy() for b in B0[lo:hi]], C0.copy())), regs=regs,
-                          n_iter_max=5, tol=None, absolute_tol=None, return_errors=True, constant_feasibility_penalty=True,
-                          group=group)
+                          return_errors=True, constant_feasibility_penalty=True, group=group, **STOP)
 bounds = [0, 2, 6]
 cmf, diag = run(bounds[rank], bounds[rank + 1], dist.group.WORLD)
 if rank == 0:
@@ -118,13 +121,17 @@ if rank == 0:
     err = dict(A=float(np.linalg.norm(cmf[1][0] - ref_cmf[1][0][:2]) / np.linalg.norm(ref_cmf[1][0][:2])),
                C=float(np.linalg.norm(cmf[1][2] - ref_cmf[1][2]) / np.linalg.norm(ref_cmf[1][2])),
                rec=float(max(abs(a - b) / b for a, b in zip(diag.rec_errors, ref_diag.rec_errors))))
+    if STOP["tol"]:
+        assert (diag.n_iter, diag.message) == (ref_diag.n_iter, ref_diag.message), (diag.n_iter, ref_diag.n_iter)
+        assert 1 <= diag.n_iter < STOP["n_iter_max"] and diag.message.startswith("FEASIBILITY GAP CRITERION AND RELATIVE")
+        assert len(diag.rec_errors) == diag.n_iter + 1
     print("SHARDED_RESULT " + json.dumps(err), flush=True)
 dist.barrier()
 dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("stack", ["pf2", "readme"])
+@pytest.mark.parametrize("stack", ["pf2", "readme", "pf2_stop"])
 def test_two_ranks_sharing_the_gpu_equal_single_process(tmp_path, stack):
     """cmf_aoadmm(group=) with the REAL engine: 2 processes share cuda:0, collectives over gloo (RCCL refuses two ranks on one
     device); PARAFAC2 + constant feasibility penalty exercise every reduction of the step path; the "readme" stack adds the
