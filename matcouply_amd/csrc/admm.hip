@@ -1421,24 +1421,29 @@ __global__ __launch_bounds__(256) void k_sum_doubles(const double *__restrict__ 
 }
 
 
+// column sum of a [n_rows, ncols] fp64 table by one workgroup of 256 or 1024 threads (fixed order for a given block size: the
+// launchers pick the size from the table lengths alone, so it is the same on every rank and in every iteration)
 static __device__ double block_colsum(const double *__restrict__ tab, int n_rows, int ncols, int col, double *sm) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int nt = blockDim.x;
     int e = threadIdx.x;
-    for (; e + 768 < n_rows; e += 1024) {
+    for (; e + 3 * nt < n_rows; e += 4 * nt) {
         s0 += tab[(long)e * ncols + col];
-        s1 += tab[(long)(e + 256) * ncols + col];
-        s2 += tab[(long)(e + 512) * ncols + col];
-        s3 += tab[(long)(e + 768) * ncols + col];
+        s1 += tab[(long)(e + nt) * ncols + col];
+        s2 += tab[(long)(e + 2 * nt) * ncols + col];
+        s3 += tab[(long)(e + 3 * nt) * ncols + col];
     }
-    for (; e < n_rows; e += 256) s0 += tab[(long)e * ncols + col];
+    for (; e < n_rows; e += nt) s0 += tab[(long)e * ncols + col];
     double s = wave_sum((s0 + s1) + (s2 + s3));
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
     __syncthreads();
-    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    double t = 0.0;
+    for (int w = 0; w < (nt >> 6); w += 4) t += (sm[w] + sm[w + 1]) + (sm[w + 2] + sm[w + 3]);
+    return t;
 }
 
-__global__ __launch_bounds__(256) void k_diag_final(DiagTables T, int include_replicated, double *__restrict__ out) {
-    __shared__ double sm[4];
+__global__ __launch_bounds__(1024) void k_diag_final(DiagTables T, int include_replicated, double *__restrict__ out) {
+    __shared__ double sm[16];
     const int b = blockIdx.x;
     if (b < 3 * DIAG_COLS) {
         const int t = b / DIAG_COLS, col = b - t * DIAG_COLS;
@@ -1531,10 +1536,10 @@ static __device__ void verdict_eval(const double *out, const int *nreg, const St
     __threadfence_system();
 }
 
-__global__ __launch_bounds__(256) void k_diag_verdict(DiagTables T, double *__restrict__ out, StopRuleDev R,
-                                                      int *__restrict__ gate, double *__restrict__ state,
-                                                      double *__restrict__ verdict_row, int *__restrict__ status_host) {
-    __shared__ double sm[4];
+__global__ __launch_bounds__(1024) void k_diag_verdict(DiagTables T, double *__restrict__ out, StopRuleDev R,
+                                                       int *__restrict__ gate, double *__restrict__ state,
+                                                       double *__restrict__ verdict_row, int *__restrict__ status_host) {
+    __shared__ double sm[16];
     __shared__ int last;
     if (*gate != 0) return;  // an earlier iteration has stopped the run: nothing is evaluated any more
     const int b = blockIdx.x;
@@ -2148,7 +2153,9 @@ DiagTables mcl_diag_tables(const mcl_context *c, bool a_from_rows) {
 }
 
 int mcl_launch_diag_tables(mcl_context *c, const DiagTables &T, double *out, int include_replicated) {
-    hipLaunchKernelGGL(k_diag_final, dim3(3 * DIAG_COLS + 3), dim3(256), 0, c->stream, T, include_replicated, out);
+    // long tables (thousands of B tiles: config 4 / 5) are summed by 1024 threads per column: a quarter of the dependent loads
+    const int nt = std::max(T.rows[0], std::max(T.rows[1], T.rows[2])) > 2048 ? 1024 : 256;
+    hipLaunchKernelGGL(k_diag_final, dim3(3 * DIAG_COLS + 3), dim3(nt), 0, c->stream, T, include_replicated, out);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
@@ -2176,7 +2183,9 @@ int mcl_launch_verdict(mcl_context *c, const double *vec, const mcl_stop_rule *r
 int mcl_launch_diag_verdict(mcl_context *c, double *out, const mcl_stop_rule *rule, int it, double *verdict_row,
                             int *status_dev) {
     const StopRuleDev R = rule_dev(c, rule, it);
-    hipLaunchKernelGGL(k_diag_verdict, dim3(3 * DIAG_COLS + 3), dim3(256), 0, c->stream, mcl_diag_tables(c, true), out, R,
+    const DiagTables T = mcl_diag_tables(c, true);
+    const int nt = std::max(T.rows[0], std::max(T.rows[1], T.rows[2])) > 2048 ? 1024 : 256;
+    hipLaunchKernelGGL(k_diag_verdict, dim3(3 * DIAG_COLS + 3), dim3(nt), 0, c->stream, T, out, R,
                        c->gate, c->stop_state, verdict_row, status_dev);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;

@@ -1112,10 +1112,13 @@ int mcl_run(mcl_context *c, int32_t n_iter_max, int32_t update_A, int32_t update
         // bounded run-ahead: wait (without synchronising the stream) until the device is at most `ahead` verdicts behind
         long spins = 0;
         while (!status->stopped && it - status->progress >= ahead) {
-            if ((++spins & 0x3fff) == 0 && hipStreamQuery(c->stream) == hipSuccess && it - status->progress >= ahead &&
-                !status->stopped) {
-                rc = fail(c, "mcl_run: the stream drained without the verdict kernel reporting progress");
-                break;
+            if ((++spins & 0x3fff) == 0) {  // every 16 K spins: is the stream still working?
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q != hipErrorNotReady && it - status->progress >= ahead && !status->stopped) {
+                    rc = fail(c, q == hipSuccess ? "mcl_run: the stream drained without the verdict kernel reporting progress"
+                                                 : std::string("mcl_run: ") + hipGetErrorString(q));
+                    break;
+                }
             }
             __builtin_ia32_pause();
         }

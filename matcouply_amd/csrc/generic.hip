@@ -879,7 +879,9 @@ static __device__ __forceinline__ void ur4_refill_coop(UniRing4 &st, UniPrefetch
                                                        const double *__restrict__ gsy, const double *__restrict__ gq,
                                                        const int *__restrict__ gcw, long base, long rs, int col) {
     if (__builtin_amdgcn_ballot_w64(st.cnt <= 1 && st.mem_n > 0) == 0) return;  // wave-uniform
-    const int room = RC - 2 - st.cnt;
+    // a lane joins when its own ring is at most half full: it will run dry soon (joining whenever there was room made every
+    // lane prefetch four times as often as it refilled, and most of those prefetches were invalidated by the next spill)
+    const int room = st.cnt <= RC / 2 ? RC - 2 - st.cnt : 0;
     if (pf.n > 0) {
         if (room >= pf.n) {
             ur4_take_prefetched<RC, NRF>(st, pf, lane);
