@@ -338,6 +338,10 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         if backend == "nccl":
+            # one node by contract (rendezvous on 127.0.0.1): RCCL's out-of-band bootstrap may use the loopback interface
+            # too - a container without a routable interface (or with an unresolvable hostname) then cannot stall it
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
