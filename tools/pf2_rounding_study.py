@@ -50,21 +50,21 @@ def b_phase(st, flags):
         for i in range(I):
             s, e = rp[i], rp[i + 1]
             V = rnd("v", rho[i] * ((Zpf[s:e] - Upf[s:e]) + (Zl2[s:e] - Ul2[s:e])) + XC[s:e] * A[i])
-            Bn[s:e] = f32(mm("solve_acc", V, Linv[i]))  # B is stored in fp32
+            Bn[s:e] = rnd("st_B", mm("solve_acc", V, Linv[i]))  # B is stored in fp32
             Y = rnd("y_sum", Bn[s:e] + Upf[s:e])
             T = rnd("t_store", polar_T(Y.T @ Y, Delta))
-            Pn[s:e] = f32(mm("p_acc", Y, T))
+            Pn[s:e] = rnd("st_P", mm("p_acc", Y, T))
             accD += rho[i] * (Pn[s:e].T @ Y)
         B, P = Bn, Pn
-        Delta = f32(accD / rho.sum())
+        Delta = rnd("st_Delta", accD / rho.sum())
         Zpf = rnd("z_store", mm("z_acc", P, Delta))
-        Upf = f32(B - (Zpf - Upf))
+        Upf = rnd("st_Upf", B - (Zpf - Upf))
         for i in range(I):
             s, e = rp[i], rp[i + 1]
             Y = B[s:e] + Ul2[s:e]
             nrm = np.sqrt((Y ** 2).sum(0))
-            Zl2[s:e] = f32(Y * (bound / np.maximum(nrm, bound)))
-        Ul2 = f32(B - (Zl2 - Ul2))
+            Zl2[s:e] = rnd("st_Zl2", Y * (bound / np.maximum(nrm, bound)))
+        Ul2 = rnd("st_Ul2", B - (Zl2 - Ul2))
     return B, Zpf, Upf
 
 
@@ -99,6 +99,13 @@ def main():
     report("exact: y_sum t_store p_acc", {"y_sum": False, "t_store": False, "p_acc": False})
     report("exact: y_sum t_store p_acc solve_acc v linv", {k: False for k in ("y_sum", "t_store", "p_acc", "solve_acc", "v", "linv")})
     report("exact: all but xc_acc xc_store", {k: False for k in sites if not k.startswith("xc")})
+    # composition of the storage floor: every compute site exact, ONE stored array kept exact as well
+    stores = ["st_B", "st_P", "st_Delta", "st_Upf", "st_Zl2", "st_Ul2"]
+    exact = {k: False for k in sites}
+    for k in stores:
+        report(f"compute exact, storage fp32 except {k}", dict(exact, **{k: False}))
+    report("compute exact, B and U_pf2 stored exactly", dict(exact, st_B=False, st_Upf=False))
+    report("compute exact, every array stored exactly", dict(exact, **{k: False for k in stores}))
 
 
 if __name__ == "__main__":
