@@ -750,12 +750,16 @@ __global__ __launch_bounds__(64) void k_slab_unimodal_v3(const int *__restrict__
 //   * ring entries are 20 bytes and the ring holds 8: 10 KB of LDS per wave, 16 waves per CU.
 // The records of the right-to-left sweep are stored at the position they belong to, so both emit loops index rows.
 // ---------------------------------------------------------------------------------------------------------
+template <class T>
+static __device__ __forceinline__ unsigned lds_addr(T *p) {  // byte offset of a __shared__ object in LDS
+    return (unsigned)(unsigned long)(__attribute__((address_space(3))) T *)p;
+}
 #define RC4 8  // ring entries of the throughput form (MODE 0); the latency form (MODE 1: one wave per SIMD) has LDS for 16
 struct UniRing4 {
     double *sy, *q;  // LDS [RC][64]
     int *cw;         // LDS [RC][64]
     int h, cnt;      // ring index of its top entry, number of entries in the ring
-    long mem_n;      // entries spilled to global memory
+    int mem_n;       // entries spilled to global memory
 };
 struct UniRec {
     float lev;
@@ -784,26 +788,31 @@ struct UniPrefetch {
     int n;
 };
 
+// Push; a full ring spills its bottom entry to global memory first.  (Tried: cooperative spills of 2 / 4 / 8 entries at a time, so
+// that the lanes of a rising flank fall into step - faster on synthetic columns, slower on the iterates of a converged run,
+// whose stacks are hundreds of entries deep: emptier rings mean more refills, and there the kernel is bound by those bytes.)
 template <int RC, int NRF>
-static __device__ __forceinline__ void ur4_push(UniRing4 &st, UniPrefetch<NRF> &pf, int lane, double sy, int cw, double q,
+static __device__ __forceinline__ void ur4_push(UniRing4 &st, UniPrefetch<NRF> &pf, int lane, bool act, double sy, int cw, double q,
                                                 double *__restrict__ gsy, double *__restrict__ gq, int *__restrict__ gcw,
                                                 long base, long rs, int col) {
-    if (st.cnt == RC) {  // spill the bottom entry of the ring
-        const int b = ((st.h - RC + 1) & (RC - 1)) * 64 + lane;
-        const long idx = (base + st.mem_n) * rs + col;
-        gsy[idx] = st.sy[b];
-        gq[idx] = st.q[b];
-        gcw[idx] = st.cw[b];
-        st.mem_n += 1;
-        st.cnt = RC - 1;
-        pf.n = 0;  // the prefetched entries are no longer the top of the spill area
+    if (act) {
+        if (st.cnt == RC) {
+            const int b = ((st.h - RC + 1) & (RC - 1)) * 64 + lane;
+            const long idx = (base + st.mem_n) * rs + col;
+            gsy[idx] = st.sy[b];
+            gq[idx] = st.q[b];
+            gcw[idx] = st.cw[b];
+            st.mem_n += 1;
+            st.cnt = RC - 1;
+            pf.n = 0;  // the prefetched entries are no longer the top of the spill area
+        }
+        st.h = (st.h + 1) & (RC - 1);
+        const int t = st.h * 64 + lane;
+        st.sy[t] = sy;
+        st.q[t] = q;
+        st.cw[t] = cw;
+        st.cnt += 1;
     }
-    st.h = (st.h + 1) & (RC - 1);
-    const int t = st.h * 64 + lane;
-    st.sy[t] = sy;
-    st.q[t] = q;
-    st.cw[t] = cw;
-    st.cnt += 1;
 }
 
 // prefetched entries -> ring, below its bottom entry (needs room for pf.n entries)
@@ -831,37 +840,29 @@ static __device__ __forceinline__ void ur4_prefetch(const UniRing4 &st, UniPrefe
         const long idx = (base + (st.mem_n > i ? st.mem_n - 1 - i : 0)) * rs + col;
         pf.sy[i] = gsy[idx], pf.q[i] = gq[idx], pf.cw[i] = gcw[idx];
     }
-    pf.n = st.mem_n < (long)NRF ? (int)st.mem_n : NRF;
+    pf.n = st.mem_n < NRF ? st.mem_n : NRF;
 }
 
+// a lane that has to pop finds its ring empty but has spilled entries (rare: the cooperative refill below keeps the rings
+// topped up): prefetched entries if it has them, else a blocking refill
 template <int RC, int NRF>
-static __device__ __forceinline__ bool ur4_pop(UniRing4 &st, UniPrefetch<NRF> &pf, int lane, double &sy, int &cw, double &q,
-                                               const double *__restrict__ gsy, const double *__restrict__ gq,
-                                               const int *__restrict__ gcw, long base, long rs, int col) {
-    if (st.cnt == 0) {
-        if (st.mem_n == 0) return false;
-        if (pf.n > 0) {
-            ur4_take_prefetched<RC, NRF>(st, pf, lane);
-        } else {
-            const int nref = st.mem_n >= RC / 2 ? RC / 2 : (int)st.mem_n;  // refill (independent loads, one latency)
-            for (int i = 0; i < nref; ++i) {
-                const long idx = (base + st.mem_n - 1 - i) * rs + col;
-                const int t = ((st.h - i) & (RC - 1)) * 64 + lane;
-                st.sy[t] = gsy[idx];
-                st.q[t] = gq[idx];
-                st.cw[t] = gcw[idx];
-            }
-            st.mem_n -= nref;
-            st.cnt = nref;
+static __device__ __forceinline__ void ur4_refill_dry(UniRing4 &st, UniPrefetch<NRF> &pf, int lane,
+                                                      const double *__restrict__ gsy, const double *__restrict__ gq,
+                                                      const int *__restrict__ gcw, long base, long rs, int col) {
+    if (pf.n > 0) {
+        ur4_take_prefetched<RC, NRF>(st, pf, lane);
+    } else {
+        const int nref = st.mem_n >= RC / 2 ? RC / 2 : st.mem_n;  // independent loads, one latency
+        for (int i = 0; i < nref; ++i) {
+            const long idx = (base + st.mem_n - 1 - i) * rs + col;
+            const int t = ((st.h - i) & (RC - 1)) * 64 + lane;
+            st.sy[t] = gsy[idx];
+            st.q[t] = gq[idx];
+            st.cw[t] = gcw[idx];
         }
+        st.mem_n -= nref;
+        st.cnt = nref;
     }
-    const int tp = st.h * 64 + lane;
-    sy = st.sy[tp];
-    q = st.q[tp];
-    cw = st.cw[tp];
-    st.h = (st.h - 1) & (RC - 1);
-    st.cnt -= 1;
-    return true;
 }
 
 // Cooperative, prefetched refill (round 3).  On smooth, nearly unimodal columns - what the iterates of a converging run
@@ -889,7 +890,7 @@ static __device__ __forceinline__ void ur4_refill_coop(UniRing4 &st, UniPrefetch
         }
     } else if (st.mem_n > 0 && room > 0) {
         const int want = room < NRF ? room : NRF;
-        const int nref = st.mem_n < (long)want ? (int)st.mem_n : want;
+        const int nref = st.mem_n < want ? st.mem_n : want;
         double vsy[NRF], vq[NRF];
         int vcw[NRF];
 #pragma unroll
@@ -962,40 +963,90 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
     UniRing4 st;
     UniPrefetch<NRF> pf;
     st.sy = ring_d[0], st.q = ring_d[1], st.cw = ring_i;
+    // byte addresses of this lane's slot 0 in the rings (the pooling loop addresses LDS itself)
+    const int lds_d = (int)lds_addr(&ring_d[0][0]) + lane * 8, lds_i = (int)lds_addr(&ring_i[0]) + lane * 4;
     static_assert((RC & (RC - 1)) == 0, "ring indices wrap by masking");
     double csy, ccw, curQ, cum2;  // block being built (count kept as a double), Q including it, sum of y^2
     double tsy, tcw, tQ;          // cached top of the stack below it
-    bool has_top;
+    int ht;  // 1: there is a cached top
     float levf;
     auto reset = [&]() {
         st.h = 0, st.cnt = 0, st.mem_n = 0, pf.n = 0;
         cum2 = 0.0, csy = 0.0, ccw = 1.0, curQ = 0.0;
         tsy = 0.0, tcw = 1.0, tQ = 0.0;
-        has_top = false, levf = 0.f;
+        ht = 0, levf = 0.f;
     };
     // one element: returns the prefix error; leaves (levf, ccw) = record of the block ending at this element
     auto step = [&](double v, bool first) -> double {
         if (sc.coop) ur4_refill_coop<RC, NRF>(st, pf, lane, gsy, gq, gcw, s, rs, col);
         cum2 += v * v;
-        if (!first) {  // the finished block becomes the cached top; the previous top moves into the ring
-            if (has_top) ur4_push<RC, NRF>(st, pf, lane, tsy, (int)tcw, tQ, gsy, gq, gcw, s, rs, col);
+        // the finished block becomes the cached top; the previous top moves into the ring
+        ur4_push<RC, NRF>(st, pf, lane, !first && ht != 0, tsy, (int)tcw, tQ, gsy, gq, gcw, s, rs, col);
+        if (!first) {
             tsy = csy, tcw = ccw, tQ = curQ;
-            has_top = true;
+            ht = 1;
         }
         csy = v;
         ccw = 1.0;
-        while (has_top && csy * tcw <= tsy * ccw) {  // mean(cur) <= mean(top): pool
-            csy += tsy;
-            ccw += tcw;
-            int icw;
-            has_top = ur4_pop<RC, NRF>(st, pf, lane, tsy, icw, tQ, gsy, gq, gcw, s, rs, col);
-            tcw = (double)icw;
+        // pooling: while mean(cur) <= mean(top).  The loop is the divergent core of the kernel and the kernel is bound by
+        // instruction issue, so the loop is written out (the compiler's version of the same source carries 70-85 instructions
+        // per trip, most of them copies and mask algebra; this one 27): its exits - no lane pools / a pooling lane has run dry -
+        // are decided wave-wide, what remains under the lane predicate is the straight-line pop.  With an empty ring the pop
+        // reads a slot whose contents are not used (ht = 0) and moves h, which is as good a position as any other.
+        while (true) {
+            int dry_exit;
+            double t0, t1;
+            unsigned long long m_need, m_b, m_save;
+            int a1, a2, icw;
+            asm volatile(
+                "s_mov_b32 %[flag], 0\n"
+                "L_pool_%=:\n"
+                "v_mul_f64 %[t0], %[csy], %[tcw]\n"
+                "v_mul_f64 %[t1], %[tsy], %[ccw]\n"
+                "v_cmp_ne_u32_e32 vcc, 0, %[ht]\n"
+                "v_cmp_le_f64_e64 %[mn], %[t0], %[t1]\n"
+                "s_and_b64 %[mn], %[mn], vcc\n"
+                "s_cbranch_scc0 L_done_%=\n"
+                "v_cmp_eq_u32_e32 vcc, 0, %[cnt]\n"
+                "v_cmp_lt_i32_e64 %[mb], 0, %[memn]\n"
+                "s_and_b64 vcc, vcc, %[mb]\n"
+                "s_and_b64 vcc, vcc, %[mn]\n"
+                "s_cbranch_scc1 L_dry_%=\n"
+                "s_and_saveexec_b64 %[ms], %[mn]\n"
+                "v_add_f64 %[csy], %[csy], %[tsy]\n"
+                "v_add_f64 %[ccw], %[ccw], %[tcw]\n"
+                "v_lshl_add_u32 %[a1], %[h], 9, %[ldsd]\n"
+                "v_lshl_add_u32 %[a2], %[h], 8, %[ldsi]\n"
+                "ds_read_b64 %[tsy], %[a1]\n"
+                "ds_read_b64 %[tq], %[a1] offset:%[qoff]\n"
+                "ds_read_b32 %[icw], %[a2]\n"
+                "v_cmp_lt_i32_e32 vcc, 0, %[cnt]\n"
+                "v_cndmask_b32_e64 %[ht], 0, 1, vcc\n"
+                "v_add_u32_e32 %[h], -1, %[h]\n"
+                "v_and_b32_e32 %[h], %[msk], %[h]\n"
+                "v_max_i32_e32 %[cnt], 1, %[cnt]\n"
+                "v_add_u32_e32 %[cnt], -1, %[cnt]\n"
+                "s_waitcnt lgkmcnt(0)\n"
+                "v_cvt_f64_i32_e32 %[tcw], %[icw]\n"
+                "s_mov_b64 exec, %[ms]\n"
+                "s_branch L_pool_%=\n"
+                "L_dry_%=:\n"
+                "s_mov_b32 %[flag], 1\n"
+                "L_done_%=:\n"
+                : [flag] "=&s"(dry_exit), [t0] "=&v"(t0), [t1] "=&v"(t1), [mn] "=&s"(m_need), [mb] "=&s"(m_b), [ms] "=&s"(m_save),
+                  [a1] "=&v"(a1), [a2] "=&v"(a2), [icw] "=&v"(icw), [csy] "+v"(csy), [ccw] "+v"(ccw), [tsy] "+v"(tsy),
+                  [tcw] "+v"(tcw), [tq] "+v"(tQ), [ht] "+v"(ht), [h] "+v"(st.h), [cnt] "+v"(st.cnt)
+                : [memn] "v"(st.mem_n), [ldsd] "v"(lds_d), [ldsi] "v"(lds_i), [qoff] "n"(RC * 64 * 8), [msk] "n"(RC - 1)
+                : "vcc", "scc", "memory");
+            if (dry_exit == 0) break;  // wave-uniform
+            if (ht != 0 && csy * tcw <= tsy * ccw && st.cnt == 0 && st.mem_n > 0)
+                ur4_refill_dry<RC, NRF>(st, pf, lane, gsy, gq, gcw, s, rs, col);
         }
         // a block with a negative mean is clamped to level 0 and contributes q = 0; every block below it has a smaller
         // mean, so their Q is exactly 0 too and the prefix error comes out as cum2 without a special case
         const double lev = csy * rcp_count(ccw);
         const double levc = nonneg ? fmax(lev, 0.0) : lev;
-        curQ = (has_top ? tQ : 0.0) + csy * levc;
+        curQ = (ht != 0 ? tQ : 0.0) + csy * levc;
         levf = (float)levc;
         return cum2 - curQ;
     };
