@@ -236,7 +236,9 @@ int mcl_profile_read(mcl_context *ctx, int32_t which, double *total_ms, int32_t 
  * switches select other kernel forms or other summation orders (MCL_SEG_ROWS, MCL_XC_WAVES, MCL_NO_ROWS64, MCL_NO_SWEEP, ...)
  * and move results at the 1e-6 level.  mcl_active_switches() returns the space-separated names of the MCL_* switches the
  * context found in its environment ("" = clean); a host should refuse, or at least log, a non-empty answer
- * (matcouply_amd.cmf_aoadmm issues a RuntimeWarning). */
+ * (matcouply_amd.cmf_aoadmm issues a RuntimeWarning).  A library built with -DMCL_NO_ENV_SWITCHES
+ * (MCL_BUILD_DEFS=-DMCL_NO_ENV_SWITCHES python -c "import __graft_entry__ as g; g.build()") never consults the
+ * environment: every switch keeps its default and mcl_active_switches() is always "". */
 int mcl_reload_switches(mcl_context *ctx);
 const char *mcl_active_switches(const mcl_context *ctx);
 

@@ -146,6 +146,10 @@ int64_t plan(mcl_context *c, char *base) {
 }
 
 void read_switches(mcl_switches &w) {
+#ifdef MCL_NO_ENV_SWITCHES  // release build (MCL_BUILD_DEFS=-DMCL_NO_ENV_SWITCHES): the environment is not consulted
+    w = mcl_switches{};
+    return;
+#endif
     auto flag = [](const char *name) { return getenv(name) != nullptr; };
     auto num = [](const char *name, int dflt) {
         const char *e = getenv(name);
@@ -176,6 +180,9 @@ std::string switches_in_env() {
         "MCL_BSEG_ROWS", "MCL_XC_WAVES", "MCL_XT_WAVES", "MCL_SWEEP_WAVES", "MCL_XC_DBG", "MCL_XT_DBG", "MCL_XT_DEPTH",
         "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT"};
     std::string out;
+#ifdef MCL_NO_ENV_SWITCHES
+    return out;
+#endif
     for (const char *n : names)
         if (getenv(n) != nullptr) out += (out.empty() ? "" : " ") + std::string(n);
     return out;
