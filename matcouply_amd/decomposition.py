@@ -994,12 +994,12 @@ def cmf_aoadmm(
             n_ran = (stop_it - done + 1) if stopped else n_now
             ring_h, verdict_h = ring[base:base + n_ran].cpu().numpy(), verdict[base:base + n_ran].cpu().numpy()
             feasibility_gaps.extend(read_diag_rows(ring_h)[1])
-            for v_rec, v_loss, _, v_flags in verdict_h:
-                flags = int(v_flags)
-                feasibility_criterion = bool(flags & _engine.VERDICT_FEASIBLE) if feasibility_tol else feasibility_tol
-                if flags & _engine.VERDICT_LOSS_EVALUATED:
-                    rec_errors.append(float(v_rec))
-                    losses.append(float(v_loss))
+            if len(verdict_h):
+                flags = verdict_h[:, 3].astype(np.int64)
+                feasibility_criterion = bool(flags[-1] & _engine.VERDICT_FEASIBLE) if feasibility_tol else feasibility_tol
+                evaluated = (flags & _engine.VERDICT_LOSS_EVALUATED) != 0
+                rec_errors.extend(verdict_h[evaluated, 0].tolist())
+                losses.extend(verdict_h[evaluated, 1].tolist())
             done += n_ran
             if not stopped:
                 code = 0
@@ -1022,12 +1022,12 @@ def cmf_aoadmm(
                 n_now, tol, absolute_tol, feasibility_tol, initial_loss=losses[-1], penalty_weight=weights,
                 evaluate_loss_always=return_errors, update_A=update_A, update_B=update_B_is, update_C=update_C)
             feasibility_gaps.extend(read_diag_rows(ring_h)[1])
-            for v_rec, v_loss, _, v_flags in verdict_h:
-                flags = int(v_flags)
-                feasibility_criterion = bool(flags & _engine.VERDICT_FEASIBLE) if feasibility_tol else feasibility_tol
-                if flags & _engine.VERDICT_LOSS_EVALUATED:  # not on infeasible iterates unless errors are recorded (Q10)
-                    rec_errors.append(float(v_rec))
-                    losses.append(float(v_loss))
+            if len(verdict_h):
+                flags = verdict_h[:, 3].astype(np.int64)
+                feasibility_criterion = bool(flags[-1] & _engine.VERDICT_FEASIBLE) if feasibility_tol else feasibility_tol
+                evaluated = (flags & _engine.VERDICT_LOSS_EVALUATED) != 0  # not on infeasible iterates unless errors are recorded (Q10)
+                rec_errors.extend(verdict_h[evaluated, 0].tolist())
+                losses.extend(verdict_h[evaluated, 1].tolist())
             done += n_ran
         it = done - 1
         if code:
