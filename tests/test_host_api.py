@@ -247,6 +247,26 @@ def test_seeded_keyword_run_pins_rng_order(checker_engine):
     assert rel_err(np.concatenate(admm_vars.duals[1][1]), arrs["dual_B1"]) < 1e-6
 
 
+def test_vectorised_ring_readers_equal_the_per_iteration_host_loop(checker_engine, capsys):
+    """The fixed-count call (mcl_iterate) and the call under a stopping rule (mcl_run) turn their diagnostics / verdict rings
+    into rec_errors, losses and feasibility gaps in ONE vectorised pass; `verbose` takes the per-iteration host loop
+    (read_diag + _StopRule).  Same lists, to the bit - values, lengths and the stopping iteration."""
+    c1 = load_npz("c1_data.npz")
+    matrices = split_rows(c1["X"], c1["row_ptr"])
+    kw = dict(non_negative=True, l1_penalty={2: 0.1}, l2_norm_bound={1: 1.0}, l2_penalty={0: 0.05}, parafac2=True,
+              return_errors=True, random_state=0)
+    for tols in (dict(tol=None, absolute_tol=None, n_iter_max=12), dict(tol=1e-3, absolute_tol=1e-10, n_iter_max=60)):
+        _, quiet = dec.cmf_aoadmm(matrices, 3, **kw, **tols)
+        _, loud = dec.cmf_aoadmm(matrices, 3, verbose=1, **kw, **tols)
+        capsys.readouterr()
+        assert quiet.n_iter == loud.n_iter and quiet.message == loud.message
+        assert list(quiet.rec_errors) == list(loud.rec_errors) and list(quiet.regularized_loss) == list(loud.regularized_loss)
+        assert len(quiet.feasibility_gaps) == len(loud.feasibility_gaps)
+        for ga, gb in zip(quiet.feasibility_gaps, loud.feasibility_gaps):
+            assert [list(m) for m in ga] == [list(m) for m in gb]
+        assert quiet.satisfied_feasibility_condition == loud.satisfied_feasibility_condition
+
+
 README_KW = dict(non_negative=True, l1_penalty={2: 0.1}, l2_norm_bound=[1, 1, 0], parafac2=True, unimodal={1: True},
                  constant_feasibility_penalty=True, random_state=0)
 
