@@ -595,10 +595,11 @@ def cmf_aoadmm(
     rank's rows at ``cmf.rows_of_rank`` (the ADMM variables of mode 0 stay rank-local).  Per outer iteration
     the ranks exchange the fp64 normal equations ``[G | R]`` of the C-phase, the diagnostic sums while a stopping rule is
     active, one ``r*r + 1`` reduction per inner iteration with PARAFAC2 and a scalar MAX per phase with a constant
-    feasibility penalty.  NOT supported with ``group=`` (``NotImplementedError``): ``TotalVariationPenalty`` on any mode,
-    host-evaluated (user-defined / overridden) penalties on mode 1, matrix penalties on mode 0 other than the L2 ball
-    (PARAFAC2 is mode 1 only; the L2 ball on A needs ``constant_feasibility_penalty``, as in the reference).  None of these
-    occurs in the BASELINE configurations.
+    feasibility penalty.  A ``TotalVariationPenalty`` on the ``B_i`` or on ``C`` works under ``group=`` (its value, summed on
+    the host, travels with the diagnostic sums; the run then takes the host-driven loop).  NOT supported with ``group=``
+    (``NotImplementedError``): host-evaluated (user-defined / overridden) penalties on mode 1 and matrix penalties on mode 0
+    other than the L2 ball - total variation along the rows of ``A`` included (PARAFAC2 is mode 1 only; the L2 ball on A
+    needs ``constant_feasibility_penalty``, as in the reference).  None of these occurs in the BASELINE configurations.
 
     >>> import numpy as np, matcouply_amd
     >>> len(matcouply_amd.decomposition._listify({1: 0.5}, "l1_penalty"))
@@ -877,6 +878,8 @@ def cmf_aoadmm(
                 mode_gaps.append(np.sqrt(d[base]) / fnorm)
                 if isinstance(reg, penalties.L1Penalty):
                     reg_penalty += reg.reg_strength * d[base + 1]
+                elif sharded and mode == 1 and native[mode][k].kind == _engine.PEN_TV:
+                    reg_penalty += d[base + 1]  # this rank's matrices only: summed over the ranks with the vector (diagnostics())
                 elif native[mode][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV):  # value computed on device tensors
                     factor = [eng.B[sl] for sl in row_slices] if mode == 1 else (eng.A if mode == 0 else eng.C)
                     reg_penalty += float(reg.penalty(factor))
@@ -912,6 +915,12 @@ def cmf_aoadmm(
 
     def diagnostics():
         vec = eng.diagnostics(include_replicated=(rank_id == 0))
+        if sharded:
+            # a total-variation penalty on the B_i: its value is summed on the host (TotalVariationPenalty.penalty) over THIS
+            # rank's matrices - it travels in the penalty-value slot of the vector and is summed over the ranks with it
+            for k, reg in enumerate(regs[1]):
+                if native[1][k].kind == _engine.PEN_TV:
+                    vec[_engine.DIAG_REG + (_engine.MCL_MAX_REGS + k) * 2 + 1] = float(reg.penalty([eng.B[sl] for sl in row_slices]))
         all_reduce(vec)
         return read_diag(vec)
 
@@ -932,9 +941,7 @@ def cmf_aoadmm(
     host_value = any(r.kind == _engine.PEN_TV for m in range(3) for r in native[m])  # penalty value needs a host call
     fast_path = ((not (tol or absolute_tol)) and not sharded and not verbose and n_iter_max > 0 and not any(has_ext)
                  and not host_value)
-    if host_value and sharded:
-        raise NotImplementedError("TotalVariationPenalty is not supported with group= (its penalty value is summed on the host)")
-    lazy_diag = (not (tol or absolute_tol)) and sharded and not verbose and n_iter_max > 0
+    lazy_diag = (not (tol or absolute_tol)) and sharded and not verbose and n_iter_max > 0 and not host_value
     # stopping rule on the device (mcl_run): single device, every penalty native, silent.  (tol set with absolute_tol=None is
     # a TypeError in the reference's comparison - the host loop below raises it the same way.)
     device_stop = (bool(tol or absolute_tol) and not sharded and not verbose and n_iter_max > 0 and not any(has_ext)

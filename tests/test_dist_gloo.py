@@ -30,6 +30,9 @@ CASES = {
     # ranks), PARAFAC2 + unimodality + L2 ball on the B_i, L1 on C, constant feasibility penalty
     "readme_stack": dict(non_negative=True, l1_penalty={2: 0.1}, l2_norm_bound=[1, 1, 0], parafac2=True,
                          unimodal={1: True}, constant_feasibility_penalty=True),
+    # total variation on the B_i and on C: the penalty value is summed on the host - under sharding this rank's share travels in
+    # the diagnostics vector (mode 1) / is counted once (replicated mode 2)
+    "tv_B_and_C": dict(),
 }
 
 
@@ -56,6 +59,10 @@ def _explicit_state(case, mats, r, seed=9):
         regs[0] = [("nn", mk((I, r)), mk((I, r)))]
         regs[1] = [("nn", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
         regs[2] = [("l1nn", mk((K, r)), mk((K, r)))]
+    elif case == "tv_B_and_C":
+        regs[0] = [("nn", mk((I, r)), mk((I, r)))]
+        regs[1] = [("tv", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
+        regs[2] = [("tvl1", mk((K, r)), mk((K, r)))]
     elif case == "readme_stack":
         regs[0] = [("ballnn", mk((I, r)), mk((I, r)))]
         regs[1] = [("pf2", ([np.eye(m.shape[0], r) for m in mats], mk((r, r))), [mk((m.shape[0], r)) for m in mats]),
@@ -94,6 +101,10 @@ def _build(regs_spec, lo, hi):
                 out[m].append(pen.L2Ball(1.0, non_negativity=True, aux_init=aux, dual_init=dual))
             elif kind == "uninn":
                 out[m].append(pen.Unimodality(non_negativity=True, aux_init=aux, dual_init=dual))
+            elif kind == "tv":
+                out[m].append(pen.TotalVariationPenalty(0.05, aux_init=aux, dual_init=dual))
+            elif kind == "tvl1":
+                out[m].append(pen.TotalVariationPenalty(0.03, l1_strength=0.02, aux_init=aux, dual_init=dual))
     return out
 
 
