@@ -99,6 +99,7 @@ P0 = [np.eye(j, 4) for j in J]; D0 = mk((4, 4)); dualP = [mk((j, 4)) for j in J]
 auxL, dualL = [mk((j, 4)) for j in J], [mk((j, 4)) for j in J]
 auxU, dualU = [mk((j, 4)) for j in J], [mk((j, 4)) for j in J]
 README_STACK = os.environ.get("STACK") == "readme"  # README.rst:66-91 of the reference: L2 ball on A, unimodal B_i
+TV_STACK = os.environ.get("STACK") == "tv"
 # STACK = "pf2_stop": the PARAFAC2 stack WITH a stopping rule - under sharding it is evaluated on the device too
 # (mcl_gate_begin / mcl_verdict on the all-reduced vector; chunks of 8 iterations, gated kernels behind a hit)
 STOP = dict(n_iter_max=60, tol=2e-2, absolute_tol=1e-12, feasibility_tol=float("inf")) if os.environ.get("STACK") == "pf2_stop" \
@@ -108,19 +109,23 @@ def run(lo, hi, group):
             [pen.Parafac2(aux_init=([p.copy() for p in P0[lo:hi]], D0.copy()), dual_init=[d.copy() for d in dualP[lo:hi]]),
              pen.L2Ball(1.0, aux_init=[a.copy() for a in auxL[lo:hi]], dual_init=[d.copy() for d in dualL[lo:hi]])],
             [pen.L1Penalty(0.05, non_negativity=True, aux_init=auxC.copy(), dual_init=dualC.copy())]]
+    if TV_STACK:  # total variation on the B_i (value summed over the ranks with the diagnostics vector) and on the replicated C
+        regs[1] = [pen.TotalVariationPenalty(0.05, aux_init=[a.copy() for a in auxL[lo:hi]], dual_init=[d.copy() for d in dualL[lo:hi]])]
+        regs[2] = [pen.TotalVariationPenalty(0.03, l1_strength=0.02, aux_init=auxC.copy(), dual_init=dualC.copy())]
     if README_STACK:
         regs[0] = [pen.L2Ball(1.0, non_negativity=True, aux_init=auxA[lo:hi].copy(), dual_init=dualA[lo:hi].copy())]
         regs[1].insert(1, pen.Unimodality(non_negativity=True, aux_init=[a.copy() for a in auxU[lo:hi]],
                                           dual_init=[d.copy() for d in dualU[lo:hi]]))
     return dec.cmf_aoadmm(mats[lo:hi], 4, init=(None, (A0[lo:hi].copy(), [b.copy() for b in B0[lo:hi]], C0.copy())), regs=regs,
-                          return_errors=True, constant_feasibility_penalty=True, group=group, **STOP)
+                          return_errors=True, constant_feasibility_penalty=not TV_STACK, group=group, **STOP)
 bounds = [0, 2, 6]
 cmf, diag = run(bounds[rank], bounds[rank + 1], dist.group.WORLD)
 if rank == 0:
     ref_cmf, ref_diag = run(0, 6, None)
     err = dict(A=float(np.linalg.norm(cmf[1][0] - ref_cmf[1][0][:2]) / np.linalg.norm(ref_cmf[1][0][:2])),
                C=float(np.linalg.norm(cmf[1][2] - ref_cmf[1][2]) / np.linalg.norm(ref_cmf[1][2])),
-               rec=float(max(abs(a - b) / b for a, b in zip(diag.rec_errors, ref_diag.rec_errors))))
+               rec=float(max(abs(a - b) / b for a, b in zip(diag.rec_errors, ref_diag.rec_errors))),
+               loss=float(max(abs(a - b) / b for a, b in zip(diag.regularized_loss, ref_diag.regularized_loss))))
     if STOP["tol"]:
         assert (diag.n_iter, diag.message) == (ref_diag.n_iter, ref_diag.message), (diag.n_iter, ref_diag.n_iter)
         assert 1 <= diag.n_iter < STOP["n_iter_max"] and diag.message.startswith("FEASIBILITY GAP CRITERION AND RELATIVE")
@@ -131,7 +136,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("stack", ["pf2", "readme", "pf2_stop"])
+@pytest.mark.parametrize("stack", ["pf2", "readme", "pf2_stop", "tv"])
 def test_two_ranks_sharing_the_gpu_equal_single_process(tmp_path, stack):
     """cmf_aoadmm(group=) with the REAL engine: 2 processes share cuda:0, collectives over gloo (RCCL refuses two ranks on one
     device); PARAFAC2 + constant feasibility penalty exercise every reduction of the step path; the "readme" stack adds the
