@@ -596,8 +596,10 @@ def cmf_aoadmm(
     the ranks exchange the fp64 normal equations ``[G | R]`` of the C-phase, the diagnostic sums while a stopping rule is
     active, one ``r*r + 1`` reduction per inner iteration with PARAFAC2 and a scalar MAX per phase with a constant
     feasibility penalty.  A ``TotalVariationPenalty`` on the ``B_i`` or on ``C`` works under ``group=`` (its value, summed on
-    the host, travels with the diagnostic sums; the run then takes the host-driven loop).  NOT supported with ``group=``
-    (``NotImplementedError``): host-evaluated (user-defined / overridden) penalties on mode 1 and matrix penalties on mode 0
+    the host, travels with the diagnostic sums; the run then takes the host-driven loop), and so does a host-evaluated
+    (user-defined / overridden) ``MatrixPenalty`` on the ``B_i`` - its prox acts on one matrix at a time.  NOT supported with
+    ``group=`` (``NotImplementedError``): host-evaluated ``MatricesPenalty`` classes on mode 1 (they may couple matrices
+    of different ranks) and matrix penalties on mode 0
     other than the L2 ball - total variation along the rows of ``A`` included (PARAFAC2 is mode 1 only; the L2 ball on A
     needs ``constant_feasibility_penalty``, as in the reference).  None of these occurs in the BASELINE configurations.
 
@@ -775,8 +777,11 @@ def cmf_aoadmm(
             eng.B_solve()
             for k, reg in enumerate(native[1]):
                 if reg.kind == _engine.PEN_EXTERNAL:
-                    if sharded:
-                        raise NotImplementedError("host-evaluated penalties on mode 1 are not supported with group=")
+                    if sharded and not isinstance(regs[1][k], penalties.MatrixPenalty):
+                        # a MatricesPenalty may couple the B_i of different ranks (as PARAFAC2 does); a MatrixPenalty's prox
+                        # acts on one matrix at a time, so every rank can evaluate it on its own matrices
+                        raise NotImplementedError("host-evaluated penalties on mode 1 that act on all matrices at once "
+                                                  "(MatricesPenalty) are not supported with group=")
                     host_prox_B(k)
                     continue
                 eng.B_prox_local(k)
@@ -878,7 +883,7 @@ def cmf_aoadmm(
                 mode_gaps.append(np.sqrt(d[base]) / fnorm)
                 if isinstance(reg, penalties.L1Penalty):
                     reg_penalty += reg.reg_strength * d[base + 1]
-                elif sharded and mode == 1 and native[mode][k].kind == _engine.PEN_TV:
+                elif sharded and mode == 1 and native[mode][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV):
                     reg_penalty += d[base + 1]  # this rank's matrices only: summed over the ranks with the vector (diagnostics())
                 elif native[mode][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV):  # value computed on device tensors
                     factor = [eng.B[sl] for sl in row_slices] if mode == 1 else (eng.A if mode == 0 else eng.C)
@@ -916,10 +921,11 @@ def cmf_aoadmm(
     def diagnostics():
         vec = eng.diagnostics(include_replicated=(rank_id == 0))
         if sharded:
-            # a total-variation penalty on the B_i: its value is summed on the host (TotalVariationPenalty.penalty) over THIS
-            # rank's matrices - it travels in the penalty-value slot of the vector and is summed over the ranks with it
+            # penalties on the B_i whose value is summed on the host (total variation, host-evaluated MatrixPenalty classes):
+            # the value over THIS rank's matrices travels in the penalty-value slot of the vector and is summed over the
+            # ranks with it
             for k, reg in enumerate(regs[1]):
-                if native[1][k].kind == _engine.PEN_TV:
+                if native[1][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV):
                     vec[_engine.DIAG_REG + (_engine.MCL_MAX_REGS + k) * 2 + 1] = float(reg.penalty([eng.B[sl] for sl in row_slices]))
         all_reduce(vec)
         return read_diag(vec)
@@ -938,7 +944,8 @@ def cmf_aoadmm(
     feasibility_criterion = None
 
     it = -1  # Needed if n_iter_max <= 0
-    host_value = any(r.kind == _engine.PEN_TV for m in range(3) for r in native[m])  # penalty value needs a host call
+    # penalty values that need a host call per iteration (the device-resident loops below do not apply)
+    host_value = any(r.kind in (_engine.PEN_TV, _engine.PEN_EXTERNAL) for m in range(3) for r in native[m])
     fast_path = ((not (tol or absolute_tol)) and not sharded and not verbose and n_iter_max > 0 and not any(has_ext)
                  and not host_value)
     lazy_diag = (not (tol or absolute_tol)) and sharded and not verbose and n_iter_max > 0 and not host_value

@@ -100,6 +100,16 @@ auxL, dualL = [mk((j, 4)) for j in J], [mk((j, 4)) for j in J]
 auxU, dualU = [mk((j, 4)) for j in J], [mk((j, 4)) for j in J]
 README_STACK = os.environ.get("STACK") == "readme"  # README.rst:66-91 of the reference: L2 ball on A, unimodal B_i
 TV_STACK = os.environ.get("STACK") == "tv"
+EXT_STACK = os.environ.get("STACK") == "ext"
+class Ridge(pen.MatrixPenalty):
+    """alpha * ||x||^2: prox x / (1 + 2 alpha / rho)"""
+    def __init__(self, alpha, aux_init="random_uniform", dual_init="random_uniform"):
+        super().__init__(aux_init, dual_init)
+        self.alpha = alpha
+    def factor_matrix_update(self, factor_matrix, feasibility_penalty, aux):
+        return factor_matrix / (1.0 + 2.0 * self.alpha / feasibility_penalty)
+    def penalty(self, x):
+        return sum(self.alpha * float((xi * xi).sum()) for xi in (x if isinstance(x, (list, tuple)) else [x]))
 # STACK = "pf2_stop": the PARAFAC2 stack WITH a stopping rule - under sharding it is evaluated on the device too
 # (mcl_gate_begin / mcl_verdict on the all-reduced vector; chunks of 8 iterations, gated kernels behind a hit)
 STOP = dict(n_iter_max=60, tol=2e-2, absolute_tol=1e-12, feasibility_tol=float("inf")) if os.environ.get("STACK") == "pf2_stop" \
@@ -112,12 +122,14 @@ def run(lo, hi, group):
     if TV_STACK:  # total variation on the B_i (value summed over the ranks with the diagnostics vector) and on the replicated C
         regs[1] = [pen.TotalVariationPenalty(0.05, aux_init=[a.copy() for a in auxL[lo:hi]], dual_init=[d.copy() for d in dualL[lo:hi]])]
         regs[2] = [pen.TotalVariationPenalty(0.03, l1_strength=0.02, aux_init=auxC.copy(), dual_init=dualC.copy())]
+    if EXT_STACK:  # a user-defined MatrixPenalty on the B_i: prox and value evaluated on the host, per matrix, on every rank
+        regs[1] = [Ridge(0.3, aux_init=[a.copy() for a in auxL[lo:hi]], dual_init=[d.copy() for d in dualL[lo:hi]])]
     if README_STACK:
         regs[0] = [pen.L2Ball(1.0, non_negativity=True, aux_init=auxA[lo:hi].copy(), dual_init=dualA[lo:hi].copy())]
         regs[1].insert(1, pen.Unimodality(non_negativity=True, aux_init=[a.copy() for a in auxU[lo:hi]],
                                           dual_init=[d.copy() for d in dualU[lo:hi]]))
     return dec.cmf_aoadmm(mats[lo:hi], 4, init=(None, (A0[lo:hi].copy(), [b.copy() for b in B0[lo:hi]], C0.copy())), regs=regs,
-                          return_errors=True, constant_feasibility_penalty=not TV_STACK, group=group, **STOP)
+                          return_errors=True, constant_feasibility_penalty=not (TV_STACK or EXT_STACK), group=group, **STOP)
 bounds = [0, 2, 6]
 cmf, diag = run(bounds[rank], bounds[rank + 1], dist.group.WORLD)
 if rank == 0:
@@ -136,7 +148,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("stack", ["pf2", "readme", "pf2_stop", "tv"])
+@pytest.mark.parametrize("stack", ["pf2", "readme", "pf2_stop", "tv", "ext"])
 def test_two_ranks_sharing_the_gpu_equal_single_process(tmp_path, stack):
     """cmf_aoadmm(group=) with the REAL engine: 2 processes share cuda:0, collectives over gloo (RCCL refuses two ranks on one
     device); PARAFAC2 + constant feasibility penalty exercise every reduction of the step path; the "readme" stack adds the
