@@ -1115,13 +1115,15 @@ int mcl_run(mcl_context *c, int32_t n_iter_max, int32_t update_A, int32_t update
     };
     set_gate(c->gate);
     int rc = 0, enqueued = 0;
+    // the status words are written by the device (mapped pinned memory): every read in the wait loop is a volatile read
+    const volatile mcl_run_status *seen = status;
     for (int it = 0; it < n_iter_max && rc == 0; ++it) {
         // bounded run-ahead: wait (without synchronising the stream) until the device is at most `ahead` verdicts behind
         long spins = 0;
-        while (!status->stopped && it - status->progress >= ahead) {
+        while (!seen->stopped && it - seen->progress >= ahead) {
             if ((++spins & 0x3fff) == 0) {  // every 16 K spins: is the stream still working?
                 const hipError_t q = hipStreamQuery(c->stream);
-                if (q != hipErrorNotReady && it - status->progress >= ahead && !status->stopped) {
+                if (q != hipErrorNotReady && it - seen->progress >= ahead && !seen->stopped) {
                     rc = fail(c, q == hipSuccess ? "mcl_run: the stream drained without the verdict kernel reporting progress"
                                                  : std::string("mcl_run: ") + hipGetErrorString(q));
                     break;
@@ -1129,7 +1131,7 @@ int mcl_run(mcl_context *c, int32_t n_iter_max, int32_t update_A, int32_t update
             }
             __builtin_ia32_pause();
         }
-        if (rc || status->stopped) break;
+        if (rc || seen->stopped) break;
         if (update_B) rc = mcl_update_B(c);
         if (rc == 0 && update_C) {
             rc = mcl_update_C_local(c);
