@@ -591,6 +591,8 @@ def main():
                                    "sample": "not timed at N > 1: see the cpu_baseline of the N = 1 line of the same workload"}
         print(json.dumps(out), flush=True)
     if world > 1:
+        # the engine's own communicator (`direct`) is left to process exit: nothing more is sent on it, and tearing it down here
+        # would add a collective step that can only delay or block the exit of a finished run
         dist.destroy_process_group()
 
 

@@ -115,11 +115,9 @@ class DirectComm:
             self.lib.ncclCommDestroy(self._comm)
             self._comm = ctypes.c_void_p()
 
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+    # no __del__: a communicator still alive at interpreter shutdown is left to process exit - ncclCommDestroy from a finaliser
+    # (after torch.distributed or the HIP runtime have shut down, or while peers are already gone) can block or crash the exit
+    # of an otherwise successful run; hosts that want it released call close() on every rank, after a barrier
 
     @classmethod
     def try_create(cls, group):
