@@ -260,7 +260,7 @@ def spawn_ranks(n):
     return rc if rc else (0 if json_lines else 1)
 
 
-def api_block(cfg, X, row_ptr, n_short=100, n_long=400):
+def api_block(cfg, X, row_ptr, n_short=100, n_long=1000):
     """Outer iterations / s of the PUBLIC call - `cmf_aoadmm(PackedMatrices, rank, ...)` - on the resident data, with
     `tol=None` (fixed iteration count: mcl_iterate) and with the DEFAULT tolerances (tol=1e-8, absolute_tol=1e-10,
     feasibility_tol=1e-4: the stopping rule evaluated on the device, mcl_run).  Every call pays the set-up of the
