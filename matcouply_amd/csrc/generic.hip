@@ -1021,9 +1021,9 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                 "ds_read_b64 %[tq], %[a1] offset:%[qoff]\n"
                 "ds_read_b32 %[icw], %[a2]\n"
                 "v_cmp_lt_i32_e32 vcc, 0, %[cnt]\n"
+                "v_add_u32_e32 %[h], -1, %[h]\n"      // two VALU instructions between the compare and the select that reads
+                "v_and_b32_e32 %[h], %[msk], %[h]\n"  // its VCC: gfx940+ needs two wait states there (no interlock)
                 "v_cndmask_b32_e64 %[ht], 0, 1, vcc\n"
-                "v_add_u32_e32 %[h], -1, %[h]\n"
-                "v_and_b32_e32 %[h], %[msk], %[h]\n"
                 "v_max_i32_e32 %[cnt], 1, %[cnt]\n"
                 "v_add_u32_e32 %[cnt], -1, %[cnt]\n"
                 "s_waitcnt lgkmcnt(0)\n"
