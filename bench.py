@@ -67,6 +67,24 @@ CONFIGS["r32"] = dict(CONFIGS["c3"], r=32, desc="rank-32 variant of config 3: I=
 CONFIGS["c2"]["api_kwargs"] = dict(non_negative=True)
 CONFIGS["c3"]["api_kwargs"] = dict(non_negative=True, l1_penalty={2: 0.1})
 CONFIGS["c4"]["api_kwargs"] = dict(parafac2=True, l2_norm_bound={1: 1.0})
+_T0 = time.perf_counter()
+WALL_S = {}  # wall time of every leg of this command (rank 0), printed on stderr as it goes and in the JSON line
+
+
+def leg(name, t_start):
+    """Record the wall time of one leg and say so on stderr (the JSON line on stdout stays the only stdout output)."""
+    dt = time.perf_counter() - t_start
+    WALL_S[name] = round(WALL_S.get(name, 0.0) + dt, 3)
+    if int(os.environ.get("RANK", "0")) == 0:
+        try:  # bytes this process has read through read() so far (files, libraries loaded with read): names a cold-cache leg
+            with open("/proc/self/io") as f:
+                rchar = int(f.read().split("rchar:")[1].split()[0]) / 1e6
+        except (OSError, ValueError, IndexError):
+            rchar = float("nan")
+        print(f"[bench] {name}: {dt:.2f} s (t+{time.perf_counter() - _T0:.1f} s, {rchar:.0f} MB read so far)", file=sys.stderr, flush=True)
+    return time.perf_counter()
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix rate (v_mfma_f32_16x16x4_f32: 256 flop/cycle/CU)
 
@@ -76,6 +94,7 @@ def make_shard(cfg, rank, world, device, seed=0):
     import torch
 
     I, J, K, r = cfg["I"], cfg["J"], cfg["K"], cfg["r"]
+    from matcouply_amd._engine import cmf_to_packed
     from matcouply_amd.decomposition import partition_slabs
 
     J_all = np.random.RandomState(0).randint(128, 1025, I) if J == "ragged" else np.full(I, J)
@@ -97,16 +116,18 @@ def make_shard(cfg, rank, world, device, seed=0):
             A_t = torch.rand((n, r), generator=g, device=device) + 0.1
             mu = torch.rand((n, 1, r), generator=g, device=device)
             sig = 0.05 + 0.2 * torch.rand((n, 1, r), generator=g, device=device)
-            Xc = torch.einsum("ijr,ir,kr->ijk", torch.exp(-0.5 * ((t - mu) / sig) ** 2), A_t, C_true)
+            B_t = torch.exp(-0.5 * ((t - mu) / sig) ** 2).reshape(n * J, r).contiguous()
+            Xc = cmf_to_packed(A_t, B_t, C_true, row_ptr[:n + 1])
             Xc += 0.05 * torch.randn(Xc.shape, generator=g, device=device)
-            X[i0 * J:(i0 + n) * J] = Xc.reshape(n * J, K)
+            X[i0 * J:(i0 + n) * J] = Xc
             del Xc
         return X, row_ptr, I_loc
     A_true = torch.rand((I_loc, r), generator=g, device=device) + 0.1
-    B_true = torch.rand((I_loc, J, r), generator=g, device=device)
-    X = torch.einsum("ijr,ir,kr->ijk", B_true, A_true, C_true)
+    B_true = torch.rand((I_loc * J, r), generator=g, device=device)
+    # the library's own dense-reconstruction kernel (mcl_cmf_to_packed), not a torch GEMM: the bench then never loads
+    # rocBLAS / hipBLASLt and their kernel libraries (hundreds of MB to page in on a cold box)
+    X = cmf_to_packed(A_true, B_true, C_true, row_ptr)
     X += 0.05 * torch.randn(X.shape, generator=g, device=device)
-    X = X.reshape(I_loc * J, K).contiguous()
     return X, row_ptr, I_loc
 
 
@@ -124,11 +145,12 @@ def make_ragged_shard(cfg, lo, hi, rank, device, seed):
     C_true = torch.rand((K, r), generator=g, device=device)
     g.manual_seed(seed + 1000 + rank)
     A_true = torch.rand((hi - lo, r), generator=g, device=device) + 0.1
-    slab = torch.repeat_interleave(torch.arange(hi - lo, device=device), torch.as_tensor(J, device=device))
     B_true = torch.rand((N, r), generator=g, device=device)
-    X = (B_true * A_true[slab]) @ C_true.T
+    from matcouply_amd._engine import cmf_to_packed
+
+    X = cmf_to_packed(A_true, B_true, C_true, row_ptr)
     X += 0.05 * torch.randn(X.shape, generator=g, device=device)
-    return X.contiguous(), row_ptr, hi - lo
+    return X, row_ptr, hi - lo
 
 
 def make_engine(cfg, X, row_ptr, I_loc, rank, device, seed=1):
@@ -191,6 +213,7 @@ def usable_cores():
 
 def cpu_baseline(cfg, budget_s=15.0):
     """Oracle (NumPy, fp64 like the reference) on the host cores, bounded sample: a subset of the slabs, >= 1 iteration."""
+    t_leg = time.perf_counter()
     from oracle import aoadmm_oracle as orc
 
     cores = usable_cores()
@@ -204,22 +227,27 @@ def cpu_baseline(cfg, budget_s=15.0):
 
     J_all = np.random.RandomState(0).randint(128, 1025, I) if J == "ragged" else None  # config 4
 
-    def timed(I_s, iters):
+    def timed(I_s, iters, tag):
+        t_sub = time.perf_counter()
         X, row_ptr = orc.synthetic_problem(I_s, J if J_all is None else J_all[:I_s], K, r, seed=0, dtype=np.float64)
         st = orc.random_state_for(X, row_ptr, r, cfg["regs"], seed=1)
+        t_sub = leg(f"cpu_baseline.{tag}.synthesis", t_sub)
         st.update_B(); st.update_C(); st.update_A()  # warm-up iteration (BLAS thread pool, page faults)
+        t_sub = leg(f"cpu_baseline.{tag}.warmup_iteration", t_sub)
         t0 = time.perf_counter()
         for _ in range(iters):
             st.update_B(); st.update_C(); st.update_A()
             st.feasibility_gaps(); st.loss(st.rec_error_from_A_byproducts())
+        leg(f"cpu_baseline.{tag}.timed_iterations", t_sub)
         return (time.perf_counter() - t0) / iters
 
+    t_leg = leg("cpu_baseline.import+threadpool", t_leg)
     I_probe = min(I, 64)
-    t_probe = timed(I_probe, 1)
+    t_probe = timed(I_probe, 1, "probe")
     per_slab = t_probe / I_probe
     I_s = int(min(I, max(I_probe, budget_s / 3.0 / max(per_slab, 1e-9))))
     iters = 2
-    t_iter = timed(I_s, iters)
+    t_iter = timed(I_s, iters, "sample")
     value = 1.0 / (t_iter * I / I_s)
     survey = {"c3": 0.41, "c2": 7.5}.get(cfg.get("name"))
     return dict(value=value, unit="outer-iters/s", cores=cores, kind="port",
@@ -279,7 +307,9 @@ def api_block(cfg, X, row_ptr, n_short=100, n_long=1000):
         t0 = time.perf_counter()
         _, diag = dec.cmf_aoadmm(packed, cfg["r"], n_iter_max=n, random_state=0, return_errors=True, **kw, **tols)
         torch.cuda.synchronize()
-        return time.perf_counter() - t0, diag.n_iter
+        dt = time.perf_counter() - t0
+        print(f"[bench] api call n_iter_max={n} {tols or 'default tolerances'}: {dt:.3f} s, n_iter {diag.n_iter}", file=sys.stderr, flush=True)
+        return dt, diag.n_iter
 
     out = {"call": "cmf_aoadmm(PackedMatrices, rank=%d, %s, return_errors=True, random_state=0)" % (
         cfg["r"], ", ".join(f"{k}={v}" for k, v in kw.items())), "n_iter_max": [n_short, n_long]}
@@ -287,7 +317,7 @@ def api_block(cfg, X, row_ptr, n_short=100, n_long=1000):
     for name, tols in (("tol_none", dict(tol=None, absolute_tol=None)), ("default_tol", dict())):
         # the set-up part of a call (host RNG, upload) varies by milliseconds from call to call and only ever adds time:
         # each length is timed `reps` times and the fastest call is kept
-        reps = 3
+        reps = 2
         (t1, n1) = min(call(n_short, **tols) for _ in range(reps))
         (t2, n2) = min(call(n_long, **tols) for _ in range(reps))
         rate = (n2 - n1) / (t2 - t1) if n2 > n1 and t2 > t1 else n2 / t2
@@ -310,6 +340,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true", help="skip the `api` block (timing of the public cmf_aoadmm call)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--wall-budget", type=float, default=240.0,
+                    help="seconds this command should stay under: the two optional legs after the timed regions (the `api` "
+                         "block, the CPU baseline) are shortened or skipped - and say so in the JSON line - when the mandatory "
+                         "legs (imports, device, data, timed regions) have used the budget up, e.g. on a box with cold caches")
     args = ap.parse_args()
 
     # RCCL shares device buffers between the ranks of a node through dmabuf IPC; the legacy IPC mode is not supported by the
@@ -321,8 +355,11 @@ def main():
         # line is forwarded and the children's exit code is ours.  (No exec: replacing a process is not allowed on the
         # GPU boxes once anything has initialised the device, and a child keeps the parent free to report failures.)
         return spawn_ranks(args.gpus)
+    t_leg = time.perf_counter()
     import torch
     import torch.distributed as dist
+
+    t_leg = leg("import_torch", t_leg)
 
     cfg = dict(CONFIGS[args.config], name=args.config)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -350,8 +387,15 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    torch.zeros(1, device=device)
+    torch.cuda.synchronize()
+    t_leg = leg("device_init" + ("+process_group" if world > 1 else ""), t_leg)
     X, row_ptr, I_loc = make_shard(cfg, rank, world, device)
+    torch.cuda.synchronize()
+    t_leg = leg("data_synthesis", t_leg)
     eng = make_engine(cfg, X, row_ptr, I_loc, rank, device)
+    torch.cuda.synchronize()
+    t_leg = leg("engine_setup", t_leg)
     from matcouply_amd._engine import DIAG_LEN
 
     n_regions = max(1, args.regions)
@@ -366,6 +410,7 @@ def main():
         from matcouply_amd._rccl import DirectComm
 
         direct = DirectComm.try_create(dist.group.WORLD)
+        t_leg = leg("rccl_direct_comm", t_leg)
 
     def all_reduce(t, **kw):
         n_coll[0] += 1
@@ -417,6 +462,7 @@ def main():
         step(scratch[it])
     eng.flush_diagnostics()
     sync()
+    t_leg = leg("warmup", t_leg)
     # Settling (un-timed, on top of --warmup): a fresh device ramps its clocks over the first ~100 ms of work - with 5
     # warm-up steps (0.8 ms at config 3) the first timed regions of round 2 fell monotonically by 10 %.  Keep stepping in
     # probe regions of --steps steps until >= --settle-ms have passed AND two consecutive probes agree within 2 %
@@ -445,6 +491,7 @@ def main():
     # HIP events inside the library around every `stride`-th launch of the timed region: an event pair opens ~5 us
     # dispatch gaps before and after the kernel (11 us per step when every launch is bracketed - measured), so the
     # timed loop samples ~10 launches instead of taxing all of them
+    t_leg = leg("settling", t_leg)
     prof_stride = max(1, (n_regions * args.steps) // 10)
     eng.profile_enable(n_regions * args.steps, stride=prof_stride)
     region_s = []
@@ -465,6 +512,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # per region: the slowest rank
         region_s = [float(v) for v in t.cpu()]
     elapsed = float(np.median(region_s))
+    t_leg = leg("timed_regions", t_leg)
     coll_per_step = (n_coll[0] - coll_before - n_regions) / max(1, n_regions * args.steps)  # without the ring reductions
 
     # the replicated factor must be bit-identical on every rank (a divergent C would silently corrupt the fit)
@@ -581,19 +629,32 @@ def main():
         if final is not None:
             xsq, inner, model = final[5], final[3], final[4]
             out["final_rel_rec_error"] = round(float(np.sqrt(max(0.0, xsq - 2 * inner + model) / xsq)), 6)
+        t_leg = leg("roofline+checks", t_leg)
+        left = lambda: args.wall_budget - (time.perf_counter() - _T0)
         if world == 1 and not args.no_api:
-            out["api"] = api_block(cfg, X, row_ptr)
+            if left() > 0.5 * args.wall_budget:
+                out["api"] = api_block(cfg, X, row_ptr)
+            else:
+                out["api"] = {"skipped": f"{time.perf_counter() - _T0:.0f} s of the --wall-budget of {args.wall_budget:.0f} s were "
+                                         "used before this optional leg (wall_s names the slow leg)"}
+            t_leg = leg("api_block", t_leg)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_budget)
+            # the CPU leg is part of the contract line: never skipped, but its sample shrinks with the time that is left
+            out["cpu_baseline"] = cpu_baseline(cfg, max(1.0, min(args.cpu_budget, 0.25 * left())))
+            t_leg = leg("cpu_baseline", t_leg)
         elif world > 1:
             # the CPU leg is timed on rank 0 at N = 1 only (task contract); the N > 1 lines point at it
             out["cpu_baseline"] = {"value": None, "unit": "outer-iters/s", "cores": None, "kind": "port",
                                    "sample": "not timed at N > 1: see the cpu_baseline of the N = 1 line of the same workload"}
+        WALL_S["total_until_print"] = round(time.perf_counter() - _T0, 3)
+        out["wall_s"] = dict(WALL_S)
         print(json.dumps(out), flush=True)
     if world > 1:
         # the engine's own communicator (`direct`) is left to process exit: nothing more is sent on it, and tearing it down here
         # would add a collective step that can only delay or block the exit of a finished run
         dist.destroy_process_group()
+    if rank == 0:
+        print(f"[bench] done (t+{time.perf_counter() - _T0:.1f} s); interpreter teardown follows", file=sys.stderr, flush=True)
 
 
 if __name__ == "__main__":

@@ -53,9 +53,11 @@ def _load():
 class DirectComm:
     """RCCL communicator over the ranks of a torch.distributed process group; collectives on torch's CURRENT stream."""
 
-    INIT_TIMEOUT_S = 90.0  # ncclCommInitRank is a collective bootstrap: bounded, so that a start-up problem costs time, not the run
+    # ncclCommInitRank is a collective bootstrap: bounded, so that a start-up problem costs time, not the run (on one node
+    # it takes 1-3 s; try_create() makes every rank fall back to torch.distributed together when one of them times out)
+    INIT_TIMEOUT_S = float(os.environ.get("MCL_RCCL_INIT_TIMEOUT_S", "30"))
 
-    def __init__(self, group):
+    def __init__(self, group, device=None):
         import threading
 
         import torch
@@ -68,8 +70,12 @@ class DirectComm:
         uid = _UniqueId()
         if self.rank == 0:
             self._check(self.lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
-        dev_index = torch.cuda.current_device()
+        # the communicator, its self-test and every later collective belong to ONE device: the engine's (the caller's data),
+        # which need not be torch's current device when a host has not called set_device(local_rank)
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
         dev = torch.device("cuda", dev_index)
+        self.device = dev
         t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(dev)
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
@@ -104,6 +110,8 @@ class DirectComm:
         torch = self._torch
         if not (t.is_cuda and t.is_contiguous()):
             raise ValueError("DirectComm.all_reduce needs a contiguous CUDA tensor")
+        if t.device != self.device:
+            raise ValueError(f"DirectComm of {self.device} asked to reduce a tensor on {t.device}")
         dt = {torch.float32: _NCCL_FLOAT32, torch.float64: _NCCL_FLOAT64}[t.dtype]
         stream = torch.cuda.current_stream(t.device).cuda_stream
         self._check(self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), dt, _NCCL_MAX if op == "max" else _NCCL_SUM,
@@ -120,7 +128,7 @@ class DirectComm:
     # of an otherwise successful run; hosts that want it released call close() on every rank, after a barrier
 
     @classmethod
-    def try_create(cls, group):
+    def try_create(cls, group, device=None):
         """A working DirectComm for `group`, or None: only for RCCL ("nccl") groups, only if a self-test - an fp64 SUM and
         an fp32 MAX all-reduce compared with torch.distributed's - passes on EVERY rank; never raises."""
         import torch
@@ -133,7 +141,9 @@ class DirectComm:
                 return None
         except Exception:
             return None
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
 
         def agreed(ok):
             """every rank takes the same decision: MIN over the ranks of the local verdict (a torch.distributed collective
@@ -148,7 +158,7 @@ class DirectComm:
         # 1) the communicator (bounded bootstrap); no other collective until every rank has reported
         comm = None
         try:
-            comm = cls(group)
+            comm = cls(group, dev)
         except Exception:
             comm = None
         if not agreed(comm is not None):
@@ -167,7 +177,7 @@ class DirectComm:
             dist.all_reduce(b_ref, op=dist.ReduceOp.MAX, group=group)
             comm.all_reduce(a)
             comm.all_reduce(b, "max")
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(dev)
             # same ring / tree, same order of the sums inside RCCL: equal to rounding at worst, usually to the bit
             ok = bool(torch.allclose(a, a_ref, rtol=1e-13, atol=0.0) and torch.equal(b, b_ref))
         except Exception:

@@ -523,13 +523,27 @@ def _default_engine_factory(**kw):
 _DIRECT_COMMS = {}
 
 
-def _direct_comm(group):
-    """the cached direct RCCL communicator of a process group (None: use torch.distributed), see _rccl.py"""
-    key = id(group)
-    if key not in _DIRECT_COMMS:
-        from . import _rccl
+def _direct_comm(group, device=None):
+    """the cached direct RCCL communicator of a process group on `device` (None: use torch.distributed), see _rccl.py.
+    The cache entry is tied to the RESOLVED group object (the default group changes identity when a host destroys and
+    re-creates it), its world size, this rank and the device: an entry whose group is gone is dropped, not reused."""
+    import torch.distributed as dist
 
-        _DIRECT_COMMS[key] = (group, _rccl.DirectComm.try_create(group))  # the group is kept alive with its communicator
+    from . import _rccl
+
+    resolved = group if group is not None else dist.group.WORLD
+    try:
+        key = (id(resolved), dist.get_world_size(group), dist.get_rank(group), str(device))
+    except Exception:
+        return None
+    try:  # entries of process groups that have been destroyed since (their communicators are abandoned with them)
+        alive = dist.distributed_c10d._world.pg_map
+        for k in [k for k, (g, _) in _DIRECT_COMMS.items() if g not in alive]:
+            del _DIRECT_COMMS[k]
+    except Exception:
+        pass
+    if key not in _DIRECT_COMMS:
+        _DIRECT_COMMS[key] = (resolved, _rccl.DirectComm.try_create(group, device))  # the group is kept alive with its communicator
     return _DIRECT_COMMS[key][1]
 
 
@@ -702,7 +716,8 @@ def cmf_aoadmm(
     # A + U all-reduced in every inner iteration; other matrix penalties are not supported.
     sharded_ball_A = sharded and any(r.kind == _engine.PEN_L2BALL for r in native[0])
     if sharded and not all(r.kind in (_engine.PEN_NN, _engine.PEN_BOX, _engine.PEN_L1, _engine.PEN_L2BALL)
-                             for r in native[0]):
+                             or (r.kind == _engine.PEN_EXTERNAL and isinstance(reg, penalties.RowVectorPenalty))  # row by row
+                             for r, reg in zip(native[0], regs[0])):
         raise NotImplementedError("this matrix penalty on mode 0 couples rows that live on different ranks; "
                                   "not supported with group=")
     if sharded_ball_A and not constant_A:
@@ -710,12 +725,13 @@ def cmf_aoadmm(
 
     # RCCL groups: the collectives go straight onto the engine's stream through a communicator of the engine's own
     # (_rccl.DirectComm: no stream hand-over); any other backend (gloo in the CPU tests), or a failed self-test: torch's
-    direct = _direct_comm(group) if (sharded and sub is None) else None
+    direct = _direct_comm(group, X.device) if (sharded and sub is None) else None
 
     def all_reduce(t, op="sum"):
         if not sharded:
             return
-        if direct is not None and is_torch(t) and t.is_cuda and t.dtype in (torch.float32, torch.float64) and t.is_contiguous():
+        if (direct is not None and is_torch(t) and t.is_cuda and t.device == direct.device
+                and t.dtype in (torch.float32, torch.float64) and t.is_contiguous()):
             direct.all_reduce(t, op)
         elif sharded:
             dist.all_reduce(t, op=(dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM), group=group)
@@ -756,12 +772,21 @@ def cmf_aoadmm(
         """decomposition.py:90-117 on device tensors: relative change and every feasibility gap of the mode below inner_tol"""
         if not check_inner:
             return False
-        nrm = torch.linalg.norm(F.double())
-        if float(torch.linalg.norm(F.double() - F_old.double())) > inner_tol * float(nrm):
+        # squared norms in fp64: [ |F|^2, |F - F_old|^2, |F - aux_k|^2 ... ].  With group= the rows of modes 0 and 1 live on
+        # different ranks: the sums are all-reduced, so that every rank leaves the inner loop at the same iteration and the
+        # test is the reference's (over ALL B_i); C is replicated and needs nothing
+        F64 = F.double()
+        sq = torch.stack([(F64 ** 2).sum(), ((F64 - F_old.double()) ** 2).sum()]
+                         + [((F64 - nat.aux.double()) ** 2).sum() for nat in native[mode]])
+        if sharded and mode != 2:
+            all_reduce(sq)
+        sq = sq.cpu().numpy()
+        nrm = float(np.sqrt(sq[0]))
+        if float(np.sqrt(sq[1])) > inner_tol * nrm:
             return False
         if not native[mode]:
             return True
-        return max(float(torch.linalg.norm(F.double() - nat.aux.double()) / nrm) for nat in native[mode]) < inner_tol
+        return max(float(np.sqrt(v)) / nrm for v in sq[2:]) < inner_tol
 
     def do_update_B():
         if not needs_B_steps:
@@ -925,6 +950,8 @@ def cmf_aoadmm(
             # the value over THIS rank's matrices travels in the penalty-value slot of the vector and is summed over the
             # ranks with it
             for k, reg in enumerate(regs[1]):
+                if isinstance(reg, penalties.L1Penalty):
+                    continue  # read_diag takes reg_strength * sum|B| from the native slot, which is summed over the ranks already
                 if native[1][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV):
                     vec[_engine.DIAG_REG + (_engine.MCL_MAX_REGS + k) * 2 + 1] = float(reg.penalty([eng.B[sl] for sl in row_slices]))
         all_reduce(vec)
@@ -984,40 +1011,46 @@ def cmf_aoadmm(
         weights = [[(reg.reg_strength if isinstance(reg, penalties.L1Penalty) else 0.0) for reg in regs[m]] for m in range(3)]
         eng.gate_begin(tol, absolute_tol, feasibility_tol, initial_loss=losses[-1], penalty_weight=weights,
                        evaluate_loss_always=return_errors)
-        chunk, done, code, stop_it = 8, 0, 0, -1
-        ring = torch.zeros((n_iter_max if n_iter_max <= 4096 else 4096, _engine.DIAG_LEN), dtype=torch.float64, device=device)
-        verdict = torch.zeros((ring.shape[0], 4), dtype=torch.float64, device=device)
-        while done < n_iter_max and not code:
-            n_now = min(chunk, n_iter_max - done)
-            base = done % ring.shape[0]
-            if base + n_now > ring.shape[0]:
-                base = 0
-            for j in range(n_now):
-                if update_B_is:
-                    do_update_B()
-                if update_C:
-                    do_update_C()
-                if update_A:
-                    do_update_A()
-                eng.diagnostics(include_replicated=(rank_id == 0), out=ring[base + j])
-                all_reduce(ring[base + j])
-                eng.verdict(ring[base + j], done + j, verdict[base + j])
-            if is_torch(ring) and ring.is_cuda:
-                torch.cuda.synchronize(device)
-            stopped, stop_it, code = eng.gate_status()
-            n_ran = (stop_it - done + 1) if stopped else n_now
-            ring_h, verdict_h = ring[base:base + n_ran].cpu().numpy(), verdict[base:base + n_ran].cpu().numpy()
-            feasibility_gaps.extend(read_diag_rows(ring_h)[1])
-            if len(verdict_h):
-                flags = verdict_h[:, 3].astype(np.int64)
-                feasibility_criterion = bool(flags[-1] & _engine.VERDICT_FEASIBLE) if feasibility_tol else feasibility_tol
-                evaluated = (flags & _engine.VERDICT_LOSS_EVALUATED) != 0
-                rec_errors.extend(verdict_h[evaluated, 0].tolist())
-                losses.extend(verdict_h[evaluated, 1].tolist())
-            done += n_ran
-            if not stopped:
-                code = 0
-        eng.gate_end(bool(code))
+        gate_closed = False
+        try:
+            chunk, done, code, stop_it = 8, 0, 0, -1
+            ring = torch.zeros((n_iter_max if n_iter_max <= 4096 else 4096, _engine.DIAG_LEN), dtype=torch.float64, device=device)
+            verdict = torch.zeros((ring.shape[0], 4), dtype=torch.float64, device=device)
+            while done < n_iter_max and not code:
+                n_now = min(chunk, n_iter_max - done)
+                base = done % ring.shape[0]
+                if base + n_now > ring.shape[0]:
+                    base = 0
+                for j in range(n_now):
+                    if update_B_is:
+                        do_update_B()
+                    if update_C:
+                        do_update_C()
+                    if update_A:
+                        do_update_A()
+                    eng.diagnostics(include_replicated=(rank_id == 0), out=ring[base + j])
+                    all_reduce(ring[base + j])
+                    eng.verdict(ring[base + j], done + j, verdict[base + j])
+                if is_torch(ring) and ring.is_cuda:
+                    torch.cuda.synchronize(device)
+                stopped, stop_it, code = eng.gate_status()
+                n_ran = (stop_it - done + 1) if stopped else n_now
+                ring_h, verdict_h = ring[base:base + n_ran].cpu().numpy(), verdict[base:base + n_ran].cpu().numpy()
+                feasibility_gaps.extend(read_diag_rows(ring_h)[1])
+                if len(verdict_h):
+                    flags = verdict_h[:, 3].astype(np.int64)
+                    feasibility_criterion = bool(flags[-1] & _engine.VERDICT_FEASIBLE) if feasibility_tol else feasibility_tol
+                    evaluated = (flags & _engine.VERDICT_LOSS_EVALUATED) != 0
+                    rec_errors.extend(verdict_h[evaluated, 0].tolist())
+                    losses.extend(verdict_h[evaluated, 1].tolist())
+                done += n_ran
+                if not stopped:
+                    code = 0
+            eng.gate_end(bool(code))
+            gate_closed = True
+        finally:
+            if not gate_closed:  # an exception inside the loop (a failed collective, a NotImplementedError of a step): never
+                eng.gate_end(True)  # leave the context gated - its kernels would silently do nothing from then on
         it = done - 1
         if code:
             satisfied_stopping_condition = True

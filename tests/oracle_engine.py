@@ -8,7 +8,7 @@ import torch
 from matcouply_amd import _engine
 from oracle import aoadmm_oracle as orc
 
-KIND_NAME = {1: "nn", 2: "box", 3: "l1", 4: "l2ball", 5: "unimodal", 6: "parafac2", 8: "tv"}
+KIND_NAME = {1: "nn", 2: "box", 3: "l1", 4: "l2ball", 5: "unimodal", 6: "parafac2", 7: "external", 8: "tv"}
 
 
 def _desc(reg):
@@ -213,7 +213,27 @@ class OracleEngine:
     def rho(self, mode):
         if mode == 0:
             return torch.as_tensor(np.asarray(self.rho_A_used, dtype=np.float64))
-        raise NotImplementedError("checker engine: rho() is implemented for mode 0 only")
+        if mode == 1:
+            return torch.as_tensor(np.asarray(self.rho_B, dtype=np.float64))
+        return torch.as_tensor(np.asarray([self.rho_C], dtype=np.float64))
+
+    # step form of the C inner loop (host-evaluated prox in between): mcl_C_begin / mcl_C_solve / mcl_C_end
+    def C_begin(self):
+        r, n = self.r, len(self.regs[2])
+        GR = self.GR.numpy()
+        G, self.R_C = GR[: r * r].reshape(r, r), GR[r * r:].reshape(self.K, r).copy()
+        self.rho_C = 0.5 * np.trace(G) * self.scale
+        self.Linv_C = np.linalg.inv(G + (self.rho_C * n + self.l2[2]) * np.eye(r))
+
+    def C_solve(self):
+        T = self.R_C.copy()
+        for reg in self.regs[2]:
+            T += self.rho_C * (self._n(reg.aux) - self._n(reg.dual))
+        self._n(self.C)[...] = T @ self.Linv_C
+        self.by_products = None
+
+    def C_end(self):
+        pass
 
     def update_A(self):
         self.A_begin()
@@ -318,7 +338,7 @@ class OracleEngine:
                 inner.__name__ = fn.__name__
                 return inner
             for name in ("B_begin", "B_factor", "B_solve", "B_prox_local", "B_prox_finish", "B_end", "update_B", "update_C_local",
-                         "update_C_finish", "A_begin", "A_finish", "A_factor", "A_solve", "A_end", "update_A"):
+                         "update_C_finish", "A_begin", "A_finish", "A_factor", "A_solve", "A_end", "update_A", "C_begin", "C_solve", "C_end"):
                 setattr(type(self), name, gated(getattr(type(self), name)))
             type(self)._gated = True
 

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the product's sharded driver (`cmf_aoadmm(..., group=...)`: slabs split over ranks,
+"""CPU, world sizes 2 / 4 / 8 over gloo: the product's sharded driver (`cmf_aoadmm(..., group=...)`: slabs split over ranks,
 all-reduce of the C-mode normal equations / diagnostics / PARAFAC2 coordinate sums / constant-rho maxima) must
 reproduce the single-process run.  The checker engine stands in for the HIP engine (no GPU here)."""
 import json
@@ -33,13 +33,28 @@ CASES = {
     # total variation on the B_i and on C: the penalty value is summed on the host - under sharding this rank's share travels in
     # the diagnostics vector (mode 1) / is counted once (replicated mode 2)
     "tv_B_and_C": dict(),
+    # inner_tol set: every penalty is evaluated on the host (PEN_EXTERNAL), the inner loops stop on the reference's test -
+    # over ALL B_i, i.e. on all-reduced norms under sharding - and the L1 value on the B_i must not be scaled twice
+    "inner_tol_l1B": dict(),
 }
+
+
+J_ALL = [12, 11, 9, 10, 5, 6, 3, 4, 5, 3, 4, 6, 3, 4]  # ragged: the ranks' shares are uneven in slabs AND in rows
+
+
+def _bounds(world):
+    """contiguous slab ranges balanced by rows (the product's own partition_slabs)"""
+    from matcouply_amd.decomposition import partition_slabs
+
+    parts = partition_slabs(J_ALL, world)
+    assert all(len(p) for p in parts)
+    return [int(parts[0][0])] + [int(p[-1]) + 1 for p in parts]
 
 
 def _problem():
     rng = np.random.RandomState(5)
-    I, K, r = 6, 9, 3
-    J = [7, 4, 9, 5, 8, 6]
+    I, K, r = len(J_ALL), 9, 3
+    J = J_ALL
     A, C = rng.uniform(0.1, 1.1, (I, r)), rng.uniform(size=(K, r))
     mats = [(rng.uniform(size=(j, r)) * A[i]) @ C.T + 0.05 * rng.standard_normal((j, K)) for i, j in enumerate(J)]
     init = (None, (rng.uniform(size=(I, r)), [rng.uniform(size=(j, r)) for j in J], rng.uniform(size=(K, r))))
@@ -58,6 +73,10 @@ def _explicit_state(case, mats, r, seed=9):
     if case == "c3_nn_l1C":
         regs[0] = [("nn", mk((I, r)), mk((I, r)))]
         regs[1] = [("nn", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
+        regs[2] = [("l1nn", mk((K, r)), mk((K, r)))]
+    elif case == "inner_tol_l1B":
+        regs[0] = [("nn", mk((I, r)), mk((I, r)))]
+        regs[1] = [("l1B", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
         regs[2] = [("l1nn", mk((K, r)), mk((K, r)))]
     elif case == "tv_B_and_C":
         regs[0] = [("nn", mk((I, r)), mk((I, r)))]
@@ -93,6 +112,8 @@ def _build(regs_spec, lo, hi):
                 out[m].append(pen.NonNegativity(aux_init=aux, dual_init=dual))
             elif kind == "l1nn":
                 out[m].append(pen.L1Penalty(0.1, non_negativity=True, aux_init=aux, dual_init=dual))
+            elif kind == "l1B":
+                out[m].append(pen.L1Penalty(0.3, aux_init=aux, dual_init=dual))
             elif kind == "pf2":
                 out[m].append(pen.Parafac2(aux_init=aux, dual_init=dual))
             elif kind == "ball":
@@ -127,6 +148,7 @@ def _run_with_checker(dec, case, lo, hi, group):
     cmf, diag = dec.cmf_aoadmm(mats[lo:hi], r, init=(None, (A0[lo:hi].copy(), [b.copy() for b in B0[lo:hi]], C0.copy())),
                                regs=_build(regs_spec, lo, hi), return_errors=True, constant_feasibility_penalty=const, group=group,
                                **(json.loads(os.environ["MCL_TEST_RUN_KW"]) if os.environ.get("MCL_TEST_RUN_KW") else RUN_KW),
+                               **(dict(inner_tol=3e-2, inner_n_iter_max=12) if case == "inner_tol_l1B" else {}),
                                gather_A=group is not None)
     return cmf, diag
 
@@ -135,7 +157,7 @@ def _worker(rank, world, port, case, q):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    bounds = [0, 4, 6]  # uneven split of the 6 slabs
+    bounds = _bounds(world)
     cmf, diag = _run(case, bounds[rank], bounds[rank + 1], dist.group.WORLD)
     q.put((rank, cmf[1][0], np.concatenate(cmf[1][1]), cmf[1][2], diag.rec_errors, diag.regularized_loss,
            [[list(map(float, g)) for g in it] for it in diag.feasibility_gaps], np.asarray(cmf.A_all), cmf.rows_of_rank,
@@ -143,25 +165,44 @@ def _worker(rank, world, port, case, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", sorted(CASES))
-def test_two_rank_sharded_run_equals_single_process(case):
-    sys.path.insert(0, REPO)
-    ref_cmf, ref_diag = _run(case, 0, 6, None)
+def _spawn(world, case, salt=0):
+    import socket
+
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(rk, 2, port, case, q)) for rk in range(2)]
+    with socket.socket() as sock:  # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, case, q)) for rk in range(world)]
     for p in procs:
         p.start()
-    results = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        results = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    return results
+
+
+# world size 2: every stack; 4 and 8 ranks (the driver's scaling points): the stacks with the most collectives per iteration
+SHARDED_RUNS = [(2, c) for c in sorted(CASES)] + [(w, c) for w in (4, 8) for c in ("c3_nn_l1C", "readme_stack", "inner_tol_l1B")]
+
+
+@pytest.mark.parametrize("world,case", SHARDED_RUNS, ids=[f"{c}-x{w}" for w, c in SHARDED_RUNS])
+def test_two_rank_sharded_run_equals_single_process(world, case):
+    sys.path.insert(0, REPO)
+    ref_cmf, ref_diag = _run(case, 0, len(J_ALL), None)
+    results = _spawn(world, case)
+    bounds = _bounds(world)
+    assert len({hi - lo for lo, hi in zip(bounds, bounds[1:])}) > 1 or world == len(J_ALL)  # uneven shares
     A = np.concatenate([res[1] for res in results])
     # gather_A=True: every rank also holds the WHOLE A (one all-gather at the end), its own rows at rows_of_rank
     for rk, res in enumerate(results):
         np.testing.assert_array_equal(res[7], A)
-        assert res[8] == ((0, 4), (4, 6))[rk]
+        assert res[8] == (bounds[rk], bounds[rk + 1])
         np.testing.assert_array_equal(res[7][res[8][0]:res[8][1]], res[1])
     B = np.concatenate([res[2] for res in results])
     np.testing.assert_allclose(A, ref_cmf[1][0], rtol=1e-9, atol=1e-12)
@@ -174,11 +215,15 @@ def test_two_rank_sharded_run_equals_single_process(case):
         for got_it, ref_it in zip(res[6], ref_gaps):
             for g, rg in zip(got_it, ref_it):
                 np.testing.assert_allclose(g, rg, rtol=1e-8, atol=1e-12)
-    np.testing.assert_array_equal(results[0][3], results[1][3])
+    for res in results[1:]:  # the replicated factor C: bit-identical on every rank
+        np.testing.assert_array_equal(results[0][3], res[3])
+    if case == "inner_tol_l1B":  # the inner loops did stop early somewhere (otherwise the case pins nothing)
+        assert len(ref_diag.rec_errors) == RUN_KW["n_iter_max"] + 1
 
 
+@pytest.mark.parametrize("world", [2, 8])
 @pytest.mark.parametrize("rule", sorted(STOP_RULES))
-def test_two_rank_sharded_run_with_a_stopping_rule(rule, monkeypatch):
+def test_two_rank_sharded_run_with_a_stopping_rule(rule, world, monkeypatch):
     """the stopping rule under sharding (mcl_gate_begin / mcl_verdict, here restated by the checker engine): the phases are
     stepped with their reductions, the diagnostics vector is all-reduced, every rank evaluates the rule on the same bits and
     the loop runs in fixed chunks - same stopping iteration, message, lists and factors as the single-process call"""
@@ -186,17 +231,8 @@ def test_two_rank_sharded_run_with_a_stopping_rule(rule, monkeypatch):
     kw = STOP_RULES[rule]
     monkeypatch.setenv("MCL_TEST_RUN_KW", json.dumps(kw))  # (the workers are spawned processes: passed through the environment)
     case = "pf2_ball_constant"
-    ref_cmf, ref_diag = _run(case, 0, 6, None)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + ((os.getpid() + 17) % 2000)
-    procs = [ctx.Process(target=_worker, args=(rk, 2, port, case, q)) for rk in range(2)]
-    for p in procs:
-        p.start()
-    results = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    ref_cmf, ref_diag = _run(case, 0, len(J_ALL), None)
+    results = _spawn(world, case)
     if rule == "relative":
         assert ref_diag.message.startswith("FEASIBILITY GAP CRITERION AND RELATIVE") and 1 <= ref_diag.n_iter < kw["n_iter_max"]
     else:

@@ -39,18 +39,29 @@ def test_single_rank_line():
     assert m["unit"] == "TFLOP/s" and m["peak"] == 157.3 and 0 < m["frac"] < 1 and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # every leg of the command accounts for its wall time (the driver's run took 521 s and nothing said where),
+    # on stderr as it goes and in the line; the whole command stays far inside the driver's timeout
+    w = d["wall_s"]
+    for name in ("import_torch", "device_init", "data_synthesis", "engine_setup", "warmup", "settling", "timed_regions",
+                 "api_block", "cpu_baseline", "total_until_print"):
+        assert name in w, sorted(w)
+        assert f"[bench] {name}:" in out.stderr or name == "total_until_print"
+    legs = sum(v for k, v in w.items() if "." not in k and k != "total_until_print")
+    assert abs(legs - w["total_until_print"]) < 1.0 and w["total_until_print"] < 90.0, w
     # a --gpus value that does not match an EXISTING launch is refused instead of silently re-labelled
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
 
 
-def test_gpus_2_without_a_launcher_spawns_its_own_ranks():
+@pytest.mark.parametrize("n", [2, 4])
+def test_gpus_2_without_a_launcher_spawns_its_own_ranks(n):
     """the driver's command form: `python bench.py --gpus N ...` with no torch.distributed.run around it;
-    two ranks share this box's one GPU over gloo"""
+    N ranks share this box's one GPU over gloo (N = 8 cannot be rehearsed on the card: a GPU box admits at most 6 processes
+    on it - the 8-rank collectives are covered on the CPU by tests/test_dist_gloo.py)"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(MCL_BENCH_SHARE_GPU="1", MCL_BENCH_BACKEND="gloo")
-    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--config", "c3_8th", "--steps", "4",
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--config", "c3_4th", "--steps", "4",
                           "--warmup", "2", "--regions", "2", "--settle-ms", "20"], env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -58,26 +69,29 @@ def test_gpus_2_without_a_launcher_spawns_its_own_ranks():
     assert len(lines) == 1, out.stdout[-2000:]  # ONE JSON line on stdout, nothing else
     d = json.loads(lines[0])
     assert all(k in d for k in REQUIRED), sorted(set(REQUIRED) - set(d))
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["replicated_C_bit_identical"] is True
-    assert d["collectives_per_step"] == 1.0
+    assert d["n_gpus"] == n and d["scaling"] == "strong" and d["replicated_C_bit_identical"] is True
+    assert d["collectives_per_step"] == 1.0 and d["config"]["sum_J"] == 256 * 512  # the WHOLE problem, split n ways
     assert d["cpu_baseline"]["value"] is None and "N = 1" in d["cpu_baseline"]["sample"]
+    assert d["wall_s"]["total_until_print"] < 120.0, d["wall_s"]
+    if n != 2:
+        return
     # a failing rank turns into a non-zero exit code of the launcher (here: an unknown process-group backend)
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--config", "c3_8th"], env=dict(env, MCL_BENCH_BACKEND="no_such_backend"),
                          capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0
 
 
-@pytest.mark.parametrize("config", ["c3_8th", "c4"])
-def test_two_ranks_sharing_the_gpu(config):
+@pytest.mark.parametrize("config,n", [("c3_8th", 2), ("c4", 2), ("c4", 4)])
+def test_two_ranks_sharing_the_gpu(config, n):
     env = dict(os.environ, MCL_BENCH_SHARE_GPU="1", MCL_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    port = str(29400 + (os.getpid() + len(config)) % 200)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", port, os.path.join(REPO, "bench.py"), "--gpus", "2", "--config", config, "--steps", "4",
+    port = str(29400 + (os.getpid() + len(config) + 7 * n) % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--config", config, "--steps", "4",
            "--warmup", "2", "--regions", "2", "--settle-ms", "20"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"]["value"] is None
+    assert d["n_gpus"] == n and d["scaling"] == "strong" and d["cpu_baseline"]["value"] is None
     assert d["replicated_C_bit_identical"] is True
     assert d["collectives_per_step"] == (6.0 if config == "c4" else 1.0)  # [G | R] (+ PARAFAC2 per inner iteration)
     assert 0 < d["final_rel_rec_error"] < 1
