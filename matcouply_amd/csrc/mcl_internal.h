@@ -66,7 +66,7 @@ struct TileMap {
 struct mcl_switches {
     bool no_sweep = false, no_pass_chain = false, no_pf2_delta_fusion = false, ns_plain = false, pf2_jacobi = false;
     bool no_stack_fusion = false, no_solve_stats = false, no_next_b = false, no_fused_gram = false, no_fused_c = false;
-    bool a_finish_cols = false, xc_norow = false, unimodal_v3 = false, stats_reduce = false;
+    bool a_finish_cols = false, xc_norow = false, uni_noprune = false, stats_reduce = false;
     bool no_rows64 = false, no_uni_coop = false;
     bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_x_nt = false, no_sweep_half = false, no_multi_c = false, no_diag_defer = false, xc_depth1 = false;
     int x_nt_mb = 0, seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
@@ -192,6 +192,7 @@ struct mcl_context {
     double *colsq = nullptr;    // [max(I,1), r]   per-slab column sums of squares (L2Ball)
     double *uni_f64 = nullptr;  // unimodal regression scratch: 8 fp64 arrays of (rows + slabs) * r
     int *uni_i32 = nullptr;     //                              2 int32 arrays of rows * r
+    float *uni_sink = nullptr;  // two floats per lane of the unimodal kernels: where predicated-off stores of the emit loops go
     double *pf2_S = nullptr;    // [I, r, r]  Y_i^T Y_i (fp64)
     float *pf2_T = nullptr;     // [I, r, r]  P_i = Y_i T_i
     double *pf2_T64 = nullptr;  // [I, r, r]  the same before its rounding (fp64 row passes: rows64)
@@ -330,3 +331,4 @@ bool mcl_stats_can_ride_in_solve(const mcl_context *c, int mode);  // generic.hi
 bool mcl_stats_reduce_in_algebra(const mcl_context *c);            // generic.hip
 int mcl_launch_rows_finish_solve_stats(mcl_context *c);           // generic.hip: finish of iteration t + solve / stats of t + 1
 int mcl_launch_rows_solve_stats(mcl_context *c);                  // generic.hip: B solve + per-tile statistics + reduce
+int mcl_launch_unimodal(mcl_context *c, const int *ext, int n_slabs, float *F, const RegSet &rs, int mode, int k);  // unimodal.hip

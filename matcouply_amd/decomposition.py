@@ -533,6 +533,8 @@ def _direct_comm(group, device=None):
 
     resolved = group if group is not None else dist.group.WORLD
     try:
+        if device is None or getattr(device, "index", None) is None:  # the caller's current device, as DirectComm resolves it
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else device
         key = (id(resolved), dist.get_world_size(group), dist.get_rank(group), str(device))
     except Exception:
         return None

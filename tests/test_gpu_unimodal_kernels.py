@@ -1,7 +1,7 @@
 """-m gpu: the unimodal-regression prox (matcouply/_unimodal_regression.py:27-141, penalties.py:1014-1015) through every
-organisation of the native kernel - one lane per column (throughput form), the two sweeps split over waves + split
-search / emit launch (latency form, picked automatically for few columns), and the previous kernel generation - against
-the oracle's regression on the same fp32 inputs.  The fits are fp32 roundings of fp64 block means: equal up to one
+organisation of the native kernel - one lane per column with the two sweeps pruned by a bound (throughput form), the same
+without pruning, the two sweeps split over waves + split search / emit launch (latency form, picked automatically for few
+columns) - against the oracle's regression on the same fp32 inputs.  The fits are fp32 roundings of fp64 block means: equal up to one
 unit in the last place unless a split decision differed, which would show as an O(1) difference."""
 import os
 
@@ -59,9 +59,9 @@ def test_unimodal_kernel_forms_agree_with_oracle(shape, nonneg, data):
     B0, U0 = eng.B.clone(), eng.regs[1][0].dual.clone()
     Y = (B0 + U0).cpu().numpy().astype(np.float64)  # the fp32 sum the kernels form, as exact doubles
     want = np.concatenate([orc.unimodal_columns(Y[row_ptr[i]: row_ptr[i + 1]], nonneg) for i in range(len(J))])
-    saved = {k: os.environ.get(k) for k in ("MCL_UNI_SPLIT", "MCL_UNIMODAL_V3")}
+    saved = {k: os.environ.get(k) for k in ("MCL_UNI_SPLIT", "MCL_UNI_NOPRUNE")}
     try:
-        for env in ({"MCL_UNI_SPLIT": "0"}, {"MCL_UNI_SPLIT": "1"}, {"MCL_UNIMODAL_V3": "1"}):
+        for env in ({"MCL_UNI_SPLIT": "0"}, {"MCL_UNI_SPLIT": "0", "MCL_UNI_NOPRUNE": "1"}, {"MCL_UNI_SPLIT": "1"}):
             for k in saved:
                 os.environ.pop(k, None)
             os.environ.update(env)
