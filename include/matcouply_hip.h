@@ -220,7 +220,8 @@ int mcl_cmf_to_packed(const float *A, const float *B, const float *C, const floa
  * segment of the X passes, 14 first segment of every wave; 15 / 16 / 17 the same for the bsegs of the one-pass sweep */
 float *mcl_internal_buffer(mcl_context *ctx, int32_t which, int64_t *count);
 /* name of the kernel variant chosen for the current problem: which = 0 X C pass, 1 X^T B pass, 2 fused B-phase rows,
- * 3 one-pass sweep (B-phase + X^T B in a single pass over X; empty when the problem is not eligible) */
+ * 3 one-pass sweep (B-phase + X^T B in a single pass over X; empty when the problem is not eligible), 4 non-empty when the
+ * problem runs in the exact-products mode (at most 2^20 elements of X: every contraction as fp64 sums of exact products) */
 const char *mcl_kernel_variant(mcl_context *ctx, int32_t which);
 /* HIP-event timing of the named kernels on the context's stream (for bench.py's roofline block).
  * mcl_profile_enable(ctx, capacity): record up to `capacity` launches per kernel slot (0 disables and frees);

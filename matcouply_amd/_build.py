@@ -21,17 +21,28 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=True):
-    if not force and not _stale():
+def build_library(force=False, verbose=True, defs=None, out_lib=None, build_dir=None, only=None):
+    """Compile the sources and link the library.  `defs` (default: $MCL_BUILD_DEFS) are extra compiler options, e.g.
+    -DMCL_NO_ENV_SWITCHES for a release build; `out_lib` / `build_dir` put the result somewhere else (tests); `only` lists the
+    sources to compile into `build_dir`, the other objects are taken from the in-tree build (compiled first if missing)."""
+    out_lib = out_lib or LIB
+    if out_lib == LIB and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    defs = os.environ.get("MCL_BUILD_DEFS", "").split()  # e.g. -DMCL_NS_STAMPS: instrumented builds of the tools/, never shipped
+    if defs is None:
+        defs = os.environ.get("MCL_BUILD_DEFS", "").split()  # e.g. -DMCL_NS_STAMPS: instrumented builds of the tools/, never shipped
+    tree_dir = os.path.join(HERE, "build")
+    build_dir = build_dir or tree_dir
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    os.makedirs(build_dir, exist_ok=True)
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + defs + EXTRA_FLAGS.get(src, []) + [
+        name = src.replace(".hip", ".o")
+        if only is not None and src not in only and os.path.exists(os.path.join(tree_dir, name)):
+            objs.append(os.path.join(tree_dir, name))  # unchanged by `defs`: the in-tree object
+            continue
+        obj = os.path.join(build_dir, name)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + list(defs) + EXTRA_FLAGS.get(src, []) + [
             "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -47,11 +58,11 @@ def build_library(force=False, verbose=True):
             print(f"hipcc failed on {src}:\n{out}", file=sys.stderr)
     if failed:
         raise RuntimeError("building libmatcouply_hip.so failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_lib] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out_lib
 
 
 if __name__ == "__main__":

@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void k_B_systems(const double *__restrict__ Ct
 // (D: row = (l >> 4) + 4 reg, col = l & 15).  Only used when mode 1 has no penalty: a rare, accuracy-first path.
 template <int NB>
 __global__ __launch_bounds__(256) void k_contract_xc_f64(const float *__restrict__ X, const float *__restrict__ C, long N,
-                                                         int K, int r, double *__restrict__ XC64) {
+                                                         int K, int r, double *__restrict__ XC64,
+                                                         float *__restrict__ XC32 = nullptr) {
     typedef double f64x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
@@ -252,7 +253,10 @@ __global__ __launch_bounds__(256) void k_contract_xc_f64(const float *__restrict
         for (int v = 0; v < 4; ++v) {
             const long j = row0 + kk + 4 * v;
             const int col = 16 * nb + i;
-            if (j < N && col < r) XC64[j * r + col] = acc[nb][v];
+            if (j < N && col < r) {
+                XC64[j * r + col] = acc[nb][v];
+                if (XC32 != nullptr) XC32[j * r + col] = (float)acc[nb][v];  // exact-products mode: the image the row kernels read
+            }
         }
 }
 
@@ -1699,6 +1703,20 @@ int mcl_launch_B_systems(mcl_context *c) {
     dim3 grid((unsigned)((c->I + 3) / 4)), block(256);
     DISPATCH_RP_T(c, k_B_systems, grid, block, c->CtC64, c->A, (int)c->I, c->r, (float)c->opt.feasibility_penalty_scale,
                   (float)c->opt.l2_penalty[1], c->regs[1].n, c->opt.constant_B, c->rho_max, c->rhoB, c->LinvB, c->LinvB64);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+// exact-products mode (mcl_exact_mode): X C as fp64 sums of exact products, with its once-rounded fp32 image
+int mcl_launch_exact_xc(mcl_context *c) {
+    if (c->N == 0) return 0;
+    const dim3 g((unsigned)(((c->N + 15) / 16 + 3) / 4));
+    if (c->NB == 1)
+        hipLaunchKernelGGL(k_contract_xc_f64<1>, g, dim3(256), 0, c->stream, c->X, c->C, (long)c->N, (int)c->K, c->r, c->XC64, c->XC);
+    else if (c->NB == 2)
+        hipLaunchKernelGGL(k_contract_xc_f64<2>, g, dim3(256), 0, c->stream, c->X, c->C, (long)c->N, (int)c->K, c->r, c->XC64, c->XC);
+    else
+        hipLaunchKernelGGL(k_contract_xc_f64<4>, g, dim3(256), 0, c->stream, c->X, c->C, (long)c->N, (int)c->K, c->r, c->XC64, c->XC);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

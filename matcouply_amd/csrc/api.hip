@@ -1,6 +1,9 @@
 // C ABI of libmatcouply_hip.so: context, workspace carve-up and the orchestration of the kernels per phase.
 // One function per reference entry point (see include/matcouply_hip.h for the file:line each one replaces).
+#include <time.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 
@@ -52,7 +55,8 @@ int64_t plan(mcl_context *c, char *base) {
     tm(c->tilesC, c->h_ctile_slab.size());
     tm(c->tilesA, c->h_atile_slab.size());
     tm(c->segs, c->h_seg_slab.size());
-    c->sweep_planned = mcl_sweep_shape_ok(c);
+    c->exact = mcl_exact_mode(c);
+    c->sweep_planned = !c->exact && mcl_sweep_shape_ok(c);
     if (c->sweep_planned) {
         tm(c->bsegs, c->h_bseg_slab.size());
         c->slab_bseg_ptr = b.take<int>(I + 1);
@@ -82,7 +86,7 @@ int64_t plan(mcl_context *c, char *base) {
     c->LinvB = b.take<float>(I * r * r);
     c->rows64 = c->NB == 1 && has_kind(c, MCL_PEN_PARAFAC2) && !c->sw.no_rows64;
     c->LinvB64 = (c->regs[1].n == 0 || c->rows64) ? b.take<double>(I * r * r) : nullptr;
-    c->XC64 = (c->regs[1].n == 0) ? b.take<double>(N * r) : nullptr;
+    c->XC64 = (c->regs[1].n == 0 || c->exact) ? b.take<double>(N * r) : nullptr;
     c->rho_max = b.take<float>(2);
     c->partials = b.take<double>((int64_t)mcl_contract_n_partials(c) * E);
     c->GR = b.take<double>(E);
@@ -147,6 +151,17 @@ int64_t plan(mcl_context *c, char *base) {
     return (b.off + 255) & ~int64_t(255);
 }
 
+// one polite spin of a wait loop, whatever the host CPU is
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
+
 void read_switches(mcl_switches &w) {
 #ifdef MCL_NO_ENV_SWITCHES  // release build (MCL_BUILD_DEFS=-DMCL_NO_ENV_SWITCHES): the environment is not consulted
     w = mcl_switches{};
@@ -170,6 +185,11 @@ void read_switches(mcl_switches &w) {
     w.xc_waves = num("MCL_XC_WAVES", 0), w.xt_waves = num("MCL_XT_WAVES", 0), w.sweep_waves = num("MCL_SWEEP_WAVES", 0);
     w.xc_dbg = num("MCL_XC_DBG", 0), w.xt_dbg = num("MCL_XT_DBG", 0), w.xt_depth = num("MCL_XT_DEPTH", 0);
     w.sweep_dbg = num("MCL_SWEEP_DBG", 0), w.reduce_el = num("MCL_REDUCE_EL", 0), w.uni_split = num("MCL_UNI_SPLIT", -1);
+    w.exact = num("MCL_EXACT", -1);
+    if (const char *e = getenv("MCL_RUN_WATCHDOG_S")) {  // an operating parameter, not a kernel form (not listed by mcl_active_switches)
+        const double v = atof(e);
+        if (v > 0) w.run_watchdog_s = v;
+    }
 }
 
 // names of the MCL_* switches present in the environment (what mcl_active_switches reports)
@@ -180,7 +200,7 @@ std::string switches_in_env() {
         "MCL_UNI_NOPRUNE", "MCL_STATS_REDUCE", "MCL_NO_ROWS64", "MCL_NO_UNI_COOP", "MCL_NO_A_FUSION", "MCL_NO_A_WIDE", "MCL_NO_BSEG_GROUPS",
         "MCL_NO_SWEEP_HALF", "MCL_NO_X_NT", "MCL_X_NT_MB", "MCL_NO_MULTI_C", "MCL_NO_DIAG_DEFER", "MCL_XC_DEPTH1", "MCL_SEG_ROWS",
         "MCL_BSEG_ROWS", "MCL_XC_WAVES", "MCL_XT_WAVES", "MCL_SWEEP_WAVES", "MCL_XC_DBG", "MCL_XT_DBG", "MCL_XT_DEPTH",
-        "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT"};
+        "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT", "MCL_EXACT"};
     std::string out;
 #ifdef MCL_NO_ENV_SWITCHES
     return out;
@@ -260,6 +280,11 @@ int ensure_ctc(mcl_context *c) {
 }
 
 int ensure_xc(mcl_context *c) {
+    if (!c->xc_valid && c->exact) {  // exact-products mode: fp64 sums of exact products, rounded once for the fp32 image
+        if (int rc = mcl_launch_exact_xc(c)) return rc;
+        c->xc_did_gram = false;
+        c->xc_valid = true;
+    }
     if (!c->xc_valid) {
         if (!c->cfrag_valid) {
             if (int rc = mcl_launch_build_cfrag(c)) return rc;
@@ -821,6 +846,7 @@ int mcl_update_C_local(mcl_context *c) {
     if (c && c->diag_pending && ready_noflush(c) == 0 && !c->b_finish_pending && c->mseg_valid && c->grpart_valid)
         return mcl_launch_reduce_weighted(c);  // ... with the deferred diagnostics reduction on its spare workgroup
     if (int rc = ready(c)) return rc;
+    if (c->exact) return mcl_launch_exact_gr(c);
     if (c->mseg_valid && c->grpart_valid) return mcl_launch_reduce_weighted(c);
     if (int rc = mcl_launch_contract_xt(c)) return rc;
     return mcl_launch_reduce_partials(c);
@@ -1120,10 +1146,27 @@ int mcl_run(mcl_context *c, int32_t n_iter_max, int32_t update_A, int32_t update
     // the status words are written by the device (mapped pinned memory): every read in the wait loop is a volatile read
     const volatile mcl_run_status *seen = status;
     for (int it = 0; it < n_iter_max && rc == 0; ++it) {
-        // bounded run-ahead: wait (without synchronising the stream) until the device is at most `ahead` verdicts behind
+        // bounded run-ahead: wait (without synchronising the stream) until the device is at most `ahead` verdicts behind.
+        // A short spin first (the common wait is a fraction of an iteration), then sleeps that back off to 50 us - the queue
+        // holds `ahead` iterations of work, so the host core is free while the device catches up; the stream is polled about
+        // once per millisecond of waiting, and a device that reports NO progress for MCL_RUN_WATCHDOG_S seconds (120; one
+        // outer iteration of the largest BASELINE configuration takes 0.12 s) ends the call with an error instead of a hang.
         long spins = 0;
+        int last_progress = seen->progress;
+        auto t_progress = std::chrono::steady_clock::now(), t_query = t_progress;
+        long sleep_ns = 2000;
         while (!seen->stopped && it - seen->progress >= ahead) {
-            if ((++spins & 0x3fff) == 0) {  // every 16 K spins: is the stream still working?
+            if (++spins <= 2000) {
+                cpu_relax();
+                continue;
+            }
+            const timespec ts{0, sleep_ns};
+            nanosleep(&ts, nullptr);
+            sleep_ns = std::min<long>(sleep_ns * 2, 50000);
+            const auto now = std::chrono::steady_clock::now();
+            if (seen->progress != last_progress) last_progress = seen->progress, t_progress = now;
+            if (now - t_query >= std::chrono::milliseconds(1)) {  // is the stream still working?
+                t_query = now;
                 const hipError_t q = hipStreamQuery(c->stream);
                 if (q != hipErrorNotReady && it - seen->progress >= ahead && !seen->stopped) {
                     rc = fail(c, q == hipSuccess ? "mcl_run: the stream drained without the verdict kernel reporting progress"
@@ -1131,7 +1174,11 @@ int mcl_run(mcl_context *c, int32_t n_iter_max, int32_t update_A, int32_t update
                     break;
                 }
             }
-            __builtin_ia32_pause();
+            if (now - t_progress >= std::chrono::duration<double>(c->sw.run_watchdog_s)) {
+                rc = fail(c, "mcl_run: no verdict from the device for " + std::to_string((int)c->sw.run_watchdog_s) +
+                                 " s (MCL_RUN_WATCHDOG_S): giving up the wait; the stream is left as it is");
+                break;
+            }
         }
         if (rc || seen->stopped) break;
         if (update_B) rc = mcl_update_B(c);
@@ -1291,7 +1338,8 @@ int mcl_reload_switches(mcl_context *c) {
 const char *mcl_active_switches(const mcl_context *c) { return c ? c->active_switches.c_str() : ""; }
 
 const char *mcl_kernel_variant(mcl_context *c, int32_t which) {
-    if (!c || which < 0 || which > 3) return "";
+    if (!c || which < 0 || which > 4) return "";
+    if (which == 4) return c->exact ? "exact products (fp64 sums; small problem)" : "";
     return c->variant[which].c_str();
 }
 

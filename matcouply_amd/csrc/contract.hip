@@ -843,7 +843,7 @@ template <int NB>
 __global__ __launch_bounds__(256) void k_slab_gram(const float *__restrict__ B, const float *__restrict__ XC,
                                                    const int *__restrict__ row_ptr, int r, float *__restrict__ rhsA,
                                                    float *__restrict__ BtB, double *__restrict__ rhs64,
-                                                   double *__restrict__ btb64) {
+                                                   double *__restrict__ btb64, const double *__restrict__ XC64) {
     constexpr int W = 16 * NB;
     __shared__ double ldsG[W * W];
     __shared__ double ldsP[4][W];
@@ -866,13 +866,14 @@ __global__ __launch_bounds__(256) void k_slab_gram(const float *__restrict__ B, 
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int col = 16 * nb + c16;
-            float b = 0.f, x = 0.f;
+            float b = 0.f;
+            double x = 0.0;
             if (j < e && col < r) {
                 b = B[j * r + col];
-                x = XC[j * r + col];
+                x = XC64 != nullptr ? XC64[j * r + col] : (double)XC[j * r + col];  // exact-products mode: the unrounded X C
             }
             bv[nb] = (double)b;
-            p[nb] = fma((double)b, (double)x, p[nb]);
+            p[nb] = fma((double)b, x, p[nb]);
         }
 #pragma unroll
         for (int a = 0; a < NB; ++a)
@@ -1112,13 +1113,74 @@ int mcl_launch_slab_gram(mcl_context *c) {
     dim3 grid((unsigned)c->I);
     if (c->NB == 1)
         hipLaunchKernelGGL(k_slab_gram<1>, grid, dim3(256), 0, c->stream, c->B, c->XC, c->row_ptr_dev, c->r, c->rhsA,
-                           c->BtB, c->seg_rhs, c->seg_btb);
+                           c->BtB, c->seg_rhs, c->seg_btb, c->exact ? (const double *)c->XC64 : nullptr);
     else if (c->NB == 2)
         hipLaunchKernelGGL(k_slab_gram<2>, grid, dim3(256), 0, c->stream, c->B, c->XC, c->row_ptr_dev, c->r, c->rhsA,
-                           c->BtB, c->seg_rhs, c->seg_btb);
+                           c->BtB, c->seg_rhs, c->seg_btb, c->exact ? (const double *)c->XC64 : nullptr);
     else
         hipLaunchKernelGGL(k_slab_gram<4>, grid, dim3(256), 0, c->stream, c->B, c->XC, c->row_ptr_dev, c->r, c->rhsA,
-                           c->BtB, c->seg_rhs, c->seg_btb);
+                           c->BtB, c->seg_rhs, c->seg_btb, c->exact ? (const double *)c->XC64 : nullptr);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Exact-products mode.  The MFMA contractions above multiply exactly and accumulate in fp32 chains (summed in fp64 per
+// segment): [G | R], X C and the A-phase tables carry relative errors of 1e-8 .. 4e-8, and a penalty-free mode - solved with
+// the un-shifted normal equations, as the reference does with its fp64 SVD (decomposition.py:252-256, 319-321) - multiplies
+// them by the condition number of its system (tools/parity_probe.py fuzz:142: cond 2e4 -> C off by 2.3e-5; fuzz:260: cond
+// 1.5e5 -> A off by 7e-4).  On LARGE problems the roundings of 1e5..1e7 rows average out (config 4: [G | R] to 6e-9, C to
+// 8e-8 at cond 600) and the passes over X are what the iteration costs; on SMALL problems neither holds: every kernel is
+// launch-bound and a few hundred rows do not average anything.  So problems of at most 2^20 elements of X (4 MB: an eighth of
+// config 2, the smallest BASELINE configuration) take every contraction as fp64 sums of EXACT products of the stored fp32
+// values - what the reference's arithmetic gives on the same inputs up to 1e-16 - and keep fp64 through the solves:
+//   X C            k_contract_xc_f64 (fp64 MFMA; admm.hip) -> XC64 and its once-rounded fp32 image for the row kernels
+//   [G | R]        k_exact_gr below -> GR, no partials, no sweep
+//   rhs_i, B_i^T B_i   k_slab_gram from XC64 -> the fp64 tables k_A_finish reads (and the reconstruction error)
+// MCL_EXACT=1 / 0 forces the mode on / off (the parity tests of the fast kernels run small problems with MCL_EXACT=0).
+// ---------------------------------------------------------------------------------------------------------
+bool mcl_exact_mode(const mcl_context *c) {
+    if (c->sw.exact >= 0) return c->sw.exact != 0;
+    return c->N * c->K <= (int64_t(1) << 20);
+}
+
+// Block b < ceil(K / 16): R[16 b + (t & 15)][c] for c = t >> 4, + 16, ...;  last block: G.  Every output is ONE sequential fp64
+// sum over the rows in order (deterministic); (b a) is an exact product of two fp32 values, x (b a) rounds once in the fma.
+__global__ __launch_bounds__(256) void k_exact_gr(const float *__restrict__ X, const float *__restrict__ B,
+                                                  const float *__restrict__ A, const int *__restrict__ slab_of_row, long N,
+                                                  int K, int r, double *__restrict__ GR) {
+    const int t = threadIdx.x;
+    const int kblocks = (K + 15) / 16;
+    if ((int)blockIdx.x < kblocks) {
+        const int k = 16 * blockIdx.x + (t & 15);
+        double *R = GR + (long)r * r;
+        for (int c0 = t >> 4; c0 < r; c0 += 16) {
+            double acc = 0.0;
+            if (k < K)
+                for (long j = 0; j < N; ++j) {
+                    const double ba = (double)B[j * r + c0] * (double)A[(long)slab_of_row[j] * r + c0];
+                    acc = fma((double)X[j * K + k], ba, acc);
+                }
+            if (k < K) R[(long)k * r + c0] = acc;
+        }
+    } else {
+        for (int p = t; p < r * r; p += 256) {
+            const int c1 = p / r, c2 = p - c1 * r;
+            double acc = 0.0;
+            for (long j = 0; j < N; ++j) {
+                const long i = slab_of_row[j];
+                const double b1 = (double)B[j * r + c1] * (double)A[i * r + c1], b2 = (double)B[j * r + c2] * (double)A[i * r + c2];
+                acc = fma(b1, b2, acc);
+            }
+            GR[p] = acc;
+        }
+    }
+}
+
+int mcl_launch_exact_gr(mcl_context *c) {
+    const int kblocks = (int)((c->K + 15) / 16);
+    hipLaunchKernelGGL(k_exact_gr, dim3((unsigned)(kblocks + 1)), dim3(256), 0, c->stream, c->X, c->B, c->A, c->slab_of_row,
+                       (long)c->N, (int)c->K, c->r, c->GR);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

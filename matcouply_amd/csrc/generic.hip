@@ -770,7 +770,7 @@ struct TileStats {
 #define NS_STAMP(i) do { } while (0)
 #endif
 template <int NB, bool TILES>
-__global__ __launch_bounds__((TILES && NB == 1) ? 128 : 64) void k_pf2_algebra_ns(double *__restrict__ S, const float *__restrict__ Delta,
+__global__ __launch_bounds__((TILES && NB == 1) ? 128 : 64) __attribute__((amdgpu_waves_per_eu(2))) void k_pf2_algebra_ns(double *__restrict__ S, const float *__restrict__ Delta,
                                                        const float *__restrict__ rho, const int *__restrict__ ext, int r,
                                                        float *__restrict__ T, double *__restrict__ acc_out,
                                                        int *__restrict__ status, TileStats ts, RegSet regs,

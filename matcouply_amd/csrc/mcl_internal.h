@@ -71,6 +71,8 @@ struct mcl_switches {
     bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_x_nt = false, no_sweep_half = false, no_multi_c = false, no_diag_defer = false, xc_depth1 = false;
     int x_nt_mb = 0, seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
     int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
+    int exact = -1;  // MCL_EXACT: 1 / 0 force the exact-products mode on / off (default -1: by problem size, mcl_exact_mode)
+    double run_watchdog_s = 120.0;  // mcl_run: seconds without a verdict from the device before the wait gives up (MCL_RUN_WATCHDOG_S)
 };
 
 struct mcl_context {
@@ -116,6 +118,7 @@ struct mcl_context {
     long long *sweep_cycles = nullptr;  // [n_blocks, 4 waves, 6] per-section cycle counts (MCL_SWEEP_DBG & 32)
     bool grpart_valid = false;     // GRpart was weighted with the current A (and mseg_valid)
     bool sweep_planned = false;    // the workspace holds the sweep buffers
+    bool exact = false;            // exact-products mode (small problems): X C, [G | R] and the A-phase tables from fp64 sums of exact products
     bool mseg_valid = false;       // Mpart / part_btb correspond to the current B
     bool seg_from_sweep = false;   // k_A_finish sums seg_rhs / part_btb over bsegs instead of segments
     float *XC = nullptr;        // [N, r]   X C  (cached between the A-phase and the next B-phase)
@@ -230,7 +233,7 @@ struct mcl_context {
     double *stat_gram = nullptr;       // [tilesB, (16 NB)^2]  per-tile Y^T Y, Y = B + U_pf2 (fp64 MFMA result order)
     double *stat_colsq = nullptr;      // [tilesB, MCL_MAX_REGS, r]  per-tile column sums of squares of (B + U_k)
 
-    std::string variant[4];
+    std::string variant[5];
 
     // optional HIP-event timing of kernel slots (0: X C pass, 1: X^T B pass, 2: fused B rows, 3: one-pass sweep)
     int prof_capacity = 0;
@@ -331,4 +334,7 @@ bool mcl_stats_can_ride_in_solve(const mcl_context *c, int mode);  // generic.hi
 bool mcl_stats_reduce_in_algebra(const mcl_context *c);            // generic.hip
 int mcl_launch_rows_finish_solve_stats(mcl_context *c);           // generic.hip: finish of iteration t + solve / stats of t + 1
 int mcl_launch_rows_solve_stats(mcl_context *c);                  // generic.hip: B solve + per-tile statistics + reduce
+bool mcl_exact_mode(const mcl_context *c);                      // contract.hip
+int mcl_launch_exact_xc(mcl_context *c);                         // contract.hip: XC64 (+ its fp32 image) = X C, exact products
+int mcl_launch_exact_gr(mcl_context *c);                         // contract.hip: GR = [G | R] of this rank's slabs, exact products
 int mcl_launch_unimodal(mcl_context *c, const int *ext, int n_slabs, float *F, const RegSet &rs, int mode, int k);  // unimodal.hip

@@ -62,7 +62,7 @@ def test_incomplete_step_round_is_an_error():
     eng.close()
 
 
-def test_deferred_diagnostics_equal_immediate_ones():
+def test_deferred_diagnostics_equal_immediate_ones(fast_kernels):
     """mcl_diagnostics_deferred: the reduction rides on the next C-phase reduction kernel (sweep path) or is flushed by the
     next other entry point; the vector must describe the factors at the time of the call and equal mcl_diagnostics."""
     import torch
@@ -148,7 +148,7 @@ def test_deferred_diagnostics_survive_a_setter_or_destroy(how):
     eng.close()
 
 
-def test_a_deferral_crosses_at_most_one_sweep():
+def test_a_deferral_crosses_at_most_one_sweep(fast_kernels):
     """two mcl_update_B in a row with a deferral pending - the second sweep would overwrite the mode-1
     table the deferral recorded; the vector must still describe the iterate at the time of the deferring call."""
     import torch
@@ -207,3 +207,57 @@ def test_events_order_a_side_stream_collective():
         results.append(to_np(eng.C))
         eng.close()
     assert np.array_equal(results[0], results[1])
+
+
+RELEASE_BUILD = r'''
+import os, sys, json, warnings
+sys.path.insert(0, os.environ["REPO"])
+import numpy as np, torch
+from matcouply_amd import _engine
+_engine.LIB_PATH = os.environ["MCL_TEST_LIB"]          # the release build of this test, not the in-tree library
+import bench
+os.environ["MCL_NO_SWEEP"] = "1"                        # a kernel-form switch a debug build obeys
+os.environ["MCL_RUN_WATCHDOG_S"] = "7"
+cfg = dict(bench.CONFIGS["c2"], I=64)                 # 2 M elements of X: above the exact-products size, the sweep is planned
+dev = torch.device("cuda", 0)
+X, row_ptr, I_loc = bench.make_shard(cfg, 0, 1, dev)
+with warnings.catch_warnings(record=True) as caught:
+    warnings.simplefilter("always")
+    eng = bench.make_engine(cfg, X, row_ptr, I_loc, 0, dev)
+eng.iterate(2)
+torch.cuda.synchronize()
+print("RELEASE " + json.dumps(dict(active=eng.lib.mcl_active_switches(eng._h).decode(), sweep=eng.kernel_variant(3),
+                                   warned=[str(w.message)[:60] for w in caught if "MCL_" in str(w.message)],
+                                   lib=os.path.realpath(eng.lib._name))), flush=True)
+'''
+
+
+def test_release_build_ignores_the_environment_switches(tmp_path):
+    """-DMCL_NO_ENV_SWITCHES (MCL_BUILD_DEFS of matcouply_amd/_build.py): the build a host embeds never consults the MCL_*
+    environment - a kernel-form switch is ignored, mcl_active_switches() reports nothing, no warning is raised.  Only
+    api.hip reads the environment, so the test compiles that one file and links it with the in-tree objects."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from matcouply_amd import _build
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = _build.build_library(defs=["-DMCL_NO_ENV_SWITCHES"], out_lib=str(tmp_path / "libmatcouply_hip_release.so"),
+                               build_dir=str(tmp_path), only=["api.hip"], verbose=False)
+    script = tmp_path / "release.py"
+    script.write_text(RELEASE_BUILD)
+    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, REPO=repo, MCL_TEST_LIB=lib), capture_output=True,
+                         text=True, timeout=300)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RELEASE ")]
+    assert line, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads(line[0].split(" ", 1)[1])
+    assert d["lib"] == os.path.realpath(lib)
+    assert d["active"] == "" and d["warned"] == []
+    assert d["sweep"].startswith("k_sweep<"), d  # MCL_NO_SWEEP=1 was not obeyed: the one-pass sweep is still planned
+    # the in-tree (debug-capable) build does obey it - the switch is real
+    dbg = subprocess.run([sys.executable, str(script)], env=dict(os.environ, REPO=repo, MCL_TEST_LIB=_build.LIB),
+                         capture_output=True, text=True, timeout=300)
+    d2 = json.loads([l for l in dbg.stdout.splitlines() if l.startswith("RELEASE ")][0].split(" ", 1)[1])
+    assert "MCL_NO_SWEEP" in d2["active"] and d2["sweep"] == "" and d2["warned"]

@@ -170,7 +170,7 @@ def _engine_state(eng):
 
 
 @pytest.mark.parametrize("stack", ["sweep", "pf2", "full"])
-def test_run_ahead_leaves_the_state_of_the_stopping_iteration(stack):
+def test_run_ahead_leaves_the_state_of_the_stopping_iteration(stack, kernel_paths):
     """C ABI level: mcl_run with run-ahead 1 / 8 / 64 stops on the same iteration and leaves the same bits as stepping
     exactly that many iterations with mcl_iterate - the gated kernels of the iterations enqueued behind the verdict did
     nothing - for the sweep path, the PARAFAC2 chain and the full penalty stack (every kernel family that writes state)"""

@@ -90,7 +90,7 @@ def _compare(cmf, admm, diag, st, res, tol, tol_rec=1e-5):
 
 
 @pytest.mark.parametrize("fname", TRAJ)
-def test_golden_trajectories(fname):
+def test_golden_trajectories(fname, kernel_paths):
     from tests.test_oracle_golden import _traj_state
 
     arrs = load_npz(fname)

@@ -63,3 +63,38 @@ def test_random_configuration(seed):
     errs = _compare(cmf, admm, diag, st, res, 1e-5, 1e-5)
     print(seed, {k: case[k] for k in ("I", "K", "r", "const", "inner")}, [[d["kind"] for d in m] for m in case["regs"]],
           f"worst {max(errs.values()):.1e} polar cond {res['polar_cond']:.0e}")
+
+
+@pytest.mark.parametrize("seed", [45, 135, 142, 237])
+def test_ill_conditioned_penalty_free_modes(seed):
+    """Draws whose penalty-free modes have normal equations of condition 2e3 .. 5e5 (tools/parity_probe.py fuzz:<seed>): the
+    reference solves them with an fp64 SVD (decomposition.py:252-256, 319-321); fp32-accumulated [G | R] / X C (relative error
+    1e-8 .. 4e-8 on a few hundred rows) put C or the reconstruction error at 1.2e-5 .. 2.3e-5.  Small problems therefore take
+    every contraction as fp64 sums of exact products (csrc/contract.hip: mcl_exact_mode): inside the flat 1e-5, and better
+    than the fast kernels on the same draw."""
+    from oracle import aoadmm_oracle as orc
+
+    def run(exact):
+        old = os.environ.get("MCL_EXACT")
+        os.environ.pop("MCL_EXACT", None)
+        if not exact:
+            os.environ["MCL_EXACT"] = "0"
+        try:
+            case = _draw_case(np.random.RandomState(1000 + seed))
+            X, row_ptr = orc.synthetic_problem(case["I"], case["J"], case["K"], case["r"], seed=seed, dtype=np.float64)
+            X = X.astype(np.float32).astype(np.float64)
+            st = orc.random_state_for(X, row_ptr, case["r"], case["regs"], seed=seed + 1, l2=case["l2"],
+                                      inner_n_iter_max=case["inner"], feasibility_penalty_scale=case["scale"],
+                                      constant_A=case["const"], constant_B=case["const"])
+            cmf, admm, diag, res = _run_both(st, 2)
+            return _compare(cmf, admm, diag, st, res, 1.0, 1.0)  # errors only; the bars are applied below
+        finally:
+            os.environ.pop("MCL_EXACT", None)
+            if old is not None:
+                os.environ["MCL_EXACT"] = old
+
+    exact, fast = run(True), run(False)
+    worst = lambda e: max(v for k, v in e.items() if not (k[0] == "P" and k[1] != "D"))
+    print(seed, f"exact products {worst(exact):.1e}   fast kernels {worst(fast):.1e}")
+    assert worst(exact) < 1e-5, exact
+    assert worst(fast) > worst(exact)

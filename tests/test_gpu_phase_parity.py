@@ -8,7 +8,7 @@ import pytest
 from tests.helpers import engine_from_oracle_state, load_npz, manifest_of, rel_err, to_np
 from tests.test_oracle_golden import _phase_state
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("kernel_paths")]  # phase goldens: both arithmetic paths
 TOL = 1e-5
 
 

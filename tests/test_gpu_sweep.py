@@ -9,7 +9,7 @@ import pytest
 
 from tests.helpers import engine_from_oracle_state, rel_err, to_np
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fast_kernels")]  # the subject is the sweep kernel
 
 NN = {"kind": "nn"}
 CASES = {
