@@ -548,7 +548,7 @@ def main():
     def pmc_traffic(kernel_variant):
         """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), if the
         profile was taken on this configuration; counters are collected in separate runs, never inside this one."""
-        for rnd in ("r3", "r2", "r1"):
+        for rnd in ("r4", "r3", "r2", "r1"):
             path = os.path.join(REPO, "profiles", f"{rnd}_{args.config}_pmc_traffic.json")
             if os.path.exists(path):
                 break
