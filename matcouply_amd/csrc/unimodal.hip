@@ -22,7 +22,17 @@ struct UniScratch {
     int *stL, *stR;
     float *sink;  // two floats per lane: target of the emit loops' predicated-off stores
     int coop;     // cooperative ring refill (ur4_refill_coop); 0: MCL_NO_UNI_COOP (A/B switch)
+    double *spL, *spR;  // packed spill areas (3 doubles per entry) of the left-to-right / right-to-left sweep
+    int spill_layout;   // 0 packed lane-private entries; 1 lane-private, one array per field; 2 interleaved by column (round 3)
+#ifdef MCL_UNI_DBG  // timing experiments only (wrong results): 1 no record stores, 2 no error stores, 4 no spill stores, 8 no emit
+    int dbg;
+#endif
 };
+#ifdef MCL_UNI_DBG
+#define UNI_DBG(bit) (sc.dbg & (bit))
+#else
+#define UNI_DBG(bit) false
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // Unimodality, fourth version (default).  Same projection and the same decision rules as v3 / the reference
@@ -50,6 +60,9 @@ struct UniRing4 {
     int *cw;         // LDS [RC][64]
     int h, cnt;      // ring index of its top entry, number of entries in the ring
     int mem_n;       // entries spilled to global memory
+#ifdef MCL_UNI_DBG
+    int dbg;
+#endif
 };
 struct UniRec {
     float lev;
@@ -88,14 +101,19 @@ struct UniPrefetch {
 template <int RC, int NRF>
 static __device__ __forceinline__ void ur4_push(UniRing4 &st, UniPrefetch<NRF> &pf, int lane, bool act, double sy, int cw, double q,
                                                 double *__restrict__ gsy, double *__restrict__ gq, int *__restrict__ gcw,
-                                                long base, long rs, int col) {
+                                                long base, long rs, int col, int spk) {
     if (act) {
         if (st.cnt == RC) {
             const int b = ((st.h - RC + 1) & (RC - 1)) * 64 + lane;
             const long idx = (base + st.mem_n) * rs + col;
-            gsy[idx] = st.sy[b];
-            gq[idx] = st.q[b];
-            gcw[idx] = st.cw[b];
+#ifdef MCL_UNI_DBG
+            if (!(st.dbg & 4))
+#endif
+            {
+                gsy[idx * spk] = st.sy[b];
+                gq[idx * spk] = st.q[b];
+                gcw[idx * (spk == 3 ? 6 : 1)] = st.cw[b];
+            }
             st.mem_n += 1;
             st.cnt = RC - 1;
             pf.n = 0;  // the prefetched entries are no longer the top of the spill area
@@ -128,11 +146,11 @@ static __device__ __forceinline__ void ur4_take_prefetched(UniRing4 &st, UniPref
 template <int NRF>
 static __device__ __forceinline__ void ur4_prefetch(const UniRing4 &st, UniPrefetch<NRF> &pf, const double *__restrict__ gsy,
                                                     const double *__restrict__ gq, const int *__restrict__ gcw, long base,
-                                                    long rs, int col) {
+                                                    long rs, int col, int spk) {
 #pragma unroll
     for (int i = 0; i < NRF; ++i) {  // unconditional clamped loads
         const long idx = (base + (st.mem_n > i ? st.mem_n - 1 - i : 0)) * rs + col;
-        pf.sy[i] = gsy[idx], pf.q[i] = gq[idx], pf.cw[i] = gcw[idx];
+        pf.sy[i] = gsy[idx * spk], pf.q[i] = gq[idx * spk], pf.cw[i] = gcw[idx * (spk == 3 ? 6 : 1)];
     }
     pf.n = st.mem_n < NRF ? st.mem_n : NRF;
 }
@@ -142,7 +160,7 @@ static __device__ __forceinline__ void ur4_prefetch(const UniRing4 &st, UniPrefe
 template <int RC, int NRF>
 static __device__ __forceinline__ void ur4_refill_dry(UniRing4 &st, UniPrefetch<NRF> &pf, int lane,
                                                       const double *__restrict__ gsy, const double *__restrict__ gq,
-                                                      const int *__restrict__ gcw, long base, long rs, int col) {
+                                                      const int *__restrict__ gcw, long base, long rs, int col, int spk) {
     if (pf.n > 0) {
         ur4_take_prefetched<RC, NRF>(st, pf, lane);
     } else {
@@ -150,9 +168,9 @@ static __device__ __forceinline__ void ur4_refill_dry(UniRing4 &st, UniPrefetch<
         for (int i = 0; i < nref; ++i) {
             const long idx = (base + st.mem_n - 1 - i) * rs + col;
             const int t = ((st.h - i) & (RC - 1)) * 64 + lane;
-            st.sy[t] = gsy[idx];
-            st.q[t] = gq[idx];
-            st.cw[t] = gcw[idx];
+            st.sy[t] = gsy[idx * spk];
+            st.q[t] = gq[idx * spk];
+            st.cw[t] = gcw[idx * (spk == 3 ? 6 : 1)];
         }
         st.mem_n -= nref;
         st.cnt = nref;
@@ -172,7 +190,7 @@ static __device__ __forceinline__ void ur4_refill_dry(UniRing4 &st, UniPrefetch<
 template <int RC, int NRF>
 static __device__ __forceinline__ void ur4_refill_coop(UniRing4 &st, UniPrefetch<NRF> &pf, int lane,
                                                        const double *__restrict__ gsy, const double *__restrict__ gq,
-                                                       const int *__restrict__ gcw, long base, long rs, int col) {
+                                                       const int *__restrict__ gcw, long base, long rs, int col, int spk) {
     if (__builtin_amdgcn_ballot_w64(st.cnt <= 1 && st.mem_n > 0) == 0) return;  // wave-uniform
     // a lane joins when its own ring is at most half full: it will run dry soon (joining whenever there was room made every
     // lane prefetch four times as often as it refilled, and most of those prefetches were invalidated by the next spill)
@@ -180,7 +198,7 @@ static __device__ __forceinline__ void ur4_refill_coop(UniRing4 &st, UniPrefetch
     if (pf.n > 0) {
         if (room >= pf.n) {
             ur4_take_prefetched<RC, NRF>(st, pf, lane);
-            ur4_prefetch<NRF>(st, pf, gsy, gq, gcw, base, rs, col);
+            ur4_prefetch<NRF>(st, pf, gsy, gq, gcw, base, rs, col, spk);
         }
     } else if (st.mem_n > 0 && room > 0) {
         const int want = room < NRF ? room : NRF;
@@ -190,7 +208,7 @@ static __device__ __forceinline__ void ur4_refill_coop(UniRing4 &st, UniPrefetch
 #pragma unroll
         for (int i = 0; i < NRF; ++i) {  // independent clamped loads: one latency
             const long idx = (base + (st.mem_n > i ? st.mem_n - 1 - i : 0)) * rs + col;
-            vsy[i] = gsy[idx], vq[i] = gq[idx], vcw[i] = gcw[idx];
+            vsy[i] = gsy[idx * spk], vq[i] = gq[idx * spk], vcw[i] = gcw[idx * (spk == 3 ? 6 : 1)];
         }
 #pragma unroll
         for (int i = 0; i < NRF; ++i) {
@@ -201,7 +219,7 @@ static __device__ __forceinline__ void ur4_refill_coop(UniRing4 &st, UniPrefetch
         }
         st.mem_n -= nref;
         st.cnt += nref;
-        ur4_prefetch<NRF>(st, pf, gsy, gq, gcw, base, rs, col);
+        ur4_prefetch<NRF>(st, pf, gsy, gq, gcw, base, rs, col, spk);
     }
 }
 
@@ -249,15 +267,38 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
     double *__restrict__ errL = sc.eL, *__restrict__ errR = sc.eR;
     // spill areas of the block stack: the concurrent right-to-left sweep of MODE 1 has its own
     // (MODE 3 switches between the two areas: its left-to-right sweep pauses while the right-to-left one runs)
-    double *gsy = (MODE == 1 && do_R) ? sc.sw : sc.sy, *gq = (MODE == 1 && do_R) ? sc.cum2 : sc.sy2;
-    int *gcw = (MODE == 1 && do_R) ? sc.stR : sc.stL;
+    // layout 0 (default): one packed 24-byte entry (sum, Q, count) per depth; 1 / 2 (A/B switches): three arrays
+    const int spk = sc.spill_layout == 0 ? 3 : 1;
+    double *gsy, *gq;
+    int *gcw;
+    auto spill_area = [&](bool right) {
+        if (sc.spill_layout == 0) {
+            double *p = right ? sc.spR : sc.spL;
+            gsy = p, gq = p + 1, gcw = reinterpret_cast<int *>(p + 2);
+        } else {
+            gsy = right ? sc.sw : sc.sy, gq = right ? sc.cum2 : sc.sy2, gcw = right ? sc.stR : sc.stL;
+        }
+    };
+    spill_area(MODE == 1 && do_R);
     UniRec *__restrict__ recL = reinterpret_cast<UniRec *>(sc.lvL), *__restrict__ recR = reinterpret_cast<UniRec *>(sc.lvR);
     const long rs = r;
     const long eb = (long)s + slab;  // n + 1 error entries per slab
+    // Spill areas: entry k of a lane at (sp_base + k) * sp_rs + sp_col.  The per-position arrays (errors, records) are
+    // column-interleaved because the lanes of a slab walk the POSITIONS in lockstep; the depth of the spilled stack is the
+    // lane's own, so its spill area is lane-private and contiguous (round 4): consecutive spills of a lane fill the same
+    // 64-byte sectors - the write-back L2 sends them out as whole lines - and a refill of 8 entries reads one sector per
+    // array instead of eight; the three fields of an entry sit side by side (24 bytes).  (MCL_UNI_SPILL_LAYOUT=2: the interleaved
+    // layout of round 3, =1: lane-private but one array per field - for A/B.)
+    const long sp_rs = sc.spill_layout == 2 ? rs : 1;
+    const long sp_base = sc.spill_layout == 2 ? (long)s : (long)s * rs + (long)col * n;
+    const int sp_col = sc.spill_layout == 2 ? col : 0;
 
     UniRing4 st;
     UniPrefetch<NRF> pf;
     st.sy = ring_d[0], st.q = ring_d[1], st.cw = ring_i;
+#ifdef MCL_UNI_DBG
+    st.dbg = sc.dbg;
+#endif
     // byte addresses of this lane's slot 0 in the rings (the pooling loop addresses LDS itself)
     const int lds_d = (int)lds_addr(&ring_d[0][0]) + lane * 8, lds_i = (int)lds_addr(&ring_i[0]) + lane * 4;
     static_assert((RC & (RC - 1)) == 0, "ring indices wrap by masking");
@@ -273,10 +314,10 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
     };
     // one element: returns the prefix error; leaves (levf, ccw) = record of the block ending at this element
     auto step = [&](double v, bool first) -> double {
-        if (sc.coop) ur4_refill_coop<RC, NRF>(st, pf, lane, gsy, gq, gcw, s, rs, col);
+        if (sc.coop) ur4_refill_coop<RC, NRF>(st, pf, lane, gsy, gq, gcw, sp_base, sp_rs, sp_col, spk);
         cum2 += v * v;
         // the finished block becomes the cached top; the previous top moves into the ring
-        ur4_push<RC, NRF>(st, pf, lane, !first && ht != 0, tsy, (int)tcw, tQ, gsy, gq, gcw, s, rs, col);
+        ur4_push<RC, NRF>(st, pf, lane, !first && ht != 0, tsy, (int)tcw, tQ, gsy, gq, gcw, sp_base, sp_rs, sp_col, spk);
         if (!first) {
             tsy = csy, tcw = ccw, tQ = curQ;
             ht = 1;
@@ -335,7 +376,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                 : "vcc", "scc", "memory");
             if (dry_exit == 0) break;  // wave-uniform
             if (ht != 0 && csy * tcw <= tsy * ccw && st.cnt == 0 && st.mem_n > 0)
-                ur4_refill_dry<RC, NRF>(st, pf, lane, gsy, gq, gcw, s, rs, col);
+                ur4_refill_dry<RC, NRF>(st, pf, lane, gsy, gq, gcw, sp_base, sp_rs, sp_col, spk);
         }
         // a block with a negative mean is clamped to level 0 and contributes q = 0; every block below it has a smaller
         // mean, so their Q is exactly 0 too and the prefix error comes out as cum2 without a special case
@@ -400,10 +441,10 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                         if (i0 + j < m) {
                             eLm = step(vb[j], i0 + j == 0);
                             ep += rs;
-                            __builtin_nontemporal_store(eLm, ep);
+                            if (!UNI_DBG(2)) __builtin_nontemporal_store(eLm, ep);
                             UniRec rc;
                             rc.lev = levf, rc.len = (int)ccw;
-                            st_rec_nt(rp, rc);
+                            if (!UNI_DBG(1)) st_rec_nt(rp, rc);
                             rp += rs;
                         }
                     }
@@ -414,14 +455,14 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
             for (int kk = 0; kk < RC; ++kk) {
                 if (kk < st.cnt) {
                     const int b = ((st.h - st.cnt + 1 + kk) & (RC - 1)) * 64 + lane;
-                    const long idx = ((long)s + st.mem_n + kk) * rs + col;
-                    gsy[idx] = st.sy[b], gq[idx] = st.q[b], gcw[idx] = st.cw[b];
+                    const long idx = (sp_base + st.mem_n + kk) * sp_rs + sp_col;
+                    gsy[idx * spk] = st.sy[b], gq[idx * spk] = st.q[b], gcw[idx * (spk == 3 ? 6 : 1)] = st.cw[b];
                 }
             }
             const int L_mem = st.mem_n + st.cnt, L_ht = ht;
             const double L_csy = csy, L_ccw = ccw, L_curQ = curQ, L_cum2 = cum2, L_tsy = tsy, L_tcw = tcw, L_tQ = tQ;
             // B: right to left
-            gsy = sc.sw, gq = sc.cum2, gcw = sc.stR;
+            spill_area(true);
             reset();
             double best = (m == n) ? eLm : __builtin_inf();
             split3 = n;
@@ -456,11 +497,11 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                             const double er = step(vb[j], i == 0);
                             UniRec rc;
                             rc.lev = levf, rc.len = (int)ccw;
-                            st_rec_nt(rp, rc);
+                            if (!UNI_DBG(1)) st_rec_nt(rp, rc);
                             rp -= rs;
                             const int tt = n - 1 - i;
                             if (tt > m) {
-                                __builtin_nontemporal_store(er, eRp + (long)tt * rs);
+                                if (!UNI_DBG(2)) __builtin_nontemporal_store(er, eRp + (long)tt * rs);
                             } else {
                                 const double tot = eb_l[j] + er;
                                 if (tot <= best) {
@@ -476,7 +517,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
             // C: resume the left-to-right sweep at element m
             if (m < n) {
                 const double R_cum2 = cum2;
-                gsy = sc.sy, gq = sc.sy2, gcw = sc.stL;
+                spill_area(false);
                 st.h = 0, st.cnt = 0, st.mem_n = L_mem, pf.n = 0;
                 csy = L_csy, ccw = L_ccw, curQ = L_curQ, cum2 = L_cum2, tsy = L_tsy, tcw = L_tcw, tQ = L_tQ, ht = L_ht;
                 const float *fp = F + ((long)s + m) * rs + col, *up = U + ((long)s + m) * rs + col;
@@ -509,7 +550,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                             const double el = step(vb[j], m + i == 0);
                             UniRec rc;
                             rc.lev = levf, rc.len = (int)ccw;
-                            st_rec_nt(rp, rc);
+                            if (!UNI_DBG(1)) st_rec_nt(rp, rc);
                             rp += rs;
                             const double tot = el + (i == nc - 1 ? 0.0 : er_l[j]);  // t = m + i + 1
                             if (tot < best) {
@@ -554,7 +595,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                     __builtin_nontemporal_store(er, ep);
                     UniRec rc;
                     rc.lev = levf, rc.len = (int)ccw;
-                    st_rec_nt(rp, rc);
+                    if (!UNI_DBG(1)) st_rec_nt(rp, rc);
                     rp += rs;
                 }
             }
@@ -594,7 +635,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                     const double er = step(vb[j], i == 0);
                     UniRec rc;
                     rc.lev = levf, rc.len = (int)ccw;
-                    st_rec_nt(rp, rc);
+                    if (!UNI_DBG(1)) st_rec_nt(rp, rc);
                     rp -= rs;
                     if (MODE == 0) {
                         const double tot = eb_l[j] + er;
@@ -670,6 +711,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
             }
         }
     }
+    if (UNI_DBG(8)) return;
     // emit, positions in lockstep over the wave (EB records per batch, the next batch in flight).
     // Left fit: chain from position split-1 downwards.
     constexpr int EB = 16;
@@ -745,10 +787,15 @@ static UniScratch uni_scratch(mcl_context *c) {
     UniScratch s;
     double *d = c->uni_f64;
     s.lvL = d, s.lvR = d + n1, s.eL = d + 2 * n1, s.eR = d + 3 * n1;
-    s.sy = d + 4 * n1, s.sy2 = d + 5 * n1, s.sw = d + 6 * n1, s.cum2 = d + 7 * n1;
+    s.spL = d + 4 * n1, s.spR = d + 7 * n1;  // 3 n1 doubles each; the A/B layouts use parts of them as separate arrays
+    s.sy = s.spL, s.sy2 = s.spL + n1, s.sw = s.spR, s.cum2 = s.spR + n1;
     s.stL = c->uni_i32, s.stR = c->uni_i32 + maxrows * c->r;
     s.sink = c->uni_sink;
     s.coop = c->sw.no_uni_coop ? 0 : 1;
+    s.spill_layout = c->sw.uni_spill_layout;
+#ifdef MCL_UNI_DBG
+    s.dbg = getenv("MCL_UNI_DBG") ? atoi(getenv("MCL_UNI_DBG")) : 0;
+#endif
     return s;
 }
 
