@@ -24,6 +24,16 @@ struct UniScratch {
     int coop;     // cooperative ring refill (ur4_refill_coop); 0: MCL_NO_UNI_COOP (A/B switch)
     double *spL, *spR;  // packed spill areas (3 doubles per entry) of the left-to-right / right-to-left sweep
     int spill_layout;   // 0 packed lane-private entries; 1 lane-private, one array per field; 2 interleaved by column (round 3)
+// ring entries per lane / entries per refill / elements per load batch (build-time; the defaults are the measured best)
+#ifndef MCL_UNI_RC
+#define MCL_UNI_RC 16
+#endif
+#ifndef MCL_UNI_NRF
+#define MCL_UNI_NRF 8
+#endif
+#ifndef MCL_UNI_UB
+#define MCL_UNI_UB 8
+#endif
 #ifdef MCL_UNI_DBG  // timing experiments only (wrong results): 1 no record stores, 2 no error stores, 4 no spill stores, 8 no emit
     int dbg;
 #endif
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
     MCL_GATE(regs.gate);
     // ring entries per lane: 8 in the throughput form (10 KB per wave, 16 waves per CU); the latency form runs at most two
     // waves per SIMD and takes 16 (20 KB per wave) with refills of 8 - half as many spills and refills on deep stacks
-    constexpr int RC = 16, NRF = 8;
+    constexpr int RC = MCL_UNI_RC, NRF = MCL_UNI_NRF;
     __shared__ double ring_d[2][MODE == 2 ? 1 : RC * 64];
     __shared__ int ring_i[MODE == 2 ? 1 : RC * 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;  // MODE 2: four waves work on the same 64 columns
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
         return cum2 - curQ;
     };
 
-    constexpr int UB = 8;  // elements per load batch; the NEXT batch is in flight while the current one is pooled
+    constexpr int UB = MCL_UNI_UB;  // elements per load batch; the NEXT batch is in flight while the current one is pooled
     int n_split_out = 0;   // MODE 3: the split its schedule found
     // ---- pruned sweeps (MODE 3) ------------------------------------------------------------------------------------
     // total(t) = eL[t] + eR[t] (error of the best increasing fit of [0, t) + of the best decreasing fit of [t, n)) is

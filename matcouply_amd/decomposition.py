@@ -615,9 +615,10 @@ def cmf_aoadmm(
     the host, travels with the diagnostic sums; the run then takes the host-driven loop), and so does a host-evaluated
     (user-defined / overridden) ``MatrixPenalty`` on the ``B_i`` - its prox acts on one matrix at a time.  NOT supported with
     ``group=`` (``NotImplementedError``): host-evaluated ``MatricesPenalty`` classes on mode 1 (they may couple matrices
-    of different ranks) and matrix penalties on mode 0
-    other than the L2 ball - total variation along the rows of ``A`` included (PARAFAC2 is mode 1 only; the L2 ball on A
-    needs ``constant_feasibility_penalty``, as in the reference).  None of these occurs in the BASELINE configurations.
+    of different ranks).  Matrix penalties on mode 0 (L2 ball, unimodality, total variation along the rows of ``A``, a
+    user's ``MatrixPenalty``) need ``constant_feasibility_penalty``, as in the reference; the L2 ball all-reduces its column
+    norms, every other one is evaluated by each rank on the all-gathered ``A`` (I x rank floats).  None of these occurs in the
+    BASELINE configurations.
 
     >>> import numpy as np, matcouply_amd
     >>> len(matcouply_amd.decomposition._listify({1: 0.5}, "l1_penalty"))
@@ -717,13 +718,18 @@ def cmf_aoadmm(
     # (the README case: l2_norm_bound on A with a constant feasibility penalty) needs the r column sums of squares of
     # A + U all-reduced in every inner iteration; other matrix penalties are not supported.
     sharded_ball_A = sharded and any(r.kind == _engine.PEN_L2BALL for r in native[0])
-    if sharded and not all(r.kind in (_engine.PEN_NN, _engine.PEN_BOX, _engine.PEN_L1, _engine.PEN_L2BALL)
-                             or (r.kind == _engine.PEN_EXTERNAL and isinstance(reg, penalties.RowVectorPenalty))  # row by row
-                             for r, reg in zip(native[0], regs[0])):
-        raise NotImplementedError("this matrix penalty on mode 0 couples rows that live on different ranks; "
-                                  "not supported with group=")
-    if sharded_ball_A and not constant_A:
-        raise NotImplementedError("an L2 ball on mode 0 needs constant_feasibility_penalty (as in the reference)")
+    # ... any other matrix penalty (unimodality, total variation along the rows of A, a user's MatrixPenalty) is evaluated by
+    # EVERY rank on the all-gathered matrix A + U (I x r floats: small) through the penalty's own prox, each rank keeping its
+    # rows - the reference's arithmetic, replicated; row-separable kinds stay rank-local
+    def _local_on_A(nat, reg):
+        return nat.kind in (_engine.PEN_NN, _engine.PEN_BOX, _engine.PEN_L1) or (
+            nat.kind == _engine.PEN_EXTERNAL and isinstance(reg, penalties.RowVectorPenalty))
+
+    gathered_A = [sharded and nat.kind != _engine.PEN_L2BALL and not _local_on_A(nat, reg)
+                  for nat, reg in zip(native[0], regs[0])]
+    if (sharded_ball_A or any(gathered_A)) and not constant_A:
+        raise NotImplementedError("a matrix penalty on mode 0 needs constant_feasibility_penalty (as in the reference, "
+                                  "which has no row update for it)")
 
     # RCCL groups: the collectives go straight onto the engine's stream through a communicator of the engine's own
     # (_rccl.DirectComm: no stream hand-over); any other backend (gloo in the CPU tests), or a failed self-test: torch's
@@ -853,8 +859,32 @@ def cmf_aoadmm(
         nat.dual.copy_(eng.A - (z - nat.dual))
         nat.aux.copy_(z)
 
+    a_counts = []
+
+    def gather_rows_A(t):
+        """all ranks' rows of a mode-0 matrix, in rank order (uneven shares: padded for the collective, trimmed after)"""
+        if not a_counts:
+            n_loc = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+            cnt = [torch.zeros_like(n_loc) for _ in range(world)]
+            dist.all_gather(cnt, n_loc, group=group)
+            a_counts.extend(int(c.item()) for c in cnt)
+        padded = torch.zeros((max(a_counts), t.shape[1]), dtype=t.dtype, device=t.device)
+        padded[: t.shape[0]] = t
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded, group=group)
+        return torch.cat([p[:c] for p, c in zip(parts, a_counts)], 0)
+
+    def sharded_gathered_prox_A(k, rho_a):
+        """matrix penalty on the sharded A (decomposition.py:203): the penalty's prox on the gathered A + U, own rows kept"""
+        reg, nat = regs[0][k], native[0][k]
+        full = reg.factor_matrix_update(gather_rows_A(eng.A + nat.dual), float(rho_a[0]), gather_rows_A(nat.aux))
+        lo = sum(a_counts[:rank_id])
+        z = reg.aux_as_matrix(full)[lo:lo + a_counts[rank_id]].to(nat.aux.dtype)
+        nat.dual.copy_(eng.A - (z - nat.dual))
+        nat.aux.copy_(z)
+
     def do_update_A():
-        if sharded_ball_A and not has_ext[0]:
+        if sharded_ball_A or any(gathered_A):
             eng.A_begin()
             all_reduce(eng.A_rho_max(), "max")
             eng.A_factor()
@@ -866,6 +896,8 @@ def cmf_aoadmm(
                 for k, nat in enumerate(native[0]):
                     if nat.kind == _engine.PEN_L2BALL:
                         sharded_ball_prox_A(k, rho_a)
+                    elif gathered_A[k]:
+                        sharded_gathered_prox_A(k, rho_a)
                     else:
                         host_prox_matrix(0, k, eng.A, rho_a, True)
                 if inner_converged(eng.A, A_old, 0):
@@ -912,8 +944,10 @@ def cmf_aoadmm(
                     reg_penalty += reg.reg_strength * d[base + 1]
                 elif sharded and mode == 1 and native[mode][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV):
                     reg_penalty += d[base + 1]  # this rank's matrices only: summed over the ranks with the vector (diagnostics())
-                elif native[mode][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV):  # value computed on device tensors
-                    factor = [eng.B[sl] for sl in row_slices] if mode == 1 else (eng.A if mode == 0 else eng.C)
+                elif native[mode][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV) or (mode == 0 and sharded and gathered_A[k]):
+                    # value computed on device tensors; a sharded A is gathered first (every rank adds the same, whole value)
+                    factor = [eng.B[sl] for sl in row_slices] if mode == 1 else (
+                        (gather_rows_A(eng.A) if sharded else eng.A) if mode == 0 else eng.C)
                     reg_penalty += float(reg.penalty(factor))
             gaps.append(mode_gaps)
             if l2_penalty[mode]:
@@ -974,7 +1008,7 @@ def cmf_aoadmm(
 
     it = -1  # Needed if n_iter_max <= 0
     # penalty values that need a host call per iteration (the device-resident loops below do not apply)
-    host_value = any(r.kind in (_engine.PEN_TV, _engine.PEN_EXTERNAL) for m in range(3) for r in native[m])
+    host_value = any(r.kind in (_engine.PEN_TV, _engine.PEN_EXTERNAL) for m in range(3) for r in native[m]) or any(gathered_A)
     fast_path = ((not (tol or absolute_tol)) and not sharded and not verbose and n_iter_max > 0 and not any(has_ext)
                  and not host_value)
     lazy_diag = (not (tol or absolute_tol)) and sharded and not verbose and n_iter_max > 0 and not host_value

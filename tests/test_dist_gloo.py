@@ -36,6 +36,9 @@ CASES = {
     # inner_tol set: every penalty is evaluated on the host (PEN_EXTERNAL), the inner loops stop on the reference's test -
     # over ALL B_i, i.e. on all-reduced norms under sharding - and the L1 value on the B_i must not be scaled twice
     "inner_tol_l1B": dict(),
+    # matrix penalties on A other than the L2 ball: unimodality down the rows of A and total variation along them couple rows
+    # that live on different ranks - every rank evaluates the prox on the all-gathered A + U and keeps its rows
+    "matrix_penalties_on_A": dict(constant_feasibility_penalty=True),
 }
 
 
@@ -77,6 +80,10 @@ def _explicit_state(case, mats, r, seed=9):
     elif case == "inner_tol_l1B":
         regs[0] = [("nn", mk((I, r)), mk((I, r)))]
         regs[1] = [("l1B", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
+        regs[2] = [("l1nn", mk((K, r)), mk((K, r)))]
+    elif case == "matrix_penalties_on_A":
+        regs[0] = [("uninn", mk((I, r)), mk((I, r))), ("tvA", mk((I, r)), mk((I, r)))]
+        regs[1] = [("nn", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
         regs[2] = [("l1nn", mk((K, r)), mk((K, r)))]
     elif case == "tv_B_and_C":
         regs[0] = [("nn", mk((I, r)), mk((I, r)))]
@@ -124,6 +131,8 @@ def _build(regs_spec, lo, hi):
                 out[m].append(pen.Unimodality(non_negativity=True, aux_init=aux, dual_init=dual))
             elif kind == "tv":
                 out[m].append(pen.TotalVariationPenalty(0.05, aux_init=aux, dual_init=dual))
+            elif kind == "tvA":
+                out[m].append(pen.TotalVariationPenalty(0.04, aux_init=aux, dual_init=dual))
             elif kind == "tvl1":
                 out[m].append(pen.TotalVariationPenalty(0.03, l1_strength=0.02, aux_init=aux, dual_init=dual))
     return out
@@ -188,7 +197,8 @@ def _spawn(world, case, salt=0):
 
 
 # world size 2: every stack; 4 and 8 ranks (the driver's scaling points): the stacks with the most collectives per iteration
-SHARDED_RUNS = [(2, c) for c in sorted(CASES)] + [(w, c) for w in (4, 8) for c in ("c3_nn_l1C", "readme_stack", "inner_tol_l1B")]
+SHARDED_RUNS = [(2, c) for c in sorted(CASES)] + [(w, c) for w in (4, 8) for c in ("c3_nn_l1C", "readme_stack", "inner_tol_l1B")] \
+    + [(4, "matrix_penalties_on_A")]
 
 
 @pytest.mark.parametrize("world,case", SHARDED_RUNS, ids=[f"{c}-x{w}" for w, c in SHARDED_RUNS])

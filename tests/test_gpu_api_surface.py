@@ -101,6 +101,8 @@ auxU, dualU = [mk((j, 4)) for j in J], [mk((j, 4)) for j in J]
 README_STACK = os.environ.get("STACK") == "readme"  # README.rst:66-91 of the reference: L2 ball on A, unimodal B_i
 TV_STACK = os.environ.get("STACK") == "tv"
 EXT_STACK = os.environ.get("STACK") == "ext"
+MATA_STACK = os.environ.get("STACK") == "matA"  # matrix penalties on the sharded A: evaluated on the all-gathered A + U
+auxA2, dualA2 = mk((6, 4)), mk((6, 4))
 class Ridge(pen.MatrixPenalty):
     """alpha * ||x||^2: prox x / (1 + 2 alpha / rho)"""
     def __init__(self, alpha, aux_init="random_uniform", dual_init="random_uniform"):
@@ -124,6 +126,9 @@ def run(lo, hi, group):
         regs[2] = [pen.TotalVariationPenalty(0.03, l1_strength=0.02, aux_init=auxC.copy(), dual_init=dualC.copy())]
     if EXT_STACK:  # a user-defined MatrixPenalty on the B_i: prox and value evaluated on the host, per matrix, on every rank
         regs[1] = [Ridge(0.3, aux_init=[a.copy() for a in auxL[lo:hi]], dual_init=[d.copy() for d in dualL[lo:hi]])]
+    if MATA_STACK:
+        regs[0] = [pen.Unimodality(non_negativity=True, aux_init=auxA[lo:hi].copy(), dual_init=dualA[lo:hi].copy()),
+                   pen.TotalVariationPenalty(0.04, aux_init=auxA2[lo:hi].copy(), dual_init=dualA2[lo:hi].copy())]
     if README_STACK:
         regs[0] = [pen.L2Ball(1.0, non_negativity=True, aux_init=auxA[lo:hi].copy(), dual_init=dualA[lo:hi].copy())]
         regs[1].insert(1, pen.Unimodality(non_negativity=True, aux_init=[a.copy() for a in auxU[lo:hi]],
@@ -148,7 +153,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("stack", ["pf2", "readme", "pf2_stop", "tv", "ext"])
+@pytest.mark.parametrize("stack", ["pf2", "readme", "pf2_stop", "tv", "ext", "matA"])
 def test_two_ranks_sharing_the_gpu_equal_single_process(tmp_path, stack):
     """cmf_aoadmm(group=) with the REAL engine: 2 processes share cuda:0, collectives over gloo (RCCL refuses two ranks on one
     device); PARAFAC2 + constant feasibility penalty exercise every reduction of the step path; the "readme" stack adds the
