@@ -186,6 +186,7 @@ void read_switches(mcl_switches &w) {
     w.xc_dbg = num("MCL_XC_DBG", 0), w.xt_dbg = num("MCL_XT_DBG", 0), w.xt_depth = num("MCL_XT_DEPTH", 0);
     w.sweep_dbg = num("MCL_SWEEP_DBG", 0), w.reduce_el = num("MCL_REDUCE_EL", 0), w.uni_split = num("MCL_UNI_SPLIT", -1);
     w.exact = num("MCL_EXACT", -1);
+    if (const char *e = getenv("MCL_RUN_SPINS")) w.run_spins = atol(e);  // operating parameter of mcl_run's wait (see there)
     if (const char *e = getenv("MCL_RUN_WATCHDOG_S")) {  // an operating parameter, not a kernel form (not listed by mcl_active_switches)
         const double v = atof(e);
         if (v > 0) w.run_watchdog_s = v;
@@ -1156,7 +1157,7 @@ int mcl_run(mcl_context *c, int32_t n_iter_max, int32_t update_A, int32_t update
         auto t_progress = std::chrono::steady_clock::now(), t_query = t_progress;
         long sleep_ns = 2000;
         while (!seen->stopped && it - seen->progress >= ahead) {
-            if (++spins <= 2000) {
+            if (++spins <= c->sw.run_spins) {
                 cpu_relax();
                 continue;
             }

@@ -73,6 +73,7 @@ struct mcl_switches {
     int x_nt_mb = 0, seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
     int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
     int exact = -1;  // MCL_EXACT: 1 / 0 force the exact-products mode on / off (default -1: by problem size, mcl_exact_mode)
+    long run_spins = 2000;          // mcl_run: polite spins of a wait before it starts to sleep (MCL_RUN_SPINS)
     double run_watchdog_s = 120.0;  // mcl_run: seconds without a verdict from the device before the wait gives up (MCL_RUN_WATCHDOG_S)
 };
 
