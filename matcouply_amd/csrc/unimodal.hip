@@ -57,14 +57,14 @@ struct UniScratch {
 //     emitted from the records by walking the chain from the split outwards (no third pooling sweep);
 //   * the emit loops walk POSITIONS in lockstep over the wave (loads and stores of the r lanes of a slab coalesce),
 //     records are fetched in unconditional 8-element batches;
-//   * ring entries are 20 bytes and the ring holds 8: 10 KB of LDS per wave, 16 waves per CU.
+//   * ring entries are 20 bytes and the ring holds MCL_UNI_RC = 16 of them in EVERY form: 20 KB of LDS per wave, two waves
+//     per SIMD (measured against 8 entries at three waves per SIMD and against deeper / shallower load batches: slower).
 // The records of the right-to-left sweep are stored at the position they belong to, so both emit loops index rows.
 // ---------------------------------------------------------------------------------------------------------
 template <class T>
 static __device__ __forceinline__ unsigned lds_addr(T *p) {  // byte offset of a __shared__ object in LDS
     return (unsigned)(unsigned long)(__attribute__((address_space(3))) T *)p;
 }
-#define RC4 8  // ring entries of the throughput form (MODE 0); the latency form (MODE 1: one wave per SIMD) has LDS for 16
 struct UniRing4 {
     double *sy, *q;  // LDS [RC][64]
     int *cw;         // LDS [RC][64]
@@ -258,8 +258,8 @@ template <int MODE>
 __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const int *__restrict__ ext, int n_slabs, float *__restrict__ F,
                                                          RegSet regs, int k, int r, UniScratch sc) {
     MCL_GATE(regs.gate);
-    // ring entries per lane: 8 in the throughput form (10 KB per wave, 16 waves per CU); the latency form runs at most two
-    // waves per SIMD and takes 16 (20 KB per wave) with refills of 8 - half as many spills and refills on deep stacks
+    // ring entries per lane and entries per refill (see the defaults above; round 4 re-measured RC = 8 / NRF = 4 / UB = 4 at
+    // three waves per SIMD: 14.5 ms against 10.2 ms per call at config 5 - the depth of the load batches matters more)
     constexpr int RC = MCL_UNI_RC, NRF = MCL_UNI_NRF;
     __shared__ double ring_d[2][MODE == 2 ? 1 : RC * 64];
     __shared__ int ring_i[MODE == 2 ? 1 : RC * 64];
