@@ -60,6 +60,7 @@ CONFIGS["c5_32nd"] = dict(CONFIGS["c5s"], I=256, J=2048, K=1024, desc="1/32 of c
 CONFIGS["c3_8th"] = dict(CONFIGS["c3"], I=128, desc="one eighth of config 3 (the per-rank shard of an 8-GPU run): I=128 J_i=512 K=256 rank=16")
 CONFIGS["c3_half"] = dict(CONFIGS["c3"], I=512, desc="one half of config 3 (the per-rank shard of a 2-GPU run): I=512 J_i=512 K=256 rank=16")
 CONFIGS["c3_4th"] = dict(CONFIGS["c3"], I=256, desc="one quarter of config 3 (the per-rank shard of a 4-GPU run): I=256 J_i=512 K=256 rank=16")
+CONFIGS["c3_64th"] = dict(CONFIGS["c3"], I=16, J=256, desc="a small problem (1 M elements of X: the exact-products mode of the library): I=16 J_i=256 K=256 rank=16")
 CONFIGS["c3r"] = dict(CONFIGS["c3"], J="ragged", desc="config 3 with the ragged slabs of config 4: I=1024 J_i in [128,1024] K=256 rank=16")
 CONFIGS["k512"] = dict(CONFIGS["c3"], I=512, J=512, K=512, desc="K=512 variant of config 3 (same bytes of X): I=512 J_i=512 K=512 rank=16")
 CONFIGS["r32"] = dict(CONFIGS["c3"], r=32, desc="rank-32 variant of config 3: I=1024 J_i=512 K=256 rank=32")

@@ -229,23 +229,28 @@ __global__ __launch_bounds__(256) void k_contract_xc_f64(const float *__restrict
     f64x4 acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = f64x4{0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        float xv[4], cv[NB][4];
+    for (int k0 = 0; k0 < K; k0 += 32) {  // two 16-column steps per trip: their loads are independent and issued together
+        float xv[2][4], cv[2][NB][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = k0 + 4 * kk + s;
-            xv[s] = (k < K) ? X[jx * K + k] : 0.f;
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int col = 16 * nb + i;
-                cv[nb][s] = (k < K && col < r) ? C[(long)k * r + col] : 0.f;
+            for (int s = 0; s < 4; ++s) {
+                const int k = k0 + 16 * h + 4 * kk + s;
+                const int kc = min(k, K - 1);  // unconditional loads at clamped indices, masked by a multiplication (no branch per load)
+                xv[h][s] = X[jx * K + kc] * ((k < K) ? 1.f : 0.f);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int col = 16 * nb + i;
+                    cv[h][nb][s] = C[(long)kc * r + min(col, r - 1)] * ((k < K && col < r) ? 1.f : 0.f);
+                }
             }
-        }
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                acc[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xv[s], (double)cv[nb][s], acc[nb], 0, 0, 0);
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xv[h][s], (double)cv[h][nb][s], acc[nb], 0, 0, 0);
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)

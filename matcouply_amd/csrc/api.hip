@@ -90,6 +90,7 @@ int64_t plan(mcl_context *c, char *base) {
     c->rho_max = b.take<float>(2);
     c->partials = b.take<double>((int64_t)mcl_contract_n_partials(c) * E);
     c->GR = b.take<double>(E);
+    c->exact_part = c->exact ? b.take<double>(std::max<int64_t>(1, (N + 255) / 256) * E) : nullptr;
     c->GRf = b.take<float>(E);
     c->LinvC64 = b.take<double>(r * r);
     c->rhoC = b.take<float>(1);

@@ -1133,9 +1133,11 @@ int mcl_launch_slab_gram(mcl_context *c) {
 // 8e-8 at cond 600) and the passes over X are what the iteration costs; on SMALL problems neither holds: every kernel is
 // launch-bound and a few hundred rows do not average anything.  So problems of at most 2^20 elements of X (4 MB: an eighth of
 // config 2, the smallest BASELINE configuration) take every contraction as fp64 sums of EXACT products of the stored fp32
-// values - what the reference's arithmetic gives on the same inputs up to 1e-16 - and keep fp64 through the solves:
+// values - what the reference's arithmetic gives on the same inputs up to 1e-16 - and keep fp64 through the solves.  Cost
+// (tools/exact_mode_cost.py; no sweep, two more launches per iteration): 43 against 39 us per iteration at the size of
+// BASELINE config 1, 61 against 39 us at the 2^20 limit (rank 16), 154 against 112 us there at rank 32.
 //   X C            k_contract_xc_f64 (fp64 MFMA; admm.hip) -> XC64 and its once-rounded fp32 image for the row kernels
-//   [G | R]        k_exact_gr below -> GR, no partials, no sweep
+//   [G | R]        k_exact_gr below (fp64 MFMA over 256-row chunks, summed in a fixed order) -> GR, no sweep
 //   rhs_i, B_i^T B_i   k_slab_gram from XC64 -> the fp64 tables k_A_finish reads (and the reconstruction error)
 // MCL_EXACT=1 / 0 forces the mode on / off (the parity tests of the fast kernels run small problems with MCL_EXACT=0).
 // ---------------------------------------------------------------------------------------------------------
@@ -1144,43 +1146,111 @@ bool mcl_exact_mode(const mcl_context *c) {
     return c->N * c->K <= (int64_t(1) << 20);
 }
 
-// Block b < ceil(K / 16): R[16 b + (t & 15)][c] for c = t >> 4, + 16, ...;  last block: G.  Every output is ONE sequential fp64
-// sum over the rows in order (deterministic); (b a) is an exact product of two fp32 values, x (b a) rounds once in the fma.
-__global__ __launch_bounds__(256) void k_exact_gr(const float *__restrict__ X, const float *__restrict__ B,
-                                                  const float *__restrict__ A, const int *__restrict__ slab_of_row, long N,
-                                                  int K, int r, double *__restrict__ GR) {
-    const int t = threadIdx.x;
+// [G | R] of the exact-products mode on the fp64 MFMA.  Block (x, y): row chunk y (256 rows: the unit of the fixed-order sum),
+// x < ceil(K / 16): the 16 x r tile R[16 x .. + 15][:], x == ceil(K / 16): G.  One wave; per group of 4 rows lane
+// (i = l & 15, kk = l >> 4) feeds A[i][kk] = X[row + kk][16 x + i] (resp. (b a)[row + kk][16 na + i]) and
+// B[kk][j = i] = (b a)[row + kk][16 nb + i]; (b a) is an exact product of two fp32 values, the MFMA rounds each fp64 multiply-add
+// once.  D: lane l, register v = D[(l >> 4) + 4 v][l & 15].  Every output is a sum over the rows in ascending order
+// (k_exact_gr_reduce adds the chunks in ascending order): deterministic, and the same on every rank layout of the same rows.
+template <int NB>
+__global__ __launch_bounds__(64) void k_exact_gr(const float *__restrict__ X, const float *__restrict__ B,
+                                                 const float *__restrict__ A, const int *__restrict__ slab_of_row, long N, int K,
+                                                 int r, double *__restrict__ part) {
+    const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
     const int kblocks = (K + 15) / 16;
+    const long c0 = (long)blockIdx.y * 256, c1 = min(c0 + 256, N);
+    const long E = (long)r * r + (long)K * r;
+    double *out = part + (long)blockIdx.y * E;
+    // unconditional loads at clamped indices, masked by a MULTIPLICATION (a select lets the compiler sink the loads into a
+    // branch again, and a branch per load serialises the memory round trips of a trip); rows / columns past the end
+    // contribute an exact zero (the clamped element is finite data of the same arrays)
+    auto ba = [&](long row, int col) -> double {
+        const long rc = min(row, c1 - 1);
+        const int cc = min(col, r - 1);
+        const double mask = (row < c1 && col < r) ? 1.0 : 0.0;
+        return ((double)B[rc * r + cc] * mask) * (double)A[(long)slab_of_row[rc] * r + cc];
+    };
     if ((int)blockIdx.x < kblocks) {
-        const int k = 16 * blockIdx.x + (t & 15);
-        double *R = GR + (long)r * r;
-        for (int c0 = t >> 4; c0 < r; c0 += 16) {
-            double acc = 0.0;
-            if (k < K)
-                for (long j = 0; j < N; ++j) {
-                    const double ba = (double)B[j * r + c0] * (double)A[(long)slab_of_row[j] * r + c0];
-                    acc = fma((double)X[j * K + k], ba, acc);
-                }
-            if (k < K) R[(long)k * r + c0] = acc;
-        }
-    } else {
-        for (int p = t; p < r * r; p += 256) {
-            const int c1 = p / r, c2 = p - c1 * r;
-            double acc = 0.0;
-            for (long j = 0; j < N; ++j) {
-                const long i = slab_of_row[j];
-                const double b1 = (double)B[j * r + c1] * (double)A[i * r + c1], b2 = (double)B[j * r + c2] * (double)A[i * r + c2];
-                acc = fma(b1, b2, acc);
+        const int k = 16 * blockIdx.x + i;
+        f64x4 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (long g = c0; g < c1; g += 16) {  // four groups of 4 rows per trip: their loads are independent and issued together
+            double x[4], w[4][NB];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long row = g + 4 * u + kk;
+                x[u] = (double)X[min(row, c1 - 1) * K + min(k, K - 1)] * ((row < c1 && k < K) ? 1.0 : 0.0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) w[u][nb] = ba(row, 16 * nb + i);
             }
-            GR[p] = acc;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], w[u][nb], acc[nb], 0, 0, 0);
         }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ko = 16 * blockIdx.x + kk + 4 * v, col = 16 * nb + i;
+                if (ko < K && col < r) out[(long)r * r + (long)ko * r + col] = acc[nb][v];
+            }
+    } else {
+        f64x4 acc[NB][NB];
+#pragma unroll
+        for (int na = 0; na < NB; ++na)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[na][nb] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (long g = c0; g < c1; g += 16) {
+            double v[4][NB];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) v[u][nb] = ba(g + 4 * u + kk, 16 * nb + i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int na = 0; na < NB; ++na)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[na][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u][na], v[u][nb], acc[na][nb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int na = 0; na < NB; ++na)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int a = 16 * na + kk + 4 * v, b = 16 * nb + i;
+                    if (a < r && b < r) out[(long)a * r + b] = acc[na][nb][v];
+                }
     }
+}
+
+__global__ __launch_bounds__(256) void k_exact_gr_reduce(const double *__restrict__ part, int n_chunks, long E,
+                                                         double *__restrict__ GR) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    double s = 0.0;
+    for (int c = 0; c < n_chunks; ++c) s += part[(long)c * E + e];  // ascending: fixed order
+    GR[e] = s;
 }
 
 int mcl_launch_exact_gr(mcl_context *c) {
     const int kblocks = (int)((c->K + 15) / 16);
-    hipLaunchKernelGGL(k_exact_gr, dim3((unsigned)(kblocks + 1)), dim3(256), 0, c->stream, c->X, c->B, c->A, c->slab_of_row,
-                       (long)c->N, (int)c->K, c->r, c->GR);
+    const int n_chunks = (int)std::max<int64_t>(1, (c->N + 255) / 256);
+    const long E = (long)c->K * c->r + (long)c->r * c->r;
+    const dim3 grid((unsigned)(kblocks + 1), (unsigned)n_chunks);
+    double *part = n_chunks == 1 ? c->GR : c->exact_part;  // one chunk (<= 256 rows): its sums ARE [G | R], no second launch
+    if (c->NB == 1)
+        hipLaunchKernelGGL(k_exact_gr<1>, grid, dim3(64), 0, c->stream, c->X, c->B, c->A, c->slab_of_row, (long)c->N, (int)c->K, c->r, part);
+    else if (c->NB == 2)
+        hipLaunchKernelGGL(k_exact_gr<2>, grid, dim3(64), 0, c->stream, c->X, c->B, c->A, c->slab_of_row, (long)c->N, (int)c->K, c->r, part);
+    else
+        hipLaunchKernelGGL(k_exact_gr<4>, grid, dim3(64), 0, c->stream, c->X, c->B, c->A, c->slab_of_row, (long)c->N, (int)c->K, c->r, part);
+    if (n_chunks > 1)
+        hipLaunchKernelGGL(k_exact_gr_reduce, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, c->exact_part, n_chunks, E, c->GR);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

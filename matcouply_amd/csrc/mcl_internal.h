@@ -120,6 +120,7 @@ struct mcl_context {
     long long *sweep_cycles = nullptr;  // [n_blocks, 4 waves, 6] per-section cycle counts (MCL_SWEEP_DBG & 32)
     bool grpart_valid = false;     // GRpart was weighted with the current A (and mseg_valid)
     bool sweep_planned = false;    // the workspace holds the sweep buffers
+    double *exact_part = nullptr;  // exact-products mode: [G | R] per 256-row chunk (fp64), summed in a fixed order
     bool exact = false;            // exact-products mode (small problems): X C, [G | R] and the A-phase tables from fp64 sums of exact products
     bool mseg_valid = false;       // Mpart / part_btb correspond to the current B
     bool seg_from_sweep = false;   // k_A_finish sums seg_rhs / part_btb over bsegs instead of segments
