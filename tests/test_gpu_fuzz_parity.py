@@ -98,3 +98,43 @@ def test_ill_conditioned_penalty_free_modes(seed):
     print(seed, f"exact products {worst(exact):.1e}   fast kernels {worst(fast):.1e}")
     assert worst(exact) < 1e-5, exact
     assert worst(fast) > worst(exact)
+
+
+def test_exact_products_mode_is_not_a_performance_cliff():
+    """The mode serves the sizes most users of the reference have (its own examples are 15 matrices of 50 x 20): it may cost a
+    launch or two per iteration, not a multiple - its first form (one sequential sum per output) was 20x slower than the fast
+    kernels at the size limit and nothing noticed.  Guard: at most 2.5x at the limit (measured 1.6x), 1.6x at BASELINE config 1's
+    size (measured 1.1x)."""
+    import time
+
+    import torch
+
+    import bench
+
+    dev = torch.device("cuda", 0)
+    old = os.environ.get("MCL_EXACT")
+    try:
+        for (I, J, K, r), bound in (((16, 256, 256, 16), 2.5), ((15, 50, 20, 3), 1.6)):
+            t = {}
+            for exact in ("1", "0"):
+                os.environ["MCL_EXACT"] = exact
+                cfg = dict(bench.CONFIGS["c3"], I=I, J=J, K=K, r=r)
+                X, row_ptr, I_loc = bench.make_shard(cfg, 0, 1, dev)
+                eng = bench.make_engine(cfg, X, row_ptr, I_loc, 0, dev)
+                assert (eng.kernel_variant(4) != "") == (exact == "1")
+                eng.iterate(50)
+                torch.cuda.synchronize()
+                best = float("inf")
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    eng.iterate(200)
+                    torch.cuda.synchronize()
+                    best = min(best, (time.perf_counter() - t0) / 200)
+                t[exact] = best
+                eng.close()
+            print(f"I={I} J={J} K={K} r={r}: exact {1e6 * t['1']:.1f} us, fast {1e6 * t['0']:.1f} us per iteration")
+            assert t["1"] < bound * t["0"], (I, J, K, r, t)
+    finally:
+        os.environ.pop("MCL_EXACT", None)
+        if old is not None:
+            os.environ["MCL_EXACT"] = old
