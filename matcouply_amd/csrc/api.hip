@@ -121,11 +121,9 @@ int64_t plan(mcl_context *c, char *base) {
     c->colsq = b.take<double>(std::max<int64_t>(I, 1) * r * MCL_MAX_REGS);  // one table per penalty slot (fused stack)
     if (has_kind(c, MCL_PEN_UNIMODAL)) {
         c->uni_f64 = b.take<double>(10 * (maxrows + std::max<int64_t>(I, 1)) * r);
-        c->uni_i32 = b.take<int>(2 * maxrows * r);
         c->uni_sink = b.take<float>(2 * 64 * ((std::max<int64_t>(I, 1) * r + 63) / 64));
     } else {
         c->uni_f64 = nullptr;
-        c->uni_i32 = nullptr;
         c->uni_sink = nullptr;
     }
     // per-tile statistics of the B solve pass (fused generic stacks)
@@ -180,7 +178,7 @@ void read_switches(mcl_switches &w) {
     w.no_fused_gram = flag("MCL_NO_FUSED_GRAM"), w.no_fused_c = flag("MCL_NO_FUSED_C");
     w.a_finish_cols = flag("MCL_A_FINISH_COLS"), w.xc_norow = flag("MCL_XC_NOROW");
     w.uni_noprune = flag("MCL_UNI_NOPRUNE"), w.stats_reduce = flag("MCL_STATS_REDUCE");
-    w.no_rows64 = flag("MCL_NO_ROWS64"), w.no_uni_coop = flag("MCL_NO_UNI_COOP"), w.uni_spill_layout = num("MCL_UNI_SPILL_LAYOUT", 0);
+    w.no_rows64 = flag("MCL_NO_ROWS64"), w.no_uni_coop = flag("MCL_NO_UNI_COOP");
     w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_a_wide = flag("MCL_NO_A_WIDE"), w.no_bseg_groups = flag("MCL_NO_BSEG_GROUPS"), w.no_sweep_half = flag("MCL_NO_SWEEP_HALF"), w.no_x_nt = flag("MCL_NO_X_NT"), w.x_nt_mb = num("MCL_X_NT_MB", 0), w.no_multi_c = flag("MCL_NO_MULTI_C"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1");
     w.seg_rows = num("MCL_SEG_ROWS", 0), w.bseg_rows = num("MCL_BSEG_ROWS", 0);
     w.xc_waves = num("MCL_XC_WAVES", 0), w.xt_waves = num("MCL_XT_WAVES", 0), w.sweep_waves = num("MCL_SWEEP_WAVES", 0);
@@ -202,7 +200,7 @@ std::string switches_in_env() {
         "MCL_UNI_NOPRUNE", "MCL_STATS_REDUCE", "MCL_NO_ROWS64", "MCL_NO_UNI_COOP", "MCL_NO_A_FUSION", "MCL_NO_A_WIDE", "MCL_NO_BSEG_GROUPS",
         "MCL_NO_SWEEP_HALF", "MCL_NO_X_NT", "MCL_X_NT_MB", "MCL_NO_MULTI_C", "MCL_NO_DIAG_DEFER", "MCL_XC_DEPTH1", "MCL_SEG_ROWS",
         "MCL_BSEG_ROWS", "MCL_XC_WAVES", "MCL_XT_WAVES", "MCL_SWEEP_WAVES", "MCL_XC_DBG", "MCL_XT_DBG", "MCL_XT_DEPTH",
-        "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT", "MCL_EXACT", "MCL_UNI_SPILL_LAYOUT"};
+        "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT", "MCL_EXACT"};
     std::string out;
 #ifdef MCL_NO_ENV_SWITCHES
     return out;

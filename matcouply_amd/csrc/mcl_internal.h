@@ -68,7 +68,6 @@ struct mcl_switches {
     bool no_stack_fusion = false, no_solve_stats = false, no_next_b = false, no_fused_gram = false, no_fused_c = false;
     bool a_finish_cols = false, xc_norow = false, uni_noprune = false, stats_reduce = false;
     bool no_rows64 = false, no_uni_coop = false;
-    int uni_spill_layout = 0;  // MCL_UNI_SPILL_LAYOUT (unimodal.hip)
     bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_x_nt = false, no_sweep_half = false, no_multi_c = false, no_diag_defer = false, xc_depth1 = false;
     int x_nt_mb = 0, seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
     int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
@@ -197,7 +196,6 @@ struct mcl_context {
 
     double *colsq = nullptr;    // [max(I,1), r]   per-slab column sums of squares (L2Ball)
     double *uni_f64 = nullptr;  // unimodal regression scratch: 10 fp64 arrays of (rows + slabs) * r
-    int *uni_i32 = nullptr;     //                              2 int32 arrays of rows * r
     float *uni_sink = nullptr;  // two floats per lane of the unimodal kernels: where predicated-off stores of the emit loops go
     double *pf2_S = nullptr;    // [I, r, r]  Y_i^T Y_i (fp64)
     float *pf2_T = nullptr;     // [I, r, r]  P_i = Y_i T_i

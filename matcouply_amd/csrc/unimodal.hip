@@ -18,12 +18,10 @@
 // Scratch arrays are column-interleaved (index * r + col) so the r threads of a slab access them coalesced.
 // ---------------------------------------------------------------------------------------------------------
 struct UniScratch {
-    double *lvL, *lvR, *eL, *eR, *sy, *sy2, *sw, *cum2;
-    int *stL, *stR;
+    double *lvL, *lvR, *eL, *eR;
     float *sink;  // two floats per lane: target of the emit loops' predicated-off stores
     int coop;     // cooperative ring refill (ur4_refill_coop); 0: MCL_NO_UNI_COOP (A/B switch)
     double *spL, *spR;  // packed spill areas (3 doubles per entry) of the left-to-right / right-to-left sweep
-    int spill_layout;   // 0 packed lane-private entries; 1 lane-private, one array per field; 2 interleaved by column (round 3)
 // ring entries per lane / entries per refill / elements per load batch (build-time; the defaults are the measured best)
 #ifndef MCL_UNI_RC
 #define MCL_UNI_RC 16
@@ -92,6 +90,14 @@ static __device__ __forceinline__ UniRec ld_rec_nt(const UniRec *p) {
     return rc;
 }
 
+// Spill area of a lane: packed 24-byte entries (sum, Q: fp64; count: int32 + pad), contiguous by depth - `sp` points at the
+// lane's entry 0.  Every address below is the lane's base plus a small offset (one 64-bit add per access, no multiplies).
+static __device__ __forceinline__ void sp_store(double *sp, int k, double sy, double q, int cw) {
+    double *e = sp + 3 * (long)k;
+    e[0] = sy, e[1] = q;
+    *reinterpret_cast<int *>(e + 2) = cw;
+}
+
 // The top NRF entries of the spill area, prefetched into registers (see ur4_refill_coop): n of them are valid copies of the
 // spill indices [mem_n - n, mem_n).
 template <int NRF>
@@ -110,20 +116,14 @@ struct UniPrefetch {
 // really buries most entries more than a ring deep before a collapse exposes them again.)
 template <int RC, int NRF>
 static __device__ __forceinline__ void ur4_push(UniRing4 &st, UniPrefetch<NRF> &pf, int lane, bool act, double sy, int cw, double q,
-                                                double *__restrict__ gsy, double *__restrict__ gq, int *__restrict__ gcw,
-                                                long base, long rs, int col, int spk) {
+                                                double *__restrict__ sp) {
     if (act) {
         if (st.cnt == RC) {
             const int b = ((st.h - RC + 1) & (RC - 1)) * 64 + lane;
-            const long idx = (base + st.mem_n) * rs + col;
 #ifdef MCL_UNI_DBG
             if (!(st.dbg & 4))
 #endif
-            {
-                gsy[idx * spk] = st.sy[b];
-                gq[idx * spk] = st.q[b];
-                gcw[idx * (spk == 3 ? 6 : 1)] = st.cw[b];
-            }
+                sp_store(sp, st.mem_n, st.sy[b], st.q[b], st.cw[b]);
             st.mem_n += 1;
             st.cnt = RC - 1;
             pf.n = 0;  // the prefetched entries are no longer the top of the spill area
@@ -152,15 +152,14 @@ static __device__ __forceinline__ void ur4_take_prefetched(UniRing4 &st, UniPref
     pf.n = 0;
 }
 
-// request the next entries of the spill area (top first); nothing waits for them here
+// request the next entries of the spill area (top first); nothing waits for them here.  Unconditional loads at clamped depths
+// (entries past the bottom read slot 0 and are never used: pf.n counts the valid ones)
 template <int NRF>
-static __device__ __forceinline__ void ur4_prefetch(const UniRing4 &st, UniPrefetch<NRF> &pf, const double *__restrict__ gsy,
-                                                    const double *__restrict__ gq, const int *__restrict__ gcw, long base,
-                                                    long rs, int col, int spk) {
+static __device__ __forceinline__ void ur4_prefetch(const UniRing4 &st, UniPrefetch<NRF> &pf, const double *__restrict__ sp) {
 #pragma unroll
-    for (int i = 0; i < NRF; ++i) {  // unconditional clamped loads
-        const long idx = (base + (st.mem_n > i ? st.mem_n - 1 - i : 0)) * rs + col;
-        pf.sy[i] = gsy[idx * spk], pf.q[i] = gq[idx * spk], pf.cw[i] = gcw[idx * (spk == 3 ? 6 : 1)];
+    for (int i = 0; i < NRF; ++i) {
+        const double *e = sp + 3 * (long)max(st.mem_n - 1 - i, 0);
+        pf.sy[i] = e[0], pf.q[i] = e[1], pf.cw[i] = *reinterpret_cast<const int *>(e + 2);
     }
     pf.n = st.mem_n < NRF ? st.mem_n : NRF;
 }
@@ -168,19 +167,17 @@ static __device__ __forceinline__ void ur4_prefetch(const UniRing4 &st, UniPrefe
 // a lane that has to pop finds its ring empty but has spilled entries (rare: the cooperative refill below keeps the rings
 // topped up): prefetched entries if it has them, else a blocking refill
 template <int RC, int NRF>
-static __device__ __forceinline__ void ur4_refill_dry(UniRing4 &st, UniPrefetch<NRF> &pf, int lane,
-                                                      const double *__restrict__ gsy, const double *__restrict__ gq,
-                                                      const int *__restrict__ gcw, long base, long rs, int col, int spk) {
+static __device__ __forceinline__ void ur4_refill_dry(UniRing4 &st, UniPrefetch<NRF> &pf, int lane, const double *__restrict__ sp) {
     if (pf.n > 0) {
         ur4_take_prefetched<RC, NRF>(st, pf, lane);
     } else {
         const int nref = st.mem_n >= RC / 2 ? RC / 2 : st.mem_n;  // independent loads, one latency
         for (int i = 0; i < nref; ++i) {
-            const long idx = (base + st.mem_n - 1 - i) * rs + col;
+            const double *e = sp + 3 * (long)(st.mem_n - 1 - i);
             const int t = ((st.h - i) & (RC - 1)) * 64 + lane;
-            st.sy[t] = gsy[idx * spk];
-            st.q[t] = gq[idx * spk];
-            st.cw[t] = gcw[idx * (spk == 3 ? 6 : 1)];
+            st.sy[t] = e[0];
+            st.q[t] = e[1];
+            st.cw[t] = *reinterpret_cast<const int *>(e + 2);
         }
         st.mem_n -= nref;
         st.cnt = nref;
@@ -198,9 +195,7 @@ static __device__ __forceinline__ void ur4_refill_dry(UniRing4 &st, UniPrefetch<
 // steps ago), or with a blocking load when a spill has invalidated them - and requests the next NRF.  The lanes fall
 // into step, and on a falling flank no refill waits for memory at all.
 template <int RC, int NRF>
-static __device__ __forceinline__ void ur4_refill_coop(UniRing4 &st, UniPrefetch<NRF> &pf, int lane,
-                                                       const double *__restrict__ gsy, const double *__restrict__ gq,
-                                                       const int *__restrict__ gcw, long base, long rs, int col, int spk) {
+static __device__ __forceinline__ void ur4_refill_coop(UniRing4 &st, UniPrefetch<NRF> &pf, int lane, const double *__restrict__ sp) {
     if (__builtin_amdgcn_ballot_w64(st.cnt <= 1 && st.mem_n > 0) == 0) return;  // wave-uniform
     // a lane joins when its own ring is at most half full: it will run dry soon (joining whenever there was room made every
     // lane prefetch four times as often as it refilled, and most of those prefetches were invalidated by the next spill)
@@ -208,7 +203,7 @@ static __device__ __forceinline__ void ur4_refill_coop(UniRing4 &st, UniPrefetch
     if (pf.n > 0) {
         if (room >= pf.n) {
             ur4_take_prefetched<RC, NRF>(st, pf, lane);
-            ur4_prefetch<NRF>(st, pf, gsy, gq, gcw, base, rs, col, spk);
+            ur4_prefetch<NRF>(st, pf, sp);
         }
     } else if (st.mem_n > 0 && room > 0) {
         const int want = room < NRF ? room : NRF;
@@ -217,8 +212,8 @@ static __device__ __forceinline__ void ur4_refill_coop(UniRing4 &st, UniPrefetch
         int vcw[NRF];
 #pragma unroll
         for (int i = 0; i < NRF; ++i) {  // independent clamped loads: one latency
-            const long idx = (base + (st.mem_n > i ? st.mem_n - 1 - i : 0)) * rs + col;
-            vsy[i] = gsy[idx * spk], vq[i] = gq[idx * spk], vcw[i] = gcw[idx * (spk == 3 ? 6 : 1)];
+            const double *e = sp + 3 * (long)max(st.mem_n - 1 - i, 0);
+            vsy[i] = e[0], vq[i] = e[1], vcw[i] = *reinterpret_cast<const int *>(e + 2);
         }
 #pragma unroll
         for (int i = 0; i < NRF; ++i) {
@@ -229,7 +224,7 @@ static __device__ __forceinline__ void ur4_refill_coop(UniRing4 &st, UniPrefetch
         }
         st.mem_n -= nref;
         st.cnt += nref;
-        ur4_prefetch<NRF>(st, pf, gsy, gq, gcw, base, rs, col, spk);
+        ur4_prefetch<NRF>(st, pf, sp);
     }
 }
 
@@ -277,31 +272,18 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
     double *__restrict__ errL = sc.eL, *__restrict__ errR = sc.eR;
     // spill areas of the block stack: the concurrent right-to-left sweep of MODE 1 has its own
     // (MODE 3 switches between the two areas: its left-to-right sweep pauses while the right-to-left one runs)
-    // layout 0 (default): one packed 24-byte entry (sum, Q, count) per depth; 1 / 2 (A/B switches): three arrays
-    const int spk = sc.spill_layout == 0 ? 3 : 1;
-    double *gsy, *gq;
-    int *gcw;
-    auto spill_area = [&](bool right) {
-        if (sc.spill_layout == 0) {
-            double *p = right ? sc.spR : sc.spL;
-            gsy = p, gq = p + 1, gcw = reinterpret_cast<int *>(p + 2);
-        } else {
-            gsy = right ? sc.sw : sc.sy, gq = right ? sc.cum2 : sc.sy2, gcw = right ? sc.stR : sc.stL;
-        }
-    };
+    double *sp;  // this lane's spill area of the sweep that is running (see "Spill areas" below)
+    auto spill_area = [&](bool right) { sp = (right ? sc.spR : sc.spL) + 3 * ((long)s * r + (long)col * n); };
     spill_area(MODE == 1 && do_R);
     UniRec *__restrict__ recL = reinterpret_cast<UniRec *>(sc.lvL), *__restrict__ recR = reinterpret_cast<UniRec *>(sc.lvR);
     const long rs = r;
     const long eb = (long)s + slab;  // n + 1 error entries per slab
-    // Spill areas: entry k of a lane at (sp_base + k) * sp_rs + sp_col.  The per-position arrays (errors, records) are
-    // column-interleaved because the lanes of a slab walk the POSITIONS in lockstep; the depth of the spilled stack is the
-    // lane's own, so its spill area is lane-private and contiguous (round 4): consecutive spills of a lane fill the same
-    // 64-byte sectors - the write-back L2 sends them out as whole lines - and a refill of 8 entries reads one sector per
-    // array instead of eight; the three fields of an entry sit side by side (24 bytes).  (MCL_UNI_SPILL_LAYOUT=2: the interleaved
-    // layout of round 3, =1: lane-private but one array per field - for A/B.)
-    const long sp_rs = sc.spill_layout == 2 ? rs : 1;
-    const long sp_base = sc.spill_layout == 2 ? (long)s : (long)s * rs + (long)col * n;
-    const int sp_col = sc.spill_layout == 2 ? col : 0;
+    // Spill areas.  The per-position arrays (errors, records) are column-interleaved because the lanes of a slab walk the
+    // POSITIONS in lockstep; the depth of the spilled stack is the lane's own, so its spill area is lane-private and contiguous
+    // (round 4): packed 24-byte entries (sum, Q, count), entry k of (slab, column) at 3 (s r + col n + k) doubles of the sweep's
+    // array.  Consecutive spills of a lane fill the same 64-byte sectors - the write-back L2 sends them out as whole lines -
+    // and a refill of 8 entries reads 192 contiguous bytes.  (Same box, config 5 at outer iteration 30, pruned sweeps: 13.2 ms
+    // with round 3's column-interleaved areas, 11.7 ms lane-private with one array per field, 10.2 ms packed.)
 
     UniRing4 st;
     UniPrefetch<NRF> pf;
@@ -324,10 +306,10 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
     };
     // one element: returns the prefix error; leaves (levf, ccw) = record of the block ending at this element
     auto step = [&](double v, bool first) -> double {
-        if (sc.coop) ur4_refill_coop<RC, NRF>(st, pf, lane, gsy, gq, gcw, sp_base, sp_rs, sp_col, spk);
+        if (sc.coop) ur4_refill_coop<RC, NRF>(st, pf, lane, sp);
         cum2 += v * v;
         // the finished block becomes the cached top; the previous top moves into the ring
-        ur4_push<RC, NRF>(st, pf, lane, !first && ht != 0, tsy, (int)tcw, tQ, gsy, gq, gcw, sp_base, sp_rs, sp_col, spk);
+        ur4_push<RC, NRF>(st, pf, lane, !first && ht != 0, tsy, (int)tcw, tQ, sp);
         if (!first) {
             tsy = csy, tcw = ccw, tQ = curQ;
             ht = 1;
@@ -386,7 +368,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                 : "vcc", "scc", "memory");
             if (dry_exit == 0) break;  // wave-uniform
             if (ht != 0 && csy * tcw <= tsy * ccw && st.cnt == 0 && st.mem_n > 0)
-                ur4_refill_dry<RC, NRF>(st, pf, lane, gsy, gq, gcw, sp_base, sp_rs, sp_col, spk);
+                ur4_refill_dry<RC, NRF>(st, pf, lane, sp);
         }
         // a block with a negative mean is clamped to level 0 and contributes q = 0; every block below it has a smaller
         // mean, so their Q is exactly 0 too and the prefix error comes out as cum2 without a special case
@@ -465,8 +447,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
             for (int kk = 0; kk < RC; ++kk) {
                 if (kk < st.cnt) {
                     const int b = ((st.h - st.cnt + 1 + kk) & (RC - 1)) * 64 + lane;
-                    const long idx = (sp_base + st.mem_n + kk) * sp_rs + sp_col;
-                    gsy[idx * spk] = st.sy[b], gq[idx * spk] = st.q[b], gcw[idx * (spk == 3 ? 6 : 1)] = st.cw[b];
+                    sp_store(sp, st.mem_n + kk, st.sy[b], st.q[b], st.cw[b]);
                 }
             }
             const int L_mem = st.mem_n + st.cnt, L_ht = ht;
@@ -797,12 +778,9 @@ static UniScratch uni_scratch(mcl_context *c) {
     UniScratch s;
     double *d = c->uni_f64;
     s.lvL = d, s.lvR = d + n1, s.eL = d + 2 * n1, s.eR = d + 3 * n1;
-    s.spL = d + 4 * n1, s.spR = d + 7 * n1;  // 3 n1 doubles each; the A/B layouts use parts of them as separate arrays
-    s.sy = s.spL, s.sy2 = s.spL + n1, s.sw = s.spR, s.cum2 = s.spR + n1;
-    s.stL = c->uni_i32, s.stR = c->uni_i32 + maxrows * c->r;
+    s.spL = d + 4 * n1, s.spR = d + 7 * n1;  // 3 n1 doubles each
     s.sink = c->uni_sink;
     s.coop = c->sw.no_uni_coop ? 0 : 1;
-    s.spill_layout = c->sw.uni_spill_layout;
 #ifdef MCL_UNI_DBG
     s.dbg = getenv("MCL_UNI_DBG") ? atoi(getenv("MCL_UNI_DBG")) : 0;
 #endif

@@ -27,15 +27,13 @@ torch.cuda.synchronize()
 print(f"{name}: {n_it} outer iterations done; {X.shape[0] * cfg['r'] / 1e6:.1f} M elements per call", flush=True)
 B0, U0 = eng.B.clone(), reg.dual.clone()
 eng.B_begin(); eng.B_factor()
-forms = [("round 3: no pruning, interleaved spills", {"MCL_UNI_SPLIT": "0", "MCL_UNI_NOPRUNE": "1", "MCL_UNI_SPILL_LAYOUT": "2"}),
-         ("pruned sweeps, interleaved spills", {"MCL_UNI_SPLIT": "0", "MCL_UNI_SPILL_LAYOUT": "2"}),
-         ("pruned sweeps, lane-private spills, 3 arrays", {"MCL_UNI_SPLIT": "0", "MCL_UNI_SPILL_LAYOUT": "1"}),
-         ("pruned sweeps, packed lane-private (default)", {"MCL_UNI_SPLIT": "0"})]
+forms = [("no pruning", {"MCL_UNI_SPLIT": "0", "MCL_UNI_NOPRUNE": "1"}),
+         ("pruned sweeps (default)", {"MCL_UNI_SPLIT": "0"})]
 if len(sys.argv) > 3 and sys.argv[3] == "latency":
     forms.append(("latency form (MODE 1 + 2)", {"MCL_UNI_SPLIT": "1"}))
 ref = None
 for label, env in forms:
-    for k in ("MCL_UNI_SPLIT", "MCL_UNI_NOPRUNE", "MCL_UNI_SPILL_LAYOUT"):
+    for k in ("MCL_UNI_SPLIT", "MCL_UNI_NOPRUNE"):
         os.environ.pop(k, None)
     os.environ.update(env)
     eng.reload_switches()
@@ -55,8 +53,8 @@ for label, env in forms:
           + (f" (max {float((ref - reg.aux).abs().max()):.2e})" if nd else ""), flush=True)
 eng.B.copy_(B0); reg.dual.copy_(U0)
 eng.B_end()
-for label, env in (("round 3", {"MCL_UNI_NOPRUNE": "1", "MCL_UNI_SPILL_LAYOUT": "2"}), ("default", {})):
-    for k in ("MCL_UNI_SPLIT", "MCL_UNI_NOPRUNE", "MCL_UNI_SPILL_LAYOUT"):
+for label, env in (("no pruning", {"MCL_UNI_NOPRUNE": "1"}), ("default", {})):
+    for k in ("MCL_UNI_SPLIT", "MCL_UNI_NOPRUNE"):
         os.environ.pop(k, None)
     os.environ.update(env)
     eng.reload_switches()
