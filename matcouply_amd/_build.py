@@ -36,10 +36,14 @@ def build_library(force=False, verbose=True, defs=None, out_lib=None, build_dir=
     objs = []
     procs = []
     os.makedirs(build_dir, exist_ok=True)
+    # an in-tree object older than a source or header may have another idea of the context's layout: never link it
+    newest_dep = max(os.path.getmtime(d) for d in [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+                     + [os.path.join(HERE, "..", "include", "matcouply_hip.h")])
     for src in SOURCES:
         name = src.replace(".hip", ".o")
-        if only is not None and src not in only and os.path.exists(os.path.join(tree_dir, name)):
-            objs.append(os.path.join(tree_dir, name))  # unchanged by `defs`: the in-tree object
+        tree_obj = os.path.join(tree_dir, name)
+        if only is not None and src not in only and os.path.exists(tree_obj) and os.path.getmtime(tree_obj) >= newest_dep:
+            objs.append(tree_obj)  # unchanged by `defs` and not older than any source / header: the in-tree object
             continue
         obj = os.path.join(build_dir, name)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + list(defs) + EXTRA_FLAGS.get(src, []) + [
