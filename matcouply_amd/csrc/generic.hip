@@ -552,7 +552,8 @@ __global__ __launch_bounds__(256) void k_pf2_gram(const int *__restrict__ ext, c
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int col = 16 * nb + c16;
-            y[nb] = (j < e && col < r) ? (double)(F[j * r + col] + U[j * r + col]) : 0.0;
+            // the EXACT sum of the two stored values (an fp32 sum would round Y by 6e-8: times cond(Y Delta^T) in the polar factor)
+            y[nb] = (j < e && col < r) ? (double)F[j * r + col] + (double)U[j * r + col] : 0.0;
         }
 #pragma unroll
         for (int a = 0; a < NB; ++a)
@@ -1109,16 +1110,24 @@ __global__ __launch_bounds__(256) void k_pf2_apply(ModeView mv, const float *__r
     FOR_ROW_BLOCKS() {
         const bool ok = 16 * rb + row16 < nrows;
         const long j = row0 + 16 * rb + (ok ? row16 : 0);
-        f32x4 y[NBR], p[NBR];
+        // Y = F + U as an unevaluated sum y + yl of two floats (Knuth's two-sum: exact), P = y T + yl T: the polar factor of the
+        // SAME matrix whose Gram k_pf2_gram formed, not of its fp32 rounding
+        f32x4 y[NBR], yl[NBR], p[NBR], pl[NBR];
 #pragma unroll
         for (int h = 0; h < NBR; ++h) {
             const f32x4 f = row_ld4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r);
             const f32x4 u = row_ld4<VEC>(U, j, 16 * h + 4 * g, ok, r);
             y[h] = f + u;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float bb = y[h][v] - f[v];
+                yl[h][v] = (f[v] - (y[h][v] - bb)) + (u[v] - bb);
+            }
         }
         Ts.apply(y, p);
+        Ts.apply(yl, pl);
 #pragma unroll
-        for (int h = 0; h < NBR; ++h) row_st4<VEC>(P, j, 16 * h + 4 * g, ok, r, p[h]);
+        for (int h = 0; h < NBR; ++h) row_st4<VEC>(P, j, 16 * h + 4 * g, ok, r, p[h] + pl[h]);
     }
 }
 
