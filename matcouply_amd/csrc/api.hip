@@ -137,6 +137,7 @@ int64_t plan(mcl_context *c, char *base) {
         c->pf2_acc = b.take<double>(I * (r * r + 1));
         c->pf2_red = b.take<float>(r * r + 1);
         c->pf2_status = b.take<int>(I);
+        c->pf2_qr = b.take<double>(N * r);  // Y_i Delta^T of the slabs k_pf2_polar_qr takes
 #ifdef MCL_NS_STAMPS
         c->pf2_xmin = b.take<float>(I + 16 * I + 64);  // + 8 int64 stamps per slab (tools/ns_stamps.py)
 #else
@@ -144,6 +145,7 @@ int64_t plan(mcl_context *c, char *base) {
 #endif
     } else {
         c->pf2_status = nullptr;
+        c->pf2_qr = nullptr;
         c->pf2_xmin = nullptr;
         c->pf2_S = nullptr, c->pf2_T = nullptr, c->pf2_acc = nullptr, c->pf2_red = nullptr, c->pf2_T64 = nullptr;
     }

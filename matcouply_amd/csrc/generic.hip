@@ -584,7 +584,8 @@ __global__ __launch_bounds__(256) void k_pf2_gram(const int *__restrict__ ext, c
 // space).  Called by the stand-alone kernel below and by k_pf2_algebra_ns for the slabs it cannot handle.
 static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const float *__restrict__ Delta, double rh, int r,
                                        int slab, int lane, float *__restrict__ T, double *__restrict__ acc_out,
-                                       double *__restrict__ T64 = nullptr) {
+                                       double *__restrict__ T64 = nullptr, int *__restrict__ qr_flag = nullptr,
+                                       bool full_rank_expected = false) {
     double *Sm = smd, *G = smd + r * r, *V = G + r * r, *lam = V + r * r, *D = lam + r;  // D: Delta in fp64 [r*r]
     const int n2 = r * r;
     for (int e = lane; e < n2; e += 64) {
@@ -652,8 +653,13 @@ static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const fl
         __syncthreads();
     }
     __syncthreads();
-    double lmax = 0.0;
-    for (int k = 0; k < r; ++k) lmax = fmax(lmax, G[k * r + k]);
+    double lmax = 0.0, lmin = 1e300;
+    for (int k = 0; k < r; ++k) lmax = fmax(lmax, G[k * r + k]), lmin = fmin(lmin, G[k * r + k]);
+    // G = (Y Delta^T)^T (Y Delta^T) squares the condition number: beyond cond(Y Delta^T) ~ 1e5 its small eigenvalues are
+    // rounding (at 1e7 the pseudo-inverse threshold below removes them and the factor comes out rank-deficient: errors of
+    // 0.2 in P, tools/parity_probe.py fuzz:133).  A slab with at least r rows is flagged for k_pf2_polar_qr, which works on
+    // Y Delta^T itself; what is written below is then overwritten.
+    if (qr_flag != nullptr && lane == 0) qr_flag[slab] = (full_rank_expected && !(lmin > 1e-10 * lmax)) ? 2 : 0;
     if (lane < r) {
         const double l = G[lane * r + lane];
         lam[lane] = (l > 1e-14 * lmax && l > 0.0) ? 1.0 / sqrt(l) : 0.0;  // pseudo-inverse square root
@@ -688,13 +694,163 @@ static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const fl
 
 __global__ __launch_bounds__(64) void k_pf2_algebra(const double *__restrict__ S, const float *__restrict__ Delta,
                                                     const float *__restrict__ rho, int r, float *__restrict__ T,
-                                                    double *__restrict__ acc_out, const int *__restrict__ status,
-                                                    double *__restrict__ T64) {
+                                                    double *__restrict__ acc_out, int *__restrict__ status, int use_status,
+                                                    double *__restrict__ T64, const int *__restrict__ ext) {
     extern __shared__ double smd[];
-    if (status != nullptr && status[blockIdx.x] <= 0) return;  // already done by the Newton-Schulz kernel (-iterations)
-    if (status != nullptr && status[blockIdx.x] == 77) return;  // debugging hook
+    // use_status: entries <= 0 were done by the Newton-Schulz kernel (-iterations); this kernel leaves 2 (k_pf2_polar_qr
+    // takes the slab) or 0 in the entry of every slab it handles
+    if (use_status && status[blockIdx.x] <= 0) return;
+    if (use_status && status[blockIdx.x] == 77) return;  // debugging hook
     const int slab = blockIdx.x;
-    pf2_jacobi_slab(smd, S + (long)slab * r * r, Delta, (double)rho[slab], r, slab, threadIdx.x, T, acc_out, T64);
+    pf2_jacobi_slab(smd, S + (long)slab * r * r, Delta, (double)rho[slab], r, slab, threadIdx.x, T, acc_out, T64, status,
+                    ext[slab + 1] - ext[slab] >= r);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Polar factor of an ill-conditioned slab without squaring its condition number (the slabs k_pf2_algebra flags with 2):
+//   A = Y_i Delta^T (J_i x r, fp64, Y_i = F + U exactly)  ->  Householder QR in place  ->  R (r x r)
+//   ->  one-sided Jacobi on the columns of R (Hestenes): R V = U Sigma  ->  (A^T A)^-1/2 = V Sigma^-1 V^T = W
+//   ->  T_i = Delta^T W,  acc_i = rho_i T_i^T S   (what pf2_jacobi_slab writes, decomposition of penalties.py:1224-1250's SVD)
+// R inherits the singular values of A to eps * cond relative accuracy (the Gram route: eps * cond^2), the one-sided Jacobi
+// keeps it.  One workgroup per flagged slab; rare by construction (cond >= 1e5: typically the first inner iteration from a
+// random dual), so simplicity beats speed: the reflections are applied column-parallel, the rotations by one wave.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pf2_polar_qr(const int *__restrict__ ext, const float *__restrict__ F,
+                                                      const float *__restrict__ U, const float *__restrict__ Delta,
+                                                      const float *__restrict__ rho, int r, const double *__restrict__ S,
+                                                      const int *__restrict__ status, double *__restrict__ Aws,
+                                                      float *__restrict__ T, double *__restrict__ acc_out,
+                                                      double *__restrict__ T64, const int *__restrict__ gate) {
+    MCL_GATE(gate);
+    const int slab = blockIdx.x;
+    if (status[slab] != 2) return;
+    const int s = ext[slab], n = ext[slab + 1] - s;
+    if (n < r) return;  // (never flagged)
+    extern __shared__ double sq[];
+    const int n2 = r * r;
+    double *D = sq, *R = D + n2, *V = R + n2, *red = V + n2, *lam = red + 4 * 64;  // red: 4 row chunks x 64 columns
+    __shared__ double sh_alpha, sh_beta, sh_vkk;
+    const int tid = threadIdx.x, lane = tid & 63, chunk = tid >> 6;
+    for (int e = tid; e < n2; e += 256) D[e] = (double)Delta[e];
+    __syncthreads();
+    double *A = Aws + (long)s * r;
+    for (long idx = tid; idx < (long)n * r; idx += 256) {
+        const long j = idx / r;
+        const int c = (int)(idx - j * r);
+        const float *f = F + ((long)s + j) * r, *u = U + ((long)s + j) * r;
+        double acc = 0.0;
+        for (int k = 0; k < r; ++k) acc = fma((double)f[k] + (double)u[k], D[c * r + k], acc);
+        A[idx] = acc;
+    }
+    __syncthreads();
+    for (int k = 0; k < r; ++k) {
+        // ||A[k:n, k]||^2
+        double p = 0.0;
+        for (int j = k + tid; j < n; j += 256) p = fma(A[(long)j * r + k], A[(long)j * r + k], p);
+        p = wave_sum_d(p);
+        if (lane == 0) red[chunk] = p;
+        __syncthreads();
+        if (tid == 0) {
+            const double nrm2 = (red[0] + red[1]) + (red[2] + red[3]);
+            const double xk = A[(long)k * r + k];
+            const double alpha = -copysign(sqrt(nrm2), xk);
+            const double vkk = xk - alpha;
+            const double vtv = (nrm2 - xk * xk) + vkk * vkk;
+            sh_alpha = alpha, sh_vkk = vkk, sh_beta = vtv > 0.0 ? 2.0 / vtv : 0.0;
+        }
+        __syncthreads();
+        const double vkk = sh_vkk, beta = sh_beta;
+        // w_c = beta v^T A[k:n, c] for the columns c > k: thread (chunk, lane) sums rows k + chunk, k + chunk + 4, ... of column k + 1 + lane
+        for (int c0 = k + 1; c0 < r; c0 += 64) {
+            const int c = c0 + lane;
+            double dot = 0.0;
+            if (c < r)
+                for (int j = k + chunk; j < n; j += 4) {
+                    const double vj = (j == k) ? vkk : A[(long)j * r + k];
+                    dot = fma(vj, A[(long)j * r + c], dot);
+                }
+            red[chunk * 64 + lane] = dot;
+            __syncthreads();
+            if (c < r) {
+                const double w = beta * ((red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]));
+                for (int j = k + chunk; j < n; j += 4) {
+                    const double vj = (j == k) ? vkk : A[(long)j * r + k];
+                    A[(long)j * r + c] = fma(-vj, w, A[(long)j * r + c]);
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) A[(long)k * r + k] = sh_alpha;  // row k of A now holds row k of R
+        __syncthreads();
+    }
+    for (int e = tid; e < n2; e += 256) {
+        const int a = e / r, b = e - a * r;
+        R[e] = (b >= a) ? A[(long)a * r + b] : 0.0;
+        V[e] = (a == b) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (chunk == 0) {  // one wave: lane i owns row i of R and of V (r <= 64)
+        const bool act = lane < r;
+        const int i = act ? lane : 0;
+        for (int sweep = 0; sweep < 40; ++sweep) {
+            int rotated = 0;
+            for (int pc = 0; pc < r - 1; ++pc)
+                for (int qc = pc + 1; qc < r; ++qc) {
+                    const double rp = act ? R[i * r + pc] : 0.0, rq = act ? R[i * r + qc] : 0.0;
+                    const double al = wave_sum_d(rp * rp), be = wave_sum_d(rq * rq), ga = wave_sum_d(rp * rq);
+                    if (fabs(ga) > 1e-15 * sqrt(al * be) && ga != 0.0) {  // wave-uniform
+                        const double zeta = (be - al) / (2.0 * ga);
+                        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                        if (act) {
+                            R[i * r + pc] = cs * rp - sn * rq;
+                            R[i * r + qc] = sn * rp + cs * rq;
+                            const double vp = V[i * r + pc], vq = V[i * r + qc];
+                            V[i * r + pc] = cs * vp - sn * vq;
+                            V[i * r + qc] = sn * vp + cs * vq;
+                        }
+                        rotated = 1;
+                    }
+                }
+            if (!rotated) break;
+        }
+        double smax = 0.0;
+        for (int c = 0; c < r; ++c) {
+            const double rc = act ? R[i * r + c] : 0.0;
+            const double sg = sqrt(wave_sum_d(rc * rc));
+            if (lane == 0) lam[c] = sg;
+            smax = fmax(smax, sg);
+        }
+        if (act) lam[lane] = (lam[lane] > 1e-14 * smax && lam[lane] > 0.0) ? 1.0 / lam[lane] : 0.0;  // pseudo-inverse
+    }
+    __syncthreads();
+    // W = V diag(lam) V^T -> R;  T = D^T W -> V's place is still needed for W, so T goes to the red-free part of A's first rows?  no:
+    // r x r results fit the LDS arrays in turn: W -> R, then T -> D is NOT possible (T needs D): T -> A (global scratch, n >= r rows)
+    for (int e = tid; e < n2; e += 256) {
+        const int a = e / r, b = e - a * r;
+        double sum = 0.0;
+        for (int k = 0; k < r; ++k) sum = fma(V[a * r + k] * lam[k], V[b * r + k], sum);
+        R[e] = sum;
+    }
+    __syncthreads();
+    for (int e = tid; e < n2; e += 256) {
+        const int a = e / r, b = e - a * r;
+        double sum = 0.0;
+        for (int k = 0; k < r; ++k) sum = fma(D[k * r + a], R[k * r + b], sum);
+        V[e] = sum;  // T = Delta^T W
+    }
+    __syncthreads();
+    const double rh = (double)rho[slab];
+    const double *Sm = S + (long)slab * n2;
+    for (int e = tid; e < n2; e += 256) {
+        const int a = e / r, b = e - a * r;
+        double sum = 0.0;
+        for (int k = 0; k < r; ++k) sum = fma(V[k * r + a], Sm[k * r + b], sum);
+        acc_out[(long)slab * (n2 + 1) + e] = rh * sum;
+        T[(long)slab * n2 + e] = (float)V[e];
+        if (T64 != nullptr) T64[(long)slab * n2 + e] = V[e];
+    }
+    if (tid == 0) acc_out[(long)slab * (n2 + 1) + n2] = rh;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1659,7 +1815,7 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                 MCL_CHECK_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pf2_algebra),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
             }
-            const int *status = nullptr;
+            int *status = nullptr;
             if (c->NB <= 2 && !c->sw.pf2_jacobi) {
                 status = c->pf2_status;
                 TileStats ts{c->slab_tile_ptr, c->stat_gram, c->stat_colsq, c->colsq, 16 * c->NB, (int)c->I};
@@ -1677,9 +1833,19 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                 }
 #undef MCL_NS
             }
-            if (status == nullptr || c->NB != 1)  // rank <= 16: the Newton-Schulz kernel runs the Jacobi route itself
+            if (status == nullptr || c->NB != 1) {  // rank <= 16: the Newton-Schulz kernel runs the Jacobi route itself
                 hipLaunchKernelGGL(k_pf2_algebra, dim3((unsigned)c->I), dim3(64), sm, c->stream, c->pf2_S, rs.aux2[k],
-                                   c->rhoB, r, c->pf2_T, c->pf2_acc, status, c->pf2_T64);
+                                   c->rhoB, r, c->pf2_T, c->pf2_acc, c->pf2_status, status != nullptr ? 1 : 0, c->pf2_T64, mv.ext);
+                // ... and the slabs it finds too ill-conditioned for the Gram route (flag 2) are redone from Y Delta^T itself
+                const size_t smq = sizeof(double) * (size_t)(3 * n2 + 4 * 64 + 64);
+                if (smq > 65536) {
+                    MCL_CHECK_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pf2_polar_qr),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smq));
+                }
+                hipLaunchKernelGGL(k_pf2_polar_qr, dim3((unsigned)c->I), dim3(256), smq, c->stream, mv.ext, mv.F, rs.dual[k],
+                                   rs.aux2[k], c->rhoB, r, c->pf2_S, c->pf2_status, c->pf2_qr, c->pf2_T, c->pf2_acc,
+                                   c->pf2_T64, c->gate_active);
+            }
             if (!c->stack_fused)  // the fused finish pass applies T_i itself
                 DISPATCH_ROWS(c, vec, k_pf2_apply, grid, block, mv, (const float *)rs.dual[k], (const float *)c->pf2_T, rs.aux[k], r);
             if (c->pf2_delta_fused)  // single-process inner loop: Delta follows at once, no all-reduce in between

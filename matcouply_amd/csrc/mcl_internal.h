@@ -203,7 +203,8 @@ struct mcl_context {
     bool rows64 = false;        // rank <= 16 and a PARAFAC2 member on mode 1: the fused B-mode row passes compute in fp64
     double *pf2_acc = nullptr;  // [I, r*r + 1] per-slab rho_i P_i^T Y_i | rho_i
     float *pf2_xmin = nullptr;  // [I] 1 / ||(G_i / tr)^-1/2||_F of the last Newton-Schulz run: starting estimate of the next
-    int *pf2_status = nullptr;  // [I] 0: Newton-Schulz converged, 1: redo with the Jacobi kernel
+    int *pf2_status = nullptr;  // [I] <= 0: Newton-Schulz converged, 1: redo with the Jacobi kernel, 2: redo from Y Delta^T (k_pf2_polar_qr)
+    double *pf2_qr = nullptr;   // [N * r] fp64: Y_i Delta^T of the slabs k_pf2_polar_qr takes
     float *pf2_red = nullptr;   // [r*r + 1]  sum over this context's slabs (all-reduced by a multi-GPU host)
     std::vector<int> h_row_ptr32, h_ext;
     bool e1_from_raw_gram = false;  // BtB buffer holds B_i^T B_i (true) or Q_i = B_i^T B_i o CtC (false)

@@ -138,3 +138,49 @@ def test_exact_products_mode_is_not_a_performance_cliff():
         os.environ.pop("MCL_EXACT", None)
         if old is not None:
             os.environ["MCL_EXACT"] = old
+
+
+@pytest.mark.parametrize("seed", [133, 859])
+def test_ill_conditioned_polar_factor_takes_the_qr_route(seed):
+    """PARAFAC2 at rank 40 from a random dual: in the first inner iteration cond(Y_i Delta^T) is 1e6 .. 2e7 in most slabs.  The
+    Gram route of the polar factor squares that (its small eigenvalues are rounding; at 1e7 the pseudo-inverse threshold removes
+    them: P off by 0.2, B by 1.6e-3 after the phase); k_pf2_algebra flags such slabs and k_pf2_polar_qr redoes them from
+    Y_i Delta^T itself (Householder QR + one-sided Jacobi on R), as the reference's SVD does (penalties.py:1224-1250)."""
+    import torch
+
+    from oracle import aoadmm_oracle as orc
+    from tests.helpers import engine_from_oracle_state, rel_err, to_np
+
+    case = _draw_case(np.random.RandomState(1000 + seed))
+    assert case["r"] == 40 and [d["kind"] for d in case["regs"][1]] == ["parafac2"]
+    X, row_ptr = orc.synthetic_problem(case["I"], case["J"], case["K"], case["r"], seed=seed, dtype=np.float64)
+    X = X.astype(np.float32).astype(np.float64)
+    st = orc.random_state_for(X, row_ptr, case["r"], case["regs"], seed=seed + 1, l2=case["l2"],
+                              inner_n_iter_max=case["inner"], feasibility_penalty_scale=case["scale"],
+                              constant_A=case["const"], constant_B=case["const"])
+    r32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    st.A, st.B, st.C = r32(st.A), r32(st.B), r32(st.C)
+    st.aux[1][0] = (r32(st.aux[1][0][0]), r32(st.aux[1][0][1]))
+    st.dual[1][0] = r32(st.dual[1][0])
+    eng = engine_from_oracle_state(st)
+    conds = []
+    orig = orc.polar_factor
+
+    def recording(M):
+        sv = np.linalg.svd(M, compute_uv=False)
+        conds.append(sv[0] / sv[-1])
+        return orig(M)
+
+    orc.polar_factor = recording
+    try:
+        st.update_B()
+    finally:
+        orc.polar_factor = orig
+    eng.update_B()
+    torch.cuda.synchronize()
+    assert max(conds[: case["I"]]) > 1e6  # the first inner iteration is the ill-conditioned one
+    errs = dict(B=rel_err(to_np(eng.B), st.B), Delta=rel_err(to_np(eng.regs[1][0].aux2), st.aux[1][0][1]),
+                PDelta=rel_err(to_np(eng.regs[1][0].aux) @ to_np(eng.regs[1][0].aux2), st.aux[1][0][0] @ st.aux[1][0][1]))
+    print(seed, f"cond up to {max(conds):.1e}", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs.values()) < 1e-5, errs
+    eng.close()
