@@ -494,7 +494,7 @@ def main():
     # timed loop samples ~10 launches instead of taxing all of them
     t_leg = leg("settling", t_leg)
     prof_stride = max(1, (n_regions * args.steps) // 10)
-    eng.profile_enable(n_regions * args.steps, stride=prof_stride)
+    eng.profile_enable(128, stride=prof_stride)  # at most ~6 launches per step and site: <= ~60 timed launches each
     region_s = []
     coll_before = n_coll[0]
     for reg in range(n_regions):
@@ -526,9 +526,10 @@ def main():
         dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
         c_identical = bool(torch.equal(lo_, hi_))
 
-    # live roofline of the dominant kernel (HIP events inside the library, same stream as the kernels)
-    prof = []
-    names = {0: "X C pass", 1: "X^T (B o a) pass", 2: "fused B-phase rows", 3: "one-pass sweep (X C -> B-phase -> X^T B)"}
+    # live roofline (HIP events inside the library, same stream as the kernels): EVERY hot launch site of the step is
+    # timed; the block names the site that takes the largest share of the step (launches per step x average duration)
+    from matcouply_amd import _engine as E
+
     N_loc, K, r = X.shape[0], cfg["K"], cfg["r"]
     N_tot = N_loc
     if world > 1:
@@ -536,35 +537,87 @@ def main():
         dist.all_reduce(t)
         N_tot = int(t.item())
     S_X, S_B = 4.0 * N_loc * K, 4.0 * N_loc * r
-    n_B = len(cfg["regs"][1])
-    # algorithmic bytes per launch (reads + writes): X^T pass reads X and B; the X C pass reads X, writes XC and - with the
-    # fused per-slab Gram epilogue - also reads B; the fused B rows read XC/aux/dual and write B/aux/dual
-    xc_fused = "GRAM=" in eng.kernel_variant(0) and "GRAM=0" not in eng.kernel_variant(0)
-    # the one-pass sweep reads X once, reads aux/dual and writes B/aux/dual (X C never reaches memory)
-    alg_bytes = {0: S_X + (2 if xc_fused else 1) * S_B, 1: S_X + S_B, 2: (2 + 4 * n_B) * S_B, 3: S_X + (1 + 4 * n_B) * S_B}
-    for slot in range(4):
-        tot_ms, n = eng.profile_read(slot)
-        if n:
-            prof.append((tot_ms / n, slot, n))
-    def pmc_traffic(kernel_variant):
-        """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), if the
-        profile was taken on this configuration; counters are collected in separate runs, never inside this one."""
-        for rnd in ("r4", "r3", "r2", "r1"):
+    n_B, n_C = len(cfg["regs"][1]), len(cfg["regs"][2])
+    NBk = (r + 15) // 16
+    NBk = 4 if NBk == 3 else NBk
+    xc_fused = "GRAM=" in eng.kernel_variant(E.PROF_XC) and "GRAM=0" not in eng.kernel_variant(E.PROF_XC)
+    swept_now = eng.kernel_variant(E.PROF_SWEEP) != "" and eng.profile_launches(E.PROF_SWEEP) > 0
+    # the partial images the sweep leaves for the C- and A-phase (one per bseg, or per group of bsegs of a slab)
+    n_parts, part_floats = 0, 0
+    if swept_now:
+        pb = eng.internal(E.BUF_BSEG_PART).view(torch.int32).cpu().numpy().astype(np.int64)
+        n_parts = int((pb & 0x0FFFFFFF).max()) + 1 if len(pb) else 0
+        kc = 2 if (K <= 128 and NBk == 1) else 4 * ((K + 255) // 256)
+        part_floats = kc * 64 * 16 * NBk
+    W16 = 16 * NBk
+    n_tiles_B = int(sum((int(row_ptr[i + 1] - row_ptr[i]) + 63) // 64 for i in range(len(row_ptr) - 1)))
+    # ALGORITHMIC bytes per launch of every site (reads + writes the design needs):
+    #   X passes: X once (+ B-sized operands); fused rows / chained passes: their B-sized streams; the sweep: X once, aux / dual
+    #   in, B / aux / dual out (X C never reaches memory); the [G | R] reduction and the A-phase finish: the partial images
+    #   of the sweep (fp32 M, a-weighted Gram / fp64 B^T B); the C-phase finish: [G | R] in fp64, C and its ADMM variables;
+    #   unimodal regressions: y in, fit out, once more for the split search = 16 B per element; PARAFAC2 algebra: the per-tile
+    #   Gram statistics in, T_i out
+    alg_bytes = {
+        E.PROF_XC: S_X + (2 if xc_fused else 1) * S_B, E.PROF_XT: S_X + S_B, E.PROF_ROWS_FUSED: (2 + 4 * n_B) * S_B,
+        E.PROF_SWEEP: S_X + (1 + 4 * n_B) * S_B,
+        E.PROF_REDUCE: (4.0 * n_parts * (part_floats + W16 * W16 + W16) if swept_now else None),
+        E.PROF_C_FINISH: 8.0 * (K * r + r * r) + (1 + 4 * n_C) * 4.0 * K * r + 4.0 * K * W16,
+        E.PROF_A_FINISH: (4.0 * n_parts * part_floats + 8.0 * n_parts * r * r + 4.0 * K * W16) if swept_now else None,
+        E.PROF_ROWS_CHAIN: (3 + 2 * n_B) * S_B, E.PROF_UNIMODAL: 4 * S_B,
+        E.PROF_PF2: 8.0 * n_tiles_B * W16 * W16 + 12.0 * I_loc * r * r,
+    }
+    bound_of = {E.PROF_REDUCE: "latency (hbm figure for reference)", E.PROF_C_FINISH: "latency (hbm figure for reference)",
+                E.PROF_A_FINISH: "latency (hbm figure for reference)", E.PROF_PF2: "fp64 MFMA issue (hbm figure for reference)",
+                E.PROF_UNIMODAL: "latency of the pooling chain, then hbm"}
+    overhead_us = eng.profile_overhead_us()
+    n_steps_timed = n_regions * args.steps
+
+    def pmc_table():
+        """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), if a profile of this configuration
+        exists; counters are collected in separate runs, never inside this one."""
+        if world != 1:
+            return None, None
+        for rnd in ("r5", "r4", "r3", "r2", "r1"):
             path = os.path.join(REPO, "profiles", f"{rnd}_{args.config}_pmc_traffic.json")
             if os.path.exists(path):
-                break
-        else:
+                with open(path) as f:
+                    return json.load(f)["kernels"], os.path.relpath(path, REPO)
+        return None, None
+
+    pmc_kernels, pmc_source = pmc_table()
+
+    def pmc_traffic(kernel_variant):
+        if not pmc_kernels:
             return None
-        if world != 1:
+        base = kernel_variant.split("<")[0].split(" ")[0]
+        # a site that launches several kernel forms (chained row passes): the launch-weighted mean of its kernels
+        hits = [v for name, v in pmc_kernels.items() if name.split("<")[0] == base or
+                (base == "k_rows_finish_solve_stats" and name.split("<")[0] in ("k_rows_solve_stats", "k_rows_finish_fused"))]
+        if not hits:
             return None
-        pmc_traffic.source = os.path.relpath(path, REPO)
-        with open(path) as f:
-            kernels = json.load(f)["kernels"]
-        base = kernel_variant.split("<")[0]
-        for name, v in kernels.items():
-            if name.split("<")[0] == base:
-                return int(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
-        return None
+        n = sum(v["launches"] for v in hits)
+        return int(sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in hits) / max(n, 1))
+
+    per_kernel = []
+    for slot in range(E.PROF_SLOTS):
+        tot_ms, n = eng.profile_read(slot)
+        launches = eng.profile_launches(slot)
+        if not n or not launches:
+            continue
+        avg_us = 1e3 * tot_ms / n
+        # the event pair itself costs `overhead_us` of marker handling (calibrated on an empty pair): the kernel's share
+        net_us = max(avg_us - overhead_us, 0.0)
+        ab = alg_bytes.get(slot)
+        per_step = launches / max(1, n_steps_timed)
+        e = dict(role=E.PROF_ROLE[slot], kernel=eng.kernel_variant(slot), launches_per_step=round(per_step, 3),
+                 avg_us=round(net_us, 2), avg_us_with_event_pair=round(avg_us, 2), launches_timed=n,
+                 us_per_step=round(per_step * net_us, 2),
+                 algorithmic_bytes=int(ab) if ab else None,
+                 achieved_gbps=round(ab / (net_us * 1e-6) / 1e9, 1) if ab and net_us > 0 else None,
+                 frac=round(ab / (net_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if ab and net_us > 0 else None,
+                 traffic=pmc_traffic(eng.kernel_variant(slot)), bound=bound_of.get(slot, "hbm"), slot=slot)
+        per_kernel.append(e)
+    per_kernel.sort(key=lambda e: -e["us_per_step"])
 
     def mfma_block(slot, avg_ms):
         """The kernel's second limiter: fp32 MFMA flops it ISSUES per launch (padded rank / K as the tiles are) over the same
@@ -572,37 +625,43 @@ def main():
         SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 of profiles/r2_c3_sq_counters.json; fp32 MFMA and VALU work do not overlap on a
         SIMD (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so the sweep sits at the SUM of this and its VALU / LDS / wait time."""
         RPk = 16 * ((r + 15) // 16)
-        Kp = 128 if (slot == 3 and K <= 128 and RPk == 16) else 256 * ((K + 255) // 256) if slot == 3 else 64 * ((K + 63) // 64)
+        Kp = 128 if (slot == E.PROF_SWEEP and K <= 128 and RPk == 16) else 256 * ((K + 255) // 256) if slot == E.PROF_SWEEP else 64 * ((K + 63) // 64)
         n_inner = 5
-        flops = {0: 2.0 * N_loc * Kp * RPk + (2.0 * N_loc * RPk * RPk if xc_fused else 0.0),
-                 1: 2.0 * N_loc * Kp * RPk + 2.0 * N_loc * RPk * RPk,
-                 2: 2.0 * N_loc * RPk * RPk * n_inner,
-                 3: 4.0 * N_loc * Kp * RPk + 2.0 * N_loc * RPk * RPk * (n_inner + 2)}[slot]
+        flops = {E.PROF_XC: 2.0 * N_loc * Kp * RPk + (2.0 * N_loc * RPk * RPk if xc_fused else 0.0),
+                 E.PROF_XT: 2.0 * N_loc * Kp * RPk + 2.0 * N_loc * RPk * RPk,
+                 E.PROF_ROWS_FUSED: 2.0 * N_loc * RPk * RPk * n_inner,
+                 E.PROF_SWEEP: 4.0 * N_loc * Kp * RPk + 2.0 * N_loc * RPk * RPk * (n_inner + 2)}.get(slot)
+        if flops is None or avg_ms <= 0:
+            return None
         tf = flops / (avg_ms * 1e-3) / 1e12
         return dict(achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                     flops_per_launch=int(flops), counted="issued fp32 MFMA flops (analytic, padded tiles)")
 
     roofline = None
-    if prof:
-        avg_ms, slot, n = max(prof)
-        achieved = alg_bytes[slot] / (avg_ms * 1e-3) / 1e9
-        traffic = pmc_traffic(eng.kernel_variant(slot))
-        roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+    timed_sites = [e for e in per_kernel if e["algorithmic_bytes"]]
+    if timed_sites:
+        dom = timed_sites[0]  # the largest share of the step among the sites with an algorithmic byte count
+        slot = dom["slot"]
+        roofline = dict(bound="hbm", achieved=dom["achieved_gbps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=dom["frac"],
+                        traffic=dom["traffic"],
                         traffic_source=("static: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in separate "
-                                        "passes, not measured in this run)" % pmc_traffic.source) if traffic is not None else None,
-                        kernel=eng.kernel_variant(slot),
-                        kernel_role=names[slot], avg_us=round(avg_ms * 1e3, 2), launches_timed=n,
-                        launches_in_timed_regions=n_regions * args.steps, event_stride=prof_stride,
-                        algorithmic_bytes_per_launch=int(alg_bytes[slot]),
-                        mfma=mfma_block(slot, avg_ms),
-                        all_kernels_avg_us={names[s]: round(a * 1e3, 2) for a, s, _ in prof})
+                                        "passes, not measured in this run)" % pmc_source) if dom["traffic"] is not None else None,
+                        kernel=dom["kernel"], kernel_role=dom["role"], launches_per_step=dom["launches_per_step"],
+                        avg_us=dom["avg_us"], avg_us_with_event_pair=dom["avg_us_with_event_pair"],
+                        event_pair_overhead_us=round(overhead_us, 2), launches_timed=dom["launches_timed"],
+                        launches_in_timed_regions=int(round(dom["launches_per_step"] * n_steps_timed)), event_stride=prof_stride,
+                        algorithmic_bytes_per_launch=dom["algorithmic_bytes"],
+                        chosen_by="largest launches_per_step x avg_us of the step (per_kernel is sorted by it)",
+                        note=dom["bound"] if dom["bound"] != "hbm" else None,
+                        mfma=mfma_block(slot, dom["avg_us"] * 1e-3),
+                        per_kernel=[{k: v for k, v in e.items() if k != "slot"} for e in per_kernel],
+                        kernels_us_per_step=round(sum(e["us_per_step"] for e in per_kernel), 2))
 
     final = ring[n_regions * args.steps - 1].cpu().numpy() if args.steps else None
     if rank == 0:
         its = args.steps / elapsed
         S_X_tot, S_B_tot = 4.0 * N_tot * K, 4.0 * N_tot * r
-        swept = any(slot == 3 for _, slot, _ in prof)
+        swept = swept_now
         bytes_iter = (S_X_tot + (1 + 4 * n_B) * S_B_tot) if swept else (2 * S_X_tot + (5 + 4 * n_B) * S_B_tot)
         out = {
             "metric": "AO-ADMM outer-iters/sec", "value": round(its, 2), "unit": "outer-iters/s", "n_gpus": world,
@@ -613,7 +672,9 @@ def main():
                        "sharding": f"{world} x contiguous slab ranges" if world > 1 else "single device"},
             "algorithmic_bytes_per_iter": int(bytes_iter),
             "hbm_gbps_algorithmic": round(bytes_iter * its / 1e9, 1),
-            "roofline": roofline,
+            "roofline": (dict(roofline, step_frac=round(bytes_iter / (1e-3 * 1e3 * elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                              step_frac_is="algorithmic_bytes_per_iter / ms_per_step / peak (whole step, all kernels and gaps)")
+                         if roofline else None),
             "timed_regions": n_regions, "region_ms": [round(1e3 * v, 4) for v in region_s], "region_stat": "median",
             "region_ms_stats": {"min": round(1e3 * float(np.min(region_s)), 4), "median": round(1e3 * elapsed, 4),
                                 "q25": round(1e3 * float(np.percentile(region_s, 25)), 4),

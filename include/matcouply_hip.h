@@ -28,9 +28,11 @@ typedef struct mcl_context mcl_context;
 
 /* ABI version = what mcl_version() of a matching library returns.  History: 100 first release (fp32 [G | R]);
  * 200 mcl_c_normal_equations returns fp64 (the buffer a multi-GPU host all-reduces changed its element size);
- * 300 this header (mcl_run and the stop-rule structs, the communication-buffer and event entry points).
+ * 300 mcl_run and the stop-rule structs, the communication-buffer and event entry points;
+ * 400 this header: named indices (enum mcl_buffer_id, enum mcl_profile_slot, MCL_VARIANT_EXACT_MODE - the exact-mode query
+ *     moved from index 4 to 100), twelve profile slots, mcl_profile_launches, a failed state after mcl_run's watchdog.
  * A host MUST compare mcl_version() with the MCL_ABI_VERSION it was built against before any other call. */
-#define MCL_ABI_VERSION 300
+#define MCL_ABI_VERSION 400
 
 #define MCL_MAX_REGS 4   /* penalties per mode */
 #define MCL_MAX_RANK 64
@@ -134,7 +136,11 @@ int mcl_iterate(mcl_context *ctx, int32_t n_iter, int32_t update_A, int32_t upda
  *                 flags: bit 0 feasible, bit 1 error / loss evaluated (Q10), bits 2.. stop code}; rows beyond the stopping
  *                 iteration are not written;
  *   status        int32[4] in PINNED host memory (hipHostMalloc / a registered buffer): written by the device.
- * Unlike every other entry point this one synchronises the stream before it returns (it reports the verdict). */
+ * Unlike every other entry point this one synchronises the stream before it returns (it reports the verdict).
+ * Watchdog: a device that reports no verdict for MCL_RUN_WATCHDOG_S seconds (default 120) ends the call with an error and
+ * WITHOUT that synchronisation (a wedged stream would block it forever).  The context is then FAILED: every later entry
+ * point but mcl_last_error / mcl_destroy returns an error, and the caller must keep the workspace, both rings and `status`
+ * allocated until it has synchronised or reset the device itself (kernels that refer to them may still be enqueued). */
 typedef struct {
     double tol;                 /* relative loss criterion, decomposition.py:1039; 0 = not set */
     double absolute_tol;        /* decomposition.py:1040; only looked at when tol is set (Q8); tests the newest loss (Q9) */
@@ -215,22 +221,67 @@ int mcl_cmf_to_packed(const float *A, const float *B, const float *C, const floa
                       int64_t N, int64_t K, int32_t rank, float *out, void *hip_stream);
 
 /* ---- introspection for tests / profiling ------------------------------------------------------------- */
-/* device pointers to internal by-products: 0 rhses [I, r], 1 cross_products [I, r, r], 2 X C [sum J_i, r],
- * 3 rho_B [I], 4 rho_A [I], 5 rho_C [1]; the planner's int32 tables (read the bits): 12 / 13 first row and length of every
- * segment of the X passes, 14 first segment of every wave; 15 / 16 / 17 the same for the bsegs of the one-pass sweep */
-float *mcl_internal_buffer(mcl_context *ctx, int32_t which, int64_t *count);
-/* name of the kernel variant chosen for the current problem: which = 0 X C pass, 1 X^T B pass, 2 fused B-phase rows,
- * 3 one-pass sweep (B-phase + X^T B in a single pass over X; empty when the problem is not eligible), 4 non-empty when the
- * problem runs in the exact-products mode (at most 2^20 elements of X: every contraction as fp64 sums of exact products) */
+/* device pointers to internal by-products / planner tables (the int32 tables: read the bits) */
+enum mcl_buffer_id {
+    MCL_BUF_RHSES = 0,          /* rhses [I, r] of the A-phase (decomposition.py:147-152) */
+    MCL_BUF_CROSS_PRODUCTS = 1, /* cross_products [I, r, r] (decomposition.py:153-161) */
+    MCL_BUF_XC = 2,             /* X C [sum J_i, r] */
+    MCL_BUF_RHO_B = 3,          /* [I] */
+    MCL_BUF_RHO_A = 4,          /* [I] */
+    MCL_BUF_RHO_C = 5,          /* [1] */
+    MCL_BUF_CTC = 6,            /* C^T C [r, r] */
+    MCL_BUF_LINV_B = 7,         /* inverses of the B-phase systems [I, r, r] */
+    MCL_BUF_PF2_STATUS = 8,     /* int32 [I]: which polar-factor kernel took the slab */
+    MCL_BUF_PF2_ACC = 9,        /* fp64 bits */
+    MCL_BUF_PF2_GRAM = 10,      /* fp64 bits [I, r, r] */
+    MCL_BUF_SWEEP_CYCLES = 11,  /* int64 bits (MCL_SWEEP_DBG & 32) */
+    MCL_BUF_SEG_ROW0 = 12,      /* int32: first row of every segment of the X passes */
+    MCL_BUF_SEG_NROWS = 13,     /* int32: its length */
+    MCL_BUF_WAVE_SEG_PTR = 14,  /* int32: first segment of every wave */
+    MCL_BUF_BSEG_ROW0 = 15,     /* the same three tables for the bsegs of the one-pass sweep */
+    MCL_BUF_BSEG_NROWS = 16,
+    MCL_BUF_WAVE_BSEG_PTR = 17,
+    MCL_BUF_NS_STAMPS = 18,     /* instrumented builds (-DMCL_NS_STAMPS) only */
+    MCL_BUF_BSEG_PART = 19      /* int32 per bseg: bits 0-27 the partial image the sweep adds the bseg to */
+};
+float *mcl_internal_buffer(mcl_context *ctx, int32_t which /* enum mcl_buffer_id */, int64_t *count);
+/* The hot launch sites of the library, for HIP-event timing (bench.py's roofline block) and for asking which kernel form a
+ * problem gets.  A slot covers every launch of its role; roles that a configuration does not use stay empty. */
+enum mcl_profile_slot {
+    MCL_PROF_XC = 0,         /* X C pass (k_contract_xc_*) */
+    MCL_PROF_XT = 1,         /* X^T (B o a) pass (k_contract_xt) */
+    MCL_PROF_ROWS_FUSED = 2, /* fused inner ADMM loop of row-separable stacks (k_rows_fused) */
+    MCL_PROF_SWEEP = 3,      /* one-pass sweep: X C -> B-phase -> X^T B in a single pass over X (k_sweep) */
+    MCL_PROF_REDUCE = 4,     /* [G | R] from the partials (k_reduce_frag / k_reduce_partials / k_exact_gr) */
+    MCL_PROF_C_FINISH = 5,   /* C-phase finish (k_C_finish_* / k_C_prepare + row kernels) */
+    MCL_PROF_A_FINISH = 6,   /* A-phase finish (k_A_finish*; k_CA_finish when it also holds the C-phase finish) */
+    MCL_PROF_ROWS_CHAIN = 7, /* one chained row pass of a generic B stack (k_rows_solve_stats / _finish_solve_stats / _finish_fused) */
+    MCL_PROF_UNIMODAL = 8,   /* unimodal regressions (k_slab_unimodal_*) */
+    MCL_PROF_PF2 = 9,        /* per-slab PARAFAC2 algebra of one inner iteration (polar factors + coordinate matrix) */
+    MCL_PROF_DIAG = 10,      /* reduction of the diagnostics tables (k_diag_final / k_diag_verdict) */
+    MCL_PROF_OTHER = 11,     /* every other launch of a phase (statistics reductions, system builds, ...) */
+    MCL_PROF_SLOTS = 12
+};
+/* name of the kernel variant chosen for the current problem.  which = an mcl_profile_slot: the kernel last launched in that
+ * role ("" when the problem has not used the role yet; MCL_PROF_SWEEP stays empty when the problem is not eligible for the
+ * one-pass sweep); MCL_VARIANT_EXACT_MODE: non-empty when the problem runs in the exact-products mode (at most 2^20 elements
+ * of X: every contraction as fp64 sums of exact products) */
+#define MCL_VARIANT_EXACT_MODE 100
 const char *mcl_kernel_variant(mcl_context *ctx, int32_t which);
-/* HIP-event timing of the named kernels on the context's stream (for bench.py's roofline block).
- * mcl_profile_enable(ctx, capacity): record up to `capacity` launches per kernel slot (0 disables and frees);
- * mcl_profile_read(ctx, which, &total_ms, &count): synchronises the recorded events of slot `which` and resets it. */
+/* HIP-event timing of the launch sites on the context's stream.
+ * mcl_profile_enable(ctx, capacity): record up to `capacity` launches per slot (0 disables and frees);
+ * mcl_profile_read(ctx, slot, &total_ms, &count): synchronises the recorded events of `slot`, returns their summed
+ * duration and number, and resets the slot; mcl_profile_launches(ctx, slot): launches the slot has SEEN since
+ * mcl_profile_enable / mcl_profile_set_stride (timed or not) - launches per step = this / steps. */
 int mcl_profile_enable(mcl_context *ctx, int32_t capacity);
 /* record only every `stride`-th launch of a slot (default 1): an event pair opens ~5 us dispatch gaps on either side of
  * the kernel, so a timed loop samples its launches instead of bracketing all of them */
 int mcl_profile_set_stride(mcl_context *ctx, int32_t stride);
-int mcl_profile_read(mcl_context *ctx, int32_t which, double *total_ms, int32_t *count);
+int mcl_profile_read(mcl_context *ctx, int32_t which /* enum mcl_profile_slot */, double *total_ms, int32_t *count);
+int64_t mcl_profile_launches(mcl_context *ctx, int32_t which /* enum mcl_profile_slot */);
+/* elapsed time of an EMPTY event pair on the context's stream, measured by mcl_profile_enable (microseconds): the part of
+ * every timed launch that is the command processor's marker handling, not the kernel */
+double mcl_profile_overhead_us(mcl_context *ctx);
 /* The MCL_* environment switches (A/B experiments, debug paths; tools/README.md) are read once in mcl_create();
  * this re-reads them for an existing context (tests that compare kernel forms on one problem).
  * PRODUCTION NOTE: the parity statements of this library hold for a CLEAN environment - several

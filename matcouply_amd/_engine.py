@@ -12,13 +12,24 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmatcouply_hip.so")
 
-MCL_ABI_VERSION = 300  # include/matcouply_hip.h; checked against mcl_version() when the library is loaded
+MCL_ABI_VERSION = 400  # include/matcouply_hip.h; checked against mcl_version() when the library is loaded
 MCL_MAX_REGS = 4
 MCL_MAX_RANK = 64
 DIAG_NORM_SQ, DIAG_INNER, DIAG_MODEL_SQ, DIAG_X_SQ, DIAG_REG = 0, 3, 4, 5, 8
 DIAG_LEN = 8 + 3 * MCL_MAX_REGS * 2
 
 PEN_NN, PEN_BOX, PEN_L1, PEN_L2BALL, PEN_UNIMODAL, PEN_PARAFAC2, PEN_EXTERNAL, PEN_TV = 1, 2, 3, 4, 5, 6, 7, 8
+# enum mcl_buffer_id / enum mcl_profile_slot / MCL_VARIANT_EXACT_MODE of include/matcouply_hip.h
+(BUF_RHSES, BUF_CROSS_PRODUCTS, BUF_XC, BUF_RHO_B, BUF_RHO_A, BUF_RHO_C, BUF_CTC, BUF_LINV_B, BUF_PF2_STATUS, BUF_PF2_ACC,
+ BUF_PF2_GRAM, BUF_SWEEP_CYCLES, BUF_SEG_ROW0, BUF_SEG_NROWS, BUF_WAVE_SEG_PTR, BUF_BSEG_ROW0, BUF_BSEG_NROWS,
+ BUF_WAVE_BSEG_PTR, BUF_NS_STAMPS, BUF_BSEG_PART) = range(20)
+(PROF_XC, PROF_XT, PROF_ROWS_FUSED, PROF_SWEEP, PROF_REDUCE, PROF_C_FINISH, PROF_A_FINISH, PROF_ROWS_CHAIN, PROF_UNIMODAL,
+ PROF_PF2, PROF_DIAG, PROF_OTHER, PROF_SLOTS) = range(13)
+PROF_ROLE = {PROF_XC: "X C pass", PROF_XT: "X^T (B o a) pass", PROF_ROWS_FUSED: "fused B-phase rows",
+             PROF_SWEEP: "one-pass sweep (X C -> B-phase -> X^T B)", PROF_REDUCE: "[G | R] reduction", PROF_C_FINISH: "C-phase finish",
+             PROF_A_FINISH: "A-phase finish", PROF_ROWS_CHAIN: "chained B row pass", PROF_UNIMODAL: "unimodal regressions",
+             PROF_PF2: "PARAFAC2 per-slab algebra", PROF_DIAG: "diagnostics reduction", PROF_OTHER: "other launches"}
+VARIANT_EXACT_MODE = 100
 # short names of the native kinds (descriptor dicts of bench.py / the test helpers -> enum mcl_penalty_kind)
 KIND = {"nn": PEN_NN, "box": PEN_BOX, "l1": PEN_L1, "l2ball": PEN_L2BALL, "unimodal": PEN_UNIMODAL,
         "parafac2": PEN_PARAFAC2, "tv": PEN_TV}
@@ -32,7 +43,7 @@ EXPORTED_SYMBOLS = [
     "mcl_iterate", "mcl_run", "mcl_gate_begin", "mcl_verdict", "mcl_gate_end", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_B_end", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
     "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
-    "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_set_stride", "mcl_profile_read",
+    "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_set_stride", "mcl_profile_read", "mcl_profile_launches", "mcl_profile_overhead_us",
     "mcl_reload_switches", "mcl_active_switches", "mcl_record_event", "mcl_wait_event", "mcl_cmf_to_packed",
 ]
 
@@ -119,6 +130,8 @@ def load_library():
         "mcl_profile_enable": (ctypes.c_int, [P, I32]),
         "mcl_profile_set_stride": (ctypes.c_int, [P, I32]),
         "mcl_profile_read": (ctypes.c_int, [P, I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I32)]),
+        "mcl_profile_launches": (I64, [P, I32]),
+        "mcl_profile_overhead_us": (ctypes.c_double, [P]),
         "mcl_reload_switches": (ctypes.c_int, [P]),
         "mcl_active_switches": (ctypes.c_char_p, [P]),
         "mcl_record_event": (ctypes.c_int, [P, P]),
@@ -419,7 +432,7 @@ class HipEngine:
 
     def rho(self, mode):
         """device fp32 feasibility penalties of the current phase: mode 0 -> [I], 1 -> [I], 2 -> [1]"""
-        return self.internal({0: 4, 1: 3, 2: 5}[mode])
+        return self.internal({0: BUF_RHO_A, 1: BUF_RHO_B, 2: BUF_RHO_C}[mode])
 
     # -- introspection ------------------------------------------------------------------------------------
     def internal(self, which):
@@ -428,10 +441,10 @@ class HipEngine:
         return self._view(p, n.value, self._torch.float32)
 
     def rhses(self):
-        return self.internal(0).view(self.I, self.r)
+        return self.internal(BUF_RHSES).view(self.I, self.r)
 
     def cross_products(self):
-        return self.internal(1).view(self.I, self.r, self.r)
+        return self.internal(BUF_CROSS_PRODUCTS).view(self.I, self.r, self.r)
 
     def profile_enable(self, capacity, stride=1):
         """HIP-event pairs around up to `capacity` launches per kernel slot, every `stride`-th launch only."""
@@ -439,10 +452,18 @@ class HipEngine:
         self._check(self.lib.mcl_profile_set_stride(self._h, int(stride)))
 
     def profile_read(self, which):
-        """(total_ms, launches) of kernel slot `which` (0: X C pass, 1: X^T B pass, 2: fused B rows, 3: one-pass sweep); synchronises."""
+        """(total_ms, launches timed) of launch site `which` (a PROF_* constant = enum mcl_profile_slot); synchronises."""
         tot, n = ctypes.c_double(), ctypes.c_int32()
         self._check(self.lib.mcl_profile_read(self._h, which, ctypes.byref(tot), ctypes.byref(n)))
         return tot.value, n.value
+
+    def profile_launches(self, which):
+        """launches launch site `which` has seen since profile_enable (timed or not)"""
+        return int(self.lib.mcl_profile_launches(self._h, which))
+
+    def profile_overhead_us(self):
+        """elapsed time of an empty event pair on the engine's stream (calibrated by profile_enable)"""
+        return float(self.lib.mcl_profile_overhead_us(self._h))
 
     def reload_switches(self):
         """re-read the MCL_* environment switches (they are otherwise read once, when the context is created)"""

@@ -1688,6 +1688,7 @@ bool mcl_mode_is_row_separable(const mcl_context *c, int mode) {
     }
 
 int mcl_launch_ctc(mcl_context *c) {
+    ProfScope prof_(c, MCL_PROF_OTHER);
     const int RPc = c->RP < 4 ? 4 : c->RP;
     hipLaunchKernelGGL(k_ctc, dim3((unsigned)c->r), dim3(256), 0, c->stream, c->C, (int)c->K, c->r, RPc, c->CtC, c->CtC64);
     MCL_CHECK_HIP(c, hipGetLastError());
@@ -1695,6 +1696,7 @@ int mcl_launch_ctc(mcl_context *c) {
 }
 
 int mcl_launch_B_rho(mcl_context *c) {
+    ProfScope prof_(c, MCL_PROF_OTHER);
     MCL_CHECK_HIP(c, hipMemsetAsync(c->rho_max, 0, sizeof(float), c->stream));
     if (c->I == 0) return 0;
     hipLaunchKernelGGL(k_B_rho, dim3((unsigned)((c->I + 255) / 256)), dim3(256), 0, c->stream, c->CtC64, c->A, (int)c->I,
@@ -1704,6 +1706,7 @@ int mcl_launch_B_rho(mcl_context *c) {
 }
 
 int mcl_launch_B_systems(mcl_context *c) {
+    ProfScope prof_(c, MCL_PROF_OTHER);
     if (c->I == 0) return 0;
     dim3 grid((unsigned)((c->I + 3) / 4)), block(256);
     DISPATCH_RP_T(c, k_B_systems, grid, block, c->CtC64, c->A, (int)c->I, c->r, (float)c->opt.feasibility_penalty_scale,
@@ -1714,6 +1717,8 @@ int mcl_launch_B_systems(mcl_context *c) {
 
 // exact-products mode (mcl_exact_mode): X C as fp64 sums of exact products, with its once-rounded fp32 image
 int mcl_launch_exact_xc(mcl_context *c) {
+    ProfScope prof_(c, MCL_PROF_XC);
+    c->variant[MCL_PROF_XC] = "k_contract_xc_f64";
     if (c->N == 0) return 0;
     const dim3 g((unsigned)(((c->N + 15) / 16 + 3) / 4));
     if (c->NB == 1)
@@ -1727,6 +1732,8 @@ int mcl_launch_exact_xc(mcl_context *c) {
 }
 
 int mcl_launch_B_solve_f64(mcl_context *c) {
+    ProfScope prof_(c, MCL_PROF_ROWS_FUSED);
+    c->variant[MCL_PROF_ROWS_FUSED] = "k_contract_xc_f64 + k_B_solve_f64";
     if (c->tilesB.n_tiles == 0) return 0;
     {  // X C in fp64 (one inner iteration per phase for a penalty-free mode: computed right here)
         const dim3 g((unsigned)(((c->N + 15) / 16 + 3) / 4));
@@ -1813,11 +1820,11 @@ int mcl_launch_rows_fused(mcl_context *c, int mode) {
     double *diag = (mode == 1) ? c->diagB_tile : c->diagC_tile;
     int rc;
     if (mode == 1) {
-        ProfScope prof(c, 2);
+        ProfScope prof(c, MCL_PROF_ROWS_FUSED);
         rc = mcl_rows_fused_dispatch(c, mode, diag);
         char buf[64];
         snprintf(buf, sizeof buf, "k_rows_fused<NBR=%d,NREG=%d>", c->r <= 16 ? 1 : (c->r <= 32 ? 2 : 4), c->regs[1].n);
-        c->variant[2] = buf;
+        c->variant[MCL_PROF_ROWS_FUSED] = buf;
     } else {
         rc = mcl_rows_fused_dispatch(c, mode, diag);
     }
@@ -1853,6 +1860,7 @@ static int launch_C_fused_t(mcl_context *c) {
     else MCL_CF(false);
 #undef MCL_CF
     MCL_CHECK_HIP(c, hipGetLastError());
+    c->variant[MCL_PROF_C_FINISH] = "k_C_finish_fused<NBR=" + std::to_string(NBR) + ",NREG=" + std::to_string(NREG) + ">";
     c->diag_rows[2] = 1;
     return 0;
 }
@@ -2002,6 +2010,7 @@ __global__ __launch_bounds__(256) void k_ctc_fold(const double *__restrict__ CtC
 }
 
 int mcl_launch_ctc_fold(mcl_context *c) {
+    ProfScope prof_(c, MCL_PROF_OTHER);
     hipLaunchKernelGGL(k_ctc_fold, dim3(1), dim3(256), 0, c->stream, c->CtCpart, c->ctc_parts, c->r, c->CtC, c->CtC64);
     MCL_CHECK_HIP(c, hipGetLastError());
     c->ctc_parts = 0;
@@ -2023,6 +2032,7 @@ static int launch_C_multi_t(mcl_context *c) {
     else MCL_CM(false);
 #undef MCL_CM
     MCL_CHECK_HIP(c, hipGetLastError());
+    c->variant[MCL_PROF_C_FINISH] = "k_C_finish_multi<NREG=" + std::to_string(NREG) + ">";
     c->diag_rows[2] = nblk;
     c->ctc_parts = nblk;
     return 0;
@@ -2058,6 +2068,7 @@ int mcl_launch_C_finish_fused(mcl_context *c) {
 }
 
 int mcl_launch_A_rho(mcl_context *c) {
+    ProfScope prof_(c, MCL_PROF_OTHER);
     MCL_CHECK_HIP(c, hipMemsetAsync(c->rho_max + 1, 0, sizeof(float), c->stream));
     if (c->I == 0) return 0;
     hipLaunchKernelGGL(k_A_rho, dim3((unsigned)((c->I + 255) / 256)), dim3(256), 0, c->stream, c->seg_btb, c->CtC64,
@@ -2115,12 +2126,14 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     }
 #undef MCL_AF_ARGS
     MCL_CHECK_HIP(c, hipGetLastError());
+    c->variant[MCL_PROF_A_FINISH] = !rows_kernel ? "k_A_finish" : (c->a_rhs_wide ? (c->a_rhs_pairs ? "k_A_finish_rows_wide<SPB=2>" : "k_A_finish_rows_wide<SPB=1>") : "k_A_finish_rows");
     c->ctc_parts = 0;  // the rows kernels wrote the totals
     c->b_systems_valid = (next_B != 0);
     return 0;
 }
 
 int mcl_launch_A_e1(mcl_context *c, bool btb_is_q) {
+    ProfScope prof_(c, MCL_PROF_OTHER);
     if (c->I == 0) return 0;
     hipLaunchKernelGGL(k_A_e1, dim3((unsigned)c->I), dim3(64), 0, c->stream, c->rhsA, c->BtB, c->CtC, btb_is_q ? 1 : 0,
                        c->A, c->regs[0], c->r, c->e1, c->diagA_row);
@@ -2129,6 +2142,8 @@ int mcl_launch_A_e1(mcl_context *c, bool btb_is_q) {
 }
 
 int mcl_launch_rows_diag(mcl_context *c, int mode) {
+    ProfScope prof_(c, MCL_PROF_DIAG);
+    c->variant[MCL_PROF_DIAG] = "k_diag_final";
     const TileMap &tm = (mode == 1) ? c->tilesB : (mode == 2 ? c->tilesC : c->tilesA);
     if (tm.n_tiles == 0) return 0;
     const float *F = (mode == 1) ? c->B : (mode == 2 ? c->C : c->A);
@@ -2156,6 +2171,7 @@ int mcl_launch_rows_diag(mcl_context *c, int mode) {
 }
 
 int mcl_launch_x_sq(mcl_context *c) {
+    ProfScope prof_(c, MCL_PROF_OTHER);
     const long n = (long)c->N * c->K;
     const int nb = 1024;
     hipLaunchKernelGGL(k_sumsq_partial, dim3(nb), dim3(256), 0, c->stream, c->X, n, c->xsq_part);
@@ -2176,6 +2192,8 @@ DiagTables mcl_diag_tables(const mcl_context *c, bool a_from_rows) {
 }
 
 int mcl_launch_diag_tables(mcl_context *c, const DiagTables &T, double *out, int include_replicated) {
+    ProfScope prof_(c, MCL_PROF_DIAG);
+    c->variant[MCL_PROF_DIAG] = "k_diag_final";
     // long tables (thousands of B tiles: config 4 / 5) are summed by 1024 threads per column: a quarter of the dependent loads
     const int nt = std::max(T.rows[0], std::max(T.rows[1], T.rows[2])) > 2048 ? 1024 : 256;
     hipLaunchKernelGGL(k_diag_final, dim3(3 * DIAG_COLS + 3), dim3(nt), 0, c->stream, T, include_replicated, out);
@@ -2197,6 +2215,7 @@ static StopRuleDev rule_dev(const mcl_context *c, const mcl_stop_rule *rule, int
 
 int mcl_launch_verdict(mcl_context *c, const double *vec, const mcl_stop_rule *rule, int it, double *verdict_row,
                        int *status_dev) {
+    ProfScope prof_(c, MCL_PROF_DIAG);
     hipLaunchKernelGGL(k_verdict, dim3(1), dim3(64), 0, c->stream, vec, rule_dev(c, rule, it), c->regs[0].n, c->regs[1].n,
                        c->regs[2].n, c->gate, c->stop_state, verdict_row, status_dev);
     MCL_CHECK_HIP(c, hipGetLastError());
@@ -2208,6 +2227,8 @@ int mcl_launch_diag_verdict(mcl_context *c, double *out, const mcl_stop_rule *ru
     const StopRuleDev R = rule_dev(c, rule, it);
     const DiagTables T = mcl_diag_tables(c, true);
     const int nt = std::max(T.rows[0], std::max(T.rows[1], T.rows[2])) > 2048 ? 1024 : 256;
+    ProfScope prof_(c, MCL_PROF_DIAG);
+    c->variant[MCL_PROF_DIAG] = "k_diag_verdict";
     hipLaunchKernelGGL(k_diag_verdict, dim3(3 * DIAG_COLS + 3), dim3(nt), 0, c->stream, T, out, R,
                        c->gate, c->stop_state, verdict_row, status_dev);
     MCL_CHECK_HIP(c, hipGetLastError());

@@ -114,6 +114,7 @@ int64_t plan(mcl_context *c, char *base) {
     c->xsq_part = b.take<double>(1024);
     c->x_sq = b.take<double>(1);
     c->gate = b.take<int>(4);
+    c->mute_status = b.take<int>(4);
     c->stop_state = b.take<double>(4);
 
     // generic (non row-separable) path scratch
@@ -187,6 +188,7 @@ void read_switches(mcl_switches &w) {
     w.xc_dbg = num("MCL_XC_DBG", 0), w.xt_dbg = num("MCL_XT_DBG", 0), w.xt_depth = num("MCL_XT_DEPTH", 0);
     w.sweep_dbg = num("MCL_SWEEP_DBG", 0), w.reduce_el = num("MCL_REDUCE_EL", 0), w.uni_split = num("MCL_UNI_SPLIT", -1);
     w.exact = num("MCL_EXACT", -1);
+    w.test_mute_verdict = flag("MCL_TEST_MUTE_VERDICT");  // test hook of the mcl_run watchdog, not a kernel form
     if (const char *e = getenv("MCL_RUN_SPINS")) w.run_spins = atol(e);  // operating parameter of mcl_run's wait (see there)
     if (const char *e = getenv("MCL_RUN_WATCHDOG_S")) {  // an operating parameter, not a kernel form (not listed by mcl_active_switches)
         const double v = atof(e);
@@ -218,6 +220,7 @@ int fail(mcl_context *c, const std::string &msg) {
 }
 
 int ready_noflush(mcl_context *c) {
+    if (c->failed) return fail(c, "the context is in a failed state (" + c->failed_why + "): destroy it");
     if (!c->has_problem) return fail(c, "mcl_set_problem has not been called");
     if (!c->has_factors) return fail(c, "mcl_set_factors has not been called");
     if (!c->has_workspace) return fail(c, "mcl_set_workspace has not been called");
@@ -398,8 +401,8 @@ int mcl_create(mcl_context **out, int device, void *hip_stream) {
 
 void mcl_destroy(mcl_context *ctx) {
     if (!ctx) return;
-    (void)settle_deferred(ctx);  // a deferred diagnostics vector is still delivered
-    for (int s = 0; s < 4; ++s)
+    if (!ctx->failed) (void)settle_deferred(ctx);  // a deferred diagnostics vector is still delivered
+    for (int s = 0; s < MCL_PROF_SLOTS; ++s)
         for (hipEvent_t e : ctx->prof_ev[s]) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -865,6 +868,7 @@ double *mcl_c_normal_equations(mcl_context *c, int64_t *count) {
 
 int mcl_update_C_finish(mcl_context *c) {
     if (int rc = ready(c)) return rc;
+    ProfScope prof_(c, MCL_PROF_C_FINISH);
     if (c->opt.inner_n_iter_max > 0 && mcl_mode_is_row_separable(c, 2)) {
         // everything from the system solve to CtC / C fragments in one single-workgroup launch
         const int rc = mcl_launch_C_finish_fused(c);
@@ -958,6 +962,7 @@ float *mcl_A_rho_max(mcl_context *c) { return c ? c->rho_max + 1 : nullptr; }
 int mcl_A_finish(mcl_context *c) {
     if (int rc = ready(c)) return rc;
     if (c->opt.inner_n_iter_max <= 0) return 0;
+    ProfScope prof_(c, MCL_PROF_A_FINISH);
     c->grpart_valid = false;  // the sweep's [G | R] partials were weighted with the previous a_i
     if (mcl_mode_is_row_separable(c, 0)) {
         if (int rc = mcl_launch_A_finish(c, true)) return rc;
@@ -1145,6 +1150,8 @@ int mcl_run(mcl_context *c, int32_t n_iter_max, int32_t update_A, int32_t update
     };
     set_gate(c->gate);
     int rc = 0, enqueued = 0;
+    bool wedged = false;  // the watchdog gave up: the stream may never drain, nothing below may wait for it
+    if (c->sw.test_mute_verdict) status_dev = c->mute_status;  // test hook: the verdicts never reach the host
     // the status words are written by the device (mapped pinned memory): every read in the wait loop is a volatile read
     const volatile mcl_run_status *seen = status;
     for (int it = 0; it < n_iter_max && rc == 0; ++it) {
@@ -1177,8 +1184,13 @@ int mcl_run(mcl_context *c, int32_t n_iter_max, int32_t update_A, int32_t update
                 }
             }
             if (now - t_progress >= std::chrono::duration<double>(c->sw.run_watchdog_s)) {
-                rc = fail(c, "mcl_run: no verdict from the device for " + std::to_string((int)c->sw.run_watchdog_s) +
-                                 " s (MCL_RUN_WATCHDOG_S): giving up the wait; the stream is left as it is");
+                char secs[32];
+                snprintf(secs, sizeof secs, "%g", c->sw.run_watchdog_s);
+                rc = fail(c, std::string("mcl_run: no verdict from the device for ") + secs +
+                                 " s (MCL_RUN_WATCHDOG_S): giving up the wait WITHOUT synchronising the stream; the context is "
+                                 "failed - keep the workspace, the rings and `status` allocated until the device has been "
+                                 "synchronised or reset, then destroy the context");
+                wedged = true;
                 break;
             }
         }
@@ -1196,6 +1208,14 @@ int mcl_run(mcl_context *c, int32_t n_iter_max, int32_t update_A, int32_t update
         enqueued = it + 1;
     }
     set_gate(nullptr);
+    if (wedged) {
+        // a device that has reported nothing for the whole watchdog period may never drain its stream: a synchronisation
+        // here is the very hang the watchdog exists to end.  The enqueued kernels still refer to the caller's buffers.
+        c->failed = true;
+        c->failed_why = "mcl_run gave up waiting for the device";
+        forget_byproducts(c);
+        return rc;
+    }
     const hipError_t e = hipStreamSynchronize(c->stream);  // the call reports the verdict: the one entry point that waits
     if (e != hipSuccess && rc == 0) rc = fail(c, std::string("mcl_run: hipStreamSynchronize: ") + hipGetErrorString(e));
     if (status->stopped && enqueued > status->stop_iteration + 1) forget_byproducts(c);
@@ -1257,32 +1277,33 @@ float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {
     float *p = nullptr;
     int64_t n = 0;
     switch (which) {
-        case 0: p = c->rhsA, n = c->I * c->r; break;
-        case 1: p = c->BtB, n = c->I * c->r * c->r; break;
-        case 2: p = c->XC, n = c->N * c->r; break;
-        case 3: p = c->rhoB, n = c->I; break;
-        case 4: p = c->rhoA, n = c->I; break;
-        case 5: p = c->rhoC, n = 1; break;
-        case 6:
+        case MCL_BUF_RHSES: p = c->rhsA, n = c->I * c->r; break;
+        case MCL_BUF_CROSS_PRODUCTS: p = c->BtB, n = c->I * c->r * c->r; break;
+        case MCL_BUF_XC: p = c->XC, n = c->N * c->r; break;
+        case MCL_BUF_RHO_B: p = c->rhoB, n = c->I; break;
+        case MCL_BUF_RHO_A: p = c->rhoA, n = c->I; break;
+        case MCL_BUF_RHO_C: p = c->rhoC, n = 1; break;
+        case MCL_BUF_CTC:
             if (c->ctc_valid && c->ctc_parts > 0) (void)mcl_launch_ctc_fold(c);
             p = c->CtC, n = (int64_t)c->r * c->r;
             break;
-        case 7: p = c->LinvB, n = c->I * c->r * c->r; break;
-        case 9: p = reinterpret_cast<float *>(c->pf2_acc), n = c->pf2_acc ? 2 * c->I * ((int64_t)c->r * c->r + 1) : 0; break;
-        case 10: p = reinterpret_cast<float *>(c->pf2_S), n = c->pf2_S ? 2 * c->I * (int64_t)c->r * c->r : 0; break;
-        case 11: p = reinterpret_cast<float *>(c->sweep_cycles), n = c->sweep_cycles ? (int64_t)2048 * 6 * 2 : 0; break;
-        case 8: p = reinterpret_cast<float *>(c->pf2_status), n = c->pf2_status ? c->I : 0; break;  // int32 bits
+        case MCL_BUF_LINV_B: p = c->LinvB, n = c->I * c->r * c->r; break;
+        case MCL_BUF_PF2_ACC: p = reinterpret_cast<float *>(c->pf2_acc), n = c->pf2_acc ? 2 * c->I * ((int64_t)c->r * c->r + 1) : 0; break;
+        case MCL_BUF_PF2_GRAM: p = reinterpret_cast<float *>(c->pf2_S), n = c->pf2_S ? 2 * c->I * (int64_t)c->r * c->r : 0; break;
+        case MCL_BUF_SWEEP_CYCLES: p = reinterpret_cast<float *>(c->sweep_cycles), n = c->sweep_cycles ? (int64_t)2048 * 6 * 2 : 0; break;
+        case MCL_BUF_PF2_STATUS: p = reinterpret_cast<float *>(c->pf2_status), n = c->pf2_status ? c->I : 0; break;  // int32 bits
 #ifdef MCL_NS_STAMPS
-        case 18: p = c->pf2_xmin, n = c->pf2_xmin ? 17 * c->I : 0; break;
+        case MCL_BUF_NS_STAMPS: p = c->pf2_xmin, n = c->pf2_xmin ? 17 * c->I : 0; break;
 #endif
         // the planner's work-unit tables (int32 bits): segments of the X passes, bsegs of the sweep, and the first
         // unit of every wave (mcl_set_problem)
-        case 12: p = reinterpret_cast<float *>(c->segs.row0), n = c->segs.n_tiles; break;
-        case 13: p = reinterpret_cast<float *>(c->segs.nrows), n = c->segs.n_tiles; break;
-        case 14: p = reinterpret_cast<float *>(c->wave_seg_ptr), n = c->n_seg_waves + 1; break;
-        case 15: p = reinterpret_cast<float *>(c->bsegs.row0), n = c->bsegs.n_tiles; break;
-        case 16: p = reinterpret_cast<float *>(c->bsegs.nrows), n = c->bsegs.n_tiles; break;
-        case 17: p = reinterpret_cast<float *>(c->wave_bseg_ptr), n = c->wave_bseg_ptr ? c->n_bseg_waves + 1 : 0; break;
+        case MCL_BUF_SEG_ROW0: p = reinterpret_cast<float *>(c->segs.row0), n = c->segs.n_tiles; break;
+        case MCL_BUF_SEG_NROWS: p = reinterpret_cast<float *>(c->segs.nrows), n = c->segs.n_tiles; break;
+        case MCL_BUF_WAVE_SEG_PTR: p = reinterpret_cast<float *>(c->wave_seg_ptr), n = c->n_seg_waves + 1; break;
+        case MCL_BUF_BSEG_ROW0: p = reinterpret_cast<float *>(c->bsegs.row0), n = c->bsegs.n_tiles; break;
+        case MCL_BUF_BSEG_NROWS: p = reinterpret_cast<float *>(c->bsegs.nrows), n = c->bsegs.n_tiles; break;
+        case MCL_BUF_BSEG_PART: p = reinterpret_cast<float *>(c->bseg_part), n = c->bseg_part ? c->bsegs.n_tiles : 0; break;
+        case MCL_BUF_WAVE_BSEG_PTR: p = reinterpret_cast<float *>(c->wave_bseg_ptr), n = c->wave_bseg_ptr ? c->n_bseg_waves + 1 : 0; break;
         default: break;
     }
     if (count) *count = n;
@@ -1291,31 +1312,55 @@ float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {
 
 int mcl_profile_enable(mcl_context *c, int32_t capacity) {
     if (!c) return 1;
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < MCL_PROF_SLOTS; ++s) {
         for (hipEvent_t e : c->prof_ev[s]) (void)hipEventDestroy(e);
         c->prof_ev[s].clear();
         c->prof_used[s] = 0;
         c->prof_seen[s] = 0;
+        c->prof_launches[s] = 0;
     }
     c->prof_capacity = 0;
+    c->prof_nested = false;
     if (capacity <= 0) return 0;
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < MCL_PROF_SLOTS; ++s) {
         c->prof_ev[s].resize((size_t)2 * capacity);
         for (auto &e : c->prof_ev[s]) MCL_CHECK_HIP(c, hipEventCreate(&e));
     }
     c->prof_capacity = capacity;
+    // what an event pair adds to the kernel between its events: the marker -> dispatch and completion -> marker latencies
+    // of the command processor.  Calibrated on one tiny kernel (a 4-byte memset) against an empty pair of markers.
+    c->prof_overhead_ms = 0.0;
+    if (c->has_workspace) {
+        hipEvent_t ev[2];
+        MCL_CHECK_HIP(c, hipEventCreate(&ev[0]));
+        MCL_CHECK_HIP(c, hipEventCreate(&ev[1]));
+        float best = 1e30f;
+        for (int t = 0; t < 12; ++t) {
+            MCL_CHECK_HIP(c, hipEventRecord(ev[0], c->stream));
+            MCL_CHECK_HIP(c, hipEventRecord(ev[1], c->stream));
+            MCL_CHECK_HIP(c, hipEventSynchronize(ev[1]));
+            float ms = 0.f;
+            MCL_CHECK_HIP(c, hipEventElapsedTime(&ms, ev[0], ev[1]));
+            if (t >= 2 && ms < best) best = ms;
+        }
+        (void)hipEventDestroy(ev[0]);
+        (void)hipEventDestroy(ev[1]);
+        c->prof_overhead_ms = best < 1e29f ? (double)best : 0.0;
+    }
     return 0;
 }
+
+double mcl_profile_overhead_us(mcl_context *c) { return c ? 1e3 * c->prof_overhead_ms : 0.0; }
 
 int mcl_profile_set_stride(mcl_context *c, int32_t stride) {
     if (!c || stride < 1) return 1;
     c->prof_stride = stride;
-    for (int s = 0; s < 4; ++s) c->prof_seen[s] = 0;
+    for (int s = 0; s < MCL_PROF_SLOTS; ++s) c->prof_seen[s] = 0, c->prof_launches[s] = 0;
     return 0;
 }
 
 int mcl_profile_read(mcl_context *c, int32_t which, double *total_ms, int32_t *count) {
-    if (!c || which < 0 || which > 3 || !total_ms || !count) return 1;
+    if (!c || which < 0 || which >= MCL_PROF_SLOTS || !total_ms || !count) return 1;
     double tot = 0.0;
     const int n = c->prof_used[which];
     for (int i = 0; i < n; ++i) {
@@ -1330,6 +1375,11 @@ int mcl_profile_read(mcl_context *c, int32_t which, double *total_ms, int32_t *c
     return 0;
 }
 
+int64_t mcl_profile_launches(mcl_context *c, int32_t which) {
+    if (!c || which < 0 || which >= MCL_PROF_SLOTS) return -1;
+    return c->prof_launches[which];
+}
+
 int mcl_reload_switches(mcl_context *c) {
     if (!c) return 1;
     read_switches(c->sw);
@@ -1340,8 +1390,9 @@ int mcl_reload_switches(mcl_context *c) {
 const char *mcl_active_switches(const mcl_context *c) { return c ? c->active_switches.c_str() : ""; }
 
 const char *mcl_kernel_variant(mcl_context *c, int32_t which) {
-    if (!c || which < 0 || which > 4) return "";
-    if (which == 4) return c->exact ? "exact products (fp64 sums; small problem)" : "";
+    if (!c) return "";
+    if (which == MCL_VARIANT_EXACT_MODE) return c->exact ? "exact products (fp64 sums; small problem)" : "";
+    if (which < 0 || which >= MCL_PROF_SLOTS) return "";
     return c->variant[which].c_str();
 }
 

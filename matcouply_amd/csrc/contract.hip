@@ -940,7 +940,7 @@ static int launch_xt(mcl_context *c) {
     const int n_slices = (int)((c->K + 64 * KB - 1) / (64 * KB));
     dim3 grid((unsigned)(((nb + 7) / 8) * 8 * n_slices));  // 1-D: (row range mod 8 = XCD, slice, row range div 8), see the kernel
     const bool vec = (c->K % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->X) & 15) == 0);
-    ProfScope prof(c, 1);
+    ProfScope prof(c, MCL_PROF_XT);
     int dbg = 0, depth = 4;
     dbg = c->sw.xt_dbg;
     if (c->sw.xt_depth > 0) depth = c->sw.xt_depth;
@@ -966,7 +966,7 @@ static int launch_xt(mcl_context *c) {
     c->n_part = nb;
     char buf[96];
     snprintf(buf, sizeof buf, "k_contract_xt<KB=%d,NB=%d,VEC=%d>", KB, NB, vec ? 4 : 1);
-    c->variant[1] = buf;
+    c->variant[MCL_PROF_XT] = buf;
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
@@ -988,6 +988,8 @@ int mcl_launch_contract_xt(mcl_context *c) {
 
 int mcl_launch_reduce_partials(mcl_context *c) {
     const int E = (int)(c->K * c->r + c->r * c->r);
+    ProfScope prof(c, MCL_PROF_REDUCE);
+    c->variant[MCL_PROF_REDUCE] = "k_reduce_partials";
     hipLaunchKernelGGL(k_reduce_partials, dim3((E + 63) / 64), dim3(256), 0, c->stream, c->partials, c->n_part, E,
                        c->GR);
     MCL_CHECK_HIP(c, hipGetLastError());
@@ -997,6 +999,7 @@ int mcl_launch_reduce_partials(mcl_context *c) {
 static inline int xc_KC(const mcl_context *c) { return mcl_xc_chunks(c, nullptr); }
 
 int mcl_launch_build_cfrag(mcl_context *c) {
+    ProfScope prof_(c, MCL_PROF_OTHER);
     const int KC = mcl_cfrag_chunks(c);  // the image is shared with the sweep
     const long total = (long)KC * 4 * c->NB * 256;
     hipLaunchKernelGGL(k_build_cfrag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->C, (int)c->K,
@@ -1019,7 +1022,7 @@ static int launch_xc(mcl_context *c) {
     const unsigned grid = (unsigned)((waves + 3) / 4);
     if (grid == 0) return 0;
     const bool vec = (c->K % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->X) & 15) == 0);
-    ProfScope prof(c, 0);
+    ProfScope prof(c, MCL_PROF_XC);
     int kct = 0;
     mcl_xc_chunks(c, &kct);
     if (vec && (c->K % 256 == 0) && !c->sw.xc_norow) {
@@ -1077,7 +1080,7 @@ static int launch_xc(mcl_context *c) {
         char buf[96];
         if (creg && !c->sw.xc_depth1) snprintf(buf, sizeof buf, "k_contract_xc_256<DEPTH=2,GRAM=%d>", gram);
         else snprintf(buf, sizeof buf, "k_contract_xc_row<NB=%d,CREG=%d,GRAM=%d>", NB, creg ? 1 : 0, gram);
-        c->variant[0] = buf;
+        c->variant[MCL_PROF_XC] = buf;
         MCL_CHECK_HIP(c, hipGetLastError());
         return 0;
     }
@@ -1097,7 +1100,7 @@ static int launch_xc(mcl_context *c) {
 #undef MCL_XC
     char buf[96];
     snprintf(buf, sizeof buf, "k_contract_xc<NB=%d,VEC=%d,KCT=%d>", NB, vec ? 4 : 1, kct);
-    c->variant[0] = buf;
+    c->variant[MCL_PROF_XC] = buf;
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
@@ -1109,6 +1112,7 @@ int mcl_launch_contract_xc(mcl_context *c) {
 }
 
 int mcl_launch_slab_gram(mcl_context *c) {
+    ProfScope prof_(c, MCL_PROF_OTHER);
     if (c->I == 0) return 0;
     dim3 grid((unsigned)c->I);
     if (c->NB == 1)
@@ -1243,6 +1247,8 @@ int mcl_launch_exact_gr(mcl_context *c) {
     const long E = (long)c->K * c->r + (long)c->r * c->r;
     const dim3 grid((unsigned)(kblocks + 1), (unsigned)n_chunks);
     double *part = n_chunks == 1 ? c->GR : c->exact_part;  // one chunk (<= 256 rows): its sums ARE [G | R], no second launch
+    ProfScope prof(c, MCL_PROF_XT);  // the exact-products form of the X^T pass (and its reduction)
+    c->variant[MCL_PROF_XT] = "k_exact_gr (+ k_exact_gr_reduce)";
     if (c->NB == 1)
         hipLaunchKernelGGL(k_exact_gr<1>, grid, dim3(64), 0, c->stream, c->X, c->B, c->A, c->slab_of_row, (long)c->N, (int)c->K, c->r, part);
     else if (c->NB == 2)

@@ -1736,6 +1736,8 @@ int mcl_launch_rows_solve(mcl_context *c, int mode) {
     const float *Linv = (mode == 1) ? c->LinvB : c->LinvC;
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
     const bool vec = rows_vec_ok(c, mv, c->regs[mode], rhs);
+    ProfScope prof(c, mode == 1 ? MCL_PROF_ROWS_CHAIN : MCL_PROF_OTHER);
+    if (mode == 1) c->variant[MCL_PROF_ROWS_CHAIN] = "k_rows_solve";
     DISPATCH_ROWS(c, vec, k_rows_solve, grid, block, mv, rhs, Arows, Linv, c->regs[mode], c->r);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
@@ -1765,6 +1767,8 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
     const RegSet &rs = c->regs[mode];
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
     const bool vec = rows_vec_ok(c, mv, rs, nullptr);
+    const int kind_k = rs.kind[k];
+    ProfScope prof(c, kind_k == MCL_PEN_PARAFAC2 ? MCL_PROF_PF2 : (kind_k == MCL_PEN_UNIMODAL ? MCL_PROF_UNIMODAL : MCL_PROF_OTHER));
     switch (rs.kind[k]) {
         case MCL_PEN_NN:
         case MCL_PEN_BOX:
@@ -1824,6 +1828,7 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
     hipLaunchKernelGGL((k_pf2_algebra_ns<NB_, TILES_>), dim3((unsigned)c->I), dim3(((TILES_) && (NB_) == 1) ? 128 : 64), 0, c->stream, c->pf2_S, \
                        rs.aux2[k], c->rhoB, mv.ext, r, c->pf2_T, c->pf2_acc, c->pf2_status, ts, rs, c->pf2_xmin,     \
                        c->sw.ns_plain ? 0 : 1, c->pf2_T64)
+                c->variant[MCL_PROF_PF2] = std::string("k_pf2_algebra_ns<NB=") + std::to_string(c->NB) + (tiles ? ",TILES> (+ k_pf2_sum_delta)" : "> (+ k_pf2_sum_delta)");
                 if (c->NB == 1) {
                     if (tiles) MCL_NS(1, true);
                     else MCL_NS(1, false);
@@ -1833,6 +1838,7 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                 }
 #undef MCL_NS
             }
+            if (status == nullptr) c->variant[MCL_PROF_PF2] = "k_pf2_algebra (Jacobi) + k_pf2_polar_qr";
             if (status == nullptr || c->NB != 1) {  // rank <= 16: the Newton-Schulz kernel runs the Jacobi route itself
                 hipLaunchKernelGGL(k_pf2_algebra, dim3((unsigned)c->I), dim3(64), sm, c->stream, c->pf2_S, rs.aux2[k],
                                    c->rhoB, r, c->pf2_T, c->pf2_acc, c->pf2_status, status != nullptr ? 1 : 0, c->pf2_T64, mv.ext);
@@ -1906,6 +1912,8 @@ int mcl_launch_rows_finish_fused(mcl_context *c, int mode, bool want_diag) {
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
     const bool vec = rows_vec_ok(c, mv, rs, nullptr);
     double *diag = (mode == 1) ? c->diagB_tile : c->diagC_tile;
+    ProfScope prof(c, mode == 1 ? MCL_PROF_ROWS_CHAIN : MCL_PROF_OTHER);
+    if (mode == 1) c->variant[MCL_PROF_ROWS_CHAIN] = mcl_rows64(c) ? "k_rows_finish_solve_stats<R64> chain (solve_stats -> finish_solve_stats x (n-1) -> finish_fused)" : "k_rows_finish_solve_stats chain (solve_stats -> finish_solve_stats x (n-1) -> finish_fused)";
     if (mode == 1 && mcl_rows64(c)) {  // rank <= 16 with a PARAFAC2 member: fp64 row algebra
         if (vec)
             hipLaunchKernelGGL((k_rows_finish_fused<1, true, true>), grid, block, 0, c->stream, mv, rs, c->r, (const float *)c->pf2_T,
@@ -1940,6 +1948,8 @@ int mcl_launch_rows_finish_solve_stats(mcl_context *c) {
     const float *rhs = c->XC;
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
     const bool vec = rows_vec_ok(c, mv, c->regs[1], rhs);
+    {
+    ProfScope prof(c, MCL_PROF_ROWS_CHAIN);
 #define MCL_FSS(NBR_, VEC_, R64_)                                                                                    \
     hipLaunchKernelGGL((k_rows_finish_solve_stats<NBR_, VEC_, R64_>), grid, block, 0, c->stream, mv, rhs,              \
                        (const float *)c->A, (const float *)c->LinvB, c->regs[1], c->r, (const float *)c->pf2_T,        \
@@ -1956,6 +1966,8 @@ int mcl_launch_rows_finish_solve_stats(mcl_context *c) {
         else MCL_FSS(2, false, false);
     }
 #undef MCL_FSS
+    }
+    ProfScope prof2(c, MCL_PROF_OTHER);
     if (!mcl_stats_reduce_in_algebra(c))
         hipLaunchKernelGGL(k_stats_reduce, dim3((unsigned)c->I), dim3(256), 0, c->stream, (const int *)c->slab_tile_ptr,
                            (const double *)c->stat_gram, (const double *)c->stat_colsq, c->regs[1], c->r, 16 * c->NB,
@@ -1970,6 +1982,8 @@ int mcl_launch_rows_solve_stats(mcl_context *c) {
     const float *rhs = c->XC;
     dim3 grid((unsigned)((mv.n_tiles + 3) / 4)), block(256);
     const bool vec = rows_vec_ok(c, mv, c->regs[1], rhs);
+    {
+    ProfScope prof(c, MCL_PROF_ROWS_CHAIN);
 #define MCL_SS(NBR_, VEC_, R64_)                                                                                     \
     hipLaunchKernelGGL((k_rows_solve_stats<NBR_, VEC_, R64_>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, \
                        (const float *)c->LinvB, c->regs[1], c->r, c->stat_gram, c->stat_colsq, (const double *)c->LinvB64)
@@ -1984,6 +1998,8 @@ int mcl_launch_rows_solve_stats(mcl_context *c) {
         else MCL_SS(2, false, false);
     }
 #undef MCL_SS
+    }
+    ProfScope prof2(c, MCL_PROF_OTHER);
     if (!mcl_stats_reduce_in_algebra(c))
         hipLaunchKernelGGL(k_stats_reduce, dim3((unsigned)c->I), dim3(256), 0, c->stream, (const int *)c->slab_tile_ptr,
                            (const double *)c->stat_gram, (const double *)c->stat_colsq, c->regs[1], c->r, 16 * c->NB,

@@ -73,6 +73,7 @@ struct mcl_switches {
     int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
     int exact = -1;  // MCL_EXACT: 1 / 0 force the exact-products mode on / off (default -1: by problem size, mcl_exact_mode)
     long run_spins = 2000;          // mcl_run: polite spins of a wait before it starts to sleep (MCL_RUN_SPINS)
+    bool test_mute_verdict = false;  // MCL_TEST_MUTE_VERDICT: mcl_run's verdict kernels report into scratch (watchdog test)
     double run_watchdog_s = 120.0;  // mcl_run: seconds without a verdict from the device before the wait gives up (MCL_RUN_WATCHDOG_S)
 };
 
@@ -82,6 +83,8 @@ struct mcl_context {
     std::string active_switches;  // names of the MCL_* switches found in the environment when they were last read
     hipStream_t stream = nullptr;
     std::string err;
+    bool failed = false;      // set when mcl_run's watchdog gave up: every later entry point refuses the context
+    std::string failed_why;
 
     // problem
     const float *X = nullptr;
@@ -178,6 +181,7 @@ struct mcl_context {
     double *diagB_bufs[2] = {nullptr, nullptr};
     int diagB_parity = 0;
     // gated runs (mcl_run): device state of the stopping rule
+    int *mute_status = nullptr;        // int32[4]: where a muted run's verdict kernels report (MCL_TEST_MUTE_VERDICT)
     int *gate = nullptr;               // int32[4]: {stopped, stop_it, code, ticket of the verdict launch}
     const int *gate_active = nullptr;  // == gate while a gated run is enqueueing (copied into ModeView / RegSet), else NULL
     double *stop_state = nullptr;      // fp64[4]: {last computed loss, ...}
@@ -235,24 +239,30 @@ struct mcl_context {
     double *stat_gram = nullptr;       // [tilesB, (16 NB)^2]  per-tile Y^T Y, Y = B + U_pf2 (fp64 MFMA result order)
     double *stat_colsq = nullptr;      // [tilesB, MCL_MAX_REGS, r]  per-tile column sums of squares of (B + U_k)
 
-    std::string variant[5];
+    std::string variant[MCL_PROF_SLOTS];  // kernel last launched in every role (enum mcl_profile_slot)
 
-    // optional HIP-event timing of kernel slots (0: X C pass, 1: X^T B pass, 2: fused B rows, 3: one-pass sweep)
+    // optional HIP-event timing of the launch sites (enum mcl_profile_slot)
     int prof_capacity = 0;
-    std::vector<hipEvent_t> prof_ev[4];
-    int prof_used[4] = {0, 0, 0, 0};
-    int prof_stride = 1;               // record every prof_stride-th launch of a slot (an event pair costs ~10 us of
-    int prof_seen[4] = {0, 0, 0, 0};   // dispatch gaps around the kernel, so timed loops sample instead)
+    std::vector<hipEvent_t> prof_ev[MCL_PROF_SLOTS];
+    int prof_used[MCL_PROF_SLOTS] = {};
+    int prof_stride = 1;                  // record every prof_stride-th launch of a slot (an event pair costs ~10 us of
+    int prof_seen[MCL_PROF_SLOTS] = {};   // dispatch gaps around the kernel, so timed loops sample instead)
+    int64_t prof_launches[MCL_PROF_SLOTS] = {};  // launches seen per slot since mcl_profile_enable / _set_stride
+    double prof_overhead_ms = 0.0;        // elapsed time of an EMPTY event pair on this stream (mcl_profile_enable)
+    bool prof_nested = false;             // a ProfScope is open: launch sites inside it belong to its slot
 };
 
-// RAII helper: records start/stop events around a launch when profiling is enabled
+// RAII helper: records start/stop events around a launch site when profiling is enabled.  Scopes do not nest: a launcher
+// that calls another launcher (e.g. the C-phase finish falling back to the row kernels) keeps everything in ITS slot.
 struct ProfScope {
     mcl_context *c;
     int slot;
-    bool on;
-    ProfScope(mcl_context *ctx, int s) : c(ctx), slot(s), on(false) {
-        if (c->prof_capacity > 0 && c->prof_used[slot] < c->prof_capacity &&
-            (c->prof_seen[slot]++ % c->prof_stride) == 0) {
+    bool on, outer;
+    ProfScope(mcl_context *ctx, int s) : c(ctx), slot(s), on(false), outer(!ctx->prof_nested) {
+        if (!outer || c->prof_capacity <= 0) return;
+        c->prof_nested = true;
+        c->prof_launches[slot] += 1;
+        if (c->prof_used[slot] < c->prof_capacity && (c->prof_seen[slot]++ % c->prof_stride) == 0) {
             on = true;
             (void)hipEventRecord(c->prof_ev[slot][2 * c->prof_used[slot]], c->stream);
         }
@@ -262,6 +272,7 @@ struct ProfScope {
             (void)hipEventRecord(c->prof_ev[slot][2 * c->prof_used[slot] + 1], c->stream);
             c->prof_used[slot] += 1;
         }
+        if (outer && c->prof_capacity > 0) c->prof_nested = false;
     }
 };
 

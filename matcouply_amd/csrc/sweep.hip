@@ -931,7 +931,7 @@ static int launch_sweep_v(mcl_context *c) {
     c->n_grpart = c->n_parts;  // one partial per bseg, or per group of four bsegs of a slab
     char buf[96];
     snprintf(buf, sizeof buf, "k_sweep<KS=%d,NB=%d,NREG=%d,DEPTH=%d,NW=%d,VEC=%d>", KS, NB, NREG, DEPTH, NW, VEC ? 4 : 1);
-    c->variant[3] = buf;
+    c->variant[MCL_PROF_SWEEP] = buf;
     return 0;
 }
 
@@ -954,7 +954,7 @@ static int launch_sweep_t(mcl_context *c) {
 }
 
 int mcl_launch_sweep(mcl_context *c) {
-    ProfScope prof(c, 3);
+    ProfScope prof(c, MCL_PROF_SWEEP);
     const int ks = mcl_sweep_KS(c), n = c->regs[1].n;
 #define MCL_SW(KS_, NB_)                                  \
     switch (n) {                                          \
@@ -982,6 +982,8 @@ int mcl_launch_reduce_weighted(mcl_context *c) {
         c->diag_crossed_sweep = false;
     }
     const int blocks = (MS + W * W + el - 1) / el + (piggy.out ? MCL_PIGGY_BLOCKS : 0);
+    ProfScope prof(c, MCL_PROF_REDUCE);
+    c->variant[MCL_PROF_REDUCE] = "k_reduce_frag<" + std::to_string(el) + ">";
     if (el == 64)
         hipLaunchKernelGGL(k_reduce_frag<64>, dim3(blocks), dim3(1024), 0, c->stream, c->Mpart, c->GRpart, c->n_grpart,
                            (int)c->K, c->r, c->NB, MS, c->GR, piggy);
@@ -996,6 +998,7 @@ int mcl_launch_reduce_weighted(mcl_context *c) {
 }
 
 int mcl_launch_A_rhs_from_M(mcl_context *c) {
+    ProfScope prof(c, MCL_PROF_OTHER);
     hipLaunchKernelGGL(k_A_rhs_from_M, dim3(c->n_parts), dim3(256), 0, c->stream, c->Mpart, c->CfragS, sweep_MS(c),
                        c->NB, c->r, c->seg_rhs);
     MCL_CHECK_HIP(c, hipGetLastError());

@@ -797,6 +797,8 @@ int mcl_launch_unimodal(mcl_context *c, const int *ext, int n_slabs, float *F, c
     // fewer columns than about one wave per SIMD: the two sweeps run concurrently in different waves
     int wave_split = nwav <= 1024;
     if (c->sw.uni_split >= 0) wave_split = c->sw.uni_split;
+    c->variant[MCL_PROF_UNIMODAL] = wave_split ? "k_slab_unimodal_v4<1> + k_slab_unimodal_v4<2>"
+                                               : (c->sw.uni_noprune ? "k_slab_unimodal_v4<0>" : "k_slab_unimodal_v4<3>");
     if (wave_split) {
         hipLaunchKernelGGL(k_slab_unimodal_v4<1>, dim3(2 * nwav), dim3(64), 0, c->stream, ext, n_slabs, F, rs, k, c->r, sc);
         hipLaunchKernelGGL(k_slab_unimodal_v4<2>, dim3(nwav), dim3(256), 0, c->stream, ext, n_slabs, F, rs, k, c->r, sc);

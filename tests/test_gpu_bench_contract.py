@@ -20,6 +20,35 @@ def _last_json(stdout):
     return json.loads(lines[-1])
 
 
+def _check_per_kernel(d):
+    """roofline.per_kernel: every hot launch site of the step with its share; the block's kernel is the arg-max of
+    launches_per_step x avg_us; the kernels of a step cannot take longer than the step (VERDICT r4 #3)"""
+    r = d["roofline"]
+    pk = r["per_kernel"]
+    assert pk and all(k in e for e in pk for k in ("role", "kernel", "launches_per_step", "avg_us", "algorithmic_bytes", "traffic", "frac"))
+    shares = [e["launches_per_step"] * e["avg_us"] for e in pk]
+    with_bytes = [e for e in pk if e["algorithmic_bytes"]]
+    top = max(with_bytes, key=lambda e: e["launches_per_step"] * e["avg_us"])
+    assert r["kernel"] == top["kernel"] and r["kernel_role"] == top["role"], (r["kernel"], top["kernel"])
+    assert abs(r["avg_us"] - top["avg_us"]) < 1e-6 and r["frac"] == top["frac"]
+    assert sum(shares) <= 1e3 * d["ms_per_step"] * 1.02, (sum(shares), d["ms_per_step"], [(e["role"], e["launches_per_step"], e["avg_us"]) for e in pk])
+    assert sum(shares) >= 0.5 * 1e3 * d["ms_per_step"]  # ... and the timed sites are most of the step
+    assert 0 < r["step_frac"] < 1 and abs(r["step_frac"] - d["algorithmic_bytes_per_iter"] / (d["ms_per_step"] * 1e-3) / 8e12) < 2e-3
+
+
+def test_roofline_names_the_dominant_kernel_of_config_4():
+    """on the PARAFAC2 + L2-ball stack the dominant site is the chained row pass (six launches per iteration), not the
+    X passes (two)"""
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--config", "c4", "--steps", "5",
+                          "--warmup", "2", "--regions", "3", "--no-api", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    _check_per_kernel(d)
+    assert d["roofline"]["kernel_role"] == "chained B row pass" and d["roofline"]["launches_per_step"] == 6.0, d["roofline"]["kernel_role"]
+    roles = {e["role"]: e for e in d["roofline"]["per_kernel"]}
+    assert roles["X C pass"]["launches_per_step"] == 1.0 and roles["PARAFAC2 per-slab algebra"]["launches_per_step"] == 5.0
+
+
 def test_single_rank_line():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--config", "c2", "--steps", "6",
                           "--warmup", "2", "--regions", "3", "--cpu-budget", "2"], capture_output=True, text=True, timeout=600)
@@ -35,6 +64,7 @@ def test_single_rank_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None or str(r["traffic_source"]).startswith("static: profiles/")
+    _check_per_kernel(d)
     m = r["mfma"]
     assert m["unit"] == "TFLOP/s" and m["peak"] == 157.3 and 0 < m["frac"] < 1 and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-3
     c = d["cpu_baseline"]

@@ -4,6 +4,7 @@ import ctypes
 import numpy as np
 import pytest
 
+from matcouply_amd import _engine as _engine_mod
 from tests.helpers import engine_from_oracle_state, rel_err, to_np
 
 pytestmark = pytest.mark.gpu
@@ -83,7 +84,7 @@ def test_deferred_diagnostics_equal_immediate_ones(fast_kernels):
         for it in range(n):
             eng.update_B(); eng.update_C_local(); eng.update_C_finish(); eng.update_A()
             (eng.diagnostics_deferred if deferred else eng.diagnostics)(out=ring[it])
-        assert eng.kernel_variant(3).startswith("k_sweep<")
+        assert eng.kernel_variant(_engine_mod.PROF_SWEEP).startswith("k_sweep<")
         if deferred:
             torch.cuda.synchronize()
             assert bool(torch.isnan(ring[n - 1]).all())       # the last one is still pending ...
@@ -158,7 +159,7 @@ def test_a_deferral_crosses_at_most_one_sweep(fast_kernels):
     st = orc.random_state_for(X, row_ptr, 8, regs, seed=6)
     eng = engine_from_oracle_state(st)
     eng.update_B(); eng.update_C_local(); eng.update_C_finish(); eng.update_A()
-    assert eng.kernel_variant(3).startswith("k_sweep<")
+    assert eng.kernel_variant(_engine_mod.PROF_SWEEP).startswith("k_sweep<")
     want = eng.diagnostics().cpu().numpy()
     out = torch.full((DIAG_LEN,), float("nan"), dtype=torch.float64, device="cuda")
     eng.diagnostics_deferred(out=out)
@@ -173,7 +174,7 @@ def test_a_deferral_crosses_at_most_one_sweep(fast_kernels):
 def test_library_reports_the_header_abi_version():
     from matcouply_amd import _engine
 
-    assert _engine.load_library().mcl_version() == _engine.MCL_ABI_VERSION == 300
+    assert _engine.load_library().mcl_version() == _engine.MCL_ABI_VERSION == 400
 
 
 def test_events_order_a_side_stream_collective():
@@ -226,7 +227,7 @@ with warnings.catch_warnings(record=True) as caught:
     eng = bench.make_engine(cfg, X, row_ptr, I_loc, 0, dev)
 eng.iterate(2)
 torch.cuda.synchronize()
-print("RELEASE " + json.dumps(dict(active=eng.lib.mcl_active_switches(eng._h).decode(), sweep=eng.kernel_variant(3),
+print("RELEASE " + json.dumps(dict(active=eng.lib.mcl_active_switches(eng._h).decode(), sweep=eng.kernel_variant(_engine.PROF_SWEEP),
                                    warned=[str(w.message)[:60] for w in caught if "MCL_" in str(w.message)],
                                    lib=os.path.realpath(eng.lib._name))), flush=True)
 '''

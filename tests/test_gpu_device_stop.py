@@ -232,3 +232,58 @@ def test_run_needs_pinned_status_memory():
     rc = eng.lib.mcl_run(eng._h, 2, 1, 1, 1, ctypes.byref(rule), ring.data_ptr(), verdict.data_ptr(), pageable.data_ptr())
     assert rc != 0 and b"pinned" in eng.lib.mcl_last_error(eng._h)
     eng.close()
+
+
+WATCHDOG = r'''
+import os, sys, json, time
+sys.path.insert(0, os.environ["REPO"])
+import torch
+import bench
+from matcouply_amd import _engine
+cfg = dict(bench.CONFIGS["c2"], I=32)
+dev = torch.device("cuda", 0)
+X, row_ptr, I_loc = bench.make_shard(cfg, 0, 1, dev)
+eng = bench.make_engine(cfg, X, row_ptr, I_loc, 0, dev)
+eng.iterate(1)
+torch.cuda.synchronize()
+t0 = time.perf_counter(); torch.cuda._sleep(20000000); torch.cuda.synchronize(); per_cycle = (time.perf_counter() - t0) / 2e7
+torch.cuda._sleep(int(float(os.environ["SLEEP_S"]) / per_cycle))   # the stream stays busy: no verdict can arrive in time
+t0 = time.perf_counter()
+err = None
+try:
+    eng.run(200, 1e-8, 1e-10, 1e-4, initial_loss=1.0, penalty_weight=[[0.0], [0.0], [0.0]], evaluate_loss_always=True)
+except _engine.EngineError as e:
+    err = str(e)
+dt = time.perf_counter() - t0
+later = None
+try:
+    eng.update_B()
+except _engine.EngineError as e:
+    later = str(e)
+t1 = time.perf_counter()
+torch.cuda.synchronize()   # the device itself is fine: the enqueued work drains
+drain = time.perf_counter() - t1
+print("WATCHDOG " + json.dumps(dict(err=err, seconds=dt, later=later, drain=drain)), flush=True)
+'''
+
+
+def test_run_watchdog_returns_without_waiting_for_the_stream(tmp_path):
+    """ADVICE r4: the watchdog of mcl_run must END the call - not fall through to a stream synchronisation that blocks on the
+    very stream it gave up on.  A long sleep kernel in front of the run (and verdict kernels that report into scratch,
+    MCL_TEST_MUTE_VERDICT) keeps every verdict away; the call has to come back after MCL_RUN_WATCHDOG_S, well before the
+    stream drains, with an error, and the context refuses every later call."""
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "watchdog.py"
+    script.write_text(WATCHDOG)
+    env = dict(os.environ, REPO=repo, MCL_TEST_MUTE_VERDICT="1", MCL_RUN_WATCHDOG_S="0.4", SLEEP_S="3.0")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    line = [l for l in out.stdout.splitlines() if l.startswith("WATCHDOG ")]
+    assert line, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads(line[0].split(" ", 1)[1])
+    assert d["err"] and "MCL_RUN_WATCHDOG_S" in d["err"] and "WITHOUT synchronising" in d["err"], d
+    assert 0.3 < d["seconds"] < 1.5, d            # ~0.4 s of watchdog, not the ~3 s the sleep kernel holds the stream
+    assert d["drain"] > 0.5, d                     # ... which was indeed still busy when the call returned
+    assert d["later"] and "failed state" in d["later"], d

@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 
+from matcouply_amd import _engine as _engine_mod
 from tests.test_gpu_end_to_end import _compare, _run_both
 
 pytestmark = pytest.mark.gpu
@@ -121,7 +122,7 @@ def test_exact_products_mode_is_not_a_performance_cliff():
                 cfg = dict(bench.CONFIGS["c3"], I=I, J=J, K=K, r=r)
                 X, row_ptr, I_loc = bench.make_shard(cfg, 0, 1, dev)
                 eng = bench.make_engine(cfg, X, row_ptr, I_loc, 0, dev)
-                assert (eng.kernel_variant(4) != "") == (exact == "1")
+                assert (eng.kernel_variant(_engine_mod.VARIANT_EXACT_MODE) != "") == (exact == "1")
                 eng.iterate(50)
                 torch.cuda.synchronize()
                 best = float("inf")

@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+from matcouply_amd import _engine as _engine_mod
 from tests.helpers import engine_from_oracle_state, rel_err, to_np
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fast_kernels")]  # the subject is the sweep kernel
@@ -74,7 +75,7 @@ def test_one_iteration_phase_by_phase(name):
     for it in range(2):
         eng.update_B()
         if st.regs[1]:  # a penalty-free B is a plain least-squares update: un-shifted systems, solved in fp64 (no sweep)
-            assert eng.kernel_variant(3).startswith("k_sweep<"), "the sweep did not run: " + repr(eng.kernel_variant(3))
+            assert eng.kernel_variant(_engine_mod.PROF_SWEEP).startswith("k_sweep<"), "the sweep did not run: " + repr(eng.kernel_variant(_engine_mod.PROF_SWEEP))
         ref.update_B()
         torch.cuda.synchronize()
         errs = {"B": rel_err(to_np(eng.B), ref.B)}
@@ -167,7 +168,9 @@ def test_wave_partition_is_balanced_on_ragged_slabs():
     nn = lambda rows: NativeReg(KIND["nn"], f(rows, r), torch.zeros((rows, r), dtype=torch.float32, device=dev))
     eng = HipEngine(X, row_ptr, r, f(len(J), r), f(N, r), f(K, r), [[nn(len(J))], [nn(N)], [nn(K)]])
     ints = lambda which: eng.internal(which).view(torch.int32).cpu().numpy().astype(np.int64)
-    for (i_row0, i_n, i_ptr, cap, tol) in ((12, 13, 14, 256, 0), (15, 16, 17, 512, 2)):
+    E = _engine_mod
+    for (i_row0, i_n, i_ptr, cap, tol) in ((E.BUF_SEG_ROW0, E.BUF_SEG_NROWS, E.BUF_WAVE_SEG_PTR, 256, 0),
+                                           (E.BUF_BSEG_ROW0, E.BUF_BSEG_NROWS, E.BUF_WAVE_BSEG_PTR, 512, 2)):
         row0, n, ptr = ints(i_row0), ints(i_n), ints(i_ptr)
         assert n.min() >= 1 and n.max() <= cap
         assert np.array_equal(row0, np.concatenate([[0], np.cumsum(n)[:-1]])) and row0[-1] + n[-1] == N  # a tiling of the rows
@@ -233,5 +236,5 @@ def test_shapes_without_a_sweep_instantiation_keep_the_two_pass_path():
         st = orc.random_state_for(X, row_ptr, r, [[NN], [NN], [NN]], seed=1)
         eng = engine_from_oracle_state(st)
         eng.update_B()
-        assert eng.kernel_variant(3) == "", (J, K, r, eng.kernel_variant(3))
+        assert eng.kernel_variant(_engine_mod.PROF_SWEEP) == "", (J, K, r, eng.kernel_variant(_engine_mod.PROF_SWEEP))
         eng.close()

@@ -2,6 +2,7 @@ import os, sys
 sys.path.insert(0, "/root/repo")
 import torch, numpy as np
 import bench
+from matcouply_amd import _engine
 for name in ("c4", "c5s"):
     cfg = bench.CONFIGS[name]
     dev = torch.device("cuda", 0)
@@ -15,7 +16,7 @@ for name in ("c4", "c5s"):
                 eng._check(eng.lib.mcl_B_prox_local(eng._h, k))
                 if k == 0:
                     torch.cuda.synchronize()
-                    st = eng.internal(8).view(torch.int32).cpu().numpy()
+                    st = eng.internal(_engine.BUF_PF2_STATUS).view(torch.int32).cpu().numpy()
                     its = -st[st <= 0]
                     print(name, f"outer {it} inner {inner}: NS iterations min {its.min()} mean {its.mean():.1f} max {its.max()} fallback {(st>0).sum()}")
                 eng.B_prox_finish(k)

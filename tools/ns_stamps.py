@@ -6,6 +6,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
+from matcouply_amd import _engine
 
 cfg = bench.CONFIGS[os.environ.get("CFG", "c4")]
 dev = torch.device("cuda", 0)
@@ -14,7 +15,7 @@ eng = bench.make_engine(cfg, X, row_ptr, I_loc, 0, dev)
 for it in range(3):
     eng.update_B(); eng.update_C_local(); eng.update_C_finish(); eng.update_A()
 torch.cuda.synchronize()
-buf = eng.internal(18)
+buf = eng.internal(_engine.BUF_NS_STAMPS)
 st = buf[I_loc:I_loc + 16 * I_loc].view(torch.int64).view(I_loc, 8).cpu().numpy()
 d = np.diff(st[:, :5], axis=1).astype(np.float64)
 steps = st[:, 5]

@@ -2,6 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import bench
+from matcouply_amd import _engine
 cfg = bench.CONFIGS["c4"]
 dev = torch.device("cuda", 0)
 X, row_ptr, I_loc = bench.make_shard(cfg, 0, 1, dev)
@@ -14,8 +15,8 @@ for it in range(3):
         eng.B_solve()
         eng._check(eng.lib.mcl_B_prox_local(eng._h, 0))
         torch.cuda.synchronize()
-        st = eng.internal(8).view(torch.int32).cpu().numpy()
-        S = eng.internal(10).view(torch.float64).view(-1, r, r).cpu().numpy()
+        st = eng.internal(_engine.BUF_PF2_STATUS).view(torch.int32).cpu().numpy()
+        S = eng.internal(_engine.BUF_PF2_GRAM).view(torch.float64).view(-1, r, r).cpu().numpy()
         D = eng.regs[1][0].aux2.cpu().numpy().astype(np.float64)
         bad = np.where(st > 0)[0]
         msg = f"outer {it} inner {inner}: fallback {len(bad)}"

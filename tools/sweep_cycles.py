@@ -12,8 +12,9 @@ eng = bench.make_engine(cfg, X, row_ptr, I_loc, 0, dev)
 for it in range(5):
     eng.update_B(); eng.update_C_local(); eng.update_C_finish(); eng.update_A()
 torch.cuda.synchronize()
-c = eng.internal(11).view(torch.int64).view(-1, 6).cpu().numpy()
+c = eng.internal(_engine.BUF_SWEEP_CYCLES).view(torch.int64).view(-1, 6).cpu().numpy()
 import numpy as np
+from matcouply_amd import _engine
 names = ["tile write + issue", "(1) X C", "(2) inner loop", "(3) stores/diag/transpose", "(4) X^T B + Gram", "-"]
 tot = c[:, :5].sum(axis=1)
 print("waves", c.shape[0], "cycles per wave: mean", tot.mean(), "min", tot.min(), "max", tot.max())
@@ -26,4 +27,4 @@ per = c[:, :5].sum(axis=1)
 for nwv in (8, 4):
     if c.shape[0] % nwv == 0:
         print("by wave index (NW=%d):" % nwv, per.reshape(-1, nwv).mean(axis=0).astype(int))
-print("variant", eng.kernel_variant(3))
+print("variant", eng.kernel_variant(_engine.PROF_SWEEP))
