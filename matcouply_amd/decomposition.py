@@ -877,9 +877,23 @@ def cmf_aoadmm(
     def sharded_gathered_prox_A(k, rho_a):
         """matrix penalty on the sharded A (decomposition.py:203): the penalty's prox on the gathered A + U, own rows kept"""
         reg, nat = regs[0][k], native[0][k]
-        full = reg.factor_matrix_update(gather_rows_A(eng.A + nat.dual), float(rho_a[0]), gather_rows_A(nat.aux))
+        obj = ext_aux.get((0, k))
+        if obj is None:
+            aux_rows = nat.aux  # native kind evaluated through its host method: its aux IS the matrix
+        else:
+            # host-evaluated penalty (a user's MatrixPenalty; any matrix penalty while inner_tol is set): the object it keeps
+            # must be the matrix itself to be gathered by rows - another parametrisation cannot be split over ranks
+            aux_rows = reg.aux_as_matrix(obj)
+            if not (is_torch(obj) and is_torch(aux_rows) and tuple(obj.shape) == tuple(nat.aux.shape)
+                    and tuple(aux_rows.shape) == tuple(nat.aux.shape)):
+                raise NotImplementedError("a host-evaluated matrix penalty on mode 0 whose auxiliary variable is not the matrix "
+                                          "itself (aux_as_matrix is not the identity) is not supported with group=")
+        full = reg.factor_matrix_update(gather_rows_A(eng.A + nat.dual), float(rho_a[0]), gather_rows_A(aux_rows))
         lo = sum(a_counts[:rank_id])
+        own = full[lo:lo + a_counts[rank_id]] if obj is not None else None
         z = reg.aux_as_matrix(full)[lo:lo + a_counts[rank_id]].to(nat.aux.dtype)
+        if obj is not None:
+            ext_aux[(0, k)] = own.clone()  # this rank's rows of the object the penalty returned (what return_admm_vars hands out)
         nat.dual.copy_(eng.A - (z - nat.dual))
         nat.aux.copy_(z)
 

@@ -39,6 +39,9 @@ CASES = {
     # matrix penalties on A other than the L2 ball: unimodality down the rows of A and total variation along them couple rows
     # that live on different ranks - every rank evaluates the prox on the all-gathered A + U and keeps its rows
     "matrix_penalties_on_A": dict(constant_feasibility_penalty=True),
+    # ... and the same with inner_tol set: the two penalties are then host-evaluated (PEN_EXTERNAL) and keep their auxiliary
+    # variable in an object of their own, which must follow the gathered prox (it stayed at its initial value)
+    "inner_tol_matrix_A": dict(constant_feasibility_penalty=True),
 }
 
 
@@ -81,7 +84,7 @@ def _explicit_state(case, mats, r, seed=9):
         regs[0] = [("nn", mk((I, r)), mk((I, r)))]
         regs[1] = [("l1B", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
         regs[2] = [("l1nn", mk((K, r)), mk((K, r)))]
-    elif case == "matrix_penalties_on_A":
+    elif case in ("matrix_penalties_on_A", "inner_tol_matrix_A"):
         regs[0] = [("uninn", mk((I, r)), mk((I, r))), ("tvA", mk((I, r)), mk((I, r)))]
         regs[1] = [("nn", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
         regs[2] = [("l1nn", mk((K, r)), mk((K, r)))]
@@ -154,12 +157,12 @@ def _run_with_checker(dec, case, lo, hi, group):
     regs_spec, kw = _explicit_state(case, mats, r)
     const = kw.get("constant_feasibility_penalty", False)
     w, (A0, B0, C0) = init
-    cmf, diag = dec.cmf_aoadmm(mats[lo:hi], r, init=(None, (A0[lo:hi].copy(), [b.copy() for b in B0[lo:hi]], C0.copy())),
+    cmf, admm, diag = dec.cmf_aoadmm(mats[lo:hi], r, init=(None, (A0[lo:hi].copy(), [b.copy() for b in B0[lo:hi]], C0.copy())),
                                regs=_build(regs_spec, lo, hi), return_errors=True, constant_feasibility_penalty=const, group=group,
                                **(json.loads(os.environ["MCL_TEST_RUN_KW"]) if os.environ.get("MCL_TEST_RUN_KW") else RUN_KW),
-                               **(dict(inner_tol=3e-2, inner_n_iter_max=12) if case == "inner_tol_l1B" else {}),
-                               gather_A=group is not None)
-    return cmf, diag
+                               **(dict(inner_tol=3e-2, inner_n_iter_max=12) if case.startswith("inner_tol") else {}),
+                               gather_A=group is not None, return_admm_vars=True)
+    return cmf, diag, admm
 
 
 def _worker(rank, world, port, case, q):
@@ -167,10 +170,11 @@ def _worker(rank, world, port, case, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     bounds = _bounds(world)
-    cmf, diag = _run(case, bounds[rank], bounds[rank + 1], dist.group.WORLD)
+    cmf, diag, admm = _run(case, bounds[rank], bounds[rank + 1], dist.group.WORLD)
     q.put((rank, cmf[1][0], np.concatenate(cmf[1][1]), cmf[1][2], diag.rec_errors, diag.regularized_loss,
            [[list(map(float, g)) for g in it] for it in diag.feasibility_gaps], np.asarray(cmf.A_all), cmf.rows_of_rank,
-           (diag.n_iter, diag.message, diag.satisfied_stopping_condition, bool(diag.satisfied_feasibility_condition))))
+           (diag.n_iter, diag.message, diag.satisfied_stopping_condition, bool(diag.satisfied_feasibility_condition)),
+           [np.asarray(a) for a in admm.auxes[0]], [np.asarray(u) for u in admm.duals[0]]))
     dist.destroy_process_group()
 
 
@@ -204,9 +208,13 @@ SHARDED_RUNS = [(2, c) for c in sorted(CASES)] + [(w, c) for w in (4, 8) for c i
 @pytest.mark.parametrize("world,case", SHARDED_RUNS, ids=[f"{c}-x{w}" for w, c in SHARDED_RUNS])
 def test_two_rank_sharded_run_equals_single_process(world, case):
     sys.path.insert(0, REPO)
-    ref_cmf, ref_diag = _run(case, 0, len(J_ALL), None)
+    ref_cmf, ref_diag, ref_admm = _run(case, 0, len(J_ALL), None)
     results = _spawn(world, case)
     bounds = _bounds(world)
+    # the ADMM variables of mode 0 (rank-local rows; return_admm_vars): the ranks' rows together are the single-process ones
+    for k in range(len(ref_admm.auxes[0])):
+        np.testing.assert_allclose(np.concatenate([res[10][k] for res in results]), np.asarray(ref_admm.auxes[0][k]), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(np.concatenate([res[11][k] for res in results]), np.asarray(ref_admm.duals[0][k]), rtol=1e-9, atol=1e-12)
     assert len({hi - lo for lo, hi in zip(bounds, bounds[1:])}) > 1 or world == len(J_ALL)  # uneven shares
     A = np.concatenate([res[1] for res in results])
     # gather_A=True: every rank also holds the WHOLE A (one all-gather at the end), its own rows at rows_of_rank
@@ -227,7 +235,7 @@ def test_two_rank_sharded_run_equals_single_process(world, case):
                 np.testing.assert_allclose(g, rg, rtol=1e-8, atol=1e-12)
     for res in results[1:]:  # the replicated factor C: bit-identical on every rank
         np.testing.assert_array_equal(results[0][3], res[3])
-    if case == "inner_tol_l1B":  # the inner loops did stop early somewhere (otherwise the case pins nothing)
+    if case.startswith("inner_tol"):  # the inner loops did stop early somewhere (otherwise the case pins nothing)
         assert len(ref_diag.rec_errors) == RUN_KW["n_iter_max"] + 1
 
 
@@ -241,7 +249,7 @@ def test_two_rank_sharded_run_with_a_stopping_rule(rule, world, monkeypatch):
     kw = STOP_RULES[rule]
     monkeypatch.setenv("MCL_TEST_RUN_KW", json.dumps(kw))  # (the workers are spawned processes: passed through the environment)
     case = "pf2_ball_constant"
-    ref_cmf, ref_diag = _run(case, 0, len(J_ALL), None)
+    ref_cmf, ref_diag, _ = _run(case, 0, len(J_ALL), None)
     results = _spawn(world, case)
     if rule == "relative":
         assert ref_diag.message.startswith("FEASIBILITY GAP CRITERION AND RELATIVE") and 1 <= ref_diag.n_iter < kw["n_iter_max"]
