@@ -66,7 +66,10 @@ typedef struct {
     int32_t inner_n_iter_max;         /* decomposition.py:689 */
     int32_t constant_A;               /* constant_feasibility_penalty for mode 0 (decomposition.py:937-939) */
     int32_t constant_B;               /* ... for mode 1 (decomposition.py:940-942) */
-    int32_t reserved;
+    int32_t exact_products;           /* 0: the library decides by THIS context's size (exact-products mode up to 2^20 elements
+                                         of X); 1 / 2: force the mode on / off - a host that shards one problem over several
+                                         contexts decides by the size of the WHOLE problem, so that every rank (and every
+                                         rank layout) computes with the same arithmetic.  Looked at by mcl_set_workspace. */
 } mcl_options;
 
 /* Layout of the fp64 vector written by mcl_diagnostics(). */

@@ -572,6 +572,9 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
 int mcl_set_options(mcl_context *c, const mcl_options *opt) {
     if (!c || !opt) return 1;
     if (opt->inner_n_iter_max < 0) return fail(c, "mcl_set_options: inner_n_iter_max must be >= 0");
+    if (opt->exact_products < 0 || opt->exact_products > 2) return fail(c, "mcl_set_options: exact_products must be 0, 1 or 2");
+    if (c->has_workspace && opt->exact_products != c->opt.exact_products)
+        c->has_workspace = false;  // the carve-up depends on the mode: the workspace has to be installed again
     c->opt = *opt;
     c->b_systems_valid = false;
     return 0;
@@ -639,7 +642,10 @@ int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
     if (!c) return 1;
     if (!c->has_problem) return fail(c, "mcl_set_workspace: call mcl_set_problem first");
     if (int rc = settle_deferred(c)) return rc;  // reduces the tables of the OLD workspace before it is re-planned / zeroed
+    const bool had = c->has_workspace;
+    c->has_workspace = false;  // size the request with the mode a fresh installation would get
     const int64_t need = plan(c, nullptr);
+    c->has_workspace = had;
     if (!workspace || bytes < need) {
         if (c->has_workspace) plan(c, c->ws);  // a refused call leaves the installed workspace as it was
         return fail(c, "mcl_set_workspace: workspace too small");
@@ -648,7 +654,8 @@ int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
     if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(c, "mcl_set_workspace: workspace must be 256-byte aligned");
     c->ws = static_cast<char *>(workspace);
     c->ws_bytes = bytes;
-    plan(c, c->ws);
+    c->has_workspace = false;  // the arithmetic mode (mcl_exact_mode) is decided anew for this installation ...
+    plan(c, c->ws);            // ... and stays what it is until the next one
     hipStream_t s = c->stream;
     MCL_CHECK_HIP(c, hipMemsetAsync(c->ws, 0, (size_t)need, s));
     auto up = [&](int *dst, const std::vector<int> &src) -> hipError_t {

@@ -1146,7 +1146,14 @@ int mcl_launch_slab_gram(mcl_context *c) {
 // MCL_EXACT=1 / 0 forces the mode on / off (the parity tests of the fast kernels run small problems with MCL_EXACT=0).
 // ---------------------------------------------------------------------------------------------------------
 bool mcl_exact_mode(const mcl_context *c) {
+    // decided ONCE per installed workspace (mcl_set_workspace): the carve-up depends on it, so neither a size query nor
+    // a later mcl_reload_switches may flip it under an installed workspace
+    if (c->has_workspace) return c->exact;
     if (c->sw.exact >= 0) return c->sw.exact != 0;
+    // a host that shards one problem over several contexts says which arithmetic ALL of them use (mcl_options.exact_products:
+    // the decision belongs to the WHOLE problem, not to a rank's share of it)
+    if (c->opt.exact_products == 1) return true;
+    if (c->opt.exact_products == 2) return false;
     return c->N * c->K <= (int64_t(1) << 20);
 }
 

@@ -700,7 +700,6 @@ __global__ __launch_bounds__(64) void k_pf2_algebra(const double *__restrict__ S
     // use_status: entries <= 0 were done by the Newton-Schulz kernel (-iterations); this kernel leaves 2 (k_pf2_polar_qr
     // takes the slab) or 0 in the entry of every slab it handles
     if (use_status && status[blockIdx.x] <= 0) return;
-    if (use_status && status[blockIdx.x] == 77) return;  // debugging hook
     const int slab = blockIdx.x;
     pf2_jacobi_slab(smd, S + (long)slab * r * r, Delta, (double)rho[slab], r, slab, threadIdx.x, T, acc_out, T64, status,
                     ext[slab + 1] - ext[slab] >= r);
@@ -1081,7 +1080,7 @@ __global__ __launch_bounds__((TILES && NB == 1) ? 128 : 64) __attribute__((amdgp
     tr_lds<NB>(G, Gt, Ssm, q, c16);  // G^T (S_i has been consumed by U1: its LDS copy is free; the fallbacks below read memory)
     if (!(tr > 0.0)) {
         if (lane == 0) status[slab] = 1;
-        if (INK) pf2_jacobi_slab(Jsm, Ss, Delta, rh, r, slab, lane, T, acc_out, T64);
+        if (INK) pf2_jacobi_slab(Jsm, Ss, Delta, rh, r, slab, lane, T, acc_out, T64, status, true);  // may flag the slab (2)
         return;
     }
     NS_STAMP(2);
@@ -1191,7 +1190,7 @@ __global__ __launch_bounds__((TILES && NB == 1) ? 128 : 64) __attribute__((amdgp
     }
     if (!converged) {
         if (lane == 0) status[slab] = 1;
-        if (INK) pf2_jacobi_slab(Jsm, Ss, Delta, rh, r, slab, lane, T, acc_out, T64);  // (the LDS copy of S is gone: from memory)
+        if (INK) pf2_jacobi_slab(Jsm, Ss, Delta, rh, r, slab, lane, T, acc_out, T64, status, true);  // (the LDS copy of S is gone: from memory); may flag the slab (2)
         return;
     }
     NS_STAMP(3);
@@ -1839,9 +1838,15 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
 #undef MCL_NS
             }
             if (status == nullptr) c->variant[MCL_PROF_PF2] = "k_pf2_algebra (Jacobi) + k_pf2_polar_qr";
-            if (status == nullptr || c->NB != 1) {  // rank <= 16: the Newton-Schulz kernel runs the Jacobi route itself
+            // rank <= 16: the Newton-Schulz kernel runs the Jacobi route itself and flags the slabs whose Gram matrix is too
+            // ill-conditioned (2); the QR kernel that redoes them is launched where its launch does not count - small problems
+            // (up to 64 slabs, the exact-products mode): on a large rank <= 16 problem (config 4: 1024 slabs, 5 launches of
+            // ~3 us per iteration for slabs that do not occur there) such a slab keeps the Gram-route factor
+            const bool ink_qr = status != nullptr && c->NB == 1 && (c->I <= 64 || c->exact);
+            if (status == nullptr || c->NB != 1)
                 hipLaunchKernelGGL(k_pf2_algebra, dim3((unsigned)c->I), dim3(64), sm, c->stream, c->pf2_S, rs.aux2[k],
                                    c->rhoB, r, c->pf2_T, c->pf2_acc, c->pf2_status, status != nullptr ? 1 : 0, c->pf2_T64, mv.ext);
+            if (status == nullptr || c->NB != 1 || ink_qr) {
                 // ... and the slabs it finds too ill-conditioned for the Gram route (flag 2) are redone from Y Delta^T itself
                 const size_t smq = sizeof(double) * (size_t)(3 * n2 + 4 * 64 + 64);
                 if (smq > 65536) {

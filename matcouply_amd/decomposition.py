@@ -697,9 +697,6 @@ def cmf_aoadmm(
                 aux_t = _pack_rows(aux, device) if mode == 1 else _to_dev(aux, device)
                 native[mode].append(_engine.NativeReg(kind, aux_t, dual_t, non_negativity=nonneg, p0=p0, p1=p1))
 
-    eng = factory(X=X, row_ptr=row_ptr, rank=rank, A=A, B=B, C=C, regs=native, l2_penalty=l2_penalty,
-                  inner_n_iter_max=inner_n_iter_max, feasibility_penalty_scale=feasibility_penalty_scale,
-                  constant_A=constant_A, constant_B=constant_B)
     world = 1
     dist = None
     if group is not None:
@@ -709,6 +706,16 @@ def cmf_aoadmm(
         rank_id = dist.get_rank(group)
     else:
         rank_id = 0
+    # the arithmetic of small problems (exact-products mode) is chosen by the size of the WHOLE problem:
+    # every rank of a sharded run, and every rank layout of the same problem, then computes with the same kernels
+    exact_products = 0
+    if world > 1:
+        n_el = torch.tensor([float(X.shape[0]) * float(X.shape[1])], dtype=torch.float64, device=X.device)
+        dist.all_reduce(n_el, group=group)
+        exact_products = 1 if float(n_el.item()) <= float(1 << 20) else 2
+    eng = factory(X=X, row_ptr=row_ptr, rank=rank, A=A, B=B, C=C, regs=native, l2_penalty=l2_penalty,
+                  inner_n_iter_max=inner_n_iter_max, feasibility_penalty_scale=feasibility_penalty_scale,
+                  constant_A=constant_A, constant_B=constant_B, exact_products=exact_products)
     # the sharded code path (step calls with the reductions in between): taken with more than one rank - and, for
     # rehearsals of that path on a single-GPU box, with a one-rank group when MCL_FORCE_SHARDED_PATH=1
     sharded = world > 1 or (group is not None and os.environ.get("MCL_FORCE_SHARDED_PATH") == "1")
