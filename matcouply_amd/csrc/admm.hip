@@ -2082,8 +2082,9 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     // also prepare the next B-phase's systems when that is exact: fused inner loop, per-slab rho for B
     const bool rows_kernel = !(c->RP == 64 || c->RP == 4 || c->sw.a_finish_cols);
     // (a B-phase with fp64 row passes also needs the fp64 inverses: only the row-split kernels write them)
+    const bool b_needs_64 = mcl_rows64(c) || c->exact;  // the B-phase reads the fp64 inverses (fp64 row passes / wide.hip)
     const int next_B = (fused_inner && !c->opt.constant_B && c->regs[1].n > 0 && !c->sw.no_next_b &&
-                        (rows_kernel || !mcl_rows64(c))) ? 1 : 0;
+                        (rows_kernel || !b_needs_64)) ? 1 : 0;
     const bool seg = c->use_seg_gram;
     dim3 grid((unsigned)((c->I + 3) / 4)), block(256);
 #define MCL_AF_ARGS                                                                                                   \
@@ -2099,7 +2100,7 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
         F.Mpart = c->Mpart, F.Cfrag = c->CfragS, F.NBm = c->NB;
         F.MS = mcl_sweep_KC(c) * 64 * 16 * c->NB;
     }
-    F.LinvB64 = mcl_rows64(c) ? c->LinvB64 : nullptr;
+    F.LinvB64 = b_needs_64 ? c->LinvB64 : nullptr;
     if (!rows_kernel && c->ctc_parts > 0)
         if (int rc = mcl_launch_ctc_fold(c)) return rc;
     // ranks 5..32: rows of every system split over the lane groups (all 64 lanes busy); 64 columns fill the wave anyway

@@ -85,12 +85,22 @@ int64_t plan(mcl_context *c, char *base) {
     c->rhoB = b.take<float>(I);
     c->LinvB = b.take<float>(I * r * r);
     c->rows64 = c->NB == 1 && has_kind(c, MCL_PEN_PARAFAC2) && !c->sw.no_rows64;
-    c->LinvB64 = (c->regs[1].n == 0 || c->rows64) ? b.take<double>(I * r * r) : nullptr;
+    c->LinvB64 = (c->regs[1].n == 0 || c->rows64 || c->exact) ? b.take<double>(I * r * r) : nullptr;
     c->XC64 = (c->regs[1].n == 0 || c->exact) ? b.take<double>(N * r) : nullptr;
     c->rho_max = b.take<float>(2);
     c->partials = b.take<double>((int64_t)mcl_contract_n_partials(c) * E);
     c->GR = b.take<double>(E);
     c->exact_part = c->exact ? b.take<double>(std::max<int64_t>(1, (N + 255) / 256) * E) : nullptr;
+    for (int m = 0; m < 3; ++m) {  // fp64 state of the inner loops of modes 1 / 2 in the exact-products mode (wide.hip)
+        const int64_t rows_m = (m == 1) ? N : K;
+        const bool wide = c->exact && m != 0 && c->regs[m].n > 0;
+        c->wF[m] = wide ? b.take<double>(rows_m * r) : nullptr;
+        for (int k = 0; k < MCL_MAX_REGS; ++k) {
+            c->wZ[m][k] = (wide && k < c->regs[m].n) ? b.take<double>(rows_m * r) : nullptr;
+            c->wU[m][k] = (wide && k < c->regs[m].n) ? b.take<double>(rows_m * r) : nullptr;
+        }
+    }
+    c->wD = c->exact ? b.take<double>(r * r) : nullptr;
     c->GRf = b.take<float>(E);
     c->LinvC64 = b.take<double>(r * r);
     c->rhoC = b.take<float>(1);
@@ -134,7 +144,7 @@ int64_t plan(mcl_context *c, char *base) {
     if (has_kind(c, MCL_PEN_PARAFAC2)) {
         c->pf2_S = b.take<double>(I * r * r);
         c->pf2_T = b.take<float>(I * r * r);
-        c->pf2_T64 = c->rows64 ? b.take<double>(I * r * r) : nullptr;
+        c->pf2_T64 = (c->rows64 || c->exact) ? b.take<double>(I * r * r) : nullptr;
         c->pf2_acc = b.take<double>(I * (r * r + 1));
         c->pf2_red = b.take<float>(r * r + 1);
         c->pf2_status = b.take<int>(I);
@@ -188,6 +198,7 @@ void read_switches(mcl_switches &w) {
     w.xc_dbg = num("MCL_XC_DBG", 0), w.xt_dbg = num("MCL_XT_DBG", 0), w.xt_depth = num("MCL_XT_DEPTH", 0);
     w.sweep_dbg = num("MCL_SWEEP_DBG", 0), w.reduce_el = num("MCL_REDUCE_EL", 0), w.uni_split = num("MCL_UNI_SPLIT", -1);
     w.exact = num("MCL_EXACT", -1);
+    w.no_wide = flag("MCL_NO_WIDE");
     w.test_mute_verdict = flag("MCL_TEST_MUTE_VERDICT");  // test hook of the mcl_run watchdog, not a kernel form
     if (const char *e = getenv("MCL_RUN_SPINS")) w.run_spins = atol(e);  // operating parameter of mcl_run's wait (see there)
     if (const char *e = getenv("MCL_RUN_WATCHDOG_S")) {  // an operating parameter, not a kernel form (not listed by mcl_active_switches)
@@ -204,7 +215,7 @@ std::string switches_in_env() {
         "MCL_UNI_NOPRUNE", "MCL_STATS_REDUCE", "MCL_NO_ROWS64", "MCL_NO_UNI_COOP", "MCL_NO_A_FUSION", "MCL_NO_A_WIDE", "MCL_NO_BSEG_GROUPS",
         "MCL_NO_SWEEP_HALF", "MCL_NO_X_NT", "MCL_X_NT_MB", "MCL_NO_MULTI_C", "MCL_NO_DIAG_DEFER", "MCL_XC_DEPTH1", "MCL_SEG_ROWS",
         "MCL_BSEG_ROWS", "MCL_XC_WAVES", "MCL_XT_WAVES", "MCL_SWEEP_WAVES", "MCL_XC_DBG", "MCL_XT_DBG", "MCL_XT_DEPTH",
-        "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT", "MCL_EXACT"};
+        "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT", "MCL_EXACT", "MCL_NO_WIDE"};
     std::string out;
 #ifdef MCL_NO_ENV_SWITCHES
     return out;
@@ -619,6 +630,8 @@ int mcl_set_penalties(mcl_context *c, int32_t mode, int32_t n, const mcl_penalty
         rs.nonneg[k] = d.non_negativity;
         rs.p0[k] = (float)d.p0;
         rs.p1[k] = (float)d.p1;
+        rs.p0d[k] = d.p0;
+        rs.p1d[k] = d.p1;
         rs.aux[k] = d.aux;
         rs.dual[k] = d.dual;
         rs.aux2[k] = d.aux2;
@@ -842,6 +855,10 @@ int mcl_update_B(mcl_context *c) {
     c->e1_valid = false;
     if (c->opt.inner_n_iter_max <= 0) return 0;
     c->mseg_valid = c->grpart_valid = false;
+    if (mcl_wide_applies(c, 1)) {  // small problem: the whole inner loop in fp64 (wide.hip)
+        c->diag_valid[1] = false;
+        return mcl_wide_phase(c, 1);
+    }
     if (mcl_mode_is_row_separable(c, 1)) {
         const int rc = mcl_launch_rows_fused(c, 1);
         if (rc == 0) {
@@ -876,6 +893,16 @@ double *mcl_c_normal_equations(mcl_context *c, int64_t *count) {
 int mcl_update_C_finish(mcl_context *c) {
     if (int rc = ready(c)) return rc;
     ProfScope prof_(c, MCL_PROF_C_FINISH);
+    if (mcl_wide_applies(c, 2)) {  // small problem: the whole inner loop in fp64 (wide.hip)
+        if (int rc = mcl_launch_C_prepare(c)) return rc;
+        c->xc_valid = c->ctc_valid = c->e1_valid = false;
+        c->ctc_parts = 0;
+        c->cfrag_valid = false;
+        c->b_systems_valid = false;
+        c->diag_valid[2] = false;
+        c->variant[MCL_PROF_C_FINISH] = "k_C_prepare + fp64 inner loop (wide.hip)";
+        return mcl_wide_phase(c, 2);
+    }
     if (c->opt.inner_n_iter_max > 0 && mcl_mode_is_row_separable(c, 2)) {
         // everything from the system solve to CtC / C fragments in one single-workgroup launch
         const int rc = mcl_launch_C_finish_fused(c);

@@ -585,12 +585,12 @@ __global__ __launch_bounds__(256) void k_pf2_gram(const int *__restrict__ ext, c
 static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const float *__restrict__ Delta, double rh, int r,
                                        int slab, int lane, float *__restrict__ T, double *__restrict__ acc_out,
                                        double *__restrict__ T64 = nullptr, int *__restrict__ qr_flag = nullptr,
-                                       bool full_rank_expected = false) {
+                                       bool full_rank_expected = false, const double *__restrict__ Delta64 = nullptr) {
     double *Sm = smd, *G = smd + r * r, *V = G + r * r, *lam = V + r * r, *D = lam + r;  // D: Delta in fp64 [r*r]
     const int n2 = r * r;
     for (int e = lane; e < n2; e += 64) {
         Sm[e] = Ssrc[e];
-        D[e] = (double)Delta[e];
+        D[e] = Delta64 != nullptr ? Delta64[e] : (double)Delta[e];  // (the fp64 state of wide.hip, or the caller's fp32 matrix)
         V[e] = ((e / r) == (e % r)) ? 1.0 : 0.0;
     }
     __syncthreads();
@@ -695,14 +695,15 @@ static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const fl
 __global__ __launch_bounds__(64) void k_pf2_algebra(const double *__restrict__ S, const float *__restrict__ Delta,
                                                     const float *__restrict__ rho, int r, float *__restrict__ T,
                                                     double *__restrict__ acc_out, int *__restrict__ status, int use_status,
-                                                    double *__restrict__ T64, const int *__restrict__ ext) {
+                                                    double *__restrict__ T64, const int *__restrict__ ext,
+                                                    const double *__restrict__ Delta64 = nullptr) {
     extern __shared__ double smd[];
     // use_status: entries <= 0 were done by the Newton-Schulz kernel (-iterations); this kernel leaves 2 (k_pf2_polar_qr
     // takes the slab) or 0 in the entry of every slab it handles
     if (use_status && status[blockIdx.x] <= 0) return;
     const int slab = blockIdx.x;
     pf2_jacobi_slab(smd, S + (long)slab * r * r, Delta, (double)rho[slab], r, slab, threadIdx.x, T, acc_out, T64, status,
-                    ext[slab + 1] - ext[slab] >= r);
+                    ext[slab + 1] - ext[slab] >= r, Delta64);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -719,7 +720,9 @@ __global__ __launch_bounds__(256) void k_pf2_polar_qr(const int *__restrict__ ex
                                                       const float *__restrict__ rho, int r, const double *__restrict__ S,
                                                       const int *__restrict__ status, double *__restrict__ Aws,
                                                       float *__restrict__ T, double *__restrict__ acc_out,
-                                                      double *__restrict__ T64, const int *__restrict__ gate) {
+                                                      double *__restrict__ T64, const int *__restrict__ gate,
+                                                      const double *__restrict__ F64 = nullptr, const double *__restrict__ U64 = nullptr,
+                                                      const double *__restrict__ Delta64 = nullptr) {
     MCL_GATE(gate);
     const int slab = blockIdx.x;
     if (status[slab] != 2) return;
@@ -730,15 +733,20 @@ __global__ __launch_bounds__(256) void k_pf2_polar_qr(const int *__restrict__ ex
     double *D = sq, *R = D + n2, *V = R + n2, *red = V + n2, *lam = red + 4 * 64;  // red: 4 row chunks x 64 columns
     __shared__ double sh_alpha, sh_beta, sh_vkk;
     const int tid = threadIdx.x, lane = tid & 63, chunk = tid >> 6;
-    for (int e = tid; e < n2; e += 256) D[e] = (double)Delta[e];
+    for (int e = tid; e < n2; e += 256) D[e] = Delta64 != nullptr ? Delta64[e] : (double)Delta[e];
     __syncthreads();
     double *A = Aws + (long)s * r;
     for (long idx = tid; idx < (long)n * r; idx += 256) {
         const long j = idx / r;
         const int c = (int)(idx - j * r);
-        const float *f = F + ((long)s + j) * r, *u = U + ((long)s + j) * r;
         double acc = 0.0;
-        for (int k = 0; k < r; ++k) acc = fma((double)f[k] + (double)u[k], D[c * r + k], acc);
+        if (F64 != nullptr) {  // the fp64 state of wide.hip
+            const double *f = F64 + ((long)s + j) * r, *u = U64 + ((long)s + j) * r;
+            for (int k = 0; k < r; ++k) acc = fma(f[k] + u[k], D[c * r + k], acc);
+        } else {
+            const float *f = F + ((long)s + j) * r, *u = U + ((long)s + j) * r;
+            for (int k = 0; k < r; ++k) acc = fma((double)f[k] + (double)u[k], D[c * r + k], acc);
+        }
         A[idx] = acc;
     }
     __syncthreads();
@@ -1871,6 +1879,27 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
             c->err = "penalty kind has no native prox (EXTERNAL penalties are evaluated by the host)";
             return 1;
     }
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+// The polar factors of the PARAFAC2 member from the fp64 state of wide.hip (S_i = Y_i^T Y_i already in pf2_S): the Jacobi route
+// for every slab, then the QR route for the slabs it flags (Gram matrix too ill-conditioned) - T_i, T_i in fp64, rho_i T_i^T S_i
+int mcl_launch_pf2_jacobi_wide(mcl_context *c, int k, const double *F64, const double *U64, const double *D64) {
+    const RegSet &rs = c->regs[1];
+    const int r = c->r, n2 = r * r;
+    const size_t sm = sizeof(double) * (size_t)(4 * n2 + r);
+    if (sm > 65536)
+        MCL_CHECK_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pf2_algebra), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    ProfScope prof(c, MCL_PROF_PF2);
+    c->variant[MCL_PROF_PF2] = "k_pf2_algebra (Jacobi) + k_pf2_polar_qr on the fp64 state";
+    hipLaunchKernelGGL(k_pf2_algebra, dim3((unsigned)c->I), dim3(64), sm, c->stream, c->pf2_S, rs.aux2[k], c->rhoB, r, c->pf2_T,
+                       c->pf2_acc, c->pf2_status, 0, c->pf2_T64, c->row_ptr_dev, D64);
+    const size_t smq = sizeof(double) * (size_t)(3 * n2 + 4 * 64 + 64);
+    if (smq > 65536)
+        MCL_CHECK_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pf2_polar_qr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smq));
+    hipLaunchKernelGGL(k_pf2_polar_qr, dim3((unsigned)c->I), dim3(256), smq, c->stream, c->row_ptr_dev, c->B, rs.dual[k], rs.aux2[k],
+                       c->rhoB, r, c->pf2_S, c->pf2_status, c->pf2_qr, c->pf2_T, c->pf2_acc, c->pf2_T64, c->gate_active, F64, U64, D64);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

@@ -30,6 +30,8 @@ struct RegSet {
     float *aux[MCL_MAX_REGS];
     float *dual[MCL_MAX_REGS];
     float *aux2[MCL_MAX_REGS];
+    double p0d[MCL_MAX_REGS];  // the same parameters before their rounding to fp32 (the fp64 inner loops of wide.hip)
+    double p1d[MCL_MAX_REGS];
     const int *gate;  // stop flag of a gated run (mcl_run with a stopping rule), else NULL: see MCL_GATE
 };
 
@@ -67,7 +69,7 @@ struct mcl_switches {
     bool no_sweep = false, no_pass_chain = false, no_pf2_delta_fusion = false, ns_plain = false, pf2_jacobi = false;
     bool no_stack_fusion = false, no_solve_stats = false, no_next_b = false, no_fused_gram = false, no_fused_c = false;
     bool a_finish_cols = false, xc_norow = false, uni_noprune = false, stats_reduce = false;
-    bool no_rows64 = false, no_uni_coop = false;
+    bool no_rows64 = false, no_uni_coop = false, no_wide = false;
     bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_x_nt = false, no_sweep_half = false, no_multi_c = false, no_diag_defer = false, xc_depth1 = false;
     int x_nt_mb = 0, seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
     int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
@@ -122,6 +124,11 @@ struct mcl_context {
     long long *sweep_cycles = nullptr;  // [n_blocks, 4 waves, 6] per-section cycle counts (MCL_SWEEP_DBG & 32)
     bool grpart_valid = false;     // GRpart was weighted with the current A (and mseg_valid)
     bool sweep_planned = false;    // the workspace holds the sweep buffers
+    // exact-products mode: fp64 shadow state of the inner loops of modes 1 / 2 (wide.hip): factor, auxiliary and dual
+    // variables for the length of a phase, the PARAFAC2 coordinate matrix
+    double *wF[3] = {nullptr, nullptr, nullptr};
+    double *wZ[3][MCL_MAX_REGS] = {}, *wU[3][MCL_MAX_REGS] = {};
+    double *wD = nullptr;
     double *exact_part = nullptr;  // exact-products mode: [G | R] per 256-row chunk (fp64), summed in a fixed order
     bool exact = false;            // exact-products mode (small problems): X C, [G | R] and the A-phase tables from fp64 sums of exact products
     bool mseg_valid = false;       // Mpart / part_btb correspond to the current B
@@ -347,6 +354,8 @@ bool mcl_stats_can_ride_in_solve(const mcl_context *c, int mode);  // generic.hi
 bool mcl_stats_reduce_in_algebra(const mcl_context *c);            // generic.hip
 int mcl_launch_rows_finish_solve_stats(mcl_context *c);           // generic.hip: finish of iteration t + solve / stats of t + 1
 int mcl_launch_rows_solve_stats(mcl_context *c);                  // generic.hip: B solve + per-tile statistics + reduce
+bool mcl_wide_applies(const mcl_context *c, int mode);          // wide.hip: the fp64 inner loop of small problems takes the mode
+int mcl_wide_phase(mcl_context *c, int mode);                    // wide.hip
 bool mcl_exact_mode(const mcl_context *c);                      // contract.hip
 int mcl_launch_exact_xc(mcl_context *c);                         // contract.hip: XC64 (+ its fp32 image) = X C, exact products
 int mcl_launch_exact_gr(mcl_context *c);                         // contract.hip: GR = [G | R] of this rank's slabs, exact products
