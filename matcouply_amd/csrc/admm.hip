@@ -988,6 +988,7 @@ struct AFuse {
     double *CtC64_out;
     float *CtC_out;
     double *LinvB64;  // fp64 copy of the next B-phase's inverses (fp64 row passes of PARAFAC2 stacks: mcl_rows64), or NULL
+    double *LinvA64, *rhsA64;  // fp64 systems / right-hand sides of a host- or wide-driven inner loop (fused_inner = 0), or NULL
 };
 
 // sum_k M[k][c] C[k][c] over the bsegs sgA, sgA + step, ... < sgB, both operands in C-fragment order (element
@@ -1174,7 +1175,11 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
     if (!fused_inner) {
 #pragma unroll
         for (int j = 0; j < RL; ++j)
-            if (dok[j]) LinvA[((long)i * r + drow[j]) * r + c] = (float)col[j];
+            if (dok[j]) {
+                LinvA[((long)i * r + drow[j]) * r + c] = (float)col[j];
+                if (F.LinvA64 != nullptr) F.LinvA64[((long)i * r + drow[j]) * r + c] = col[j];
+            }
+        if (lead && F.rhsA64 != nullptr) F.rhsA64[(long)i * r + c] = rhs;
         return;
     }
 #pragma unroll
@@ -2101,6 +2106,7 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
         F.MS = mcl_sweep_KC(c) * 64 * 16 * c->NB;
     }
     F.LinvB64 = b_needs_64 ? c->LinvB64 : nullptr;
+    F.LinvA64 = c->LinvA64, F.rhsA64 = c->rhsA64;  // (allocated in the exact-products mode only)
     if (!rows_kernel && c->ctc_parts > 0)
         if (int rc = mcl_launch_ctc_fold(c)) return rc;
     // ranks 5..32: rows of every system split over the lane groups (all 64 lanes busy); 64 columns fill the wave anyway

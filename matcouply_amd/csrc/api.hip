@@ -92,8 +92,8 @@ int64_t plan(mcl_context *c, char *base) {
     c->GR = b.take<double>(E);
     c->exact_part = c->exact ? b.take<double>(std::max<int64_t>(1, (N + 255) / 256) * E) : nullptr;
     for (int m = 0; m < 3; ++m) {  // fp64 state of the inner loops of modes 1 / 2 in the exact-products mode (wide.hip)
-        const int64_t rows_m = (m == 1) ? N : K;
-        const bool wide = c->exact && m != 0 && c->regs[m].n > 0;
+        const int64_t rows_m = (m == 1) ? N : (m == 2 ? K : I);
+        const bool wide = c->exact && c->regs[m].n > 0;
         c->wF[m] = wide ? b.take<double>(rows_m * r) : nullptr;
         for (int k = 0; k < MCL_MAX_REGS; ++k) {
             c->wZ[m][k] = (wide && k < c->regs[m].n) ? b.take<double>(rows_m * r) : nullptr;
@@ -101,6 +101,8 @@ int64_t plan(mcl_context *c, char *base) {
         }
     }
     c->wD = c->exact ? b.take<double>(r * r) : nullptr;
+    c->LinvA64 = c->exact ? b.take<double>(I * r * r) : nullptr;
+    c->rhsA64 = c->exact ? b.take<double>(I * r) : nullptr;
     c->GRf = b.take<float>(E);
     c->LinvC64 = b.take<double>(r * r);
     c->rhoC = b.take<float>(1);
@@ -1008,7 +1010,11 @@ int mcl_A_finish(mcl_context *c) {
             return fail(c, "matrix penalties on mode 0 need constant_feasibility_penalty (the reference raises "
                            "AttributeError: no factor_matrix_row_update)");
         if (int rc = mcl_launch_A_finish(c, false)) return rc;
-        if (int rc = generic_inner_loop(c, 0)) return rc;
+        if (mcl_wide_applies(c, 0)) {  // small problem: the whole inner loop in fp64 (wide.hip)
+            if (int rc = mcl_wide_phase(c, 0)) return rc;
+        } else if (int rc = generic_inner_loop(c, 0)) {
+            return rc;
+        }
         if (int rc = mcl_launch_A_e1(c, true)) return rc;
     }
     c->e1_valid = true;

@@ -129,6 +129,7 @@ struct mcl_context {
     double *wF[3] = {nullptr, nullptr, nullptr};
     double *wZ[3][MCL_MAX_REGS] = {}, *wU[3][MCL_MAX_REGS] = {};
     double *wD = nullptr;
+    double *LinvA64 = nullptr, *rhsA64 = nullptr;  // fp64 copies of the A-phase systems / right-hand sides (mode 0 of wide.hip)
     double *exact_part = nullptr;  // exact-products mode: [G | R] per 256-row chunk (fp64), summed in a fixed order
     bool exact = false;            // exact-products mode (small problems): X C, [G | R] and the A-phase tables from fp64 sums of exact products
     bool mseg_valid = false;       // Mpart / part_btb correspond to the current B

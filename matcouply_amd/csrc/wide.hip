@@ -44,20 +44,51 @@ __device__ __forceinline__ double prox_rowsep_d(int kind, int nonneg, double p0,
     }
 }
 
-// f_c = sum_d t_d M[d][c] for RW rows at once: t of the rows through the wave's LDS strip (broadcast reads), M in LDS
+// The rows one wave (= one workgroup) works on: RW x G rows of ONE tile (<= 64 rows of one slab), G = 64 / RPW lane groups of
+// RPW = 16 / 32 / 64 >= r lanes; lane (grp, c) owns column c of rows jbase + q G + grp, q < RW.  Workgroups per tile:
+// ceil(64 / (RW G)) - a 4096-row factor of rank 16 is spread over 256 waves.
+constexpr int WIDE_RW = 4;
+struct RowGroup {
+    int c, grp, G, RPW, slab, nrows, jbase, r;
+    long row0;
+    bool act;
+    __device__ RowGroup(const WideRows &W, int r_) : r(r_) {
+        RPW = r <= 16 ? 16 : (r <= 32 ? 32 : 64);
+        G = 64 / RPW;
+        const int per = WIDE_RW * G, subs = (64 + per - 1) / per;
+        const int tile = blockIdx.x / subs, sub = blockIdx.x - tile * subs;
+        c = threadIdx.x % RPW, grp = threadIdx.x / RPW;
+        act = c < r;
+        slab = W.tile_slab[tile], row0 = W.tile_row0[tile], nrows = W.tile_nrows[tile];
+        jbase = sub * per;
+    }
+    __device__ bool any() const { return jbase < nrows; }  // (workgroup-uniform)
+    __device__ long idx(int q, bool &ok) const {
+        const int j = jbase + q * G + grp;
+        ok = act && j < nrows;
+        return (row0 + min(j, nrows - 1)) * r + (act ? c : 0);
+    }
+};
+static unsigned wide_grid(const WideRows &W, int r) {
+    const int G = 64 / (r <= 16 ? 16 : (r <= 32 ? 32 : 64)), per = WIDE_RW * G;
+    return (unsigned)(W.n_tiles * ((64 + per - 1) / per));
+}
+
+// f_c = sum_d t_d M[d][c] for the wave's RW x G rows at once: t of the rows through the wave's LDS strip (broadcast reads
+// within a lane group), M in LDS
 template <int RW>
-__device__ __forceinline__ void row_times_matrix(const double (&t)[RW], double (&f)[RW], double *ts, const double *Ms, int r,
-                                                 int c, bool act) {
+__device__ __forceinline__ void row_times_matrix(const double (&t)[RW], double (&f)[RW], double *ts, const double *Ms, const RowGroup &R) {
+    const int base = R.grp * R.RPW;
 #pragma unroll
-    for (int q = 0; q < RW; ++q) ts[q * 64 + c] = t[q];
+    for (int q = 0; q < RW; ++q) ts[q * 64 + base + R.c] = t[q];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the strip is written (one wave: program order suffices beyond that)
 #pragma unroll
     for (int q = 0; q < RW; ++q) f[q] = 0.0;
-    for (int d = 0; d < r; ++d) {
-        const double m = act ? Ms[d * r + c] : 0.0;
+    for (int d = 0; d < R.r; ++d) {
+        const double m = R.act ? Ms[d * R.r + R.c] : 0.0;
 #pragma unroll
-        for (int q = 0; q < RW; ++q) f[q] = fma(ts[q * 64 + d], m, f[q]);
+        for (int q = 0; q < RW; ++q) f[q] = fma(ts[q * 64 + base + d], m, f[q]);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -70,71 +101,65 @@ __global__ __launch_bounds__(64) void k_wide_rowsep(WideRows W, const double *__
                                                     const double *__restrict__ Linv64, float *__restrict__ F, RegSet regs,
                                                     int r, int inner) {
     MCL_GATE(W.gate);
-    constexpr int RW = 4;
+    constexpr int RW = WIDE_RW;
     extern __shared__ double wsm[];
     double *Ls = wsm, *ts = wsm + r * r;  // ts: RW x 64
-    const int c = threadIdx.x, tile = blockIdx.x;
-    const bool act = c < r;
-    const int slab = W.tile_slab[tile];
-    const long row0 = W.tile_row0[tile];
-    const int nrows = W.tile_nrows[tile];
-    for (int e = c; e < r * r; e += 64) Ls[e] = Linv64[(long)slab * r * r + e];
+    const RowGroup R(W, r);
+    if (!R.any()) return;
+    for (int e = threadIdx.x; e < r * r; e += 64) Ls[e] = Linv64[(long)R.slab * r * r + e];
     __syncthreads();
-    const double rho = (double)W.rho[slab];
-    const double a_c = (Arows != nullptr && act) ? (double)Arows[(long)slab * r + c] : 1.0;
+    const double rho = (double)W.rho[R.slab];
+    const double a_c = (Arows != nullptr && R.act) ? (double)Arows[(long)R.slab * r + R.c] : 1.0;
     const int n = regs.n;
     double thr[MCL_MAX_REGS];
 #pragma unroll
     for (int k = 0; k < MCL_MAX_REGS; ++k) thr[k] = (k < n) ? regs.p0d[k] / rho : 0.0;
-    for (int j0 = 0; j0 < nrows; j0 += RW) {
-        double rhs[RW], z[MCL_MAX_REGS][RW], u[MCL_MAX_REGS][RW], f[RW], t[RW];
-        bool ok[RW];
-        long idx[RW];
+    double rhs[RW], z[MCL_MAX_REGS][RW], u[MCL_MAX_REGS][RW], f[RW], t[RW];
+    bool ok[RW];
+    long idx[RW];
+#pragma unroll
+    for (int q = 0; q < RW; ++q) {
+        idx[q] = R.idx(q, ok[q]);
+        rhs[q] = ok[q] ? rhs64[idx[q]] * a_c : 0.0;
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) {
+            z[k][q] = (k < n && ok[q]) ? (double)regs.aux[k][idx[q]] : 0.0;
+            u[k][q] = (k < n && ok[q]) ? (double)regs.dual[k][idx[q]] : 0.0;
+        }
+        f[q] = 0.0;
+    }
+    for (int it = 0; it < inner; ++it) {
 #pragma unroll
         for (int q = 0; q < RW; ++q) {
-            ok[q] = act && j0 + q < nrows;
-            idx[q] = (row0 + min(j0 + q, nrows - 1)) * r + (act ? c : 0);
-            rhs[q] = ok[q] ? rhs64[idx[q]] * a_c : 0.0;
+            double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < MCL_MAX_REGS; ++k) {
-                z[k][q] = (k < n && ok[q]) ? (double)regs.aux[k][idx[q]] : 0.0;
-                u[k][q] = (k < n && ok[q]) ? (double)regs.dual[k][idx[q]] : 0.0;
-            }
-            f[q] = 0.0;
+            for (int k = 0; k < MCL_MAX_REGS; ++k)
+                if (k < n) s += z[k][q] - u[k][q];
+            t[q] = fma(rho, s, rhs[q]);
         }
-        for (int it = 0; it < inner; ++it) {
+        row_times_matrix<RW>(t, f, ts, Ls, R);
 #pragma unroll
-            for (int q = 0; q < RW; ++q) {
-                double s = 0.0;
+        for (int k = 0; k < MCL_MAX_REGS; ++k)
+            if (k < n) {
 #pragma unroll
-                for (int k = 0; k < MCL_MAX_REGS; ++k)
-                    if (k < n) s += z[k][q] - u[k][q];
-                t[q] = fma(rho, s, rhs[q]);
+                for (int q = 0; q < RW; ++q) {
+                    const double zn = prox_rowsep_d(regs.kind[k], regs.nonneg[k], regs.p0d[k], regs.p1d[k], thr[k], f[q] + u[k][q]);
+                    u[k][q] = f[q] - (zn - u[k][q]);
+                    z[k][q] = zn;
+                }
             }
-            row_times_matrix<RW>(t, f, ts, Ls, r, c, act);
+    }
+#pragma unroll
+    for (int q = 0; q < RW; ++q)
+        if (ok[q]) {
+            F[idx[q]] = (float)f[q];
 #pragma unroll
             for (int k = 0; k < MCL_MAX_REGS; ++k)
                 if (k < n) {
-#pragma unroll
-                    for (int q = 0; q < RW; ++q) {
-                        const double zn = prox_rowsep_d(regs.kind[k], regs.nonneg[k], regs.p0d[k], regs.p1d[k], thr[k], f[q] + u[k][q]);
-                        u[k][q] = f[q] - (zn - u[k][q]);
-                        z[k][q] = zn;
-                    }
+                    regs.aux[k][idx[q]] = (float)z[k][q];
+                    regs.dual[k][idx[q]] = (float)u[k][q];
                 }
         }
-#pragma unroll
-        for (int q = 0; q < RW; ++q)
-            if (ok[q]) {
-                F[idx[q]] = (float)f[q];
-#pragma unroll
-                for (int k = 0; k < MCL_MAX_REGS; ++k)
-                    if (k < n) {
-                        regs.aux[k][idx[q]] = (float)z[k][q];
-                        regs.dual[k][idx[q]] = (float)u[k][q];
-                    }
-            }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -166,53 +191,70 @@ __global__ __launch_bounds__(64) void k_wide_solve(WideRows W, WideState S, cons
                                                    const float *__restrict__ Arows, const double *__restrict__ Linv64,
                                                    float *__restrict__ F32, int n, int r) {
     MCL_GATE(W.gate);
-    constexpr int RW = 4;
+    constexpr int RW = WIDE_RW;
     extern __shared__ double wsm[];
     double *Ls = wsm, *Ds = Ls + r * r, *ts = Ds + (S.kpf2 >= 0 ? r * r : 0);
-    const int c = threadIdx.x, tile = blockIdx.x;
-    const bool act = c < r;
-    const int slab = W.tile_slab[tile];
-    const long row0 = W.tile_row0[tile];
-    const int nrows = W.tile_nrows[tile];
-    for (int e = c; e < r * r; e += 64) {
-        Ls[e] = Linv64[(long)slab * r * r + e];
+    const RowGroup R(W, r);
+    if (!R.any()) return;
+    for (int e = threadIdx.x; e < r * r; e += 64) {
+        Ls[e] = Linv64[(long)R.slab * r * r + e];
         if (S.kpf2 >= 0) Ds[e] = S.D[e];
     }
     __syncthreads();
-    const double rho = (double)W.rho[slab];
-    const double a_c = (Arows != nullptr && act) ? (double)Arows[(long)slab * r + c] : 1.0;
-    for (int j0 = 0; j0 < nrows; j0 += RW) {
-        double t[RW], f[RW], sacc[RW];
-        bool ok[RW];
-        long idx[RW];
+    const double rho = (double)W.rho[R.slab];
+    const double a_c = (Arows != nullptr && R.act) ? (double)Arows[(long)R.slab * r + R.c] : 1.0;
+    double t[RW], f[RW], sacc[RW];
+    bool ok[RW];
+    long idx[RW];
 #pragma unroll
-        for (int q = 0; q < RW; ++q) {
-            ok[q] = act && j0 + q < nrows;
-            idx[q] = (row0 + min(j0 + q, nrows - 1)) * r + (act ? c : 0);
-            sacc[q] = 0.0;
-        }
-        for (int k = 0; k < n; ++k) {
-            double z[RW];
+    for (int q = 0; q < RW; ++q) {
+        idx[q] = R.idx(q, ok[q]);
+        sacc[q] = 0.0;
+    }
+    for (int k = 0; k < n; ++k) {
+        double z[RW];
 #pragma unroll
-            for (int q = 0; q < RW; ++q) z[q] = ok[q] ? S.Z[k][idx[q]] : 0.0;
-            if (k == S.kpf2) {
-                double pd[RW];
-                row_times_matrix<RW>(z, pd, ts, Ds, r, c, act);
+        for (int q = 0; q < RW; ++q) z[q] = ok[q] ? S.Z[k][idx[q]] : 0.0;
+        if (k == S.kpf2) {
+            double pd[RW];
+            row_times_matrix<RW>(z, pd, ts, Ds, R);
 #pragma unroll
-                for (int q = 0; q < RW; ++q) z[q] = pd[q];
-            }
-#pragma unroll
-            for (int q = 0; q < RW; ++q) sacc[q] += z[q] - (ok[q] ? S.U[k][idx[q]] : 0.0);
+            for (int q = 0; q < RW; ++q) z[q] = pd[q];
         }
 #pragma unroll
-        for (int q = 0; q < RW; ++q) t[q] = ok[q] ? fma(rho, sacc[q], rhs64[idx[q]] * a_c) : 0.0;
-        row_times_matrix<RW>(t, f, ts, Ls, r, c, act);
+        for (int q = 0; q < RW; ++q) sacc[q] += z[q] - (ok[q] ? S.U[k][idx[q]] : 0.0);
+    }
 #pragma unroll
-        for (int q = 0; q < RW; ++q)
-            if (ok[q]) {
-                S.F[idx[q]] = f[q];
-                F32[idx[q]] = (float)f[q];
-            }
+    for (int q = 0; q < RW; ++q) t[q] = ok[q] ? fma(rho, sacc[q], rhs64[idx[q]] * a_c) : 0.0;
+    row_times_matrix<RW>(t, f, ts, Ls, R);
+#pragma unroll
+    for (int q = 0; q < RW; ++q)
+        if (ok[q]) {
+            S.F[idx[q]] = f[q];
+            F32[idx[q]] = (float)f[q];
+        }
+}
+
+// mode 0 (constant feasibility penalty, matrix penalties on A: decomposition.py:184-195): every row has its own system -
+// one wave per row of A, lane c owns column c
+__global__ __launch_bounds__(64) void k_wide_A_solve(WideState S, const double *__restrict__ rhsA64, const float *__restrict__ rho_max,
+                                                     const double *__restrict__ LinvA64, float *__restrict__ A32, int n, int r,
+                                                     const int *__restrict__ gate) {
+    MCL_GATE(gate);
+    __shared__ double tS[64];
+    const int i = blockIdx.x, c = threadIdx.x;
+    const bool act = c < r;
+    const long e = (long)i * r + (act ? c : 0);
+    const double rho = (double)rho_max[1];
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) s += act ? S.Z[k][e] - S.U[k][e] : 0.0;
+    tS[c] = act ? fma(rho, s, rhsA64[e]) : 0.0;
+    __syncthreads();
+    double a = 0.0;
+    for (int d = 0; d < r; ++d) a = fma(tS[d], act ? LinvA64[((long)i * r + d) * r + c] : 0.0, a);
+    if (act) {
+        S.F[e] = a;
+        A32[e] = (float)a;
     }
 }
 
@@ -474,34 +516,28 @@ __global__ __launch_bounds__(256) void k_wide_gram(WideRows W, WideState S, int 
 __global__ __launch_bounds__(64) void k_wide_pf2_apply(WideRows W, WideState S, int k, int r, const double *__restrict__ T64,
                                                        float *__restrict__ P32) {
     MCL_GATE(W.gate);
-    constexpr int RW = 4;
+    constexpr int RW = WIDE_RW;
     extern __shared__ double wsm[];
     double *Ts = wsm, *ts = wsm + r * r;
-    const int c = threadIdx.x, tile = blockIdx.x;
-    const bool act = c < r;
-    const int slab = W.tile_slab[tile];
-    const long row0 = W.tile_row0[tile];
-    const int nrows = W.tile_nrows[tile];
-    for (int e = c; e < r * r; e += 64) Ts[e] = T64[(long)slab * r * r + e];
+    const RowGroup R(W, r);
+    if (!R.any()) return;
+    for (int e = threadIdx.x; e < r * r; e += 64) Ts[e] = T64[(long)R.slab * r * r + e];
     __syncthreads();
-    for (int j0 = 0; j0 < nrows; j0 += RW) {
-        double y[RW], p[RW];
-        bool ok[RW];
-        long idx[RW];
+    double y[RW], p[RW];
+    bool ok[RW];
+    long idx[RW];
 #pragma unroll
-        for (int q = 0; q < RW; ++q) {
-            ok[q] = act && j0 + q < nrows;
-            idx[q] = (row0 + min(j0 + q, nrows - 1)) * r + (act ? c : 0);
-            y[q] = ok[q] ? S.F[idx[q]] + S.U[k][idx[q]] : 0.0;
-        }
-        row_times_matrix<RW>(y, p, ts, Ts, r, c, act);
-#pragma unroll
-        for (int q = 0; q < RW; ++q)
-            if (ok[q]) {
-                S.Z[k][idx[q]] = p[q];
-                P32[idx[q]] = (float)p[q];
-            }
+    for (int q = 0; q < RW; ++q) {
+        idx[q] = R.idx(q, ok[q]);
+        y[q] = ok[q] ? S.F[idx[q]] + S.U[k][idx[q]] : 0.0;
     }
+    row_times_matrix<RW>(y, p, ts, Ts, R);
+#pragma unroll
+    for (int q = 0; q < RW; ++q)
+        if (ok[q]) {
+            S.Z[k][idx[q]] = p[q];
+            P32[idx[q]] = (float)p[q];
+        }
 }
 
 // Delta = sum_i rho_i P_i^T Y_i / sum_i rho_i from the per-slab accumulators of the polar-factor kernels (fixed order)
@@ -533,42 +569,38 @@ __global__ __launch_bounds__(256) void k_wide_pf2_delta(const double *__restrict
 // dual step of the PARAFAC2 member: U = F - (P Delta - U), one wave per tile
 __global__ __launch_bounds__(64) void k_wide_pf2_dual(WideRows W, WideState S, RegSet regs, int k, int r) {
     MCL_GATE(W.gate);
-    constexpr int RW = 4;
+    constexpr int RW = WIDE_RW;
     extern __shared__ double wsm[];
     double *Ds = wsm, *ts = wsm + r * r;
-    const int c = threadIdx.x, tile = blockIdx.x;
-    const bool act = c < r;
-    const long row0 = W.tile_row0[tile];
-    const int nrows = W.tile_nrows[tile];
-    for (int e = c; e < r * r; e += 64) Ds[e] = S.D[e];
+    const RowGroup R(W, r);
+    if (!R.any()) return;
+    for (int e = threadIdx.x; e < r * r; e += 64) Ds[e] = S.D[e];
     __syncthreads();
-    for (int j0 = 0; j0 < nrows; j0 += RW) {
-        double p[RW], z[RW];
-        bool ok[RW];
-        long idx[RW];
+    double p[RW], z[RW];
+    bool ok[RW];
+    long idx[RW];
 #pragma unroll
-        for (int q = 0; q < RW; ++q) {
-            ok[q] = act && j0 + q < nrows;
-            idx[q] = (row0 + min(j0 + q, nrows - 1)) * r + (act ? c : 0);
-            p[q] = ok[q] ? S.Z[k][idx[q]] : 0.0;
-        }
-        row_times_matrix<RW>(p, z, ts, Ds, r, c, act);
-#pragma unroll
-        for (int q = 0; q < RW; ++q)
-            if (ok[q]) {
-                const double un = S.F[idx[q]] - (z[q] - S.U[k][idx[q]]);
-                S.U[k][idx[q]] = un;
-                regs.dual[k][idx[q]] = (float)un;
-            }
+    for (int q = 0; q < RW; ++q) {
+        idx[q] = R.idx(q, ok[q]);
+        p[q] = ok[q] ? S.Z[k][idx[q]] : 0.0;
     }
+    row_times_matrix<RW>(p, z, ts, Ds, R);
+#pragma unroll
+    for (int q = 0; q < RW; ++q)
+        if (ok[q]) {
+            const double un = S.F[idx[q]] - (z[q] - S.U[k][idx[q]]);
+            S.U[k][idx[q]] = un;
+            regs.dual[k][idx[q]] = (float)un;
+        }
 }
 
 WideRows rows_of(const mcl_context *c, int mode) {
     WideRows W{};
-    const TileMap &tm = (mode == 1) ? c->tilesB : c->tilesC;
+    const TileMap &tm = (mode == 1) ? c->tilesB : (mode == 2 ? c->tilesC : c->tilesA);
     W.tile_slab = tm.slab, W.tile_row0 = tm.row0, W.tile_nrows = tm.nrows, W.n_tiles = tm.n_tiles;
     if (mode == 1) W.ext = c->row_ptr_dev, W.n_slabs = (int)c->I, W.rho = c->rhoB;
-    else W.ext = c->ext_C, W.n_slabs = 1, W.rho = c->rhoC;
+    else if (mode == 2) W.ext = c->ext_C, W.n_slabs = 1, W.rho = c->rhoC;
+    else W.ext = c->ext_A, W.n_slabs = 1, W.rho = c->rho_max + 1;  // mode 0: one "slab" of I rows, the constant rho
     W.gate = c->gate_active;
     return W;
 }
@@ -577,11 +609,14 @@ inline unsigned blocks_for(long n) { return (unsigned)std::min<long>(std::max<lo
 
 }  // namespace
 
-// modes 1 and 2 of a problem in the exact-products mode, every penalty native: the fp64 inner loop applies
+// A problem in the exact-products mode, every penalty of the mode native: the fp64 inner loop applies to modes 1 and 2, and to
+// mode 0 where it runs an un-fused loop at all (matrix penalties on A under a constant feasibility penalty; row-separable
+// stacks on A stay in k_A_finish*, whose inner loop is fp64 already)
 bool mcl_wide_applies(const mcl_context *c, int mode) {
-    if (!c->exact || c->sw.no_wide || (mode != 1 && mode != 2)) return false;
+    if (!c->exact || c->sw.no_wide || mode < 0 || mode > 2) return false;
     const RegSet &rs = c->regs[mode];
     if (rs.n == 0 || c->opt.inner_n_iter_max <= 0 || c->wF[mode] == nullptr) return false;
+    if (mode == 0 && (!c->opt.constant_A || c->RP == 64 || c->RP == 4 || c->sw.a_finish_cols || c->LinvA64 == nullptr)) return false;
     for (int k = 0; k < rs.n; ++k)
         if (rs.kind[k] == MCL_PEN_EXTERNAL) return false;
     return true;
@@ -592,13 +627,13 @@ bool mcl_wide_applies(const mcl_context *c, int mode) {
 int mcl_wide_phase(mcl_context *c, int mode) {
     const RegSet &rs = c->regs[mode];
     const int r = c->r, n = rs.n, n_it = c->opt.inner_n_iter_max;
-    const long rows = (mode == 1) ? (long)c->N : (long)c->K;
+    const long rows = (mode == 1) ? (long)c->N : (mode == 2 ? (long)c->K : (long)c->I);
     if (rows == 0) return 0;
     WideRows W = rows_of(c, mode);
-    const double *rhs64 = (mode == 1) ? c->XC64 : c->GR + (long)r * r;
+    const double *rhs64 = (mode == 1) ? c->XC64 : (mode == 2 ? c->GR + (long)r * r : c->rhsA64);
     const float *Arows = (mode == 1) ? c->A : nullptr;
-    const double *Linv64 = (mode == 1) ? c->LinvB64 : c->LinvC64;
-    float *F32 = (mode == 1) ? c->B : c->C;
+    const double *Linv64 = (mode == 1) ? c->LinvB64 : (mode == 2 ? c->LinvC64 : c->LinvA64);
+    float *F32 = (mode == 1) ? c->B : (mode == 2 ? c->C : c->A);
     const int *slab_of_row = (mode == 1) ? c->slab_of_row : nullptr;
     bool rowsep = true;
     int kpf2 = -1;
@@ -609,9 +644,9 @@ int mcl_wide_phase(mcl_context *c, int mode) {
     }
     ProfScope prof(c, MCL_PROF_ROWS_FUSED);
     const size_t sm_one = sizeof(double) * (size_t)(r * r + 4 * 64);
-    if (rowsep) {
+    if (rowsep && mode != 0) {
         c->variant[MCL_PROF_ROWS_FUSED] = "k_wide_rowsep (fp64 inner loop)";
-        hipLaunchKernelGGL(k_wide_rowsep, dim3((unsigned)W.n_tiles), dim3(64), sm_one, c->stream, W, rhs64, Arows, Linv64, F32, rs, r, n_it);
+        hipLaunchKernelGGL(k_wide_rowsep, dim3(wide_grid(W, r)), dim3(64), sm_one, c->stream, W, rhs64, Arows, Linv64, F32, rs, r, n_it);
         MCL_CHECK_HIP(c, hipGetLastError());
         return 0;
     }
@@ -641,8 +676,12 @@ int mcl_wide_phase(mcl_context *c, int mode) {
             Q.s2[dir] = d + (5 * dir + 3) * n1, Q.er[dir] = d + (5 * dir + 4) * n1;
     }
     for (int it = 0; it < n_it; ++it) {
-        hipLaunchKernelGGL(k_wide_solve, dim3((unsigned)W.n_tiles), dim3(64), kpf2 >= 0 ? sm_two : sm_one, c->stream, W, S, rhs64, Arows,
-                           Linv64, F32, n, r);
+        if (mode == 0)
+            hipLaunchKernelGGL(k_wide_A_solve, dim3((unsigned)rows), dim3(64), 0, c->stream, S, rhs64, (const float *)c->rho_max, Linv64, F32,
+                               n, r, c->gate_active);
+        else
+            hipLaunchKernelGGL(k_wide_solve, dim3(wide_grid(W, r)), dim3(64), kpf2 >= 0 ? sm_two : sm_one, c->stream, W, S, rhs64, Arows,
+                               Linv64, F32, n, r);
         for (int k = 0; k < n; ++k) {
             switch (rs.kind[k]) {
                 case MCL_PEN_NN:
@@ -674,11 +713,11 @@ int mcl_wide_phase(mcl_context *c, int mode) {
                     }
                     hipLaunchKernelGGL(k_wide_gram, dim3((unsigned)c->I), dim3(256), sizeof(double) * 16 * r, c->stream, W, S, k, r, c->pf2_S);
                     if (int rc = mcl_launch_pf2_jacobi_wide(c, k, S.F, S.U[k], S.D)) return rc;
-                    hipLaunchKernelGGL(k_wide_pf2_apply, dim3((unsigned)W.n_tiles), dim3(64), sm_one, c->stream, W, S, k, r,
+                    hipLaunchKernelGGL(k_wide_pf2_apply, dim3(wide_grid(W, r)), dim3(64), sm_one, c->stream, W, S, k, r,
                                        (const double *)c->pf2_T64, rs.aux[k]);
                     hipLaunchKernelGGL(k_wide_pf2_delta, dim3((unsigned)(r * r)), dim3(256), 0, c->stream, (const double *)c->pf2_acc,
                                        (int)c->I, r * r, S.D, rs.aux2[k], c->pf2_red, c->gate_active);
-                    hipLaunchKernelGGL(k_wide_pf2_dual, dim3((unsigned)W.n_tiles), dim3(64), sm_one, c->stream, W, S, rs, k, r);
+                    hipLaunchKernelGGL(k_wide_pf2_dual, dim3(wide_grid(W, r)), dim3(64), sm_one, c->stream, W, S, rs, k, r);
                     break;
                 }
                 default:
