@@ -772,7 +772,8 @@ __global__ __launch_bounds__(256) void k_A_finish(float *__restrict__ BtB, const
                                                   int next_B, float l2_B, int n_regs_B, float *__restrict__ rhoB,
                                                   float *__restrict__ LinvB, const int *__restrict__ slab_seg_ptr,
                                                   const double *__restrict__ seg_rhs, const double *__restrict__ seg_btb,
-                                                  float *__restrict__ rhsA_out) {
+                                                  float *__restrict__ rhsA_out, int wide_inner, double *__restrict__ LinvA64,
+                                                  double *__restrict__ rhsA64) {
     MCL_GATE(regs.gate);
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -844,7 +845,11 @@ __global__ __launch_bounds__(256) void k_A_finish(float *__restrict__ BtB, const
     if (!fused_inner) {
 #pragma unroll
         for (int d = 0; d < RP; ++d)
-            if (act && d < r) LinvA[((long)i * r + d) * r + c] = (float)col[d];
+            if (act && d < r) {
+                LinvA[((long)i * r + d) * r + c] = (float)col[d];
+                if (LinvA64 != nullptr) LinvA64[((long)i * r + d) * r + c] = col[d];
+            }
+        if (act && rhsA64 != nullptr) rhsA64[(long)i * r + c] = rhs;
         return;
     }
     float z[MCL_MAX_REGS], u[MCL_MAX_REGS], on[MCL_MAX_REGS];
@@ -862,6 +867,38 @@ __global__ __launch_bounds__(256) void k_A_finish(float *__restrict__ BtB, const
     }
     float a = act ? a_pre : 0.f;
     const int n_it = (n == 0 && inner > 1) ? 1 : inner;
+    if (wide_inner) {  // small problems (exact-products mode): the row, its auxiliary and dual variables in fp64, rounded once
+        double zd[MCL_MAX_REGS], ud[MCL_MAX_REGS], ad = (double)a;
+        ProxClampD pd[MCL_MAX_REGS];
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) {
+            zd[k] = (double)z[k], ud[k] = (double)u[k];
+            if (k < n) pd[k].set(regs.kind[k], regs.nonneg[k], regs.p0d[k], regs.p1d[k], regs.p0d[k] / (double)rho);
+            else pd[k].set(0, 0, 0.0, 0.0, 0.0);
+        }
+        for (int it = 0; it < n_it; ++it) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < MCL_MAX_REGS; ++k)
+                if (k < n) s += zd[k] - ud[k];
+            const double t = (n > 0) ? fma((double)rho, s, rhs) : rhs;
+            double acc = 0.0;
+#pragma unroll
+            for (int d = 0; d < RP; ++d) {
+                if (d < r) acc = fma(readlane_f64(t, d), col[d], acc);
+            }
+            ad = act ? acc : 0.0;
+#pragma unroll
+            for (int k = 0; k < MCL_MAX_REGS; ++k) {
+                const double zn = pd[k](ad + ud[k]);
+                ud[k] = ad - (zn - ud[k]);
+                zd[k] = zn;
+            }
+        }
+        a = (float)ad;
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) z[k] = (float)zd[k], u[k] = (float)ud[k];
+    } else
     for (int it = 0; it < n_it; ++it) {
         float s = 0.f;
 #pragma unroll
@@ -989,6 +1026,7 @@ struct AFuse {
     float *CtC_out;
     double *LinvB64;  // fp64 copy of the next B-phase's inverses (fp64 row passes of PARAFAC2 stacks: mcl_rows64), or NULL
     double *LinvA64, *rhsA64;  // fp64 systems / right-hand sides of a host- or wide-driven inner loop (fused_inner = 0), or NULL
+    int wide_inner;            // small problems (exact-products mode): the inner loop keeps the row and its ADMM variables in fp64
 };
 
 // sum_k M[k][c] C[k][c] over the bsegs sgA, sgA + step, ... < sgB, both operands in C-fragment order (element
@@ -1197,6 +1235,40 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
         return v;
     };
     const int n_it = (n == 0 && inner > 1) ? 1 : inner;
+    if (F.wide_inner) {  // (see k_A_finish)
+        double zd[MCL_MAX_REGS], ud[MCL_MAX_REGS], ad = (double)a;
+        ProxClampD pd[MCL_MAX_REGS];
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) {
+            zd[k] = (double)z[k], ud[k] = (double)u[k];
+            if (k < n) pd[k].set(regs.kind[k], regs.nonneg[k], regs.p0d[k], regs.p1d[k], regs.p0d[k] / (double)rho);
+            else pd[k].set(0, 0, 0.0, 0.0, 0.0);
+        }
+        for (int it = 0; it < n_it; ++it) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < MCL_MAX_REGS; ++k)
+                if (k < n) s += zd[k] - ud[k];
+            const double t = (n > 0) ? fma((double)rho, s, rhs) : rhs;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < RL; ++j) {
+                const double td = bperm_f64(g * RP + g * RL + j, t);
+                if (g * RL + j < r) acc = fma(td, col[j], acc);
+            }
+            ad = group_sum(acc);  // (every lane takes part in the shuffles)
+            if (!act) ad = 0.0;
+#pragma unroll
+            for (int k = 0; k < MCL_MAX_REGS; ++k) {
+                const double zn = pd[k](ad + ud[k]);
+                ud[k] = ad - (zn - ud[k]);
+                zd[k] = zn;
+            }
+        }
+        a = (float)ad;
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) z[k] = (float)zd[k], u[k] = (float)ud[k];
+    } else
     for (int it = 0; it < n_it; ++it) {
         float sacc = 0.f;
 #pragma unroll
@@ -2107,11 +2179,12 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     }
     F.LinvB64 = b_needs_64 ? c->LinvB64 : nullptr;
     F.LinvA64 = c->LinvA64, F.rhsA64 = c->rhsA64;  // (allocated in the exact-products mode only)
+    F.wide_inner = (c->exact && !c->sw.no_wide) ? 1 : 0;
     if (!rows_kernel && c->ctc_parts > 0)
         if (int rc = mcl_launch_ctc_fold(c)) return rc;
     // ranks 5..32: rows of every system split over the lane groups (all 64 lanes busy); 64 columns fill the wave anyway
     if (!rows_kernel) {
-        DISPATCH_RP_T(c, k_A_finish, grid, block, MCL_AF_ARGS);
+        DISPATCH_RP_T(c, k_A_finish, grid, block, MCL_AF_ARGS, F.wide_inner, c->LinvA64, c->rhsA64);
     } else if (c->a_rhs_wide) {
         if (c->a_rhs_pairs) {  // two slabs per workgroup (one partial per slab, many slabs)
             const dim3 gp((unsigned)((c->I + 1) / 2));

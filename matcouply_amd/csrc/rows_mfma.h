@@ -72,6 +72,19 @@ struct ProxClamp {
     }
 };
 
+// the same operator in fp64 (the A-phase finish of small problems keeps its inner loop in double: admm.hip, wide_inner)
+struct ProxClampD {
+    double pa, pb, plo, phi;
+    __device__ __forceinline__ void set(int kind, int nonneg, double p0, double p1, double thr) {
+        pa = pb = 0.0;
+        plo = -INFINITY, phi = INFINITY;
+        if (kind == MCL_PEN_NN) pa = -INFINITY;
+        if (kind == MCL_PEN_BOX) plo = p0, phi = p1;
+        if (kind == MCL_PEN_L1) pa = nonneg ? -INFINITY : -thr, pb = thr;
+    }
+    __device__ __forceinline__ double operator()(double y) const { return fmin(fmax(y - fmin(fmax(y, pa), pb), plo), phi); }
+};
+
 template <int NBR>
 struct RowMat {
     float m[NBR][NBR][4];  // m[h'][h][kq] = M[16h + 4g + kq][16h' + row16]

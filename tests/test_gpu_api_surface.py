@@ -212,7 +212,7 @@ def test_parafac2_polar_factor_routes_agree(stack):
             os.environ["MCL_PF2_JACOBI"] = saved
 
 
-def test_step_api_defers_and_merges_the_finish_pass():
+def test_step_api_defers_and_merges_the_finish_pass(fast_kernels):
     """The B-phase through the step calls (what a multi-GPU host drives) must leave exactly the state of the single-call
     mcl_update_B: the library defers the fused prox + dual row pass of an inner iteration and merges it with the next
     mcl_B_solve; mcl_B_end (or any other entry point) issues it when no solve follows."""
