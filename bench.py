@@ -446,11 +446,10 @@ def main():
         gr = eng.update_C_local()
         if world > 1:
             all_reduce(gr)
-        # C-phase finish + A-phase, one call (what mcl_iterate - the loop behind cmf_aoadmm - issues: one kernel where the
-        # library has the merged form).  No stopping rule is active (tol=None), so the per-iteration diagnostic sums stay on
-        # the device and are all-reduced ONCE for all iterations at the end of the timed region (one collective per step
-        # remains: [G | R])
-        eng.update_C_finish_and_A()
+        eng.update_C_finish()
+        # no stopping rule is active (tol=None), so the per-iteration diagnostic sums stay on the device and are
+        # all-reduced ONCE for all iterations at the end of the timed region (one collective per step remains: [G | R])
+        eng.update_A()
         # deferred: the reduction of the diagnostics tables rides on the next step's C-phase reduction kernel (what
         # mcl_iterate - the fixed-count loop behind cmf_aoadmm - does between its iterations); flushed at the region end
         eng.diagnostics_deferred(include_replicated=(rank == 0), out=slot)

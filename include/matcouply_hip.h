@@ -108,11 +108,6 @@ double *mcl_c_normal_equations(mcl_context *ctx, int64_t *count); /* device [G (
 int mcl_update_C_finish(mcl_context *ctx);
 /* admm_update_A (decomposition.py:120-219); also leaves (rhses, cross_products) for the fast error formula. */
 int mcl_update_A(mcl_context *ctx);
-/* mcl_update_C_finish followed by mcl_update_A, as ONE call: same results bit for bit; on the one-pass path with a small
- * C-phase (rank <= 16, K <= 256, row-separable penalties on C and A) the two run as ONE kernel - every workgroup of the A-phase
- * finish recomputes the tiny C-phase finish itself - which shortens the dependent tail of an outer iteration by a launch.  A
- * host that wants C between the two phases calls them separately. */
-int mcl_update_C_finish_and_A(mcl_context *ctx);
 /* compute_feasibility_gaps + _cmf_reconstruction_error + penalty sums (decomposition.py:351-452, 916-921):
  * writes MCL_DIAG_LEN fp64 partial sums of THIS context's slabs to device memory `out`.
  * include_replicated = 0 leaves the C-mode entries (identical on every rank) at zero so that a SUM all-reduce

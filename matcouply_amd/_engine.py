@@ -38,7 +38,7 @@ KIND = {"nn": PEN_NN, "box": PEN_BOX, "l1": PEN_L1, "l2ball": PEN_L2BALL, "unimo
 EXPORTED_SYMBOLS = [
     "mcl_create", "mcl_destroy", "mcl_last_error", "mcl_version", "mcl_set_problem", "mcl_set_options",
     "mcl_set_factors", "mcl_set_penalties", "mcl_workspace_bytes", "mcl_set_workspace", "mcl_update_B",
-    "mcl_update_C_local", "mcl_c_normal_equations", "mcl_update_C_finish", "mcl_update_A", "mcl_update_C_finish_and_A", "mcl_diagnostics",
+    "mcl_update_C_local", "mcl_c_normal_equations", "mcl_update_C_finish", "mcl_update_A", "mcl_diagnostics",
     "mcl_diagnostics_deferred", "mcl_flush_diagnostics",
     "mcl_iterate", "mcl_run", "mcl_gate_begin", "mcl_verdict", "mcl_gate_end", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_B_end", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
@@ -100,7 +100,6 @@ def load_library():
         "mcl_c_normal_equations": (P, [P, ctypes.POINTER(I64)]),
         "mcl_update_C_finish": (ctypes.c_int, [P]),
         "mcl_update_A": (ctypes.c_int, [P]),
-        "mcl_update_C_finish_and_A": (ctypes.c_int, [P]),
         "mcl_diagnostics": (ctypes.c_int, [P, P, I32]),
         "mcl_diagnostics_deferred": (ctypes.c_int, [P, P, I32]),
         "mcl_flush_diagnostics": (ctypes.c_int, [P]),
@@ -297,10 +296,6 @@ class HipEngine:
 
     def update_A(self):
         self._check(self.lib.mcl_update_A(self._h))
-
-    def update_C_finish_and_A(self):
-        """update_C_finish() + update_A() in one call (one kernel where the library has the merged form)"""
-        self._check(self.lib.mcl_update_C_finish_and_A(self._h))
 
     def diagnostics(self, include_replicated=True, out=None):
         torch = self._torch

@@ -413,11 +413,7 @@ static __device__ __forceinline__ void rows_fused_tile(int lane, long row0, int 
                                                        const float *Arow, const float *__restrict__ rhs_src,
                                                        float *__restrict__ F, float *Fcopy, const RegSet &regs, int r,
                                                        int inner, double *dg, const double *__restrict__ rhs64 = nullptr,
-                                                       const RowBlock<NBR, NREG, VEC> *pre = nullptr,
-                                                       const RegSet *regs_store = nullptr, bool store = true) {
-    // regs_store: where the auxiliary / dual rows go when they are not read from their home (k_CA_finish reads a snapshot);
-    // store = false: only Fcopy is written (a workgroup that recomputes rows another workgroup owns)
-    const RegSet &rst = regs_store != nullptr ? *regs_store : regs;
+                                                       const RowBlock<NBR, NREG, VEC> *pre = nullptr) {
     const int row16 = lane & 15, g = lane >> 4;
     constexpr int NR = NREG > 0 ? NREG : 1;
 
@@ -520,14 +516,12 @@ static __device__ __forceinline__ void rows_fused_tile(int lane, long row0, int 
 #pragma unroll
         for (int h = 0; h < NBR; ++h) {
             const int col = 16 * h + 4 * g;
-            if (store) st4(F, j, col, ok, f[h]);
+            st4(F, j, col, ok, f[h]);
             if (Fcopy != nullptr) st4(Fcopy, j, col, ok, f[h]);
 #pragma unroll
             for (int k = 0; k < NREG; ++k) {
-                if (store) {
-                    st4(rst.aux[k], j, col, ok, z[k][h]);
-                    st4(rst.dual[k], j, col, ok, u[k][h]);
-                }
+                st4(regs.aux[k], j, col, ok, z[k][h]);
+                st4(regs.dual[k], j, col, ok, u[k][h]);
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -1074,13 +1068,6 @@ static __device__ __forceinline__ void m_coldot(const AFuse &F, int sgA, int sgB
     acc0 += __shfl_xor(acc0, 32), acc1 += __shfl_xor(acc1, 32);
 }
 
-// The loads of a_finish_rows_slab that do not depend on the C-phase (k_CA_finish issues them in front of its C-phase part)
-template <int RL>
-struct APre {
-    double btbv[RL];
-    float z[MCL_MAX_REGS], u[MCL_MAX_REGS], a;
-};
-
 // one wave = one slab
 template <int RP>
 static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int lane, float *__restrict__ BtB,
@@ -1095,10 +1082,7 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
                                                           const double *__restrict__ seg_rhs,
                                                           const double *__restrict__ seg_btb,
                                                           float *__restrict__ rhsA_out, const AFuse &F,
-                                                          const double *rhs_lds = nullptr,
-                                                          APre<GJRows<RP>::RL> *pre_out = nullptr,
-                                                          const APre<GJRows<RP>::RL> *pre_in = nullptr) {
-    // pre_out != nullptr: ONLY the C-independent loads (returned in *pre_out); pre_in != nullptr: the rest, from those loads
+                                                          const double *rhs_lds = nullptr) {
     constexpr int RL = GJRows<RP>::RL, G = GJRows<RP>::G;
     const int cc = lane % RP, g = lane / RP;
     const bool in_range = lane < GJRows<RP>::LANES;  // RP = 4 uses 16 lanes only
@@ -1120,10 +1104,7 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
     }
     // all global loads up front
     double ctc[RL], btbv[RL];
-    if (pre_out != nullptr) {
-#pragma unroll
-        for (int j = 0; j < RL; ++j) ctc[j] = 0.0, btbv[j] = 0.0;
-    } else if (F.ctc_parts > 0) {
+    if (F.ctc_parts > 0) {
         for (int pb = 0; pb < F.ctc_parts; pb += 4) {  // four partial blocks per trip: independent clamped loads, added in order
             double v[4][RL];
 #pragma unroll
@@ -1158,14 +1139,6 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
     float z[MCL_MAX_REGS], u[MCL_MAX_REGS], on[MCL_MAX_REGS];
     ProxClamp prox[MCL_MAX_REGS];
     const int n = regs.n;
-    float a;
-    if (pre_in != nullptr) {
-#pragma unroll
-        for (int k = 0; k < MCL_MAX_REGS; ++k) z[k] = pre_in->z[k], u[k] = pre_in->u[k];
-        a = pre_in->a;
-#pragma unroll
-        for (int j = 0; j < RL; ++j) btbv[j] = pre_in->btbv[j];
-    } else {
 #pragma unroll
     for (int k = 0; k < MCL_MAX_REGS; ++k) {
         z[k] = u[k] = 0.f;
@@ -1174,7 +1147,7 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
             u[k] = regs.dual[k][(long)i * r + c];
         }
     }
-    a = A[(long)i * r + c];
+    float a = A[(long)i * r + c];
     {  // fp64 per-segment partial Grams / right-hand sides of this slab, fixed order
         constexpr int SGB = 4;  // segments fetched per batch: independent clamped loads, summed in segment order
         for (int sb = sg0; sb < sg1; sb += SGB) {
@@ -1194,15 +1167,6 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
                     rhs_pre += rv[q];
                 }
         }
-    }
-    }
-    if (pre_out != nullptr) {
-#pragma unroll
-        for (int k = 0; k < MCL_MAX_REGS; ++k) pre_out->z[k] = z[k], pre_out->u[k] = u[k];
-        pre_out->a = a;
-#pragma unroll
-        for (int j = 0; j < RL; ++j) pre_out->btbv[j] = btbv[j];
-        return;
     }
     if (rhs_lds != nullptr) {
         // k_A_finish_rows_wide: the slab's other wave(s) stream its partials of M while this wave builds and inverts the
@@ -1455,220 +1419,6 @@ __global__ __launch_bounds__(256) void k_A_finish_rows_wide(float *__restrict__ 
     a_finish_rows_slab<RP>(i, lane, BtB, CtC, r, scale, l2, constant, rho_max, rhoA, LinvA, A, regs, inner, fused_inner, e1,
                            diag_row, next_B, l2_B, n_regs_B, rhoB, LinvB, slab_seg_ptr, seg_rhs, seg_btb, rhsA_out, F,
                            &part[sl][0][0]);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// C-phase finish AND A-phase finish in ONE launch (the sweep path, rank <= 16, K <= 256, row-separable penalties on C and A):
-// the dependent tail of an iteration was k_reduce_frag -> k_C_finish_multi -> k_A_finish_rows_wide, each ~3.5 us of launch
-// and drain before its first useful instruction.  Every workgroup of the A-phase finish needs the WHOLE new C (C^T C for
-// its systems, all K rows for rhs_i = coldot(M_i, C)) and nothing else from the C-phase - and the C-phase finish is tiny
-// (K x r rows, five inner iterations): so every workgroup computes it itself, redundantly - same inputs, same instructions,
-// same bits (as the workgroups of k_C_finish_multi already do with the r x r system) - and keeps C in LDS; workgroup 0 also
-// writes C, its ADMM variables, C^T C, the fragment image and the diagnostics row.  No cross-workgroup traffic, no ticket.
-//   stage 0  the loads that do not depend on C: the slab's M partial (stream waves: 16 KB in registers), the slab's
-//            B^T B / a_i / aux / dual (system waves), the rows of [G | R] and of C's ADMM variables (all waves)
-//   stage 1  wave 0: the C system (trace, shift, Gauss-Jordan in registers) -> L^-1 in LDS
-//   stage 2  all waves: the rows of C, one 16-row block at a time from the preloaded registers (rows_fused_tile) -> C in LDS
-//   stage 3  C^T C on the fp64 MFMA (fixed order), the fragment-order image of C in LDS
-//   stage 4  the A-phase finish of the workgroup's slab(s) as in k_A_finish_rows_wide, C^T C and C read from LDS
-// The ADMM variables of C are READ from a snapshot (taken by a spare workgroup of k_reduce_frag): workgroup 0 overwrites the
-// caller's buffers while other workgroups may still be loading.
-// ---------------------------------------------------------------------------------------------------------
-struct CSide {
-    const double *GR;
-    int K, inner, KCfrag;
-    float scale, l2;
-    float *rhoC, *LinvC, *C, *CtC, *Cfrag;
-    double *CtC64, *diag_row;
-    RegSet load, store;  // load: aux / dual point at the snapshot
-};
-
-template <int RP, int SPB, int NREG, bool VEC>
-__global__ __launch_bounds__(256) void k_CA_finish(CSide P, float *__restrict__ BtB, int I, int r, float scale, float l2,
-                                                   const float *__restrict__ rho_max, float *__restrict__ rhoA,
-                                                   float *__restrict__ LinvA, float *__restrict__ A, RegSet regs, int inner,
-                                                   double *__restrict__ e1, double *__restrict__ diag_row, int next_B,
-                                                   float l2_B, int n_regs_B, float *__restrict__ rhoB,
-                                                   float *__restrict__ LinvB, const int *__restrict__ slab_seg_ptr,
-                                                   const double *__restrict__ seg_btb, float *__restrict__ rhsA_out, AFuse F) {
-    MCL_GATE(regs.gate);
-    constexpr int RL = GJRows<RP>::RL;
-    constexpr int MAXB = 4;             // 16-row blocks of C per wave: K <= 256
-    extern __shared__ float ca_lds[];   // [C row-major: K x r][C fragment image: MS]
-    __shared__ float Ls[256];
-    __shared__ double ctc_s[256];
-    __shared__ double slots[4][256];
-    __shared__ double dsm[4][DIAG_COLS];
-    __shared__ double part[SPB][3][32];
-    __shared__ float rho_s;
-    const int K = P.K;
-    float *Cs = ca_lds, *Cfs = ca_lds + ((K * r + 3) & ~3);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int WPS = 4 / SPB;
-    const int sl = wave / WPS, role = wave % WPS;  // role 0: the slab's system wave
-    const int i = blockIdx.x * SPB + sl;
-    const bool writer = blockIdx.x == 0;
-
-    // ---- stage 0: everything that does not wait for C
-    const int nq = F.MS / 256;  // 1 KB fragments of a partial: 16 (K > 128) or 8
-    f32x4 mv[16];
-    int sgA = 0, sgB = 0;
-    if (role != 0 && i < I) {
-        sgA = slab_seg_ptr[i] + role - 1, sgB = slab_seg_ptr[i + 1];
-        const float *mp = F.Mpart + (long)min(sgA, sgB - 1) * F.MS;
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if (q < nq) mv[q] = *reinterpret_cast<const f32x4 *>(mp + 256 * q + 4 * lane);
-    }
-    APre<RL> apre;
-    if (role == 0 && i < I)
-        a_finish_rows_slab<RP>(i, lane, BtB, ctc_s, r, scale, l2, 0, rho_max, rhoA, LinvA, A, regs, inner, 1, e1, diag_row, next_B,
-                               l2_B, n_regs_B, rhoB, LinvB, slab_seg_ptr, nullptr, seg_btb, rhsA_out, F, nullptr, &apre, nullptr);
-    const int n_blk = (K + 15) >> 4;
-    RowBlock<1, NREG, VEC> cpre[MAXB];
-#pragma unroll
-    for (int b = 0; b < MAXB; ++b) {
-        const int blk = wave + 4 * b;
-        if (blk < n_blk) {
-            const int nr = min(16, K - 16 * blk);
-            cpre[b].load(lane, (long)16 * blk + ((lane & 15) < nr ? (lane & 15) : 0), r, nullptr, P.GR + (long)r * r, P.load);
-        }
-    }
-    // ---- stage 1: the C system (as in k_C_finish_multi)
-    if (wave == 0) {
-        constexpr int RPC = 16, RLC = GJRows<RPC>::RL;
-        const int cc = lane % RPC, g = lane / RPC;
-        const bool act = cc < r;
-        const int cl = act ? cc : 0;
-        double gv[RLC];
-        double tr = 0.0;
-#pragma unroll
-        for (int j = 0; j < RLC; ++j) {
-            const int d = g * RLC + j;
-            gv[j] = P.GR[(d < r ? d : r - 1) * r + cl];
-        }
-#pragma unroll
-        for (int j = 0; j < RLC; ++j)
-            if (act && g * RLC + j == cc) tr = gv[j];
-        tr = wave_sum(tr);
-        const float rho = (float)(0.5 * tr * P.scale);
-        const double shift = (double)rho * NREG + (double)P.l2;
-        double col[RLC];
-#pragma unroll
-        for (int j = 0; j < RLC; ++j) {
-            const int d = g * RLC + j;
-            double v = (d == cc) ? 1.0 : 0.0;
-            if (act && d < r) v = gv[j] + (d == cc ? shift : 0.0);
-            col[j] = v;
-        }
-        gj_inverse_rows<RPC>(col, r, lane);
-#pragma unroll
-        for (int j = 0; j < RLC; ++j) {
-            const int d = g * RLC + j;
-            if (act && d < r) {
-                Ls[d * r + cc] = (float)col[j];
-                if (writer) P.LinvC[d * r + cc] = (float)col[j];
-            }
-        }
-        if (lane == 0) {
-            rho_s = rho;
-            if (writer) P.rhoC[0] = rho;
-        }
-    }
-    __syncthreads();
-    // ---- stage 2: the rows of C
-    double dgs[DIAG_COLS];
-#pragma unroll
-    for (int k = 0; k < DIAG_COLS; ++k) dgs[k] = 0.0;
-#pragma unroll
-    for (int b = 0; b < MAXB; ++b) {
-        const int blk = wave + 4 * b;
-        if (blk < n_blk) {  // wave-uniform
-            double dg[DIAG_COLS];
-            rows_fused_tile<1, NREG, VEC>(lane, (long)16 * blk, min(16, K - 16 * blk), rho_s, Ls, nullptr, nullptr, P.C, Cs, P.load, r,
-                                          P.inner, dg, P.GR + (long)r * r, &cpre[b], &P.store, writer);
-#pragma unroll
-            for (int k = 0; k < 2 + NREG; ++k) dgs[k] += dg[k];
-        }
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 2 + NREG; ++k) dsm[wave][k] = dgs[k];
-    }
-    __syncthreads();
-    if (writer && threadIdx.x < 2 + NREG)
-        P.diag_row[threadIdx.x] = (dsm[0][threadIdx.x] + dsm[1][threadIdx.x]) + (dsm[2][threadIdx.x] + dsm[3][threadIdx.x]);
-    // ---- stage 3: C^T C (fp64 MFMA over all rows, groups of 4 rows interleaved over the waves) and the fragment image
-    {
-        typedef double f64x4 __attribute__((ext_vector_type(4)));
-        const int rsub = lane >> 4, c16 = lane & 15;
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-        const int n_grp = (K + 3) >> 2;
-        for (int gq = wave; gq < n_grp; gq += 4) {
-            const int rl = 4 * gq + rsub;
-            const double y = (rl < K && c16 < r) ? (double)Cs[rl * r + c16] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) slots[wave][(rsub + 4 * v) * 16 + c16] = acc[v];
-        for (int idx = threadIdx.x; idx < F.MS; idx += 256) {
-            const int m = idx & 3, ln = (idx >> 2) & 63, ch = idx >> 8;  // (NB = 1: chunk = idx >> 8)
-            const int k = 16 * ch + 4 * (ln >> 4) + m, col = ln & 15;
-            const float v = (k < K && col < r) ? Cs[k * r + col] : 0.f;
-            Cfs[idx] = v;
-            if (writer) P.Cfrag[idx] = v;
-        }
-        if (writer)
-            for (long idx = F.MS + threadIdx.x; idx < (long)P.KCfrag * 1024; idx += 256) P.Cfrag[idx] = 0.f;
-        __syncthreads();
-        const int e = threadIdx.x, a = e >> 4, b = e & 15;
-        const double t = (slots[0][e] + slots[1][e]) + (slots[2][e] + slots[3][e]);
-        if (a < r && b < r) {
-            ctc_s[a * r + b] = t;
-            if (writer) P.CtC64[a * r + b] = t, P.CtC[a * r + b] = (float)t;
-        }
-    }
-    __syncthreads();
-    // ---- stage 4: the A-phase finish
-    if (role != 0) {
-        double pa[2] = {0.0, 0.0};
-        auto dot4 = [](const f32x4 m, const f32x4 cfr) {
-            double d = (double)m[0] * (double)cfr[0];
-            d = fma((double)m[1], (double)cfr[1], d);
-            d = fma((double)m[2], (double)cfr[2], d);
-            return fma((double)m[3], (double)cfr[3], d);
-        };
-        if (i < I) {
-            for (int sg = sgA; sg < sgB; sg += WPS - 1) {
-                if (sg != sgA) {  // (more than one partial per stream wave: the later ones are loaded here)
-                    const float *mp = F.Mpart + (long)sg * F.MS;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        if (q < nq) mv[q] = *reinterpret_cast<const f32x4 *>(mp + 256 * q + 4 * lane);
-                }
-#pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    if (q < nq) pa[q & 1] += dot4(mv[q], *reinterpret_cast<const f32x4 *>(Cfs + 256 * q + 4 * lane));
-            }
-        }
-        double a0 = pa[0] + pa[1];
-        a0 += __shfl_xor(a0, 16);
-        a0 += __shfl_xor(a0, 32);
-        if (lane < 16) {
-            part[sl][role - 1][lane] = a0, part[sl][role - 1][16 + lane] = 0.0;
-            if (SPB == 2) part[sl][1][lane] = part[sl][1][16 + lane] = part[sl][2][lane] = part[sl][2][16 + lane] = 0.0;
-        }
-        __syncthreads();  // pairs with the barrier of the system wave behind its Gauss-Jordan (a_finish_rows_slab)
-        return;
-    }
-    if (i >= I) {  // the odd slab out of a two-slab workgroup
-        __syncthreads();
-        return;
-    }
-    AFuse F2 = F;
-    F2.ctc_parts = 0;  // C^T C is complete, in LDS
-    a_finish_rows_slab<RP>(i, lane, BtB, ctc_s, r, scale, l2, 0, rho_max, rhoA, LinvA, A, regs, inner, 1, e1, diag_row, next_B, l2_B,
-                           n_regs_B, rhoB, LinvB, slab_seg_ptr, nullptr, seg_btb, rhsA_out, F2, &part[sl][0][0], nullptr, &apre);
 }
 
 // rho_i of the A-phase alone (needed before the systems when the feasibility penalty is constant)
@@ -2458,71 +2208,6 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     MCL_CHECK_HIP(c, hipGetLastError());
     c->variant[MCL_PROF_A_FINISH] = !rows_kernel ? "k_A_finish" : (c->a_rhs_wide ? (c->a_rhs_pairs ? "k_A_finish_rows_wide<SPB=2>" : "k_A_finish_rows_wide<SPB=1>") : "k_A_finish_rows");
     c->ctc_parts = 0;  // the rows kernels wrote the totals
-    c->b_systems_valid = (next_B != 0);
-    return 0;
-}
-
-// ---- C-phase finish + A-phase finish in one launch (k_CA_finish) -------------------------------------------------------
-static bool ca_wide1(const mcl_context *c) { return c->n_parts <= 8 * c->I && (c->n_parts > c->I || c->I <= 512); }
-static bool ca_pairs(const mcl_context *c) { return !ca_wide1(c) && c->n_parts <= c->I && c->I <= 1024; }
-
-bool mcl_ca_merge_shape_ok(const mcl_context *c) {
-    if (c->sw.no_ca_merge || c->sw.a_finish_cols || c->sw.no_a_fusion || c->sw.no_a_wide || c->sw.no_fused_c) return false;
-    if (!c->sweep_planned || c->exact || c->snapC == nullptr || c->I == 0) return false;
-    if (c->NB != 1 || !(c->RP == 8 || c->RP == 16)) return false;
-    if (c->K > 256 || c->K % 4 != 0 || mcl_sweep_KC(c) * 1024 > 4096) return false;  // C and its fragment image in LDS; <= 4 row blocks per wave
-    if (c->opt.inner_n_iter_max <= 0 || c->opt.constant_A) return false;
-    if (c->regs[2].n < 1 || c->regs[2].n > 2 || !mcl_mode_is_row_separable(c, 2) || !mcl_mode_is_row_separable(c, 0)) return false;
-    return ca_wide1(c) || ca_pairs(c);
-}
-
-template <int RP, int SPB, int NREG>
-static int launch_CA_t(mcl_context *c, const CSide &P, bool vec, const AFuse &F, int next_B) {
-    const dim3 grid((unsigned)((c->I + SPB - 1) / SPB)), block(256);
-    const size_t sm = sizeof(float) * (size_t)(((c->K * c->r + 3) & ~3) + F.MS);
-#define MCL_CA(VEC_)                                                                                                            \
-    hipLaunchKernelGGL((k_CA_finish<RP, SPB, NREG, VEC_>), grid, block, sm, c->stream, P, c->BtB, (int)c->I, c->r,               \
-                       (float)c->opt.feasibility_penalty_scale, (float)c->opt.l2_penalty[0], c->rho_max, c->rhoA, c->LinvA, c->A, \
-                       c->regs[0], c->opt.inner_n_iter_max, c->e1, c->diagA_row, next_B, (float)c->opt.l2_penalty[1], c->regs[1].n, \
-                       c->rhoB, c->LinvB, (const int *)c->slab_part_ptr, (const double *)c->part_btb, c->rhsA, F)
-    if (vec) MCL_CA(true);
-    else MCL_CA(false);
-#undef MCL_CA
-    MCL_CHECK_HIP(c, hipGetLastError());
-    return 0;
-}
-
-int mcl_launch_CA_finish(mcl_context *c) {
-    const RegSet &rc = c->regs[2];
-    CSide P{};
-    P.GR = c->GR, P.K = (int)c->K, P.inner = c->opt.inner_n_iter_max, P.KCfrag = mcl_cfrag_chunks(c);
-    P.scale = (float)c->opt.feasibility_penalty_scale, P.l2 = (float)c->opt.l2_penalty[2];
-    P.rhoC = c->rhoC, P.LinvC = c->LinvC, P.C = c->C, P.CtC = c->CtC, P.Cfrag = c->Cfrag, P.CtC64 = c->CtC64, P.diag_row = c->diagC_tile;
-    P.store = rc, P.load = rc;
-    bool vec = (c->r % 4 == 0) && ((reinterpret_cast<uintptr_t>(c->C) & 15) == 0) && ((c->r * c->r) % 4 == 0);
-    for (int k = 0; k < rc.n; ++k) {
-        P.load.aux[k] = c->snapC + (long)(2 * k) * c->K * c->r;
-        P.load.dual[k] = c->snapC + (long)(2 * k + 1) * c->K * c->r;
-        vec = vec && ((reinterpret_cast<uintptr_t>(rc.aux[k]) & 15) == 0) && ((reinterpret_cast<uintptr_t>(rc.dual[k]) & 15) == 0) &&
-              ((reinterpret_cast<uintptr_t>(P.load.aux[k]) & 15) == 0) && ((reinterpret_cast<uintptr_t>(P.load.dual[k]) & 15) == 0);
-    }
-    const bool b_needs_64 = mcl_rows64(c) || c->exact;
-    const int next_B = (!c->opt.constant_B && c->regs[1].n > 0 && !c->sw.no_next_b) ? 1 : 0;
-    AFuse F{};
-    F.Mpart = c->Mpart, F.Cfrag = c->CfragS, F.NBm = c->NB, F.MS = mcl_sweep_KC(c) * 64 * 16 * c->NB;
-    F.LinvB64 = b_needs_64 ? c->LinvB64 : nullptr;
-    F.wide_inner = 0;
-    const bool pairs = ca_pairs(c);
-    c->a_rhs_pairs = pairs;
-    int rc_ = 0;
-#define MCL_CA_N(RP_, SPB_) (rc.n == 1 ? launch_CA_t<RP_, SPB_, 1>(c, P, vec, F, next_B) : launch_CA_t<RP_, SPB_, 2>(c, P, vec, F, next_B))
-    if (c->RP == 8) rc_ = pairs ? MCL_CA_N(8, 2) : MCL_CA_N(8, 1);
-    else rc_ = pairs ? MCL_CA_N(16, 2) : MCL_CA_N(16, 1);
-#undef MCL_CA_N
-    if (rc_) return rc_;
-    char buf[96];
-    snprintf(buf, sizeof buf, "k_CA_finish<RP=%d,SPB=%d,NREG=%d> (C-phase finish + A-phase finish)", c->RP, pairs ? 2 : 1, rc.n);
-    c->variant[MCL_PROF_A_FINISH] = buf;
     c->b_systems_valid = (next_B != 0);
     return 0;
 }

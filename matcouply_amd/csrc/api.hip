@@ -125,7 +125,6 @@ int64_t plan(mcl_context *c, char *base) {
     c->diag_sums = b.take<double>(3 * DIAG_COLS + 2);
     c->xsq_part = b.take<double>(1024);
     c->x_sq = b.take<double>(1);
-    c->snapC = c->sweep_planned ? b.take<float>(2 * MCL_MAX_REGS * K * r) : nullptr;
     c->gate = b.take<int>(4);
     c->mute_status = b.take<int>(4);
     c->stop_state = b.take<double>(4);
@@ -195,7 +194,7 @@ void read_switches(mcl_switches &w) {
     w.a_finish_cols = flag("MCL_A_FINISH_COLS"), w.xc_norow = flag("MCL_XC_NOROW");
     w.uni_noprune = flag("MCL_UNI_NOPRUNE"), w.stats_reduce = flag("MCL_STATS_REDUCE");
     w.no_rows64 = flag("MCL_NO_ROWS64"), w.no_uni_coop = flag("MCL_NO_UNI_COOP");
-    w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_a_wide = flag("MCL_NO_A_WIDE"), w.no_bseg_groups = flag("MCL_NO_BSEG_GROUPS"), w.no_sweep_half = flag("MCL_NO_SWEEP_HALF"), w.no_x_nt = flag("MCL_NO_X_NT"), w.x_nt_mb = num("MCL_X_NT_MB", 0), w.no_multi_c = flag("MCL_NO_MULTI_C"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1"), w.no_ca_merge = flag("MCL_NO_CA_MERGE");
+    w.no_a_fusion = flag("MCL_NO_A_FUSION"), w.no_a_wide = flag("MCL_NO_A_WIDE"), w.no_bseg_groups = flag("MCL_NO_BSEG_GROUPS"), w.no_sweep_half = flag("MCL_NO_SWEEP_HALF"), w.no_x_nt = flag("MCL_NO_X_NT"), w.x_nt_mb = num("MCL_X_NT_MB", 0), w.no_multi_c = flag("MCL_NO_MULTI_C"), w.no_diag_defer = flag("MCL_NO_DIAG_DEFER"), w.xc_depth1 = flag("MCL_XC_DEPTH1");
     w.seg_rows = num("MCL_SEG_ROWS", 0), w.bseg_rows = num("MCL_BSEG_ROWS", 0);
     w.xc_waves = num("MCL_XC_WAVES", 0), w.xt_waves = num("MCL_XT_WAVES", 0), w.sweep_waves = num("MCL_SWEEP_WAVES", 0);
     w.xc_dbg = num("MCL_XC_DBG", 0), w.xt_dbg = num("MCL_XT_DBG", 0), w.xt_depth = num("MCL_XT_DEPTH", 0);
@@ -218,7 +217,7 @@ std::string switches_in_env() {
         "MCL_UNI_NOPRUNE", "MCL_STATS_REDUCE", "MCL_NO_ROWS64", "MCL_NO_UNI_COOP", "MCL_NO_A_FUSION", "MCL_NO_A_WIDE", "MCL_NO_BSEG_GROUPS",
         "MCL_NO_SWEEP_HALF", "MCL_NO_X_NT", "MCL_X_NT_MB", "MCL_NO_MULTI_C", "MCL_NO_DIAG_DEFER", "MCL_XC_DEPTH1", "MCL_SEG_ROWS",
         "MCL_BSEG_ROWS", "MCL_XC_WAVES", "MCL_XT_WAVES", "MCL_SWEEP_WAVES", "MCL_XC_DBG", "MCL_XT_DBG", "MCL_XT_DEPTH",
-        "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT", "MCL_EXACT", "MCL_NO_WIDE", "MCL_NO_CA_MERGE"};
+        "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT", "MCL_EXACT", "MCL_NO_WIDE"};
     std::string out;
 #ifdef MCL_NO_ENV_SWITCHES
     return out;
@@ -875,7 +874,6 @@ int mcl_update_B(mcl_context *c) {
 
 // ---- C-phase -------------------------------------------------------------------------------------------
 int mcl_update_C_local(mcl_context *c) {
-    if (c) c->ca_snap_valid = false;  // (set again by the sweep path's reduction kernel when it takes the snapshot)
     if (c && c->diag_pending && ready_noflush(c) == 0 && !c->b_finish_pending && c->mseg_valid && c->grpart_valid)
         return mcl_launch_reduce_weighted(c);  // ... with the deferred diagnostics reduction on its spare workgroup
     if (int rc = ready(c)) return rc;
@@ -1030,35 +1028,6 @@ int mcl_update_A(mcl_context *c) {
     return mcl_A_finish(c);
 }
 
-// mcl_update_C_finish + mcl_update_A in ONE call - and, on the one-pass path with a small C-phase, in ONE kernel
-// (admm.hip: k_CA_finish): every workgroup of the A-phase finish recomputes the (tiny) C-phase finish itself instead of
-// waiting for a launch of its own.  Same results as the two calls, bit for bit; falls back to them whenever the merged
-// kernel does not apply.
-int mcl_update_C_finish_and_A(mcl_context *c) {
-    if (int rc = ready(c)) return rc;
-    if (c->ca_snap_valid && c->mseg_valid && mcl_ca_merge_shape_ok(c)) {
-        c->ca_snap_valid = false;
-        // the bookkeeping of mcl_update_C_finish, of mcl_A_begin (sweep branch) and of mcl_A_finish
-        c->xc_valid = false;
-        c->ctc_valid = true;
-        c->ctc_parts = 0;
-        c->cfrag_valid = true;
-        c->diag_valid[2] = true;
-        c->diag_rows[2] = 1;
-        c->use_seg_gram = true, c->seg_from_sweep = true, c->a_rhs_from_M = true, c->a_rhs_wide = true;
-        c->grpart_valid = false;
-        ProfScope prof_(c, MCL_PROF_A_FINISH);
-        if (int rc = mcl_launch_CA_finish(c)) return rc;  // sets a_rhs_pairs, b_systems_valid
-        c->e1_valid = true;
-        c->e1_from_raw_gram = false;
-        c->diag_valid[0] = true;
-        return 0;
-    }
-    c->ca_snap_valid = false;
-    if (int rc = mcl_update_C_finish(c)) return rc;
-    return mcl_update_A(c);
-}
-
 int mcl_A_factor(mcl_context *c) {
     if (int rc = ready(c)) return rc;
     if (c->use_seg_gram) return fail(c, "internal: mcl_A_factor needs the assembled per-slab Gram");
@@ -1167,14 +1136,10 @@ int mcl_iterate(mcl_context *c, int32_t n_iter, int32_t update_A, int32_t update
             if (int rc = mcl_update_B(c)) return rc;
         if (update_C) {
             if (int rc = mcl_update_C_local(c)) return rc;
-            if (update_A) {
-                if (int rc = mcl_update_C_finish_and_A(c)) return rc;
-            } else if (int rc = mcl_update_C_finish(c)) {
-                return rc;
-            }
-        } else if (update_A) {
-            if (int rc = mcl_update_A(c)) return rc;
+            if (int rc = mcl_update_C_finish(c)) return rc;
         }
+        if (update_A)
+            if (int rc = mcl_update_A(c)) return rc;
         if (diag_ring) {
             // between two iterations the reduction of the diagnostics tables is deferred: it rides on the next C-phase
             // reduction kernel when that is the sweep path's, and is issued on its own otherwise
@@ -1192,7 +1157,6 @@ int mcl_iterate(mcl_context *c, int32_t n_iter, int32_t update_A, int32_t update
 // ones, the host-side flags describe iterations that did not happen - the factors and ADMM variables are exact.
 static void forget_byproducts(mcl_context *c) {
     c->b_finish_pending = false;
-    c->ca_snap_valid = false;
     c->diag_pending = c->diag_crossed_sweep = false;
     c->step_fuse = c->step_stats = false;
     c->b_systems_valid = false;
@@ -1274,10 +1238,9 @@ int mcl_run(mcl_context *c, int32_t n_iter_max, int32_t update_A, int32_t update
         if (update_B) rc = mcl_update_B(c);
         if (rc == 0 && update_C) {
             rc = mcl_update_C_local(c);
-            if (rc == 0) rc = update_A ? mcl_update_C_finish_and_A(c) : mcl_update_C_finish(c);
-        } else if (rc == 0 && update_A) {
-            rc = mcl_update_A(c);
+            if (rc == 0) rc = mcl_update_C_finish(c);
         }
+        if (rc == 0 && update_A) rc = mcl_update_A(c);
         if (rc == 0) rc = mcl_prepare_diag_tables(c);
         if (rc == 0)
             rc = mcl_launch_diag_verdict(c, diag_ring + (int64_t)it * MCL_DIAG_LEN, rule, it,

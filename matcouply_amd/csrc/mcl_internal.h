@@ -70,7 +70,7 @@ struct mcl_switches {
     bool no_stack_fusion = false, no_solve_stats = false, no_next_b = false, no_fused_gram = false, no_fused_c = false;
     bool a_finish_cols = false, xc_norow = false, uni_noprune = false, stats_reduce = false;
     bool no_rows64 = false, no_uni_coop = false, no_wide = false;
-    bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_x_nt = false, no_sweep_half = false, no_multi_c = false, no_diag_defer = false, xc_depth1 = false, no_ca_merge = false;
+    bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_x_nt = false, no_sweep_half = false, no_multi_c = false, no_diag_defer = false, xc_depth1 = false;
     int x_nt_mb = 0, seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
     int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
     int exact = -1;  // MCL_EXACT: 1 / 0 force the exact-products mode on / off (default -1: by problem size, mcl_exact_mode)
@@ -186,10 +186,6 @@ struct mcl_context {
     // deferred diagnostics (mcl_diagnostics_deferred): the reduction of the tables rides on a spare workgroup of the NEXT
     // C-phase reduction kernel instead of a launch of its own; the sweep alternates between two B tables so that the
     // tables of iteration t stay intact while the sweep of t + 1 writes its own
-    // C-phase finish + A-phase finish in one launch (admm.hip: k_CA_finish, entry point mcl_update_C_finish_and_A).  snapC: the
-    // snapshot of C's ADMM variables the merged kernel reads (taken by a spare workgroup of the C-phase reduction kernel)
-    bool ca_snap_valid = false;
-    float *snapC = nullptr;  // [2 MCL_MAX_REGS, K, r]
     double *diagB_bufs[2] = {nullptr, nullptr};
     int diagB_parity = 0;
     // gated runs (mcl_run): device state of the stopping rule
@@ -340,8 +336,6 @@ int mcl_launch_C_solve_f64(mcl_context *c);                      // penalty-free
 int mcl_launch_C_finish_fused(mcl_context *c);
 int mcl_launch_A_rho(mcl_context *c);
 int mcl_launch_A_finish(mcl_context *c, bool fused_inner);
-bool mcl_ca_merge_shape_ok(const mcl_context *c);                // admm.hip: the problem / penalties have a k_CA_finish form
-int mcl_launch_CA_finish(mcl_context *c);                        // admm.hip: C-phase finish + A-phase finish in one launch
 int mcl_launch_A_rows_solve(mcl_context *c);
 int mcl_launch_A_e1(mcl_context *c, bool btb_is_q);
 int mcl_launch_rows_diag(mcl_context *c, int mode);

@@ -731,27 +731,12 @@ static __device__ void diag_piggy_block(const DiagPiggy &P, int which) {
     }
 }
 
-// One more spare workgroup takes the snapshot of C's auxiliary / dual variables that k_CA_finish (admm.hip) reads: its
-// workgroup 0 overwrites the caller's buffers while the other workgroups may still be loading them.
-struct SnapCopy {
-    int n;  // arrays (0: no snapshot, no spare workgroup)
-    const float *src[2 * MCL_MAX_REGS];
-    float *dst;  // [n, count]
-    int count;
-};
-
 template <int EL>  // elements per block (64: 256-byte wave loads, PS / 64 blocks; 32: twice the blocks for small PS)
 __global__ __launch_bounds__(1024) void k_reduce_frag(const float *__restrict__ Mpart, const float *__restrict__ GRpart,
                                                       int n_part, int K, int r, int NB, int MS, double *__restrict__ GR,
-                                                      DiagPiggy piggy, SnapCopy snap) {
-    const int n_snap = snap.n > 0 ? 1 : 0;
-    if (n_snap && blockIdx.x == gridDim.x - 1) {  // the last workgroup: the snapshot
-        for (int a = 0; a < snap.n; ++a)
-            for (int e = threadIdx.x; e < snap.count; e += 1024) snap.dst[(long)a * snap.count + e] = snap.src[a][e];
-        return;
-    }
-    if (piggy.out != nullptr && (int)blockIdx.x >= (int)gridDim.x - n_snap - MCL_PIGGY_BLOCKS) {  // the spare workgroups in front of it
-        diag_piggy_block(piggy, (int)(gridDim.x - n_snap - 1 - blockIdx.x));
+                                                      DiagPiggy piggy) {
+    if (piggy.out != nullptr && blockIdx.x >= gridDim.x - MCL_PIGGY_BLOCKS) {  // the spare workgroups
+        diag_piggy_block(piggy, (int)(gridDim.x - 1 - blockIdx.x));
         return;
     }
     constexpr int NG = 1024 / EL;  // interleaved groups of partials
@@ -996,24 +981,18 @@ int mcl_launch_reduce_weighted(mcl_context *c) {
         c->diag_pending = false;
         c->diag_crossed_sweep = false;
     }
-    SnapCopy snap{};
-    if (mcl_ca_merge_shape_ok(c)) {  // the C-phase / A-phase finish may run as one kernel: it reads C's ADMM variables from a snapshot
-        for (int k = 0; k < c->regs[2].n; ++k) snap.src[2 * k] = c->regs[2].aux[k], snap.src[2 * k + 1] = c->regs[2].dual[k];
-        snap.n = 2 * c->regs[2].n, snap.dst = c->snapC, snap.count = (int)(c->K * c->r);
-    }
-    c->ca_snap_valid = snap.n > 0;
-    const int blocks = (MS + W * W + el - 1) / el + (piggy.out ? MCL_PIGGY_BLOCKS : 0) + (snap.n > 0 ? 1 : 0);
+    const int blocks = (MS + W * W + el - 1) / el + (piggy.out ? MCL_PIGGY_BLOCKS : 0);
     ProfScope prof(c, MCL_PROF_REDUCE);
     c->variant[MCL_PROF_REDUCE] = "k_reduce_frag<" + std::to_string(el) + ">";
     if (el == 64)
         hipLaunchKernelGGL(k_reduce_frag<64>, dim3(blocks), dim3(1024), 0, c->stream, c->Mpart, c->GRpart, c->n_grpart,
-                           (int)c->K, c->r, c->NB, MS, c->GR, piggy, snap);
+                           (int)c->K, c->r, c->NB, MS, c->GR, piggy);
     else if (el == 32)
         hipLaunchKernelGGL(k_reduce_frag<32>, dim3(blocks), dim3(1024), 0, c->stream, c->Mpart, c->GRpart, c->n_grpart,
-                           (int)c->K, c->r, c->NB, MS, c->GR, piggy, snap);
+                           (int)c->K, c->r, c->NB, MS, c->GR, piggy);
     else
         hipLaunchKernelGGL(k_reduce_frag<16>, dim3(blocks), dim3(1024), 0, c->stream, c->Mpart, c->GRpart, c->n_grpart,
-                           (int)c->K, c->r, c->NB, MS, c->GR, piggy, snap);
+                           (int)c->K, c->r, c->NB, MS, c->GR, piggy);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

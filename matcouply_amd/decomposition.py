@@ -834,17 +834,12 @@ def cmf_aoadmm(
                     break
         eng.B_end()
 
-    def do_update_C(then_A=False):
-        """the C-phase; then_A: ... and the A-phase behind it in the same call (one kernel where the engine has the merged
-        form, mcl_update_C_finish_and_A) - returns True when it did take the A-phase along"""
+    def do_update_C():
         gr = eng.update_C_local()
         all_reduce(gr)
         if not has_ext[2]:
-            if then_A and hasattr(eng, "update_C_finish_and_A"):
-                eng.update_C_finish_and_A()
-                return True
             eng.update_C_finish()
-            return False
+            return
         eng.C_begin()
         n_it = inner_n_iter_max if native[2] else min(1, inner_n_iter_max)
         for _ in range(n_it):
@@ -908,9 +903,6 @@ def cmf_aoadmm(
             ext_aux[(0, k)] = own.clone()  # this rank's rows of the object the penalty returned (what return_admm_vars hands out)
         nat.dual.copy_(eng.A - (z - nat.dual))
         nat.aux.copy_(z)
-
-    # the A-phase needs nothing from the host between the C-phase finish and itself: it may ride in the same engine call
-    plain_A = not (sharded_ball_A or any(gathered_A) or has_ext[0] or needs_A_steps)
 
     def do_update_A():
         if sharded_ball_A or any(gathered_A):
@@ -1059,8 +1051,9 @@ def cmf_aoadmm(
         for it in range(n_iter_max):
             if update_B_is:
                 do_update_B()
-            took_A = do_update_C(then_A=update_A and plain_A) if update_C else False
-            if update_A and not took_A:
+            if update_C:
+                do_update_C()
+            if update_A:
                 do_update_A()
             if ring is not None:  # the table reduction rides on the next iteration's C-phase reduction kernel
                 eng.diagnostics_deferred(include_replicated=(rank_id == 0), out=ring[it])
@@ -1088,8 +1081,9 @@ def cmf_aoadmm(
                 for j in range(n_now):
                     if update_B_is:
                         do_update_B()
-                    took_A = do_update_C(then_A=update_A and plain_A) if update_C else False
-                    if update_A and not took_A:
+                    if update_C:
+                        do_update_C()
+                    if update_A:
                         do_update_A()
                     eng.diagnostics(include_replicated=(rank_id == 0), out=ring[base + j])
                     all_reduce(ring[base + j])
@@ -1160,8 +1154,9 @@ def cmf_aoadmm(
         for it in range(n_iter_max):
             if update_B_is:
                 do_update_B()
-            took_A = do_update_C(then_A=update_A and plain_A) if update_C else False
-            if update_A and not took_A:
+            if update_C:
+                do_update_C()
+            if update_A:
                 do_update_A()
 
             if not (stop.active or return_errors):

@@ -238,53 +238,3 @@ def test_shapes_without_a_sweep_instantiation_keep_the_two_pass_path():
         eng.update_B()
         assert eng.kernel_variant(_engine_mod.PROF_SWEEP) == "", (J, K, r, eng.kernel_variant(_engine_mod.PROF_SWEEP))
         eng.close()
-
-
-CA_CASES = {
-    # name: (I, J, K, r, penalties on C, the workgroup form expected)
-    "c2_like": (256, 256, 128, 8, [NN], "SPB=1"),
-    "c3_pairs": (600, 128, 256, 16, [{"kind": "l1", "reg_strength": 0.1, "non_negativity": True}], "SPB=2"),
-    "c3_8th": (128, 512, 256, 16, [{"kind": "l1", "reg_strength": 0.1, "non_negativity": True}], "SPB=1"),
-    "r12_two_penalties": (40, 300, 200, 12, [{"kind": "l1", "reg_strength": 0.02, "non_negativity": True},
-                                            {"kind": "box", "min_val": 0.0, "max_val": 1.5}], "SPB=1"),
-    "r5_k64": (70, 192, 64, 5, [NN], "SPB=1"),
-}
-
-
-@pytest.mark.parametrize("name", sorted(CA_CASES))
-def test_merged_C_and_A_finish_equals_the_two_calls(name):
-    """mcl_update_C_finish_and_A (one kernel, k_CA_finish: every workgroup of the A-phase finish recomputes the small C-phase
-    finish itself) against mcl_update_C_finish + mcl_update_A: every factor, ADMM variable, by-product and diagnostic sum
-    must be the SAME BITS - the merged kernel runs the same instructions on the same inputs."""
-    import torch
-
-    import bench
-    from matcouply_amd import _engine as E
-
-    I, J, K, r, regs_C, form = CA_CASES[name]
-    cfg = dict(I=I, J=J, K=K, r=r, regs=[[NN], [NN], regs_C], desc=name)
-    dev = torch.device("cuda", 0)
-    X, row_ptr, I_loc = bench.make_shard(cfg, 0, 1, dev)
-    results = []
-    for merged in (False, True):
-        eng = bench.make_engine(cfg, X, row_ptr, I_loc, 0, dev)
-        diags = []
-        for it in range(3):
-            eng.update_B()
-            eng.update_C_local()
-            if merged:
-                eng.update_C_finish_and_A()
-            else:
-                eng.update_C_finish()
-                eng.update_A()
-            diags.append(eng.diagnostics().clone())
-        torch.cuda.synchronize()
-        variant = eng.kernel_variant(E.PROF_A_FINISH)
-        assert variant.startswith("k_CA_finish<") == merged and (not merged or form in variant), variant
-        state = [eng.A, eng.B, eng.C] + [t for m in range(3) for reg in eng.regs[m] for t in (reg.aux, reg.dual)]
-        state += [eng.rhses(), eng.cross_products(), eng.internal(E.BUF_CTC), eng.internal(E.BUF_RHO_B), eng.internal(E.BUF_LINV_B),
-                  eng.internal(E.BUF_RHO_A), eng.internal(E.BUF_RHO_C)]
-        results.append([t.clone() for t in state] + diags)
-        eng.close()
-    for k, (a, b) in enumerate(zip(*results)):
-        assert torch.equal(a, b), (name, k, float((a.double() - b.double()).abs().max()))
