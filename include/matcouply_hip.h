@@ -30,7 +30,9 @@ typedef struct mcl_context mcl_context;
  * 200 mcl_c_normal_equations returns fp64 (the buffer a multi-GPU host all-reduces changed its element size);
  * 300 mcl_run and the stop-rule structs, the communication-buffer and event entry points;
  * 400 this header: named indices (enum mcl_buffer_id, enum mcl_profile_slot, MCL_VARIANT_EXACT_MODE - the exact-mode query
- *     moved from index 4 to 100), twelve profile slots, mcl_profile_launches, a failed state after mcl_run's watchdog.
+ *     moved from index 4 to 100), twelve profile slots, mcl_profile_launches, a failed state after mcl_run's watchdog,
+ *     mcl_options.exact_products, native GeneralizedL2 / UnitSimplex kinds (mcl_penalty_desc grew two fields),
+ *     mcl_penalty_value.
  * A host MUST compare mcl_version() with the MCL_ABI_VERSION it was built against before any other call. */
 #define MCL_ABI_VERSION 400
 
@@ -46,8 +48,11 @@ enum mcl_penalty_kind {
     MCL_PEN_UNIMODAL = 5, /* Unimodality     penalties.py:983-1015 */
     MCL_PEN_PARAFAC2 = 6, /* Parafac2        penalties.py:1018-1324 (mode 1 only) */
     MCL_PEN_EXTERNAL = 7, /* user prox evaluated by the host between mcl_*_solve and mcl_*_dual */
-    MCL_PEN_TV = 8        /* TotalVariationPenalty  penalties.py:750-841: p0 = TV strength, p1 = L1 strength; the prox
+    MCL_PEN_TV = 8,       /* TotalVariationPenalty  penalties.py:750-841: p0 = TV strength, p1 = L1 strength; the prox
                              (condat_tv.tv_denoise_matrix in the reference) is L. Condat's direct 1-D TV algorithm */
+    MCL_PEN_GL2 = 9,      /* GeneralizedL2Penalty   penalties.py:595-747: x^T M x per column, M = U diag(s) U^T given through
+                             `matrix` (eigenvectors, then eigenvalues); every matrix of the mode has matrix_rows rows */
+    MCL_PEN_SIMPLEX = 10  /* UnitSimplex            penalties.py:928-980: columns non-negative and summing to one */
 };
 
 typedef struct {
@@ -58,6 +63,9 @@ typedef struct {
     float *aux;             /* [rows, r] auxiliary variable; PARAFAC2: packed orthogonal bases P_i */
     float *dual;            /* [rows, r] scaled dual variable */
     float *aux2;            /* PARAFAC2: coordinate matrix Delta [r, r]; otherwise NULL */
+    const double *matrix;   /* GeneralizedL2: device fp64 [n * n + n]: U (row-major, columns = eigenvectors of M), then the n
+                               eigenvalues s (M = U diag(s) U^T, penalties.py:720); otherwise NULL */
+    int64_t matrix_rows;    /* GeneralizedL2: n = rows of every factor matrix of the mode */
 } mcl_penalty_desc;
 
 typedef struct {
@@ -122,6 +130,9 @@ int mcl_diagnostics(mcl_context *ctx, double *out, int32_t include_replicated);
  * of the fp64 sums. */
 int mcl_diagnostics_deferred(mcl_context *ctx, double *out, int32_t include_replicated);
 int mcl_flush_diagnostics(mcl_context *ctx);
+/* Value of penalty k of `mode` on the current factor, for the kinds whose value is not a column of the diagnostics vector:
+ * GeneralizedL2 - sum over the mode's matrices of trace(F^T M F) (penalties.py:737-745).  One fp64 to device memory `out`. */
+int mcl_penalty_value(mcl_context *ctx, int32_t mode, int32_t k, double *out);
 /* n outer iterations B -> C -> A on ONE device (decomposition.py:945-988); if diag_ring != NULL,
  * MCL_DIAG_LEN doubles are appended per iteration (device memory, n * MCL_DIAG_LEN doubles). */
 int mcl_iterate(mcl_context *ctx, int32_t n_iter, int32_t update_A, int32_t update_B, int32_t update_C,

@@ -18,7 +18,7 @@ MCL_MAX_RANK = 64
 DIAG_NORM_SQ, DIAG_INNER, DIAG_MODEL_SQ, DIAG_X_SQ, DIAG_REG = 0, 3, 4, 5, 8
 DIAG_LEN = 8 + 3 * MCL_MAX_REGS * 2
 
-PEN_NN, PEN_BOX, PEN_L1, PEN_L2BALL, PEN_UNIMODAL, PEN_PARAFAC2, PEN_EXTERNAL, PEN_TV = 1, 2, 3, 4, 5, 6, 7, 8
+PEN_NN, PEN_BOX, PEN_L1, PEN_L2BALL, PEN_UNIMODAL, PEN_PARAFAC2, PEN_EXTERNAL, PEN_TV, PEN_GL2, PEN_SIMPLEX = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 # enum mcl_buffer_id / enum mcl_profile_slot / MCL_VARIANT_EXACT_MODE of include/matcouply_hip.h
 (BUF_RHSES, BUF_CROSS_PRODUCTS, BUF_XC, BUF_RHO_B, BUF_RHO_A, BUF_RHO_C, BUF_CTC, BUF_LINV_B, BUF_PF2_STATUS, BUF_PF2_ACC,
  BUF_PF2_GRAM, BUF_SWEEP_CYCLES, BUF_SEG_ROW0, BUF_SEG_NROWS, BUF_WAVE_SEG_PTR, BUF_BSEG_ROW0, BUF_BSEG_NROWS,
@@ -32,14 +32,14 @@ PROF_ROLE = {PROF_XC: "X C pass", PROF_XT: "X^T (B o a) pass", PROF_ROWS_FUSED: 
 VARIANT_EXACT_MODE = 100
 # short names of the native kinds (descriptor dicts of bench.py / the test helpers -> enum mcl_penalty_kind)
 KIND = {"nn": PEN_NN, "box": PEN_BOX, "l1": PEN_L1, "l2ball": PEN_L2BALL, "unimodal": PEN_UNIMODAL,
-        "parafac2": PEN_PARAFAC2, "tv": PEN_TV}
+        "parafac2": PEN_PARAFAC2, "tv": PEN_TV, "gl2": PEN_GL2, "simplex": PEN_SIMPLEX}
 
 # every symbol include/matcouply_hip.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTED_SYMBOLS = [
     "mcl_create", "mcl_destroy", "mcl_last_error", "mcl_version", "mcl_set_problem", "mcl_set_options",
     "mcl_set_factors", "mcl_set_penalties", "mcl_workspace_bytes", "mcl_set_workspace", "mcl_update_B",
     "mcl_update_C_local", "mcl_c_normal_equations", "mcl_update_C_finish", "mcl_update_A", "mcl_diagnostics",
-    "mcl_diagnostics_deferred", "mcl_flush_diagnostics",
+    "mcl_diagnostics_deferred", "mcl_flush_diagnostics", "mcl_penalty_value",
     "mcl_iterate", "mcl_run", "mcl_gate_begin", "mcl_verdict", "mcl_gate_end", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_B_end", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
     "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = [
 class PenaltyDesc(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("non_negativity", ctypes.c_int32), ("p0", ctypes.c_double),
                 ("p1", ctypes.c_double), ("aux", ctypes.c_void_p), ("dual", ctypes.c_void_p),
-                ("aux2", ctypes.c_void_p)]
+                ("aux2", ctypes.c_void_p), ("matrix", ctypes.c_void_p), ("matrix_rows", ctypes.c_int64)]
 
 
 class Options(ctypes.Structure):
@@ -103,6 +103,7 @@ def load_library():
         "mcl_diagnostics": (ctypes.c_int, [P, P, I32]),
         "mcl_diagnostics_deferred": (ctypes.c_int, [P, P, I32]),
         "mcl_flush_diagnostics": (ctypes.c_int, [P]),
+        "mcl_penalty_value": (ctypes.c_int, [P, I32, I32, P]),
         "mcl_iterate": (ctypes.c_int, [P, I32, I32, I32, I32, P]),
         "mcl_run": (ctypes.c_int, [P, I32, I32, I32, I32, ctypes.POINTER(StopRule), P, P, P]),
         "mcl_gate_begin": (ctypes.c_int, [P, ctypes.POINTER(StopRule), P]),
@@ -181,9 +182,11 @@ def cmf_to_packed(A, B, C, row_ptr, weights=None):
 class NativeReg:
     """One penalty as the engine sees it: kind + parameters + device tensors of its ADMM variables."""
 
-    def __init__(self, kind, aux, dual, aux2=None, non_negativity=False, p0=0.0, p1=0.0):
+    def __init__(self, kind, aux, dual, aux2=None, non_negativity=False, p0=0.0, p1=0.0, matrix=None, matrix_rows=0):
         self.kind, self.aux, self.dual, self.aux2 = kind, aux, dual, aux2
         self.non_negativity, self.p0, self.p1 = bool(non_negativity), float(p0), float(p1)
+        # GeneralizedL2: fp64 tensor [n * n + n + n * n] = U (eigenvectors of the norm matrix in its columns), s, U^T
+        self.matrix, self.matrix_rows = matrix, int(matrix_rows)
 
 
 class HipEngine:
@@ -239,6 +242,14 @@ class HipEngine:
                 arr[k].p0, arr[k].p1 = reg.p0, reg.p1
                 arr[k].aux, arr[k].dual = reg.aux.data_ptr(), reg.dual.data_ptr()
                 arr[k].aux2 = reg.aux2.data_ptr() if reg.aux2 is not None else None
+                if reg.kind == PEN_GL2:
+                    n = reg.matrix_rows
+                    if not (reg.matrix is not None and reg.matrix.is_cuda and reg.matrix.dtype == torch.float64
+                            and reg.matrix.is_contiguous() and reg.matrix.numel() == 2 * n * n + n):
+                        raise EngineError("GeneralizedL2: `matrix` must be a contiguous float64 CUDA tensor [U | s | U^T]")
+                    arr[k].matrix, arr[k].matrix_rows = reg.matrix.data_ptr(), n
+                else:
+                    arr[k].matrix, arr[k].matrix_rows = None, 0
             self._check(self.lib.mcl_set_penalties(self._h, mode, n, arr))
         nbytes = self.lib.mcl_workspace_bytes(self._h)
         if nbytes < 0:
@@ -315,6 +326,13 @@ class HipEngine:
 
     def flush_diagnostics(self):
         self._check(self.lib.mcl_flush_diagnostics(self._h))
+
+    def penalty_value(self, mode, k):
+        """value of penalty k of `mode` on the current factor (kinds whose value is not in the diagnostics vector:
+        GeneralizedL2 - trace(F^T M F) summed over the mode's matrices); a 1-element float64 device tensor"""
+        out = self._torch.empty(1, dtype=self._torch.float64, device=self.device)
+        self._check(self.lib.mcl_penalty_value(self._h, int(mode), int(k), out.data_ptr()))
+        return out
 
     def iterate(self, n_iter, update_A=True, update_B=True, update_C=True, diag_ring=None):
         ptr = diag_ring.data_ptr() if diag_ring is not None else None

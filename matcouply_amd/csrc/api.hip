@@ -132,6 +132,7 @@ int64_t plan(mcl_context *c, char *base) {
     // generic (non row-separable) path scratch
     const int64_t maxrows = std::max<int64_t>(N, std::max<int64_t>(I, K));
     c->colsq = b.take<double>(std::max<int64_t>(I, 1) * r * MCL_MAX_REGS);  // one table per penalty slot (fused stack)
+    c->gl2_T = has_kind(c, MCL_PEN_GL2) ? b.take<double>(maxrows * r) : nullptr;
     if (has_kind(c, MCL_PEN_UNIMODAL)) {
         c->uni_f64 = b.take<double>(10 * (maxrows + std::max<int64_t>(I, 1)) * r);
         c->uni_sink = b.take<float>(2 * 64 * ((std::max<int64_t>(I, 1) * r + 63) / 64));
@@ -619,7 +620,14 @@ int mcl_set_penalties(mcl_context *c, int32_t mode, int32_t n, const mcl_penalty
     rs.n = n;
     for (int k = 0; k < n; ++k) {
         const mcl_penalty_desc &d = descs[k];
-        if (d.kind < MCL_PEN_NN || d.kind > MCL_PEN_TV) return fail(c, "mcl_set_penalties: unknown penalty kind");
+        if (d.kind < MCL_PEN_NN || d.kind > MCL_PEN_SIMPLEX) return fail(c, "mcl_set_penalties: unknown penalty kind");
+        if (d.kind == MCL_PEN_GL2) {
+            if (!d.matrix || d.matrix_rows < 1) return fail(c, "mcl_set_penalties: GeneralizedL2 needs its eigen-decomposition (matrix, matrix_rows)");
+            if (!c->has_problem) return fail(c, "mcl_set_penalties: call mcl_set_problem first");
+            bool rows_ok = (mode == 0) ? d.matrix_rows == c->I : (mode == 2 ? d.matrix_rows == c->K : true);
+            for (int64_t i = 0; mode == 1 && i < c->I; ++i) rows_ok = rows_ok && (c->row_ptr[i + 1] - c->row_ptr[i] == d.matrix_rows);
+            if (!rows_ok) return fail(c, "mcl_set_penalties: GeneralizedL2: every matrix of the mode must have matrix_rows rows");
+        }
         if (d.kind == MCL_PEN_TV && (d.p0 <= 0 || d.p1 < 0))
             return fail(c, "mcl_set_penalties: TV strength must be positive and its L1 strength non-negative");
         if (d.kind == MCL_PEN_PARAFAC2 && mode != 1)
@@ -634,6 +642,8 @@ int mcl_set_penalties(mcl_context *c, int32_t mode, int32_t n, const mcl_penalty
         rs.p1[k] = (float)d.p1;
         rs.p0d[k] = d.p0;
         rs.p1d[k] = d.p1;
+        rs.mat[k] = d.kind == MCL_PEN_GL2 ? d.matrix : nullptr;
+        rs.mat_rows[k] = d.kind == MCL_PEN_GL2 ? (int)d.matrix_rows : 0;
         rs.aux[k] = d.aux;
         rs.dual[k] = d.dual;
         rs.aux2[k] = d.aux2;
@@ -1126,6 +1136,14 @@ int mcl_diagnostics_deferred(mcl_context *c, double *out, int32_t include_replic
 int mcl_flush_diagnostics(mcl_context *c) {
     if (!c) return 1;
     return flush_diag(c);
+}
+
+int mcl_penalty_value(mcl_context *c, int32_t mode, int32_t k, double *out) {
+    if (!c) return 1;
+    if (int rc = ready(c)) return rc;
+    if (mode < 0 || mode > 2 || k < 0 || k >= c->regs[mode].n || !out) return fail(c, "mcl_penalty_value: bad arguments");
+    if (c->regs[mode].kind[k] != MCL_PEN_GL2) return fail(c, "mcl_penalty_value: only GeneralizedL2 penalties have a separate value");
+    return mcl_launch_gl2_value(c, mode, k, out);
 }
 
 int mcl_iterate(mcl_context *c, int32_t n_iter, int32_t update_A, int32_t update_B, int32_t update_C,

@@ -522,6 +522,140 @@ __global__ __launch_bounds__(64) void k_slab_tv(const int *__restrict__ ext, int
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// GeneralizedL2Penalty (penalties.py:595-747): prox(Y) = U (S + rho/2 I)^-1 U^T (rho/2) Y with M = U S U^T, per slab.
+// Two passes of ONE routine  out[a][c] = sum_b Mat[b][a] In[b][c]  (Mat = U for the projection onto the eigenvectors, Mat = U^T
+// for the way back: both walk Mat along its rows, coalesced), fp64 accumulation in the order of b.  Workgroup = 64 values of
+// `a` x 4 column phases; the rows of In are staged through LDS 16 at a time.  T: fp64 scratch [rows, r].
+// TIN = float (the caller's buffers) or double (the fp64 state of wide.hip).
+// ---------------------------------------------------------------------------------------------------------
+template <typename TIN, bool BACK>
+__global__ __launch_bounds__(256) void k_gl2_pass(const int *__restrict__ ext, const double *__restrict__ Mat,
+                                                  const double *__restrict__ eig, int n, int r, const float *__restrict__ rho_arr,
+                                                  const TIN *__restrict__ F, const TIN *__restrict__ D, double *__restrict__ T,
+                                                  float *__restrict__ Z32, float *__restrict__ D32, double *__restrict__ Z64,
+                                                  double *__restrict__ D64, const int *__restrict__ gate) {
+    // !BACK: T[e][c] = (rho / 2) sum_j U[j][e] (F + D)[j][c]        (D = nullptr: F alone, unscaled - the penalty value)
+    //  BACK: Z[j][c] = sum_e U^T[e][j] T[e][c] / (s_e + rho / 2), then the dual step D = F - (Z - D)
+    MCL_GATE(gate);
+    __shared__ double ins[16][64];
+    const int slab = blockIdx.y;
+    const long s0 = ext[slab];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int a = blockIdx.x * 64 + tx;
+    const double half_rho = 0.5 * (double)rho_arr[slab];
+    double acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+    for (int b0 = 0; b0 < n; b0 += 16) {
+        const int nb = min(16, n - b0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nb * r; e += 256) {
+            const int bb = e / r, c = e - bb * r;
+            const long idx = (s0 + b0 + bb) * r + c;
+            double v;
+            if (BACK) v = T[idx] / (eig[b0 + bb] + half_rho);
+            else v = (double)F[idx] + (D != nullptr ? (double)D[idx] : 0.0);
+            ins[bb][c] = v;
+        }
+        __syncthreads();
+        if (a < n)
+            for (int bb = 0; bb < nb; ++bb) {
+                const double m = Mat[(long)(b0 + bb) * n + a];
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (ty + 4 * q < r) acc[q] = fma(m, ins[bb][ty + 4 * q], acc[q]);
+            }
+    }
+    if (a >= n) return;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = ty + 4 * q;
+        if (c >= r) continue;
+        const long idx = (s0 + a) * r + c;
+        if (!BACK) {
+            T[idx] = (D != nullptr ? half_rho : 1.0) * acc[q];
+        } else {
+            const double z = acc[q], f = (double)F[idx], u = (double)D[idx];
+            const double un = f - (z - u);
+            Z32[idx] = (float)z, D32[idx] = (float)un;
+            if (Z64 != nullptr) Z64[idx] = z, D64[idx] = un;
+        }
+    }
+}
+
+// sum over all rows e of every slab of s_e sum_c T[e][c]^2 (T = U^T F): trace(F^T M F), one workgroup, fixed order
+__global__ __launch_bounds__(256) void k_gl2_value(const double *__restrict__ T, const double *__restrict__ eig, long rows, int n,
+                                                   int r, double *__restrict__ out) {
+    __shared__ double sm[256];
+    double acc = 0.0;
+    for (long e = threadIdx.x; e < rows; e += 256) {
+        double s = 0.0;
+        for (int c = 0; c < r; ++c) s = fma(T[e * r + c], T[e * r + c], s);
+        acc = fma(eig[e % n], s, acc);
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// UnitSimplex (penalties.py:928-980): per column of a slab the multiplier mu of sum_j max(y_j - mu, 0) = 1 (the reference:
+// scipy's bisection on the same bracket), aux = max(y - mu, 0).  One wave per (slab, column): 60 bisection steps narrow the
+// bracket to the linear piece of the root, where mu = (sum of the active entries - 1) / their number exactly.
+// ---------------------------------------------------------------------------------------------------------
+template <typename TIN>
+__global__ __launch_bounds__(256) void k_slab_simplex(const int *__restrict__ ext, int n_slabs, int r, const TIN *__restrict__ F,
+                                                      const TIN *__restrict__ D, float *__restrict__ Z32, double *__restrict__ Z64,
+                                                      const int *__restrict__ gate) {
+    MCL_GATE(gate);
+    const int lane = threadIdx.x & 63;
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (long)n_slabs * r) return;
+    const int slab = (int)(w / r), col = (int)(w - (long)slab * r);
+    const long s0 = ext[slab];
+    const int n = ext[slab + 1] - ext[slab];
+    if (n <= 0) return;
+    auto y_at = [&](int j) { return (double)F[(s0 + j) * r + col] + (double)D[(s0 + j) * r + col]; };
+    double mn = 1e300, mx = -1e300;
+    for (int j = lane; j < n; j += 64) {
+        const double y = y_at(j);
+        mn = fmin(mn, y), mx = fmax(mx, y);
+    }
+    for (int o = 32; o > 0; o >>= 1) mn = fmin(mn, __shfl_xor(mn, o)), mx = fmax(mx, __shfl_xor(mx, o));
+    double lo = mn - 1.0 - 1e-5, hi = mx + 1e-5;  // f(lo) > 0 > f(hi) = -1 (the reference's bracket, penalties.py:950-960)
+    lo = fmin(0.9 * lo, 1.1 * lo), hi = fmax(0.9 * hi, 1.1 * hi);
+    for (int it = 0; it < 60; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        double s = 0.0;
+        for (int j = lane; j < n; j += 64) s += fmax(y_at(j) - mid, 0.0);
+        s = wave_sum_d(s) - 1.0;
+        if (s > 0.0) lo = mid;
+        else hi = mid;
+    }
+    // on [lo, hi] the active set is constant (unless a breakpoint sits within 2^-60 of the root): the root of the linear piece
+    double sa = 0.0, cnt = 0.0;
+    for (int j = lane; j < n; j += 64) {
+        const double y = y_at(j);
+        if (y > hi) sa += y, cnt += 1.0;
+    }
+    sa = wave_sum_d(sa), cnt = wave_sum_d(cnt);
+    double mu = 0.5 * (lo + hi);
+    if (cnt > 0.0) {
+        const double m2 = (sa - 1.0) / cnt;
+        if (m2 >= lo && m2 <= hi) mu = m2;
+    }
+    for (int j = lane; j < n; j += 64) {
+        const double z = fmax(y_at(j) - mu, 0.0);
+        Z32[(s0 + j) * r + col] = (float)z;
+        if (Z64 != nullptr) Z64[(s0 + j) * r + col] = z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // PARAFAC2 prox (mode 1):  Y_i = B_i + U_i,  P_i = polar(Y_i Delta^T),  Delta <- sum rho_i P_i^T Y_i / sum rho_i
 // Gram route in fp64:  S_i = Y_i^T Y_i,  G_i = Delta S_i Delta^T = V L V^T,  W_i = V L^-1/2 V^T,
 //                      T_i = Delta^T W_i,  P_i = Y_i T_i,  P_i^T Y_i = T_i^T S_i.
@@ -1875,10 +2009,72 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                                    n2 + 1, c->pf2_red);
             break;
         }
+        case MCL_PEN_GL2: {
+            const int n = rs.mat_rows[k];
+            const double *U = rs.mat[k], *eig = U + (long)n * n, *UT = eig + n;
+            const dim3 g((unsigned)((n + 63) / 64), (unsigned)mv.n_slabs);
+            hipLaunchKernelGGL((k_gl2_pass<float, false>), g, dim3(256), 0, c->stream, mv.ext, U, eig, n, c->r, mv.rho, (const float *)mv.F,
+                               (const float *)rs.dual[k], c->gl2_T, (float *)nullptr, (float *)nullptr, (double *)nullptr, (double *)nullptr,
+                               mv.gate);
+            hipLaunchKernelGGL((k_gl2_pass<float, true>), g, dim3(256), 0, c->stream, mv.ext, UT, eig, n, c->r, mv.rho, (const float *)mv.F,
+                               (const float *)rs.dual[k], c->gl2_T, rs.aux[k], rs.dual[k], (double *)nullptr, (double *)nullptr, mv.gate);
+            break;
+        }
+        case MCL_PEN_SIMPLEX: {
+            const long nw = (long)mv.n_slabs * c->r;
+            hipLaunchKernelGGL((k_slab_simplex<float>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, c->stream, mv.ext, mv.n_slabs, c->r,
+                               (const float *)mv.F, (const float *)rs.dual[k], rs.aux[k], (double *)nullptr, mv.gate);
+            DISPATCH_ROWS(c, vec, k_rows_dual, grid, block, mv, rs, k, c->r);
+            break;
+        }
         default:
             c->err = "penalty kind has no native prox (EXTERNAL penalties are evaluated by the host)";
             return 1;
     }
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+// trace(F^T M F) summed over the matrices of the mode (penalties.py:737-745) -> out[0]
+int mcl_launch_gl2_value(mcl_context *c, int mode, int k, double *out) {
+    ModeView mv = view_of(c, mode);
+    const RegSet &rs = c->regs[mode];
+    const int n = rs.mat_rows[k];
+    const double *U = rs.mat[k], *eig = U + (long)n * n;
+    const long rows = (long)n * mv.n_slabs;
+    ProfScope prof(c, MCL_PROF_DIAG);
+    if (rows == 0) {
+        MCL_CHECK_HIP(c, hipMemsetAsync(out, 0, sizeof(double), c->stream));
+        return 0;
+    }
+    hipLaunchKernelGGL((k_gl2_pass<float, false>), dim3((unsigned)((n + 63) / 64), (unsigned)mv.n_slabs), dim3(256), 0, c->stream, mv.ext,
+                       U, eig, n, c->r, mv.rho, (const float *)mv.F, (const float *)nullptr, c->gl2_T, (float *)nullptr, (float *)nullptr,
+                       (double *)nullptr, (double *)nullptr, (const int *)nullptr);
+    hipLaunchKernelGGL(k_gl2_value, dim3(1), dim3(256), 0, c->stream, (const double *)c->gl2_T, eig, rows, n, c->r, out);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+// The wide path's (wide.hip) use of the two kernels above on its fp64 state
+int mcl_launch_gl2_wide(mcl_context *c, int mode, int k, const double *F64, double *Z64, double *D64) {
+    ModeView mv = view_of(c, mode);
+    const RegSet &rs = c->regs[mode];
+    const int n = rs.mat_rows[k];
+    const double *U = rs.mat[k], *eig = U + (long)n * n, *UT = eig + n;
+    const dim3 g((unsigned)((n + 63) / 64), (unsigned)mv.n_slabs);
+    hipLaunchKernelGGL((k_gl2_pass<double, false>), g, dim3(256), 0, c->stream, mv.ext, U, eig, n, c->r, mv.rho, F64, (const double *)D64,
+                       c->gl2_T, (float *)nullptr, (float *)nullptr, (double *)nullptr, (double *)nullptr, mv.gate);
+    hipLaunchKernelGGL((k_gl2_pass<double, true>), g, dim3(256), 0, c->stream, mv.ext, UT, eig, n, c->r, mv.rho, F64, (const double *)D64,
+                       c->gl2_T, rs.aux[k], rs.dual[k], Z64, D64, mv.gate);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int mcl_launch_simplex_wide(mcl_context *c, int mode, int k, const double *F64, const double *D64, double *Z64) {
+    ModeView mv = view_of(c, mode);
+    const long nw = (long)mv.n_slabs * c->r;
+    hipLaunchKernelGGL((k_slab_simplex<double>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, c->stream, mv.ext, mv.n_slabs, c->r, F64, D64,
+                       c->regs[mode].aux[k], Z64, mv.gate);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

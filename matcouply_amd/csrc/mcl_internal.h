@@ -32,6 +32,8 @@ struct RegSet {
     float *aux2[MCL_MAX_REGS];
     double p0d[MCL_MAX_REGS];  // the same parameters before their rounding to fp32 (the fp64 inner loops of wide.hip)
     double p1d[MCL_MAX_REGS];
+    const double *mat[MCL_MAX_REGS];  // GeneralizedL2: U [n, n] then s [n] (fp64, device)
+    int mat_rows[MCL_MAX_REGS];
     const int *gate;  // stop flag of a gated run (mcl_run with a stopping rule), else NULL: see MCL_GATE
 };
 
@@ -206,6 +208,7 @@ struct mcl_context {
     bool a_rhs_wide = false;         // ... with one workgroup (four waves) per slab: k_A_finish_rows_wide
     bool a_rhs_pairs = false;        // ... or two slabs per workgroup (one system + one streaming wave each)
 
+    double *gl2_T = nullptr;    // [max rows, r] fp64: U^T Y of the GeneralizedL2 prox / U^T F of its value
     double *colsq = nullptr;    // [max(I,1), r]   per-slab column sums of squares (L2Ball)
     double *uni_f64 = nullptr;  // unimodal regression scratch: 10 fp64 arrays of (rows + slabs) * r
     float *uni_sink = nullptr;  // two floats per lane of the unimodal kernels: where predicated-off stores of the emit loops go
@@ -361,3 +364,4 @@ bool mcl_exact_mode(const mcl_context *c);                      // contract.hip
 int mcl_launch_exact_xc(mcl_context *c);                         // contract.hip: XC64 (+ its fp32 image) = X C, exact products
 int mcl_launch_exact_gr(mcl_context *c);                         // contract.hip: GR = [G | R] of this rank's slabs, exact products
 int mcl_launch_unimodal(mcl_context *c, const int *ext, int n_slabs, float *F, const RegSet &rs, int mode, int k);  // unimodal.hip
+int mcl_launch_gl2_value(mcl_context *c, int mode, int k, double *out);  // generic.hip: sum over slabs of trace(F^T M F)

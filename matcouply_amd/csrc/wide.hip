@@ -21,6 +21,8 @@
 #include "rows_mfma.h"
 
 int mcl_launch_pf2_jacobi_wide(mcl_context *c, int k, const double *F64, const double *U64, const double *D64);  // generic.hip
+int mcl_launch_gl2_wide(mcl_context *c, int mode, int k, const double *F64, double *Z64, double *D64);             // generic.hip
+int mcl_launch_simplex_wide(mcl_context *c, int mode, int k, const double *F64, const double *D64, double *Z64);  // generic.hip
 
 namespace {
 
@@ -704,6 +706,13 @@ int mcl_wide_phase(mcl_context *c, int mode) {
                     break;
                 case MCL_PEN_TV:
                     hipLaunchKernelGGL(k_wide_tv, dim3((unsigned)((n_cols + 63) / 64)), dim3(64), 0, c->stream, W, S, rs, k, r);
+                    hipLaunchKernelGGL(k_wide_dual, dim3(blocks_for(rows * r)), dim3(256), 0, c->stream, W, S, rs, k, rows * r);
+                    break;
+                case MCL_PEN_GL2:
+                    if (int rc = mcl_launch_gl2_wide(c, mode, k, S.F, S.Z[k], S.U[k])) return rc;
+                    break;
+                case MCL_PEN_SIMPLEX:
+                    if (int rc = mcl_launch_simplex_wide(c, mode, k, S.F, S.U[k], S.Z[k])) return rc;
                     hipLaunchKernelGGL(k_wide_dual, dim3(blocks_for(rows * r)), dim3(256), 0, c->stream, W, S, rs, k, rows * r);
                     break;
                 case MCL_PEN_PARAFAC2: {

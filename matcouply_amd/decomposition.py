@@ -677,6 +677,14 @@ def cmf_aoadmm(
     for mode in range(3):
         for k, (reg, aux, dual) in enumerate(zip(regs[mode], aux_lists[mode], dual_lists[mode])):
             desc = None if check_inner else penalties.native_descriptor_of(reg)
+            gl2_matrix = None
+            if desc is not None and desc[0] == _engine.PEN_GL2:
+                # every matrix of the mode must have as many rows as the norm matrix (anything else fails in the reference's
+                # product too: left to the penalty's own method); a sharded A holds only this rank's rows of the I x I problem
+                gl2_matrix, n_gl2 = reg._native_matrix()
+                rows_m = [shape(m_)[0] for m_ in matrices] if mode == 1 else [len(matrices) if mode == 0 else shape(matrices[0])[1]]
+                if any(rw != n_gl2 for rw in rows_m) or (group is not None and mode == 0):
+                    desc = None
             dual_t = _pack_rows(dual, device) if mode == 1 else _to_dev(dual, device)
             if desc is None:
                 if mode == 1:
@@ -695,7 +703,10 @@ def cmf_aoadmm(
                                                       aux2=_to_dev(Delta, device)))
             else:
                 aux_t = _pack_rows(aux, device) if mode == 1 else _to_dev(aux, device)
-                native[mode].append(_engine.NativeReg(kind, aux_t, dual_t, non_negativity=nonneg, p0=p0, p1=p1))
+                extra = {}
+                if kind == _engine.PEN_GL2:
+                    extra = dict(matrix=torch.as_tensor(gl2_matrix, dtype=torch.float64, device=device).contiguous(), matrix_rows=n_gl2)
+                native[mode].append(_engine.NativeReg(kind, aux_t, dual_t, non_negativity=nonneg, p0=p0, p1=p1, **extra))
 
     world = 1
     dist = None
@@ -963,8 +974,10 @@ def cmf_aoadmm(
                 mode_gaps.append(np.sqrt(d[base]) / fnorm)
                 if isinstance(reg, penalties.L1Penalty):
                     reg_penalty += reg.reg_strength * d[base + 1]
-                elif sharded and mode == 1 and native[mode][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV):
+                elif sharded and mode == 1 and native[mode][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV, _engine.PEN_GL2):
                     reg_penalty += d[base + 1]  # this rank's matrices only: summed over the ranks with the vector (diagnostics())
+                elif native[mode][k].kind == _engine.PEN_GL2:
+                    reg_penalty += float(eng.penalty_value(mode, k))  # trace(F^T M F), evaluated by the engine
                 elif native[mode][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV) or (mode == 0 and sharded and gathered_A[k]):
                     # value computed on device tensors; a sharded A is gathered first (every rank adds the same, whole value)
                     factor = [eng.B[sl] for sl in row_slices] if mode == 1 else (
@@ -992,7 +1005,7 @@ def cmf_aoadmm(
                 cols.append(np.sqrt(d[:, base]) / fnorm)
                 if isinstance(reg, penalties.L1Penalty):
                     reg_pen = reg_pen + reg.reg_strength * d[:, base + 1]
-                elif native[mode][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV):
+                elif native[mode][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV, _engine.PEN_GL2):
                     raise AssertionError("read_diag_rows: host-evaluated penalty value")
             per_mode.append(np.stack(cols, axis=1) if cols else np.zeros((len(d), 0)))
             if l2_penalty[mode]:
@@ -1009,7 +1022,9 @@ def cmf_aoadmm(
             for k, reg in enumerate(regs[1]):
                 if isinstance(reg, penalties.L1Penalty):
                     continue  # read_diag takes reg_strength * sum|B| from the native slot, which is summed over the ranks already
-                if native[1][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV):
+                if native[1][k].kind == _engine.PEN_GL2:
+                    vec[_engine.DIAG_REG + (_engine.MCL_MAX_REGS + k) * 2 + 1] = float(eng.penalty_value(1, k))
+                elif native[1][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV):
                     vec[_engine.DIAG_REG + (_engine.MCL_MAX_REGS + k) * 2 + 1] = float(reg.penalty([eng.B[sl] for sl in row_slices]))
         all_reduce(vec)
         return read_diag(vec)
@@ -1029,7 +1044,7 @@ def cmf_aoadmm(
 
     it = -1  # Needed if n_iter_max <= 0
     # penalty values that need a host call per iteration (the device-resident loops below do not apply)
-    host_value = any(r.kind in (_engine.PEN_TV, _engine.PEN_EXTERNAL) for m in range(3) for r in native[m]) or any(gathered_A)
+    host_value = any(r.kind in (_engine.PEN_TV, _engine.PEN_EXTERNAL, _engine.PEN_GL2) for m in range(3) for r in native[m]) or any(gathered_A)
     fast_path = ((not (tol or absolute_tol)) and not sharded and not verbose and n_iter_max > 0 and not any(has_ext)
                  and not host_value)
     lazy_diag = (not (tol or absolute_tol)) and sharded and not verbose and n_iter_max > 0 and not host_value

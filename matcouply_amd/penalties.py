@@ -465,6 +465,15 @@ class GeneralizedL2Penalty(MatrixPenalty):
             return self._penalty(x)
         return sum(self._penalty(xi) for xi in x)
 
+    def _native_descriptor(self):
+        return (_engine.PEN_GL2, False, 0.0, 0.0)
+
+    def _native_matrix(self):
+        """what the native kernel needs of the norm matrix: fp64 [U | s | U^T] (n * n + n + n * n) and n"""
+        U = np.ascontiguousarray(np.asarray(self._U, dtype=np.float64))
+        s = np.asarray(self._s, dtype=np.float64).ravel()
+        return np.concatenate([U.ravel(), s, np.ascontiguousarray(U.T).ravel()]), U.shape[0]
+
 
 class UnitSimplex(HardConstraintMixin, MatrixPenalty):
     """Component vectors non-negative and summing to one (penalties.py:928-980).
@@ -497,6 +506,9 @@ class UnitSimplex(HardConstraintMixin, MatrixPenalty):
         k = n - 1 - np.argmax(cond[::-1], axis=0)
         mu = css[k, np.arange(y.shape[1])] / (k + 1.0)
         return np.clip(y - mu[None, :], 0, None)
+
+    def _native_descriptor(self):
+        return (_engine.PEN_SIMPLEX, False, 0.0, 0.0)
 
 
 def _prefix_isotonic(y, non_negativity):

@@ -8,7 +8,7 @@ import torch
 from matcouply_amd import _engine
 from oracle import aoadmm_oracle as orc
 
-KIND_NAME = {1: "nn", 2: "box", 3: "l1", 4: "l2ball", 5: "unimodal", 6: "parafac2", 7: "external", 8: "tv"}
+KIND_NAME = {1: "nn", 2: "box", 3: "l1", 4: "l2ball", 5: "unimodal", 6: "parafac2", 7: "external", 8: "tv", 9: "gl2", 10: "simplex"}
 
 
 def _desc(reg):
@@ -22,6 +22,11 @@ def _desc(reg):
         d["norm_bound"] = reg.p0
     elif name == "tv":
         d.update(reg_strength=reg.p0, l1_strength=reg.p1)
+    elif name == "gl2":  # the descriptor carries [U | s | U^T] of the norm matrix M = U diag(s) U^T
+        n = reg.matrix_rows
+        m = reg.matrix.numpy()
+        U, s = m[: n * n].reshape(n, n), m[n * n: n * n + n]
+        d["norm_matrix"] = (U * s) @ U.T
     return d
 
 
@@ -389,6 +394,12 @@ class OracleEngine:
 
     def gate_end(self, stopped_early):
         self._gate = None
+
+    def penalty_value(self, mode, k):
+        F = self._n((self.A, self.B, self.C)[mode])
+        M = self.descs[mode][k]["norm_matrix"]
+        mats = [F[self.row_ptr[i]: self.row_ptr[i + 1]] for i in range(self.I)] if mode == 1 else [F]
+        return torch.tensor([sum(float(np.trace(x.T @ M @ x)) for x in mats)], dtype=torch.float64)
 
     def diagnostics_deferred(self, include_replicated=True, out=None):
         return self.diagnostics(include_replicated=include_replicated, out=out)  # the checker has nothing to defer

@@ -33,8 +33,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    # mcl_penalty_desc: 2 x int32, 2 x double, 3 pointers; mcl_options: 4 doubles + 4 int32
-    assert ctypes.sizeof(_engine.PenaltyDesc) == 8 + 16 + 24
+    # mcl_penalty_desc: 2 x int32, 2 x double, 3 pointers + (ABI 400) the matrix pointer and its int64 row count;
+    # mcl_options: 4 doubles + 4 int32
+    assert ctypes.sizeof(_engine.PenaltyDesc) == 8 + 16 + 24 + 16
     assert ctypes.sizeof(_engine.Options) == 32 + 16
     assert _engine.DIAG_LEN == 8 + 3 * _engine.MCL_MAX_REGS * 2
 

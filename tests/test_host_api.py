@@ -477,7 +477,14 @@ def test_native_descriptor_only_for_unmodified_builtin_penalties():
     assert pen.native_descriptor_of(Renamed()) == pen.NonNegativity()._native_descriptor()
     assert pen.native_descriptor_of(Shifted()) is None
     assert pen.native_descriptor_of(Valued(0.1)) is None
-    assert pen.native_descriptor_of(pen.UnitSimplex()) is None
+    # round 5: UnitSimplex and GeneralizedL2Penalty have native kernels too (MCL_PEN_SIMPLEX / MCL_PEN_GL2) ...
+    assert pen.native_descriptor_of(pen.UnitSimplex())[0] == 10 and pen.native_descriptor_of(pen.GeneralizedL2Penalty(np.eye(3)))[0] == 9
+
+    class Bisected(pen.UnitSimplex):  # ... unless a subclass touches the contract
+        def factor_matrix_update(self, factor_matrix, feasibility_penalty, aux):
+            return factor_matrix
+
+    assert pen.native_descriptor_of(Bisected()) is None
 
 
 def test_substitute_engine_needs_the_test_switch(monkeypatch):
