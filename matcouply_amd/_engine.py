@@ -243,11 +243,11 @@ class HipEngine:
                 arr[k].aux, arr[k].dual = reg.aux.data_ptr(), reg.dual.data_ptr()
                 arr[k].aux2 = reg.aux2.data_ptr() if reg.aux2 is not None else None
                 if reg.kind == PEN_GL2:
-                    n = reg.matrix_rows
+                    nm = reg.matrix_rows
                     if not (reg.matrix is not None and reg.matrix.is_cuda and reg.matrix.dtype == torch.float64
-                            and reg.matrix.is_contiguous() and reg.matrix.numel() == 2 * n * n + n):
+                            and reg.matrix.is_contiguous() and reg.matrix.numel() == 2 * nm * nm + nm):
                         raise EngineError("GeneralizedL2: `matrix` must be a contiguous float64 CUDA tensor [U | s | U^T]")
-                    arr[k].matrix, arr[k].matrix_rows = reg.matrix.data_ptr(), n
+                    arr[k].matrix, arr[k].matrix_rows = reg.matrix.data_ptr(), nm
                 else:
                     arr[k].matrix, arr[k].matrix_rows = None, 0
             self._check(self.lib.mcl_set_penalties(self._h, mode, n, arr))
