@@ -31,7 +31,7 @@ typedef struct mcl_context mcl_context;
  * 300 mcl_run and the stop-rule structs, the communication-buffer and event entry points;
  * 400 this header: named indices (enum mcl_buffer_id, enum mcl_profile_slot, MCL_VARIANT_EXACT_MODE - the exact-mode query
  *     moved from index 4 to 100), twelve profile slots, mcl_profile_launches, a failed state after mcl_run's watchdog,
- *     mcl_options.exact_products, native GeneralizedL2 / UnitSimplex kinds (mcl_penalty_desc grew two fields),
+ *     mcl_options.inner_tol / exact_products, native GeneralizedL2 / UnitSimplex kinds (mcl_penalty_desc grew two fields),
  *     mcl_penalty_value.
  * A host MUST compare mcl_version() with the MCL_ABI_VERSION it was built against before any other call. */
 #define MCL_ABI_VERSION 400
@@ -71,6 +71,10 @@ typedef struct {
 typedef struct {
     double feasibility_penalty_scale; /* decomposition.py:678 */
     double l2_penalty[3];             /* per mode; None -> 0 (decomposition.py:876-877) */
+    double inner_tol;                 /* decomposition.py:90-117: > 0 ends the inner ADMM loop of a phase early - after an inner
+                                         iteration with ||x - x_old|| <= inner_tol ||x|| and every feasibility gap of the mode
+                                         below inner_tol.  Evaluated ON THE DEVICE (a flag the remaining inner launches test);
+                                         the phases then take one launch per step instead of their fused kernels.  0: not set */
     int32_t inner_n_iter_max;         /* decomposition.py:689 */
     int32_t constant_A;               /* constant_feasibility_penalty for mode 0 (decomposition.py:937-939) */
     int32_t constant_B;               /* ... for mode 1 (decomposition.py:940-942) */

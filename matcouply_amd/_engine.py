@@ -56,7 +56,7 @@ class PenaltyDesc(ctypes.Structure):
 
 class Options(ctypes.Structure):
     _fields_ = [("feasibility_penalty_scale", ctypes.c_double), ("l2_penalty", ctypes.c_double * 3),
-                ("inner_n_iter_max", ctypes.c_int32), ("constant_A", ctypes.c_int32), ("constant_B", ctypes.c_int32),
+                ("inner_tol", ctypes.c_double), ("inner_n_iter_max", ctypes.c_int32), ("constant_A", ctypes.c_int32), ("constant_B", ctypes.c_int32),
                 ("exact_products", ctypes.c_int32)]
 
 
@@ -197,7 +197,7 @@ class HipEngine:
     """
 
     def __init__(self, X, row_ptr, rank, A, B, C, regs, l2_penalty=(0.0, 0.0, 0.0), inner_n_iter_max=5,
-                 feasibility_penalty_scale=1.0, constant_A=False, constant_B=False, exact_products=0):
+                 feasibility_penalty_scale=1.0, constant_A=False, constant_B=False, exact_products=0, inner_tol=0.0):
         import torch
 
         self._torch = torch
@@ -228,6 +228,7 @@ class HipEngine:
             opt.l2_penalty[m] = float(l2_penalty[m] or 0.0)
         opt.inner_n_iter_max = int(inner_n_iter_max)
         opt.constant_A, opt.constant_B = int(bool(constant_A)), int(bool(constant_B))
+        opt.inner_tol = float(inner_tol or 0.0)  # > 0: the inner stopping test of decomposition.py:90-117, evaluated on the device
         opt.exact_products = int(exact_products)  # 0: by this context's size; 1 / 2: forced on / off (sharded hosts: by the WHOLE problem)
         self._check(self.lib.mcl_set_options(self._h, ctypes.byref(opt)))
         self._check(self.lib.mcl_set_factors(self._h, A.data_ptr(), B.data_ptr(), C.data_ptr()))

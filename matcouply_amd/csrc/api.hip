@@ -125,6 +125,8 @@ int64_t plan(mcl_context *c, char *base) {
     c->diag_sums = b.take<double>(3 * DIAG_COLS + 2);
     c->xsq_part = b.take<double>(1024);
     c->x_sq = b.take<double>(1);
+    c->inner_gate = b.take<int>(2);
+    c->inner_part = b.take<double>(std::max<int64_t>(std::max<int64_t>(c->tilesB.n_tiles, c->tilesC.n_tiles), std::max<int64_t>(I, 1)));
     c->gate = b.take<int>(4);
     c->mute_status = b.take<int>(4);
     c->stop_state = b.take<double>(4);
@@ -325,7 +327,35 @@ int ensure_cfrag_sweep(mcl_context *c) {  // CfragS aliases Cfrag: one image ser
 }
 
 // generic inner loop of mode m: solve, then per penalty prox (+ reduction) and dual update
+// The inner loop WITH the reference's inner stopping test (decomposition.py:90-117, mcl_options.inner_tol), on the device:
+// one launch per step; after every inner iteration a one-workgroup kernel takes ||x - x_old||^2 (per-tile sums of the solve
+// pass), ||x||^2 and the feasibility gaps (the per-tile diagnostics table) and sets the phase's stop flag - the launches of
+// the remaining inner iterations, already enqueued, test it first and do nothing (the MCL_GATE pattern of mcl_run).
+int checked_inner_loop(mcl_context *c, int mode) {
+    const int n_it = c->opt.inner_n_iter_max;
+    if (int rc = mcl_launch_inner_check(c, mode, true)) return rc;  // flag <- the run's stop flag (0 outside a gated run)
+    const int *run_gate = c->gate_active, *reg_gate = c->regs[mode].gate;
+    c->gate_active = c->inner_gate, c->regs[mode].gate = c->inner_gate;
+    int rc = 0;
+    for (int it = 0; it < n_it && rc == 0; ++it) {
+        rc = (mode == 0) ? mcl_launch_A_rows_solve(c, c->inner_part) : mcl_launch_rows_solve(c, mode, c->inner_part);
+        c->stack_fused = c->stats_in_solve = false;
+        c->pf2_delta_fused = !c->sw.no_pf2_delta_fusion;
+        for (int k = 0; k < c->regs[mode].n && rc == 0; ++k) {
+            rc = mcl_launch_generic_prox_local(c, mode, k);
+            if (rc == 0) rc = mcl_launch_generic_prox_finish(c, mode, k);
+        }
+        c->pf2_delta_fused = false;
+        if (rc == 0) rc = mcl_launch_rows_diag(c, mode);
+        if (rc == 0) rc = mcl_launch_inner_check(c, mode, false);
+    }
+    c->gate_active = run_gate, c->regs[mode].gate = reg_gate;
+    c->diag_valid[mode] = rc == 0 && n_it > 0 && mode != 0;  // (mode 0: mcl_launch_A_e1 follows and owns its tables)
+    return rc;
+}
+
 int generic_inner_loop(mcl_context *c, int mode) {
+    if (c->opt.inner_tol > 0.0 && c->regs[mode].n > 0) return checked_inner_loop(c, mode);
     const int n_it = (c->regs[mode].n == 0) ? std::min(1, (int)c->opt.inner_n_iter_max) : c->opt.inner_n_iter_max;
     // single-process run of the whole stack: per-slab statistics first (Gram / polar factor / Delta, column norms),
     // then ONE row pass for every prox + dual step (the step API used by multi-GPU hosts keeps one pass per penalty)
@@ -587,6 +617,7 @@ int mcl_set_options(mcl_context *c, const mcl_options *opt) {
     if (!c || !opt) return 1;
     if (opt->inner_n_iter_max < 0) return fail(c, "mcl_set_options: inner_n_iter_max must be >= 0");
     if (opt->exact_products < 0 || opt->exact_products > 2) return fail(c, "mcl_set_options: exact_products must be 0, 1 or 2");
+    if (!(opt->inner_tol >= 0.0)) return fail(c, "mcl_set_options: inner_tol must be >= 0 (0: not set)");
     if (c->has_workspace && opt->exact_products != c->opt.exact_products)
         c->has_workspace = false;  // the carve-up depends on the mode: the workspace has to be installed again
     c->opt = *opt;
@@ -871,7 +902,7 @@ int mcl_update_B(mcl_context *c) {
         c->diag_valid[1] = false;
         return mcl_wide_phase(c, 1);
     }
-    if (mcl_mode_is_row_separable(c, 1)) {
+    if (mcl_mode_is_row_separable(c, 1) && !(c->opt.inner_tol > 0.0)) {
         const int rc = mcl_launch_rows_fused(c, 1);
         if (rc == 0) {
             c->diag_valid[1] = true;
@@ -915,7 +946,8 @@ int mcl_update_C_finish(mcl_context *c) {
         c->variant[MCL_PROF_C_FINISH] = "k_C_prepare + fp64 inner loop (wide.hip)";
         return mcl_wide_phase(c, 2);
     }
-    if (c->opt.inner_n_iter_max > 0 && mcl_mode_is_row_separable(c, 2)) {
+    const bool checked_C = c->opt.inner_tol > 0.0 && c->regs[2].n > 0;  // inner stopping test: one launch per step
+    if (c->opt.inner_n_iter_max > 0 && mcl_mode_is_row_separable(c, 2) && !checked_C) {
         // everything from the system solve to CtC / C fragments in one single-workgroup launch
         const int rc = mcl_launch_C_finish_fused(c);
         if (rc == 0) {
@@ -937,7 +969,7 @@ int mcl_update_C_finish(mcl_context *c) {
         c->diag_valid[2] = false;
         return mcl_launch_C_solve_f64(c);
     }
-    if (mcl_mode_is_row_separable(c, 2)) {
+    if (mcl_mode_is_row_separable(c, 2) && !checked_C) {
         const int rc = mcl_launch_rows_fused(c, 2);
         if (rc == 0) {
             c->diag_valid[2] = true;
@@ -1010,7 +1042,12 @@ int mcl_A_finish(mcl_context *c) {
     if (c->opt.inner_n_iter_max <= 0) return 0;
     ProfScope prof_(c, MCL_PROF_A_FINISH);
     c->grpart_valid = false;  // the sweep's [G | R] partials were weighted with the previous a_i
-    if (mcl_mode_is_row_separable(c, 0)) {
+    if (mcl_mode_is_row_separable(c, 0) && c->opt.inner_tol > 0.0 && c->regs[0].n > 0) {
+        // inner stopping test: the systems, then one launch per step (k_A_rows_solve, per-row prox, table, test)
+        if (int rc = mcl_launch_A_finish(c, false)) return rc;
+        if (int rc = generic_inner_loop(c, 0)) return rc;
+        if (int rc = mcl_launch_A_e1(c, true)) return rc;
+    } else if (mcl_mode_is_row_separable(c, 0)) {
         if (int rc = mcl_launch_A_finish(c, true)) return rc;
     } else {
         for (int k = 0; k < c->regs[0].n; ++k)

@@ -83,8 +83,10 @@ static ModeView view_of(mcl_context *c, int mode) {
 template <int NBR, bool VEC>
 __global__ __launch_bounds__(256) void k_rows_solve(ModeView mv, const float *__restrict__ rhs_src,
                                                     const float *__restrict__ Arows, const float *__restrict__ Linv,
-                                                    RegSet regs, int r) {
+                                                    RegSet regs, int r, double *__restrict__ change_part) {
+    // change_part != nullptr: per tile ||f_new - f_old||^2 (the inner stopping test, decomposition.py:100-107)
     TILE_PROLOGUE();
+    double chg = 0.0;
     const float rho = mv.rho[slab];
     RowMat<NBR> L, D;
     L.load(Linv + (long)slab * r * r, r, lane);
@@ -128,8 +130,24 @@ __global__ __launch_bounds__(256) void k_rows_solve(ModeView mv, const float *__
             }
         }
         L.apply(t, f);
+        if (change_part != nullptr) {
+#pragma unroll
+            for (int h = 0; h < NBR; ++h) {
+                const f32x4 fo = row_ld4<VEC>((const float *)mv.F, j, 16 * h + 4 * g, ok, r);
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (ok && 16 * h + 4 * g + v < r) {
+                        const double d = (double)f[h][v] - (double)fo[v];
+                        chg = fma(d, d, chg);
+                    }
+            }
+        }
 #pragma unroll
         for (int h = 0; h < NBR; ++h) row_st4<VEC>(mv.F, j, 16 * h + 4 * g, ok, r, f[h]);
+    }
+    if (change_part != nullptr) {
+        chg = wave_sum_d(chg);
+        if (lane == 0) change_part[tile] = chg;
     }
 }
 
@@ -332,7 +350,7 @@ __global__ __launch_bounds__(256) void k_stats_reduce(const int *__restrict__ sl
 // mode 0: every row has its own system (decomposition.py:184-195); one wave per row
 __global__ __launch_bounds__(64) void k_A_rows_solve(const float *__restrict__ rhsA, const float *__restrict__ rhoA,
                                                      const float *__restrict__ LinvA, float *__restrict__ A,
-                                                     RegSet regs, int r) {
+                                                     RegSet regs, int r, double *__restrict__ change_part) {
     MCL_GATE(regs.gate);
     __shared__ float tS[MCL_MAX_RANK];
     const int i = blockIdx.x, lane = threadIdx.x;
@@ -345,7 +363,66 @@ __global__ __launch_bounds__(64) void k_A_rows_solve(const float *__restrict__ r
     __syncthreads();
     float a = 0.f;
     for (int d = 0; d < r; ++d) a = fmaf(tS[d], LinvA[((long)i * r + d) * r + c], a);
+    if (change_part != nullptr) {  // ||a_new - a_old||^2 of the row (the inner stopping test)
+        const double d = act ? (double)a - (double)A[(long)i * r + c] : 0.0;
+        const double s = wave_sum_d(d * d);
+        if (lane == 0) change_part[i] = s;
+    }
     if (act) A[(long)i * r + c] = a;
+}
+
+// row-separable prox + dual step of penalty k on the rows of A when every row has ITS OWN feasibility penalty rho_i
+// (decomposition.py:197-213 with factor_matrix_row_update): the threshold of an L1 penalty is reg_strength / rho_i
+__global__ __launch_bounds__(256) void k_A_rows_prox(const float *__restrict__ rhoA, float *__restrict__ A, RegSet regs, int k, int I,
+                                                     int r) {
+    MCL_GATE(regs.gate);
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)I * r) return;
+    const float rho = rhoA[e / r];
+    const float f = A[e], u = regs.dual[k][e];
+    const float z = prox_elem_g(regs.kind[k], regs.nonneg[k], regs.p0[k], regs.p1[k], regs.p0[k] / rho, f + u);
+    regs.aux[k][e] = z;
+    regs.dual[k][e] = f - (z - u);
+}
+
+// The inner stopping test of a phase (decomposition.py:90-117) on the device.  begin: flag <- the run's stop flag (a gated run
+// that has stopped stays stopped).  Otherwise: change = sum of the solve pass's per-tile ||x - x_old||^2, norm and gaps from the
+// per-tile diagnostics table (column 0: ||x||^2, columns 2 + k: ||aux_k - x||^2); converged = change <= tol * norm and
+// every gap < tol (all on square roots, as the reference compares norms) -> flag = 1.  One workgroup, fixed summation order.
+__global__ __launch_bounds__(256) void k_inner_check(int begin, const int *__restrict__ run_gate, int *__restrict__ flag,
+                                                     const double *__restrict__ change_part, int n_change,
+                                                     const double *__restrict__ diag_tab, int n_rows, int n_regs, double tol) {
+    __shared__ double sm[256];
+    if (begin) {
+        if (threadIdx.x == 0) flag[0] = (run_gate != nullptr) ? run_gate[0] : 0;
+        return;
+    }
+    if (flag[0] != 0) return;
+    auto block_sum = [&](double v) {
+        sm[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+            __syncthreads();
+        }
+        const double t = sm[0];
+        __syncthreads();
+        return t;
+    };
+    double v = 0.0;
+    for (int e = threadIdx.x; e < n_change; e += 256) v += change_part[e];
+    const double change = block_sum(v);
+    v = 0.0;
+    for (int e = threadIdx.x; e < n_rows; e += 256) v += diag_tab[(long)e * DIAG_COLS];
+    const double norm = block_sum(v);
+    bool ok = !(sqrt(change) > tol * sqrt(norm));
+    for (int k = 0; k < n_regs; ++k) {
+        v = 0.0;
+        for (int e = threadIdx.x; e < n_rows; e += 256) v += diag_tab[(long)e * DIAG_COLS + 2 + k];
+        const double gap = sqrt(block_sum(v)) / sqrt(norm);
+        ok = ok && (gap < tol);
+    }
+    if (threadIdx.x == 0 && ok) flag[0] = 1;
 }
 
 // row-separable prox + dual update of penalty k (generic path)
@@ -1869,7 +1946,18 @@ static bool rows_vec_ok(const mcl_context *c, const ModeView &mv, const RegSet &
         }                                                                                                     \
     } while (0)
 
-int mcl_launch_rows_solve(mcl_context *c, int mode) {
+int mcl_launch_inner_check(mcl_context *c, int mode, bool begin) {
+    const TileMap &tm = (mode == 1) ? c->tilesB : (mode == 2 ? c->tilesC : c->tilesA);
+    const double *tab = (mode == 1) ? c->diagB_tile : (mode == 2 ? c->diagC_tile : c->diagA_tile);
+    const int n_change = (mode == 0) ? (int)c->I : tm.n_tiles;
+    ProfScope prof(c, MCL_PROF_OTHER);
+    hipLaunchKernelGGL(k_inner_check, dim3(1), dim3(256), 0, c->stream, begin ? 1 : 0, begin ? c->gate_active : nullptr, c->inner_gate,
+                       (const double *)c->inner_part, n_change, tab, c->diag_rows[mode], c->regs[mode].n, c->opt.inner_tol);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int mcl_launch_rows_solve(mcl_context *c, int mode, double *change_part) {
     ModeView mv = view_of(c, mode);
     if (mv.n_tiles == 0) return 0;
     const float *rhs = (mode == 1) ? c->XC : c->GRf + (long)c->r * c->r;  // fp32 image of R (k_C_prepare)
@@ -1879,15 +1967,15 @@ int mcl_launch_rows_solve(mcl_context *c, int mode) {
     const bool vec = rows_vec_ok(c, mv, c->regs[mode], rhs);
     ProfScope prof(c, mode == 1 ? MCL_PROF_ROWS_CHAIN : MCL_PROF_OTHER);
     if (mode == 1) c->variant[MCL_PROF_ROWS_CHAIN] = "k_rows_solve";
-    DISPATCH_ROWS(c, vec, k_rows_solve, grid, block, mv, rhs, Arows, Linv, c->regs[mode], c->r);
+    DISPATCH_ROWS(c, vec, k_rows_solve, grid, block, mv, rhs, Arows, Linv, c->regs[mode], c->r, change_part);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
 
-int mcl_launch_A_rows_solve(mcl_context *c) {
+int mcl_launch_A_rows_solve(mcl_context *c, double *change_part) {
     if (c->I == 0) return 0;
     hipLaunchKernelGGL(k_A_rows_solve, dim3((unsigned)c->I), dim3(64), 0, c->stream, c->rhsA, c->rhoA, c->LinvA, c->A,
-                       c->regs[0], c->r);
+                       c->regs[0], c->r, change_part);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }
@@ -1915,6 +2003,11 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
         case MCL_PEN_BOX:
         case MCL_PEN_L1:
             if (c->stack_fused) break;  // no statistics; the fused finish pass does the prox
+            if (mode == 0 && !c->opt.constant_A) {  // per-row feasibility penalties (the un-fused A loop of the inner stopping test)
+                hipLaunchKernelGGL(k_A_rows_prox, dim3((unsigned)((c->I * c->r + 255) / 256)), dim3(256), 0, c->stream,
+                                   (const float *)c->rhoA, c->A, rs, k, (int)c->I, c->r);
+                break;
+            }
             DISPATCH_ROWS(c, vec, k_rows_prox_rowsep, grid, block, mv, rs, k, c->r);
             break;
         case MCL_PEN_L2BALL:

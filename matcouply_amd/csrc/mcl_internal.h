@@ -192,6 +192,8 @@ struct mcl_context {
     int diagB_parity = 0;
     // gated runs (mcl_run): device state of the stopping rule
     int *mute_status = nullptr;        // int32[4]: where a muted run's verdict kernels report (MCL_TEST_MUTE_VERDICT)
+    int *inner_gate = nullptr;         // int32[2]: stop flag of the inner loop of the current phase (mcl_options.inner_tol)
+    double *inner_part = nullptr;      // [max tiles / rows] per-tile ||x - x_old||^2 of the last solve
     int *gate = nullptr;               // int32[4]: {stopped, stop_it, code, ticket of the verdict launch}
     const int *gate_active = nullptr;  // == gate while a gated run is enqueueing (copied into ModeView / RegSet), else NULL
     double *stop_state = nullptr;      // fp64[4]: {last computed loss, ...}
@@ -331,7 +333,8 @@ int mcl_launch_B_rho(mcl_context *c);
 int mcl_launch_B_systems(mcl_context *c);
 int mcl_launch_B_solve_f64(mcl_context *c);                      // penalty-free B: B_i = ((X_i C) o a_i) L_i^-1 in fp64
 int mcl_launch_rows_fused(mcl_context *c, int mode);             // fused inner ADMM loop, row-separable penalties
-int mcl_launch_rows_solve(mcl_context *c, int mode);
+int mcl_launch_rows_solve(mcl_context *c, int mode, double *change_part = nullptr);
+int mcl_launch_inner_check(mcl_context *c, int mode, bool begin);  // generic.hip: the inner stopping test on the device
 int mcl_launch_rows_prox(mcl_context *c, int mode, int k);       // generic prox step of penalty k (local part)
 int mcl_launch_rows_prox_finish(mcl_context *c, int mode, int k);
 int mcl_launch_C_prepare(mcl_context *c);
@@ -339,7 +342,7 @@ int mcl_launch_C_solve_f64(mcl_context *c);                      // penalty-free
 int mcl_launch_C_finish_fused(mcl_context *c);
 int mcl_launch_A_rho(mcl_context *c);
 int mcl_launch_A_finish(mcl_context *c, bool fused_inner);
-int mcl_launch_A_rows_solve(mcl_context *c);
+int mcl_launch_A_rows_solve(mcl_context *c, double *change_part = nullptr);
 int mcl_launch_A_e1(mcl_context *c, bool btb_is_q);
 int mcl_launch_rows_diag(mcl_context *c, int mode);
 int mcl_launch_diag_final(mcl_context *c, double *out, int include_replicated, bool a_from_rows);

@@ -861,6 +861,7 @@ bool mcl_sweep_eligible(const mcl_context *c) {
     if (!c->sweep_planned || !mcl_sweep_shape_ok(c)) return false;
     if (c->regs[1].n == 0 || c->regs[1].n > 2 || !mcl_mode_is_row_separable(c, 1)) return false;  // n = 0: fp64 solve
     if (c->opt.inner_n_iter_max <= 0) return false;
+    if (c->opt.inner_tol > 0.0) return false;  // the inner stopping test needs a launch per inner iteration
     if (reinterpret_cast<uintptr_t>(c->X) & 15) return false;
     return true;
 }

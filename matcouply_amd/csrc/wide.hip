@@ -618,6 +618,7 @@ bool mcl_wide_applies(const mcl_context *c, int mode) {
     if (!c->exact || c->sw.no_wide || mode < 0 || mode > 2) return false;
     const RegSet &rs = c->regs[mode];
     if (rs.n == 0 || c->opt.inner_n_iter_max <= 0 || c->wF[mode] == nullptr) return false;
+    if (c->opt.inner_tol > 0.0) return false;  // (the inner stopping test runs on the one-launch-per-step fp32 kernels)
     if (mode == 0 && (!c->opt.constant_A || c->LinvA64 == nullptr)) return false;
     for (int k = 0; k < rs.n; ++k)
         if (rs.kind[k] == MCL_PEN_EXTERNAL) return false;

@@ -600,7 +600,7 @@ def cmf_aoadmm(
     ``matrices`` is a list of I arrays (NumPy or torch, J_i x K) or a :class:`PackedMatrices` already in HBM.  The
     arithmetic runs in fp32 on the device (rank x rank systems and all reductions in fp64); results are returned in the
     array type and dtype of the input.  Not supported (out of scope, raise ``NotImplementedError``): TensorLy-ALS
-    initialisations.  ``inner_tol`` > 0 is supported on a slower step path (see below in the code).  Penalties without a native kernel (user
+    initialisations.  ``inner_tol`` > 0 is evaluated by the engine on the device (single-device runs; sharded runs: on a host-driven step path).  Penalties without a native kernel (user
     subclasses of ``matcouply_amd.penalties.ADMMPenalty``) are evaluated through their own Python methods on device
     tensors between the native solve and dual-update steps.
 
@@ -643,8 +643,10 @@ def cmf_aoadmm(
     if not update_C:
         regs[2] = []
     # inner_tol > 0 (early exit of the inner ADMM loops, decomposition.py:90-117) needs a convergence test after every
-    # inner iteration: the modes then run on the step path (native solves, every prox through the penalty objects' own
-    # methods on device tensors) instead of the fused kernels - functional, not fast; the default None is the fast path
+    # inner iteration.  Single-device runs: the ENGINE evaluates it (mcl_options.inner_tol: one launch per step, a device-side
+    # flag the remaining inner launches test; native prox kernels stay native, no host synchronisation).  Sharded runs (the
+    # norms must be all-reduced over the ranks) and the CPU checker keep the step path: native solves, every prox through
+    # the penalty objects' own methods on device tensors, the test on the host
     check_inner = bool(inner_tol) and inner_tol > 0
     if isinstance(constant_feasibility_penalty, str) and constant_feasibility_penalty not in {"A", "B"}:
         raise ValueError(
@@ -670,13 +672,14 @@ def cmf_aoadmm(
         raise ValueError("The B_i matrices of `init` do not match the shapes of `matrices`")
 
     native = [[], [], []]
+    device_inner = check_inner and sub is None and group is None
     aux_lists, dual_lists = (A_aux_list, B_aux_list, C_aux_list), (A_dual_list, B_dual_list, C_dual_list)
     # host-evaluated penalties: the Python object keeps the auxiliary variable in ITS parametrisation (on the device),
     # the engine sees `aux_as_matrix` of it (reference penalties.py:311-343)
     ext_aux = {}
     for mode in range(3):
         for k, (reg, aux, dual) in enumerate(zip(regs[mode], aux_lists[mode], dual_lists[mode])):
-            desc = None if check_inner else penalties.native_descriptor_of(reg)
+            desc = None if (check_inner and not device_inner) else penalties.native_descriptor_of(reg)
             gl2_matrix = None
             if desc is not None and desc[0] == _engine.PEN_GL2:
                 # every matrix of the mode must have as many rows as the norm matrix (anything else fails in the reference's
@@ -726,7 +729,8 @@ def cmf_aoadmm(
         exact_products = 1 if float(n_el.item()) <= float(1 << 20) else 2
     eng = factory(X=X, row_ptr=row_ptr, rank=rank, A=A, B=B, C=C, regs=native, l2_penalty=l2_penalty,
                   inner_n_iter_max=inner_n_iter_max, feasibility_penalty_scale=feasibility_penalty_scale,
-                  constant_A=constant_A, constant_B=constant_B, exact_products=exact_products)
+                  constant_A=constant_A, constant_B=constant_B, exact_products=exact_products,
+                  **(dict(inner_tol=inner_tol) if device_inner else {}))
     # the sharded code path (step calls with the reductions in between): taken with more than one rank - and, for
     # rehearsals of that path on a single-GPU box, with a one-rank group when MCL_FORCE_SHARDED_PATH=1
     sharded = world > 1 or (group is not None and os.environ.get("MCL_FORCE_SHARDED_PATH") == "1")
@@ -796,7 +800,7 @@ def cmf_aoadmm(
 
     def inner_converged(F, F_old, mode):
         """decomposition.py:90-117 on device tensors: relative change and every feasibility gap of the mode below inner_tol"""
-        if not check_inner:
+        if not check_inner:  # (host-driven modes - host-evaluated penalties - run the test here even when the engine has it too)
             return False
         # squared norms in fp64: [ |F|^2, |F - F_old|^2, |F - aux_k|^2 ... ].  With group= the rows of modes 0 and 1 live on
         # different ranks: the sums are all-reduced, so that every rank leaves the inner loop at the same iteration and the

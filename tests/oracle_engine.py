@@ -32,7 +32,8 @@ def _desc(reg):
 
 class OracleEngine:
     def __init__(self, X, row_ptr, rank, A, B, C, regs, l2_penalty=(0, 0, 0), inner_n_iter_max=5,
-                 feasibility_penalty_scale=1.0, constant_A=False, constant_B=False, exact_products=0):
+                 feasibility_penalty_scale=1.0, constant_A=False, constant_B=False, exact_products=0, inner_tol=0.0):
+        assert not inner_tol  # the checker runs the inner stopping test on the host path (decomposition.py keeps it there)
         self.exact_products = int(exact_products)  # the HIP engine's arithmetic hint under group= (the checker is fp64 anyway)
         self.A, self.B, self.C, self.regs = A, B, C, regs
         self.Xn = X.numpy()

@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     # mcl_penalty_desc: 2 x int32, 2 x double, 3 pointers + (ABI 400) the matrix pointer and its int64 row count;
     # mcl_options: 4 doubles + 4 int32
     assert ctypes.sizeof(_engine.PenaltyDesc) == 8 + 16 + 24 + 16
-    assert ctypes.sizeof(_engine.Options) == 32 + 16
+    assert ctypes.sizeof(_engine.Options) == 40 + 16  # 5 doubles (ABI 400: + inner_tol) + 4 int32
     assert _engine.DIAG_LEN == 8 + 3 * _engine.MCL_MAX_REGS * 2
 
 

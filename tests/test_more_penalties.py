@@ -327,12 +327,19 @@ def test_oracle_inner_tol_matches_reference():
 
 
 @pytest.mark.gpu
-def test_solver_inner_tol_matches_reference():
-    """inner_tol > 0 through cmf_aoadmm (step path: native solves, prox of every penalty on device tensors, convergence test
-    after every inner iteration) vs the reference's trajectory.  The exit decisions compare quantities far from their
-    thresholds on this problem, so fp32 takes the same exits."""
-    from matcouply_amd import decomposition as dec
+def test_solver_inner_tol_matches_reference(kernel_paths, monkeypatch):
+    """inner_tol > 0 through cmf_aoadmm vs the reference's trajectory: the inner stopping test runs ON THE DEVICE
+    (mcl_options.inner_tol: k_inner_check sets a flag the remaining inner launches test) - the host-driven step
+    calls are forbidden here, so no inner iteration synchronises with the host.  The exit decisions compare quantities far
+    from their thresholds on this problem, so fp32 takes the same exits."""
+    from matcouply_amd import _engine, decomposition as dec
     from tests.test_host_api import make_penalty
+
+    def boom(self, *a, **kw):
+        raise AssertionError("a host-driven step call was made: the inner stopping test did not run on the device")
+
+    for name in ("B_solve", "A_solve", "C_solve", "B_prox_local"):
+        monkeypatch.setattr(_engine.HipEngine, name, boom)
 
     arrs = load_npz("more_penalties.npz")
     spec = json.loads(str(arrs["it_spec"]))
