@@ -357,3 +357,32 @@ def test_solver_inner_tol_matches_reference(kernel_paths, monkeypatch):
     assert rel_err(np.concatenate(cmf[1][1]), arrs["it_B"]) < tol
     np.testing.assert_allclose(diag.rec_errors, arrs["it_rec_errors"], rtol=1e-5)
     np.testing.assert_allclose(diag.regularized_loss, arrs["it_regularized_loss"], rtol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stack", ["pf2_ball", "uni_tv_constant", "rowsep"])
+def test_device_inner_tol_on_generic_stacks(stack, kernel_paths):
+    """the device-side inner stopping test with slab-wise penalties in the loop (PARAFAC2 + L2 ball; unimodality + total
+    variation with matrix penalties on A under a constant feasibility penalty; row-separable stacks with per-row rho on A):
+    three outer iterations against the oracle, which takes the reference's exits (decomposition.py:90-117)"""
+    from tests.test_gpu_end_to_end import _compare, _run_both
+
+    rng = np.random.RandomState(11)
+    if stack == "pf2_ball":
+        I, J, K, r, kw = 6, rng.randint(30, 80, 6), 48, 4, {}
+        regs = [[{"kind": "nn"}], [{"kind": "parafac2"}, {"kind": "l2ball", "norm_bound": 1.5}], [{"kind": "l1", "reg_strength": 0.02}]]
+    elif stack == "uni_tv_constant":
+        I, J, K, r, kw = 8, rng.randint(30, 80, 8), 40, 3, dict(constant_A=True, constant_B=True)
+        regs = [[{"kind": "l2ball", "norm_bound": 2.0, "non_negativity": True}], [{"kind": "unimodal", "non_negativity": True}],
+                [{"kind": "tv", "reg_strength": 0.01, "l1_strength": 0.0}]]
+    else:
+        I, J, K, r, kw = 7, rng.randint(30, 80, 7), 64, 5, {}
+        regs = [[{"kind": "l1", "reg_strength": 0.05}, {"kind": "nn"}], [{"kind": "nn"}], [{"kind": "box", "min_val": 0.0, "max_val": 0.9}]]
+    X, row_ptr = orc.synthetic_problem(I, J, K, r, seed=4, dtype=np.float64)
+    X = X.astype(np.float32).astype(np.float64)
+    st = orc.random_state_for(X, row_ptr, r, regs, seed=8, inner_n_iter_max=15, **kw)
+    st.inner_tol = 5e-2
+    cmf, admm, diag, res = _run_both(st, 3, inner_tol=5e-2)
+    assert min(st.inner_iters) < 15, st.inner_iters  # an early exit is actually taken somewhere
+    errs = _compare(cmf, admm, diag, st, res, 1e-5, 1e-5)
+    print(stack, kernel_paths, "inner iterations taken (oracle):", st.inner_iters, {k: f"{v:.1e}" for k, v in errs.items()})
