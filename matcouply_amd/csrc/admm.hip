@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) void k_A_finish(float *__restrict__ BtB, const
                                                   float *__restrict__ LinvB, const int *__restrict__ slab_seg_ptr,
                                                   const double *__restrict__ seg_rhs, const double *__restrict__ seg_btb,
                                                   float *__restrict__ rhsA_out, int wide_inner, double *__restrict__ LinvA64,
-                                                  double *__restrict__ rhsA64) {
+                                                  double *__restrict__ rhsA64, double *__restrict__ Q64) {
     MCL_GATE(regs.gate);
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -850,6 +850,9 @@ __global__ __launch_bounds__(256) void k_A_finish(float *__restrict__ BtB, const
                 if (LinvA64 != nullptr) LinvA64[((long)i * r + d) * r + c] = col[d];
             }
         if (act && rhsA64 != nullptr) rhsA64[(long)i * r + c] = rhs;
+#pragma unroll
+        for (int d = 0; d < RP; ++d)
+            if (act && d < r && Q64 != nullptr) Q64[((long)i * r + d) * r + c] = qcol[d];
         return;
     }
     float z[MCL_MAX_REGS], u[MCL_MAX_REGS], on[MCL_MAX_REGS];
@@ -1025,7 +1028,7 @@ struct AFuse {
     double *CtC64_out;
     float *CtC_out;
     double *LinvB64;  // fp64 copy of the next B-phase's inverses (fp64 row passes of PARAFAC2 stacks: mcl_rows64), or NULL
-    double *LinvA64, *rhsA64;  // fp64 systems / right-hand sides of a host- or wide-driven inner loop (fused_inner = 0), or NULL
+    double *LinvA64, *rhsA64, *Q64;  // fp64 systems / right-hand sides / cross products of a host- or wide-driven inner loop (fused_inner = 0), or NULL
     int wide_inner;            // small problems (exact-products mode): the inner loop keeps the row and its ADMM variables in fp64
 };
 
@@ -1218,6 +1221,9 @@ static __device__ __forceinline__ void a_finish_rows_slab(const int i, const int
                 if (F.LinvA64 != nullptr) F.LinvA64[((long)i * r + drow[j]) * r + c] = col[j];
             }
         if (lead && F.rhsA64 != nullptr) F.rhsA64[(long)i * r + c] = rhs;
+#pragma unroll
+        for (int j = 0; j < RL; ++j)
+            if (dok[j] && F.Q64 != nullptr) F.Q64[((long)i * r + drow[j]) * r + c] = qf[j];
         return;
     }
 #pragma unroll
@@ -1438,7 +1444,11 @@ __global__ void k_A_rho(const double *__restrict__ BtB, const double *__restrict
 __global__ __launch_bounds__(64) void k_A_e1(const float *__restrict__ rhsA, const float *__restrict__ BtB,
                                              const float *__restrict__ CtC, int btb_is_q, const float *__restrict__ A,
                                              RegSet regs, int r, double *__restrict__ e1,
-                                             double *__restrict__ diag_row) {
+                                             double *__restrict__ diag_row, const double *__restrict__ rhs64,
+                                             const double *__restrict__ Q64) {
+    // rhs64 / Q64: the fp64 right-hand sides / cross products the systems were built from (exact-products mode): the fast
+    // error formula ||X||^2 - 2 <X, M> + ||M||^2 cancels to rec^2, so the fp32 rounding of rhs_i and Q_i (6e-8) would reach
+    // the reconstruction error multiplied by ||X||^2 / rec^2
     MCL_GATE(regs.gate);
     const int i = blockIdx.x, lane = threadIdx.x;
     const bool act = lane < r;
@@ -1446,11 +1456,12 @@ __global__ __launch_bounds__(64) void k_A_e1(const float *__restrict__ rhsA, con
     const float a = A[(long)i * r + c];
     double qa = 0.0;
     for (int d = 0; d < r; ++d) {
-        double q = (double)BtB[((long)i * r + c) * r + d];
+        double q = Q64 != nullptr ? Q64[((long)i * r + c) * r + d] : (double)BtB[((long)i * r + c) * r + d];
         if (!btb_is_q) q *= (double)CtC[c * r + d];
         qa += q * (double)A[(long)i * r + d];
     }
-    const double inner_i = wave_sum(act ? (double)rhsA[(long)i * r + c] * (double)a : 0.0);
+    const double rhs_c = rhs64 != nullptr ? rhs64[(long)i * r + c] : (double)rhsA[(long)i * r + c];
+    const double inner_i = wave_sum(act ? rhs_c * (double)a : 0.0);
     const double model_i = wave_sum(act ? (double)a * qa : 0.0);
     const double nf = wave_sum(act ? (double)a * (double)a : 0.0);
     const double na = wave_sum(act ? fabs((double)a) : 0.0);
@@ -2178,13 +2189,13 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
         F.MS = mcl_sweep_KC(c) * 64 * 16 * c->NB;
     }
     F.LinvB64 = b_needs_64 ? c->LinvB64 : nullptr;
-    F.LinvA64 = c->LinvA64, F.rhsA64 = c->rhsA64;  // (allocated in the exact-products mode only)
+    F.LinvA64 = c->LinvA64, F.rhsA64 = c->rhsA64, F.Q64 = c->Q64;  // (allocated in the exact-products mode only)
     F.wide_inner = (c->exact && !c->sw.no_wide) ? 1 : 0;
     if (!rows_kernel && c->ctc_parts > 0)
         if (int rc = mcl_launch_ctc_fold(c)) return rc;
     // ranks 5..32: rows of every system split over the lane groups (all 64 lanes busy); 64 columns fill the wave anyway
     if (!rows_kernel) {
-        DISPATCH_RP_T(c, k_A_finish, grid, block, MCL_AF_ARGS, F.wide_inner, c->LinvA64, c->rhsA64);
+        DISPATCH_RP_T(c, k_A_finish, grid, block, MCL_AF_ARGS, F.wide_inner, c->LinvA64, c->rhsA64, c->Q64);
     } else if (c->a_rhs_wide) {
         if (c->a_rhs_pairs) {  // two slabs per workgroup (one partial per slab, many slabs)
             const dim3 gp((unsigned)((c->I + 1) / 2));
@@ -2206,6 +2217,7 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
     }
 #undef MCL_AF_ARGS
     MCL_CHECK_HIP(c, hipGetLastError());
+    c->a64_valid = !fused_inner && c->Q64 != nullptr;  // rhsA64 / Q64 / LinvA64 hold this phase's systems
     c->variant[MCL_PROF_A_FINISH] = !rows_kernel ? "k_A_finish" : (c->a_rhs_wide ? (c->a_rhs_pairs ? "k_A_finish_rows_wide<SPB=2>" : "k_A_finish_rows_wide<SPB=1>") : "k_A_finish_rows");
     c->ctc_parts = 0;  // the rows kernels wrote the totals
     c->b_systems_valid = (next_B != 0);
@@ -2215,8 +2227,11 @@ int mcl_launch_A_finish(mcl_context *c, bool fused_inner) {
 int mcl_launch_A_e1(mcl_context *c, bool btb_is_q) {
     ProfScope prof_(c, MCL_PROF_OTHER);
     if (c->I == 0) return 0;
+    // (the fp64 copies exist in the exact-products mode and are current when the systems were just built from them)
+    const bool wide = btb_is_q && c->exact && c->a64_valid;
     hipLaunchKernelGGL(k_A_e1, dim3((unsigned)c->I), dim3(64), 0, c->stream, c->rhsA, c->BtB, c->CtC, btb_is_q ? 1 : 0,
-                       c->A, c->regs[0], c->r, c->e1, c->diagA_row);
+                       c->A, c->regs[0], c->r, c->e1, c->diagA_row, wide ? (const double *)c->rhsA64 : nullptr,
+                       wide ? (const double *)c->Q64 : nullptr);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
 }

@@ -103,6 +103,7 @@ int64_t plan(mcl_context *c, char *base) {
     c->wD = c->exact ? b.take<double>(r * r) : nullptr;
     c->LinvA64 = c->exact ? b.take<double>(I * r * r) : nullptr;
     c->rhsA64 = c->exact ? b.take<double>(I * r) : nullptr;
+    c->Q64 = c->exact ? b.take<double>(I * r * r) : nullptr;
     c->GRf = b.take<float>(E);
     c->LinvC64 = b.take<double>(r * r);
     c->rhoC = b.take<float>(1);

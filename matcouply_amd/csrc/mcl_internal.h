@@ -131,7 +131,8 @@ struct mcl_context {
     double *wF[3] = {nullptr, nullptr, nullptr};
     double *wZ[3][MCL_MAX_REGS] = {}, *wU[3][MCL_MAX_REGS] = {};
     double *wD = nullptr;
-    double *LinvA64 = nullptr, *rhsA64 = nullptr;  // fp64 copies of the A-phase systems / right-hand sides (mode 0 of wide.hip)
+    double *LinvA64 = nullptr, *rhsA64 = nullptr, *Q64 = nullptr;  // fp64 copies of the A-phase systems / right-hand sides / cross products (mode 0 of wide.hip, k_A_e1)
+    bool a64_valid = false;  // ... and they belong to the systems mcl_launch_A_finish(fused_inner = false) built last
     double *exact_part = nullptr;  // exact-products mode: [G | R] per 256-row chunk (fp64), summed in a fixed order
     bool exact = false;            // exact-products mode (small problems): X C, [G | R] and the A-phase tables from fp64 sums of exact products
     bool mseg_valid = false;       // Mpart / part_btb correspond to the current B

@@ -589,6 +589,7 @@ def cmf_aoadmm(
     *,
     group=None,
     gather_A=False,
+    arithmetic="auto",
     _byproducts=None,
 ):
     r"""Fit a regularized coupled matrix factorization model with AO-ADMM on an MI355X.
@@ -606,6 +607,10 @@ def cmf_aoadmm(
 
     Sharded runs (``group=``, keyword-only, not in the reference): every rank of the ``torch.distributed`` process group
     passes ITS matrices (see :func:`partition_slabs`) and gets back its rows of ``A``, its ``B_i`` and the replicated ``C``;
+    ``arithmetic`` (keyword-only, not in the reference): ``"auto"`` - problems of at most 2^20 elements take every contraction
+    as fp64 sums of exact products and their inner ADMM loops in fp64 (the reference's own regime: parity at the storage level
+    of fp32), larger ones the fp32 matrix-core kernels; ``"exact"`` forces the former at any size (slower; for large problems
+    with ill-conditioned penalty-free modes), ``"fast"`` the latter.
     ``gather_A=True`` all-gathers the rows of ``A`` once at the end (rank order, i.e. the original order for contiguous
     partitions): the factorization returned stays the rank's own, the whole ``A`` rides along as ``cmf.A_all`` with this
     rank's rows at ``cmf.rows_of_rank`` (the ADMM variables of mode 0 stay rank-local).  Per outer iteration
@@ -722,8 +727,10 @@ def cmf_aoadmm(
         rank_id = 0
     # the arithmetic of small problems (exact-products mode) is chosen by the size of the WHOLE problem:
     # every rank of a sharded run, and every rank layout of the same problem, then computes with the same kernels
-    exact_products = 0
-    if world > 1:
+    if arithmetic not in ("auto", "exact", "fast"):
+        raise ValueError(f'arithmetic must be "auto", "exact" or "fast", not {arithmetic!r}')
+    exact_products = {"auto": 0, "exact": 1, "fast": 2}[arithmetic]
+    if world > 1 and arithmetic == "auto":
         n_el = torch.tensor([float(X.shape[0]) * float(X.shape[1])], dtype=torch.float64, device=X.device)
         dist.all_reduce(n_el, group=group)
         exact_products = 1 if float(n_el.item()) <= float(1 << 20) else 2
@@ -1350,6 +1357,7 @@ def parafac2_aoadmm(
     *,
     group=None,
     gather_A=False,
+    arithmetic="auto",
 ):
     """Alias for cmf_aoadmm with the PARAFAC2 constraint on mode 1 (reference decomposition.py:1103-1179)."""
     return cmf_aoadmm(
@@ -1361,4 +1369,4 @@ def parafac2_aoadmm(
         init_params=init_params, random_state=random_state, tol=tol, absolute_tol=absolute_tol,
         feasibility_tol=feasibility_tol, inner_tol=inner_tol, inner_n_iter_max=inner_n_iter_max, update_A=update_A,
         update_B_is=update_B_is, update_C=update_C, return_errors=return_errors, return_admm_vars=return_admm_vars,
-        verbose=verbose, group=group, gather_A=gather_A)
+        verbose=verbose, group=group, gather_A=gather_A, arithmetic=arithmetic)

@@ -197,3 +197,26 @@ def test_ill_conditioned_polar_factor_takes_the_qr_route(seed):
     print(seed, f"cond up to {max(conds):.1e}", {k: f"{v:.1e}" for k, v in errs.items()})
     assert max(errs.values()) < 1e-5, errs
     eng.close()
+
+
+def test_exact_arithmetic_can_be_forced_on_a_larger_problem():
+    """arithmetic="exact" (mcl_options.exact_products = 1): the exact-products contractions and the fp64 inner loops at a size
+    where the library would pick the fp32 matrix-core kernels (1.6 M elements of X) - for problems whose penalty-free modes are
+    ill-conditioned (here: L2 ball on the B_i, A and C free but for a small ridge).  Closer to the oracle than the fast kernels,
+    inside the flat 1e-5."""
+    from oracle import aoadmm_oracle as orc
+
+    I, K, r = 40, 128, 8
+    J = np.random.RandomState(2).randint(200, 420, I)
+    X, row_ptr = orc.synthetic_problem(I, J, K, r, seed=12, dtype=np.float64)
+    X = X.astype(np.float32).astype(np.float64)
+    assert X.size > (1 << 20)
+    regs = [[], [{"kind": "l2ball", "norm_bound": 0.7}], []]
+    worst = {}
+    for arithmetic in ("exact", "fast"):
+        st = orc.random_state_for(X, row_ptr, r, regs, seed=13, l2=[0.05, 0.0, 0.05])
+        cmf, admm, diag, res = _run_both(st, 3, arithmetic=arithmetic)
+        errs = _compare(cmf, admm, diag, st, res, 1.0, 1.0)
+        worst[arithmetic] = max(errs.values())
+    print(f"exact {worst['exact']:.1e}   fast {worst['fast']:.1e}")
+    assert worst["exact"] < 1e-5 and worst["exact"] < worst["fast"], worst
