@@ -297,8 +297,9 @@ int mcl_profile_enable(mcl_context *ctx, int32_t capacity);
 int mcl_profile_set_stride(mcl_context *ctx, int32_t stride);
 int mcl_profile_read(mcl_context *ctx, int32_t which /* enum mcl_profile_slot */, double *total_ms, int32_t *count);
 int64_t mcl_profile_launches(mcl_context *ctx, int32_t which /* enum mcl_profile_slot */);
-/* elapsed time of an EMPTY event pair on the context's stream, measured by mcl_profile_enable (microseconds): the part of
- * every timed launch that is the command processor's marker handling, not the kernel */
+/* what an event pair adds to the launch it brackets (microseconds), calibrated by mcl_profile_enable on the context's stream:
+ * a pair around one tiny operation minus that operation's marginal cost inside a pair around two of them - the part of every
+ * timed launch that is the command processor's marker handling, not the kernel */
 double mcl_profile_overhead_us(mcl_context *ctx);
 /* The MCL_* environment switches (A/B experiments, debug paths; tools/README.md) are read once in mcl_create();
  * this re-reads them for an existing context (tests that compare kernel forms on one problem).
