@@ -15,6 +15,11 @@ int mcl_rows_fused_dispatch(mcl_context *c, int mode, double *diag);  // admm.hi
 
 static std::string g_create_error;
 
+// the smallest kernel there is: what mcl_profile_enable calibrates the cost of an event pair on
+__global__ void k_prof_nop(int *p) {
+    if (threadIdx.x == 0) p[0] = 0;
+}
+
 namespace {
 
 struct Bump {
@@ -1424,7 +1429,7 @@ int mcl_profile_enable(mcl_context *c, int32_t capacity) {
     }
     c->prof_capacity = capacity;
     // What an event pair adds to the kernel between its events (the command processor's marker -> dispatch and completion ->
-    // marker handling), calibrated on a tiny operation (a 16-byte memset of a scratch word): a pair around ONE of them reads
+    // marker handling), calibrated on the smallest kernel there is (one store to a scratch word): a pair around ONE of them reads
     // T1, around TWO back to back T2 - the second one's marginal cost T2 - T1 is what such a kernel takes inside a stream of
     // kernels, so the pair itself costs T1 - (T2 - T1).  (An EMPTY pair reads ~4.5 us and over-corrects: part of it overlaps
     // with the dispatch of the kernel it brackets.)
@@ -1437,7 +1442,7 @@ int mcl_profile_enable(mcl_context *c, int32_t capacity) {
         for (int n = 1; n <= 2; ++n)
             for (int t = 0; t < 12; ++t) {
                 MCL_CHECK_HIP(c, hipEventRecord(ev[0], c->stream));
-                for (int k = 0; k < n; ++k) MCL_CHECK_HIP(c, hipMemsetAsync(c->mute_status, 0, 4 * sizeof(int), c->stream));
+                for (int k = 0; k < n; ++k) hipLaunchKernelGGL(k_prof_nop, dim3(1), dim3(64), 0, c->stream, c->mute_status);
                 MCL_CHECK_HIP(c, hipEventRecord(ev[1], c->stream));
                 MCL_CHECK_HIP(c, hipEventSynchronize(ev[1]));
                 float ms = 0.f;
