@@ -31,7 +31,9 @@ def _check_per_kernel(d, most_of_the_step=True):
     top = max(with_bytes, key=lambda e: e["launches_per_step"] * e["avg_us"])
     assert r["kernel"] == top["kernel"] and r["kernel_role"] == top["role"], (r["kernel"], top["kernel"])
     assert abs(r["avg_us"] - top["avg_us"]) < 1e-6 and r["frac"] == top["frac"]
-    assert sum(shares) <= 1e3 * d["ms_per_step"] * 1.02, (sum(shares), d["ms_per_step"], [(e["role"], e["launches_per_step"], e["avg_us"]) for e in pk])
+    # (10 %: a sampled launch carries its event pair; the calibrated overhead is subtracted, the perturbation of a 3-9 us kernel
+    # by the markers around it is not)
+    assert sum(shares) <= 1e3 * d["ms_per_step"] * 1.10, (sum(shares), d["ms_per_step"], [(e["role"], e["launches_per_step"], e["avg_us"]) for e in pk])
     if most_of_the_step:  # ... and the timed sites are most of the step (not asserted on regions of a few hundred microseconds,
         assert sum(shares) >= 0.5 * 1e3 * d["ms_per_step"]  # where the synchronisation of the region is most of its time)
     assert 0 < r["step_frac"] < 1 and abs(r["step_frac"] - d["algorithmic_bytes_per_iter"] / (d["ms_per_step"] * 1e-3) / 8e12) < 2e-3
