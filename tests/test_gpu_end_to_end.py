@@ -186,10 +186,13 @@ def test_config1_converges_like_the_reference():
     X, _ = get_simple_simulated_data(noise_level=0.2, random_state=1)
     cmf, diag = dec.parafac2_aoadmm(X, 3, non_negative=True, random_state=0, return_errors=True)
     assert diag.message == ref["message"]
-    # The default tol=1e-8 on the relative loss change is below fp32 resolution, so the iteration at which the rule
-    # fires is not a parity metric (SURVEY.md finding 4): only require the same rule to fire in the same regime.
-    assert 100 <= diag.n_iter <= 400, diag.n_iter
-    np.testing.assert_allclose(diag.rec_errors[-1], ref["final_rec_error"], rtol=1e-4)
+    # The default tol=1e-8 on the relative loss change sits at the resolution of fp32 STATE, so rounds 1-4 only asked for the same
+    # rule in the same regime (185 iterations against the reference's 219 was accepted as 100..400).  Since round 5 a problem of
+    # this size runs its inner loops in fp64 (csrc/wide.hip) and the rule fires at the reference's own iteration: 219 measured;
+    # held to +-3 (the fp32 storage of the state between phases is still there), the final error to 1e-7.
+    assert abs(diag.n_iter - ref["n_iter"]) <= 3, (diag.n_iter, ref["n_iter"])
+    np.testing.assert_allclose(diag.rec_errors[-1], ref["final_rec_error"], rtol=1e-7)
+    np.testing.assert_allclose(diag.regularized_loss[-1], ref["final_loss"], rtol=1e-6)
 
 
 SCALE_CASES = {
