@@ -107,8 +107,12 @@ def test_golden_trajectories(fname, kernel_paths):
     e = {"A": rel_err(cmf[1][0], arrs["A"]), "B": rel_err(np.concatenate(cmf[1][1]), arrs["B"]),
          "C": rel_err(cmf[1][2], arrs["C"])}
     print(fname, "20 it vs reference:", {k: f"{v:.1e}" for k, v in e.items()})
-    if max(e.values()) < 3e-6:  # measured: <= 7e-7 on six of the seven trajectories
+    if max(e.values()) < 3e-6:  # measured: <= 1e-7 on six of the seven trajectories, 1.2e-6 on the full stack (default path)
         return
+    # Round 5: on the DEFAULT path (fp64 inner loops of small problems, csrc/wide.hip) every one of the seven free-running
+    # trajectories stays inside that bar - the full stack included, whose re-pooled column the fp32 row arithmetic used to
+    # tip.  What follows is the fast-kernels leg only.
+    assert kernel_paths == "fast-kernels", (fname, e)
     # Above that the free-running trajectory has met a DISCONTINUITY of the reference's own map: the unimodal regression of
     # the full stack (traj_c5_full) pools a column differently when two candidate level sets are closer than the distance
     # the two trajectories have drifted apart by then (tools/traj_growth.py: B error 3e-6 at iteration 12, 2e-5 at 16, 98 % of
