@@ -32,7 +32,7 @@ typedef struct mcl_context mcl_context;
  * 400 this header: named indices (enum mcl_buffer_id, enum mcl_profile_slot, MCL_VARIANT_EXACT_MODE - the exact-mode query
  *     moved from index 4 to 100), twelve profile slots, mcl_profile_launches, a failed state after mcl_run's watchdog,
  *     mcl_options.inner_tol / exact_products, native GeneralizedL2 / UnitSimplex kinds (mcl_penalty_desc grew two fields),
- *     mcl_penalty_value.
+ *     mcl_penalty_value, mcl_svd_init.
  * A host MUST compare mcl_version() with the MCL_ABI_VERSION it was built against before any other call. */
 #define MCL_ABI_VERSION 400
 
@@ -237,6 +237,18 @@ int mcl_wait_event(mcl_context *ctx, void *hip_event);
  * all device pointers; enqueued on hip_stream. */
 int mcl_cmf_to_packed(const float *A, const float *B, const float *C, const float *weights, const int32_t *slab_of_row,
                       int64_t N, int64_t K, int32_t rank, float *out, void *hip_stream);
+
+/* ---- before the solver: init="svd" / "threshold_svd" (decomposition.py:41-54) for data resident in HBM ---------------------- */
+/* B_i = the leading `rank` left singular vectors of X_i (packed [N, rank]), C = the leading right singular vectors of the
+ * stacked matrices [K, rank]; threshold != 0 clips negative entries (threshold_svd).  Stateless; X, B, C, workspace, info:
+ * device pointers; row_ptr: HOST int64[I+1].  fp64 subspace iteration on the K x K Gram matrices (csrc/svdinit.hip).  The
+ * entry of largest magnitude of every column of B_i and of C is positive: a singular vector's sign is the driver's choice,
+ * so the vectors equal LAPACK's up to these signs.  info: int32[I+1] - iterations used per matrix (last: the stack), negative
+ * when the Ritz values had not settled after 400.  Synchronises the stream once (the upload of row_ptr). */
+int64_t mcl_svd_init_workspace_bytes(const int64_t *row_ptr, int64_t I, int64_t K, int32_t rank);
+int mcl_svd_init(const float *X, const int64_t *row_ptr, int64_t I, int64_t K, int32_t rank, int32_t threshold, float *B, float *C,
+                 void *workspace, int64_t workspace_bytes, int32_t *info, void *hip_stream);
+const char *mcl_svd_init_last_error(void);
 
 /* ---- introspection for tests / profiling ------------------------------------------------------------- */
 /* device pointers to internal by-products / planner tables (the int32 tables: read the bits) */

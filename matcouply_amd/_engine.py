@@ -45,6 +45,7 @@ EXPORTED_SYMBOLS = [
     "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
     "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_set_stride", "mcl_profile_read", "mcl_profile_launches", "mcl_profile_overhead_us",
     "mcl_reload_switches", "mcl_active_switches", "mcl_record_event", "mcl_wait_event", "mcl_cmf_to_packed",
+    "mcl_svd_init_workspace_bytes", "mcl_svd_init", "mcl_svd_init_last_error",
 ]
 
 
@@ -138,6 +139,9 @@ def load_library():
         "mcl_record_event": (ctypes.c_int, [P, P]),
         "mcl_wait_event": (ctypes.c_int, [P, P]),
         "mcl_cmf_to_packed": (ctypes.c_int, [P, P, P, P, P, I64, I64, I32, P, P]),
+        "mcl_svd_init_workspace_bytes": (I64, [ctypes.POINTER(I64), I64, I64, I32]),
+        "mcl_svd_init": (ctypes.c_int, [P, ctypes.POINTER(I64), I64, I64, I32, I32, P, P, P, I64, P, P]),
+        "mcl_svd_init_last_error": (ctypes.c_char_p, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -177,6 +181,35 @@ def cmf_to_packed(A, B, C, row_ptr, weights=None):
     if rc != 0:
         raise EngineError("mcl_cmf_to_packed failed")
     return out
+
+
+def svd_init(X, row_ptr, rank, threshold=False):
+    """init="svd" / "threshold_svd" on the device (mcl_svd_init): X packed [sum J_i, K] float32 CUDA tensor -> (B packed
+    [sum J_i, rank], C [K, rank], info int32 [I + 1]: subspace iterations per matrix, the stack last).  Singular vectors with
+    the entry of largest magnitude positive (LAPACK's vectors up to sign)."""
+    import torch
+
+    lib = load_library()
+    if not (X.is_cuda and X.dtype == torch.float32 and X.is_contiguous()):
+        raise EngineError("X must be a contiguous float32 CUDA tensor")
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    I, K, N = len(row_ptr) - 1, int(X.shape[1]), int(X.shape[0])
+    rp = row_ptr.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    nbytes = lib.mcl_svd_init_workspace_bytes(rp, I, K, int(rank))
+    if nbytes < 0:
+        raise EngineError("mcl_svd_init_workspace_bytes: bad arguments")
+    ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=X.device)
+    off = (-ws.data_ptr()) % 256
+    B = torch.empty((N, int(rank)), dtype=torch.float32, device=X.device)
+    C = torch.empty((K, int(rank)), dtype=torch.float32, device=X.device)
+    info = torch.zeros(I + 1, dtype=torch.int32, device=X.device)
+    with torch.cuda.device(X.device):
+        stream = torch.cuda.current_stream(X.device).cuda_stream
+        rc = lib.mcl_svd_init(X.data_ptr(), rp, I, K, int(rank), int(bool(threshold)), B.data_ptr(), C.data_ptr(), ws.data_ptr() + off,
+                              nbytes, info.data_ptr(), ctypes.c_void_p(stream))
+    if rc != 0:
+        raise EngineError(lib.mcl_svd_init_last_error().decode())
+    return B, C, info
 
 
 class NativeReg:

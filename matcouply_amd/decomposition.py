@@ -101,6 +101,16 @@ class PackedMatrices:
 # ------------------------------------------------------------------------------------------------------------
 # initialisation (decomposition.py:18-89)
 # ------------------------------------------------------------------------------------------------------------
+def _data_on_device(matrices):
+    """the matrices already live in HBM: a PackedMatrices, or torch CUDA tensors"""
+    if isinstance(matrices, PackedMatrices):
+        return is_torch(matrices.X) and matrices.X.is_cuda
+    try:
+        return len(matrices) > 0 and all(is_torch(m) and m.is_cuda for m in matrices)
+    except TypeError:
+        return False
+
+
 def initialize_cmf(matrices, rank, init, svd_fun, random_state=None, init_params=None):
     random_state = check_random_state(random_state)
     if isinstance(init, (tuple, list, CoupledMatrixFactorization)):
@@ -115,6 +125,21 @@ def initialize_cmf(matrices, rank, init, svd_fun, random_state=None, init_params
         A = random_state.uniform(size=(I, rank))
         C = random_state.uniform(size=(K, rank))
         B_is = [random_state.uniform(size=(shape(matrix)[0], rank)) for matrix in matrices]
+        return CoupledMatrixFactorization((None, [A, B_is, C]))
+    if (init == "svd" or init == "threshold_svd") and _data_on_device(matrices):
+        # data resident in HBM: the singular vectors on the device, no copy of X to the host (mcl_svd_init: fp64 subspace
+        # iteration on the Gram matrices).  The vectors are LAPACK's up to their SIGNS (largest-magnitude entry positive here):
+        # B_i and C come from independent decompositions, so the reference's trajectory from this initialiser is reproduced
+        # by the host path below only - which host-resident data keeps taking.
+        X, row_ptr = _pack(matrices, _device())
+        B, C, info = _engine.svd_init(X, row_ptr, rank, threshold=(init == "threshold_svd"))
+        if int(info.min().item()) < 0:
+            import warnings
+
+            warnings.warn("svd initialisation on the device: the subspace iteration of some matrices had not settled after 400 "
+                          "iterations (no gap behind the leading singular values); the vectors are approximate", RuntimeWarning)
+        A = torch.ones((len(row_ptr) - 1, rank), dtype=torch.float32, device=X.device)
+        B_is = [B[int(row_ptr[i]): int(row_ptr[i + 1])] for i in range(len(row_ptr) - 1)]
         return CoupledMatrixFactorization((None, [A, B_is, C]))
     if init == "svd" or init == "threshold_svd":
         # one-off set-up on the host (decomposition.py:42-53)
