@@ -132,7 +132,11 @@ int64_t plan(mcl_context *c, char *base) {
     c->xsq_part = b.take<double>(1024);
     c->x_sq = b.take<double>(1);
     c->inner_gate = b.take<int>(2);
-    c->inner_part = b.take<double>(std::max<int64_t>(std::max<int64_t>(c->tilesB.n_tiles, c->tilesC.n_tiles), std::max<int64_t>(I, 1)));
+    {
+        const int64_t max_tiles = std::max<int64_t>(std::max<int64_t>(c->tilesB.n_tiles, c->tilesC.n_tiles), std::max<int64_t>(c->tilesA.n_tiles, 1));
+        c->inner_part = b.take<double>(std::max<int64_t>((c->exact ? 16 : 1) * max_tiles, std::max<int64_t>(I, 1)));
+        c->wide_tab = c->exact ? b.take<double>(16 * max_tiles * DIAG_COLS) : nullptr;
+    }
     c->gate = b.take<int>(4);
     c->mute_status = b.take<int>(4);
     c->stop_state = b.take<double>(4);

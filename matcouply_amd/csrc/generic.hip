@@ -1946,6 +1946,15 @@ static bool rows_vec_ok(const mcl_context *c, const ModeView &mv, const RegSet &
         }                                                                                                     \
     } while (0)
 
+int mcl_launch_inner_check_raw(mcl_context *c, bool begin, const double *change_part, int n_change, const double *tab, int n_rows,
+                               int n_regs) {
+    ProfScope prof(c, MCL_PROF_OTHER);
+    hipLaunchKernelGGL(k_inner_check, dim3(1), dim3(256), 0, c->stream, begin ? 1 : 0, begin ? c->gate_active : nullptr, c->inner_gate,
+                       change_part, n_change, tab, n_rows, n_regs, c->opt.inner_tol);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
 int mcl_launch_inner_check(mcl_context *c, int mode, bool begin) {
     const TileMap &tm = (mode == 1) ? c->tilesB : (mode == 2 ? c->tilesC : c->tilesA);
     const double *tab = (mode == 1) ? c->diagB_tile : (mode == 2 ? c->diagC_tile : c->diagA_tile);

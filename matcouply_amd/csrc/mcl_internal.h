@@ -194,7 +194,8 @@ struct mcl_context {
     // gated runs (mcl_run): device state of the stopping rule
     int *mute_status = nullptr;        // int32[4]: where a muted run's verdict kernels report (MCL_TEST_MUTE_VERDICT)
     int *inner_gate = nullptr;         // int32[2]: stop flag of the inner loop of the current phase (mcl_options.inner_tol)
-    double *inner_part = nullptr;      // [max tiles / rows] per-tile ||x - x_old||^2 of the last solve
+    double *inner_part = nullptr;      // [max tiles / rows (x 16 in the exact-products mode)] per-workgroup ||x - x_old||^2 of the last solve
+    double *wide_tab = nullptr;        // exact-products mode: [16 max tiles, DIAG_COLS] the sums of the test from the fp64 state (wide.hip)
     int *gate = nullptr;               // int32[4]: {stopped, stop_it, code, ticket of the verdict launch}
     const int *gate_active = nullptr;  // == gate while a gated run is enqueueing (copied into ModeView / RegSet), else NULL
     double *stop_state = nullptr;      // fp64[4]: {last computed loss, ...}

@@ -23,6 +23,8 @@
 int mcl_launch_pf2_jacobi_wide(mcl_context *c, int k, const double *F64, const double *U64, const double *D64);  // generic.hip
 int mcl_launch_gl2_wide(mcl_context *c, int mode, int k, const double *F64, double *Z64, double *D64);             // generic.hip
 int mcl_launch_simplex_wide(mcl_context *c, int mode, int k, const double *F64, const double *D64, double *Z64);  // generic.hip
+int mcl_launch_inner_check_raw(mcl_context *c, bool begin, const double *change_part, int n_change, const double *tab, int n_rows,
+                               int n_regs);  // generic.hip
 
 namespace {
 
@@ -191,7 +193,8 @@ struct WideState {
 // F = (rhs (o a) + rho sum_k (Z_k - U_k)) L^-1, Z_k = P Delta for the PARAFAC2 member  (decomposition.py:266-273 / 328-331)
 __global__ __launch_bounds__(64) void k_wide_solve(WideRows W, WideState S, const double *__restrict__ rhs64,
                                                    const float *__restrict__ Arows, const double *__restrict__ Linv64,
-                                                   float *__restrict__ F32, int n, int r) {
+                                                   float *__restrict__ F32, int n, int r, double *__restrict__ change_part) {
+    // change_part != nullptr (inner stopping test): per workgroup ||f_new - f_old||^2, f_old = the shadow factor before this solve
     MCL_GATE(W.gate);
     constexpr int RW = WIDE_RW;
     extern __shared__ double wsm[];
@@ -229,19 +232,28 @@ __global__ __launch_bounds__(64) void k_wide_solve(WideRows W, WideState S, cons
 #pragma unroll
     for (int q = 0; q < RW; ++q) t[q] = ok[q] ? fma(rho, sacc[q], rhs64[idx[q]] * a_c) : 0.0;
     row_times_matrix<RW>(t, f, ts, Ls, R);
+    double chg = 0.0;
 #pragma unroll
     for (int q = 0; q < RW; ++q)
         if (ok[q]) {
+            if (change_part != nullptr) {
+                const double d = f[q] - S.F[idx[q]];
+                chg = fma(d, d, chg);
+            }
             S.F[idx[q]] = f[q];
             F32[idx[q]] = (float)f[q];
         }
+    if (change_part != nullptr) {
+        chg = wave_sum(chg);
+        if (threadIdx.x == 0) change_part[blockIdx.x] = chg;
+    }
 }
 
 // mode 0 (constant feasibility penalty, matrix penalties on A: decomposition.py:184-195): every row has its own system -
 // one wave per row of A, lane c owns column c
 __global__ __launch_bounds__(64) void k_wide_A_solve(WideState S, const double *__restrict__ rhsA64, const float *__restrict__ rho_max,
                                                      const double *__restrict__ LinvA64, float *__restrict__ A32, int n, int r,
-                                                     const int *__restrict__ gate) {
+                                                     const int *__restrict__ gate, double *__restrict__ change_part) {
     MCL_GATE(gate);
     __shared__ double tS[64];
     const int i = blockIdx.x, c = threadIdx.x;
@@ -254,9 +266,70 @@ __global__ __launch_bounds__(64) void k_wide_A_solve(WideState S, const double *
     __syncthreads();
     double a = 0.0;
     for (int d = 0; d < r; ++d) a = fma(tS[d], act ? LinvA64[((long)i * r + d) * r + c] : 0.0, a);
+    if (change_part != nullptr) {
+        const double d = act ? a - S.F[e] : 0.0;
+        const double sq = wave_sum(d * d);
+        if (c == 0) change_part[i] = sq;
+    }
     if (act) {
         S.F[e] = a;
         A32[e] = (float)a;
+    }
+}
+
+// The sums of the inner stopping test (decomposition.py:100-116) from the fp64 state, one table row per workgroup in the
+// layout of the diagnostics tables (column 0: ||F||^2, columns 2 + k: ||Z_k - F||^2, Z_k = P Delta for the PARAFAC2 member):
+// k_inner_check (generic.hip) takes it from there
+__global__ __launch_bounds__(64) void k_wide_sums(WideRows W, WideState S, int n, int r, double *__restrict__ tab) {
+    MCL_GATE(W.gate);
+    constexpr int RW = WIDE_RW;
+    extern __shared__ double wsm[];
+    double *Ds = wsm, *ts = wsm + (S.kpf2 >= 0 ? r * r : 0);
+    const RowGroup R(W, r);
+    double *row = tab + (long)blockIdx.x * DIAG_COLS;
+    if (!R.any()) {
+        if (threadIdx.x < DIAG_COLS) row[threadIdx.x] = 0.0;
+        return;
+    }
+    if (S.kpf2 >= 0)
+        for (int e = threadIdx.x; e < r * r; e += 64) Ds[e] = S.D[e];
+    __syncthreads();
+    double f[RW], nf = 0.0, gap[MCL_MAX_REGS];
+    bool ok[RW];
+    long idx[RW];
+#pragma unroll
+    for (int q = 0; q < RW; ++q) {
+        idx[q] = R.idx(q, ok[q]);
+        f[q] = ok[q] ? S.F[idx[q]] : 0.0;
+        nf = fma(f[q], f[q], nf);
+    }
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k) gap[k] = 0.0;
+    for (int k = 0; k < n; ++k) {
+        double z[RW];
+#pragma unroll
+        for (int q = 0; q < RW; ++q) z[q] = ok[q] ? S.Z[k][idx[q]] : 0.0;
+        if (k == S.kpf2) {
+            double pd[RW];
+            row_times_matrix<RW>(z, pd, ts, Ds, R);
+#pragma unroll
+            for (int q = 0; q < RW; ++q) z[q] = pd[q];
+        }
+        double g = 0.0;
+#pragma unroll
+        for (int q = 0; q < RW; ++q)
+            if (ok[q]) g = fma(z[q] - f[q], z[q] - f[q], g);
+#pragma unroll
+        for (int kk = 0; kk < MCL_MAX_REGS; ++kk)
+            if (kk == k) gap[kk] = g;
+    }
+    nf = wave_sum(nf);
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k) gap[k] = wave_sum(gap[k]);
+    if (threadIdx.x == 0) {
+        row[0] = nf, row[1] = 0.0;
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) row[2 + k] = gap[k];
     }
 }
 
@@ -618,7 +691,7 @@ bool mcl_wide_applies(const mcl_context *c, int mode) {
     if (!c->exact || c->sw.no_wide || mode < 0 || mode > 2) return false;
     const RegSet &rs = c->regs[mode];
     if (rs.n == 0 || c->opt.inner_n_iter_max <= 0 || c->wF[mode] == nullptr) return false;
-    if (c->opt.inner_tol > 0.0) return false;  // (the inner stopping test runs on the one-launch-per-step fp32 kernels)
+    if (c->opt.inner_tol > 0.0 && c->wide_tab == nullptr) return false;
     if (mode == 0 && (!c->opt.constant_A || c->LinvA64 == nullptr)) return false;
     for (int k = 0; k < rs.n; ++k)
         if (rs.kind[k] == MCL_PEN_EXTERNAL) return false;
@@ -647,7 +720,8 @@ int mcl_wide_phase(mcl_context *c, int mode) {
     }
     ProfScope prof(c, MCL_PROF_ROWS_FUSED);
     const size_t sm_one = sizeof(double) * (size_t)(r * r + 4 * 64);
-    if (rowsep && mode != 0) {
+    const bool checked = c->opt.inner_tol > 0.0;  // the inner stopping test (decomposition.py:90-117): one kernel per step
+    if (rowsep && mode != 0 && !checked) {
         c->variant[MCL_PROF_ROWS_FUSED] = "k_wide_rowsep (fp64 inner loop)";
         hipLaunchKernelGGL(k_wide_rowsep, dim3(wide_grid(W, r)), dim3(64), sm_one, c->stream, W, rhs64, Arows, Linv64, F32, rs, r, n_it);
         MCL_CHECK_HIP(c, hipGetLastError());
@@ -663,6 +737,22 @@ int mcl_wide_phase(mcl_context *c, int mode) {
         L.src[L.n] = rs.dual[k], L.dst[L.n] = S.U[k], L.count[L.n++] = rows * r;
     }
     if (kpf2 >= 0) L.src[L.n] = rs.aux2[kpf2], L.dst[L.n] = S.D, L.count[L.n++] = (long)r * r;
+    const int *run_gate = c->gate_active, *reg_gate = c->regs[mode].gate;
+    RegSet rs_gated = rs;  // (the kernels below take the penalty list by value)
+    if (checked) {
+        // the factor too (||f_new - f_old|| of the first iteration), and the phase's own stop flag instead of the run's
+        L.src[L.n] = F32, L.dst[L.n] = S.F, L.count[L.n++] = rows * r;
+        if (int rc = mcl_launch_inner_check_raw(c, true, nullptr, 0, nullptr, 0, 0)) return rc;
+        c->gate_active = c->inner_gate, c->regs[mode].gate = c->inner_gate;
+        W.gate = c->inner_gate, rs_gated.gate = c->inner_gate;
+    }
+    struct GateRestore {  // every return path below hands the run's gate back
+        mcl_context *c;
+        int mode;
+        const int *run_gate, *reg_gate;
+        ~GateRestore() { c->gate_active = run_gate, c->regs[mode].gate = reg_gate; }
+    } restore{c, mode, run_gate, reg_gate};
+    const RegSet &rsk = rs_gated;
     hipLaunchKernelGGL(k_wide_load, dim3(blocks_for(rows * r)), dim3(256), 0, c->stream, L);
     const size_t sm_two = sizeof(double) * (size_t)(2 * r * r + 4 * 64);
     if (sm_two > 65536) {
@@ -681,20 +771,20 @@ int mcl_wide_phase(mcl_context *c, int mode) {
     for (int it = 0; it < n_it; ++it) {
         if (mode == 0)
             hipLaunchKernelGGL(k_wide_A_solve, dim3((unsigned)rows), dim3(64), 0, c->stream, S, rhs64, (const float *)c->rho_max, Linv64, F32,
-                               n, r, c->gate_active);
+                               n, r, c->gate_active, checked ? c->inner_part : nullptr);
         else
             hipLaunchKernelGGL(k_wide_solve, dim3(wide_grid(W, r)), dim3(64), kpf2 >= 0 ? sm_two : sm_one, c->stream, W, S, rhs64, Arows,
-                               Linv64, F32, n, r);
+                               Linv64, F32, n, r, checked ? c->inner_part : nullptr);
         for (int k = 0; k < n; ++k) {
             switch (rs.kind[k]) {
                 case MCL_PEN_NN:
                 case MCL_PEN_BOX:
                 case MCL_PEN_L1:
-                    hipLaunchKernelGGL(k_wide_prox_rowsep, dim3(blocks_for(rows * r)), dim3(256), 0, c->stream, W, S, rs, k, r, rows, slab_of_row);
+                    hipLaunchKernelGGL(k_wide_prox_rowsep, dim3(blocks_for(rows * r)), dim3(256), 0, c->stream, W, S, rsk, k, r, rows, slab_of_row);
                     break;
                 case MCL_PEN_L2BALL:
                     hipLaunchKernelGGL(k_wide_colsq, dim3((unsigned)W.n_slabs), dim3(256), 0, c->stream, W, S, k, rs.nonneg[k], r, c->colsq);
-                    hipLaunchKernelGGL(k_wide_l2ball, dim3(blocks_for(rows * r)), dim3(256), 0, c->stream, W, S, rs, k, r, rows, slab_of_row,
+                    hipLaunchKernelGGL(k_wide_l2ball, dim3(blocks_for(rows * r)), dim3(256), 0, c->stream, W, S, rsk, k, r, rows, slab_of_row,
                                        (const double *)c->colsq);
                     break;
                 case MCL_PEN_UNIMODAL:
@@ -702,19 +792,19 @@ int mcl_wide_phase(mcl_context *c, int mode) {
                         c->err = "internal: unimodal scratch missing";
                         return 1;
                     }
-                    hipLaunchKernelGGL(k_wide_unimodal, dim3((unsigned)((n_cols + 63) / 64)), dim3(64), 0, c->stream, W, S, rs, k, r, Q);
-                    hipLaunchKernelGGL(k_wide_dual, dim3(blocks_for(rows * r)), dim3(256), 0, c->stream, W, S, rs, k, rows * r);
+                    hipLaunchKernelGGL(k_wide_unimodal, dim3((unsigned)((n_cols + 63) / 64)), dim3(64), 0, c->stream, W, S, rsk, k, r, Q);
+                    hipLaunchKernelGGL(k_wide_dual, dim3(blocks_for(rows * r)), dim3(256), 0, c->stream, W, S, rsk, k, rows * r);
                     break;
                 case MCL_PEN_TV:
-                    hipLaunchKernelGGL(k_wide_tv, dim3((unsigned)((n_cols + 63) / 64)), dim3(64), 0, c->stream, W, S, rs, k, r);
-                    hipLaunchKernelGGL(k_wide_dual, dim3(blocks_for(rows * r)), dim3(256), 0, c->stream, W, S, rs, k, rows * r);
+                    hipLaunchKernelGGL(k_wide_tv, dim3((unsigned)((n_cols + 63) / 64)), dim3(64), 0, c->stream, W, S, rsk, k, r);
+                    hipLaunchKernelGGL(k_wide_dual, dim3(blocks_for(rows * r)), dim3(256), 0, c->stream, W, S, rsk, k, rows * r);
                     break;
                 case MCL_PEN_GL2:
                     if (int rc = mcl_launch_gl2_wide(c, mode, k, S.F, S.Z[k], S.U[k])) return rc;
                     break;
                 case MCL_PEN_SIMPLEX:
                     if (int rc = mcl_launch_simplex_wide(c, mode, k, S.F, S.U[k], S.Z[k])) return rc;
-                    hipLaunchKernelGGL(k_wide_dual, dim3(blocks_for(rows * r)), dim3(256), 0, c->stream, W, S, rs, k, rows * r);
+                    hipLaunchKernelGGL(k_wide_dual, dim3(blocks_for(rows * r)), dim3(256), 0, c->stream, W, S, rsk, k, rows * r);
                     break;
                 case MCL_PEN_PARAFAC2: {
                     if (mode != 1) {
@@ -727,13 +817,19 @@ int mcl_wide_phase(mcl_context *c, int mode) {
                                        (const double *)c->pf2_T64, rs.aux[k]);
                     hipLaunchKernelGGL(k_wide_pf2_delta, dim3((unsigned)(r * r)), dim3(256), 0, c->stream, (const double *)c->pf2_acc,
                                        (int)c->I, r * r, S.D, rs.aux2[k], c->pf2_red, c->gate_active);
-                    hipLaunchKernelGGL(k_wide_pf2_dual, dim3(wide_grid(W, r)), dim3(64), sm_one, c->stream, W, S, rs, k, r);
+                    hipLaunchKernelGGL(k_wide_pf2_dual, dim3(wide_grid(W, r)), dim3(64), sm_one, c->stream, W, S, rsk, k, r);
                     break;
                 }
                 default:
                     c->err = "penalty kind has no native prox (EXTERNAL penalties are evaluated by the host)";
                     return 1;
             }
+        }
+        if (checked) {
+            hipLaunchKernelGGL(k_wide_sums, dim3(wide_grid(W, r)), dim3(64), sm_one, c->stream, W, S, n, r, c->wide_tab);
+            if (int rc = mcl_launch_inner_check_raw(c, false, c->inner_part, mode == 0 ? (int)rows : (int)wide_grid(W, r), c->wide_tab,
+                                                    (int)wide_grid(W, r), n))
+                return rc;
         }
     }
     MCL_CHECK_HIP(c, hipGetLastError());
