@@ -42,6 +42,9 @@ CASES = {
     # ... and the same with inner_tol set: the two penalties are then host-evaluated (PEN_EXTERNAL) and keep their auxiliary
     # variable in an object of their own, which must follow the gathered prox (it stayed at its initial value)
     "inner_tol_matrix_A": dict(constant_feasibility_penalty=True),
+    # the kinds that became native in round 5 on the replicated mode: a GeneralizedL2 penalty (its value comes from the engine,
+    # mcl_penalty_value, and is counted once) and the unit simplex on C
+    "gl2_simplex_on_C": dict(),
 }
 
 
@@ -88,6 +91,10 @@ def _explicit_state(case, mats, r, seed=9):
         regs[0] = [("uninn", mk((I, r)), mk((I, r))), ("tvA", mk((I, r)), mk((I, r)))]
         regs[1] = [("nn", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
         regs[2] = [("l1nn", mk((K, r)), mk((K, r)))]
+    elif case == "gl2_simplex_on_C":
+        regs[0] = [("nn", mk((I, r)), mk((I, r)))]
+        regs[1] = [("nn", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
+        regs[2] = [("gl2C", mk((K, r)), mk((K, r))), ("simplex", mk((K, r)), mk((K, r)))]
     elif case == "tv_B_and_C":
         regs[0] = [("nn", mk((I, r)), mk((I, r)))]
         regs[1] = [("tv", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
@@ -136,6 +143,12 @@ def _build(regs_spec, lo, hi):
                 out[m].append(pen.TotalVariationPenalty(0.05, aux_init=aux, dual_init=dual))
             elif kind == "tvA":
                 out[m].append(pen.TotalVariationPenalty(0.04, aux_init=aux, dual_init=dual))
+            elif kind == "gl2C":
+                n = aux.shape[0]
+                out[m].append(pen.GeneralizedL2Penalty(0.3 * (2 * np.eye(n) - np.eye(n, k=1) - np.eye(n, k=-1)) + 0.05 * np.eye(n),
+                                                       aux_init=aux, dual_init=dual))
+            elif kind == "simplex":
+                out[m].append(pen.UnitSimplex(aux_init=aux, dual_init=dual))
             elif kind == "tvl1":
                 out[m].append(pen.TotalVariationPenalty(0.03, l1_strength=0.02, aux_init=aux, dual_init=dual))
     return out
