@@ -909,7 +909,7 @@ int mcl_update_B(mcl_context *c) {
     if (c->opt.inner_n_iter_max <= 0) return 0;
     c->mseg_valid = c->grpart_valid = false;
     if (mcl_wide_applies(c, 1)) {  // small problem: the whole inner loop in fp64 (wide.hip)
-        c->diag_valid[1] = false;
+        c->diag_valid[1] = false;  // (set again by the row-separable form, which leaves the table itself)
         return mcl_wide_phase(c, 1);
     }
     if (mcl_mode_is_row_separable(c, 1) && !(c->opt.inner_tol > 0.0)) {

@@ -56,12 +56,16 @@ struct RowGroup {
     int c, grp, G, RPW, slab, nrows, jbase, r;
     long row0;
     bool act;
-    __device__ RowGroup(const WideRows &W, int r_) : r(r_) {
+    // one wave per workgroup (workgroup b = tile b / subs, sub-group b % subs), or - whole_tile - one workgroup per tile with
+    // one wave per sub-group (the row-separable kernel: its workgroup also sums the tile's diagnostics)
+    __device__ RowGroup(const WideRows &W, int r_, bool whole_tile = false) : r(r_) {
         RPW = r <= 16 ? 16 : (r <= 32 ? 32 : 64);
         G = 64 / RPW;
         const int per = WIDE_RW * G, subs = (64 + per - 1) / per;
-        const int tile = blockIdx.x / subs, sub = blockIdx.x - tile * subs;
-        c = threadIdx.x % RPW, grp = threadIdx.x / RPW;
+        const int tile = whole_tile ? (int)blockIdx.x : (int)blockIdx.x / subs;
+        const int sub = whole_tile ? (int)(threadIdx.x >> 6) : (int)blockIdx.x - tile * subs;
+        const int ln = threadIdx.x & 63;
+        c = ln % RPW, grp = ln / RPW;
         act = c < r;
         slab = W.tile_slab[tile], row0 = W.tile_row0[tile], nrows = W.tile_nrows[tile];
         jbase = sub * per;
@@ -73,6 +77,10 @@ struct RowGroup {
         return (row0 + min(j, nrows - 1)) * r + (act ? c : 0);
     }
 };
+static int wide_subs(int r) {  // waves a 64-row tile is spread over
+    const int G = 64 / (r <= 16 ? 16 : (r <= 32 ? 32 : 64)), per = WIDE_RW * G;
+    return (64 + per - 1) / per;
+}
 static unsigned wide_grid(const WideRows &W, int r) {
     const int G = 64 / (r <= 16 ? 16 : (r <= 32 ? 32 : 64)), per = WIDE_RW * G;
     return (unsigned)(W.n_tiles * ((64 + per - 1) / per));
@@ -101,16 +109,18 @@ __device__ __forceinline__ void row_times_matrix(const double (&t)[RW], double (
 // The whole inner loop of a row-separable stack (decomposition.py:259-285 / 326-338), one wave per tile, four rows in
 // flight per wave.  rhs64: X C (mode 1: scaled by a_i here) or R (mode 2), fp64; Linv64: [n_slabs, r, r].
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_wide_rowsep(WideRows W, const double *__restrict__ rhs64, const float *__restrict__ Arows,
-                                                    const double *__restrict__ Linv64, float *__restrict__ F, RegSet regs,
-                                                    int r, int inner) {
+__global__ __launch_bounds__(1024) void k_wide_rowsep(WideRows W, const double *__restrict__ rhs64, const float *__restrict__ Arows,
+                                                      const double *__restrict__ Linv64, float *__restrict__ F, RegSet regs,
+                                                      int r, int inner, double *__restrict__ diag_tile) {
+    // one workgroup per tile, one wave per sub-group of its rows; diag_tile: the tile's row of the mode's diagnostics table
+    // (||F||^2, sum |F|, ||Z_k - F||^2 of the rounded values the kernel stores - what k_rows_diag would read back)
     MCL_GATE(W.gate);
     constexpr int RW = WIDE_RW;
     extern __shared__ double wsm[];
-    double *Ls = wsm, *ts = wsm + r * r;  // ts: RW x 64
-    const RowGroup R(W, r);
-    if (!R.any()) return;
-    for (int e = threadIdx.x; e < r * r; e += 64) Ls[e] = Linv64[(long)R.slab * r * r + e];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
+    double *Ls = wsm, *ts = wsm + r * r + wave * (RW * 64), *dsm = wsm + r * r + n_waves * (RW * 64);  // dsm: [n_waves][DIAG_COLS]
+    const RowGroup R(W, r, true);
+    for (int e = threadIdx.x; e < r * r; e += blockDim.x) Ls[e] = Linv64[(long)R.slab * r * r + e];
     __syncthreads();
     const double rho = (double)W.rho[R.slab];
     const double a_c = (Arows != nullptr && R.act) ? (double)Arows[(long)R.slab * r + R.c] : 1.0;
@@ -132,38 +142,64 @@ __global__ __launch_bounds__(64) void k_wide_rowsep(WideRows W, const double *__
         }
         f[q] = 0.0;
     }
-    for (int it = 0; it < inner; ++it) {
+    if (R.any()) {  // (wave-uniform: a wave past the tile's end only takes part in the barriers)
+        for (int it = 0; it < inner; ++it) {
 #pragma unroll
-        for (int q = 0; q < RW; ++q) {
-            double s = 0.0;
+            for (int q = 0; q < RW; ++q) {
+                double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < MCL_MAX_REGS; ++k)
-                if (k < n) s += z[k][q] - u[k][q];
-            t[q] = fma(rho, s, rhs[q]);
-        }
-        row_times_matrix<RW>(t, f, ts, Ls, R);
-#pragma unroll
-        for (int k = 0; k < MCL_MAX_REGS; ++k)
-            if (k < n) {
-#pragma unroll
-                for (int q = 0; q < RW; ++q) {
-                    const double zn = prox_rowsep_d(regs.kind[k], regs.nonneg[k], regs.p0d[k], regs.p1d[k], thr[k], f[q] + u[k][q]);
-                    u[k][q] = f[q] - (zn - u[k][q]);
-                    z[k][q] = zn;
-                }
+                for (int k = 0; k < MCL_MAX_REGS; ++k)
+                    if (k < n) s += z[k][q] - u[k][q];
+                t[q] = fma(rho, s, rhs[q]);
             }
-    }
-#pragma unroll
-    for (int q = 0; q < RW; ++q)
-        if (ok[q]) {
-            F[idx[q]] = (float)f[q];
+            row_times_matrix<RW>(t, f, ts, Ls, R);
 #pragma unroll
             for (int k = 0; k < MCL_MAX_REGS; ++k)
                 if (k < n) {
-                    regs.aux[k][idx[q]] = (float)z[k][q];
-                    regs.dual[k][idx[q]] = (float)u[k][q];
+#pragma unroll
+                    for (int q = 0; q < RW; ++q) {
+                        const double zn = prox_rowsep_d(regs.kind[k], regs.nonneg[k], regs.p0d[k], regs.p1d[k], thr[k], f[q] + u[k][q]);
+                        u[k][q] = f[q] - (zn - u[k][q]);
+                        z[k][q] = zn;
+                    }
                 }
         }
+    }
+    double nf = 0.0, na = 0.0, gap[MCL_MAX_REGS];
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k) gap[k] = 0.0;
+#pragma unroll
+    for (int q = 0; q < RW; ++q)
+        if (ok[q]) {
+            const float ff = (float)f[q];
+            F[idx[q]] = ff;
+            nf = fma((double)ff, (double)ff, nf);
+            na += fabs((double)ff);
+#pragma unroll
+            for (int k = 0; k < MCL_MAX_REGS; ++k)
+                if (k < n) {
+                    const float zf = (float)z[k][q];
+                    regs.aux[k][idx[q]] = zf;
+                    regs.dual[k][idx[q]] = (float)u[k][q];
+                    const double dlt = (double)zf - (double)ff;
+                    gap[k] = fma(dlt, dlt, gap[k]);
+                }
+        }
+    nf = wave_sum(nf), na = wave_sum(na);
+#pragma unroll
+    for (int k = 0; k < MCL_MAX_REGS; ++k) gap[k] = wave_sum(gap[k]);
+    if (lane == 0) {
+        double *o = dsm + wave * DIAG_COLS;
+        o[0] = nf, o[1] = na;
+#pragma unroll
+        for (int k = 0; k < MCL_MAX_REGS; ++k) o[2 + k] = gap[k];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < DIAG_COLS) {
+        double tsum = 0.0;
+        for (int wv = 0; wv < n_waves; ++wv) tsum += dsm[wv * DIAG_COLS + threadIdx.x];  // fixed order
+        diag_tile[(long)blockIdx.x * DIAG_COLS + threadIdx.x] = tsum;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -723,8 +759,16 @@ int mcl_wide_phase(mcl_context *c, int mode) {
     const bool checked = c->opt.inner_tol > 0.0;  // the inner stopping test (decomposition.py:90-117): one kernel per step
     if (rowsep && mode != 0 && !checked) {
         c->variant[MCL_PROF_ROWS_FUSED] = "k_wide_rowsep (fp64 inner loop)";
-        hipLaunchKernelGGL(k_wide_rowsep, dim3(wide_grid(W, r)), dim3(64), sm_one, c->stream, W, rhs64, Arows, Linv64, F32, rs, r, n_it);
+        const int subs = wide_subs(r);
+        const size_t sm_rs = sizeof(double) * (size_t)(r * r + subs * (WIDE_RW * 64) + subs * DIAG_COLS);
+        if (sm_rs > 65536)
+            MCL_CHECK_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_wide_rowsep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_rs));
+        double *diag = (mode == 1) ? c->diagB_tile : c->diagC_tile;
+        hipLaunchKernelGGL(k_wide_rowsep, dim3((unsigned)W.n_tiles), dim3(64 * subs), sm_rs, c->stream, W, rhs64, Arows, Linv64, F32, rs, r,
+                           n_it, diag);
         MCL_CHECK_HIP(c, hipGetLastError());
+        c->diag_rows[mode] = W.n_tiles;
+        c->diag_valid[mode] = true;  // the kernel left the mode's diagnostics table
         return 0;
     }
     c->variant[MCL_PROF_ROWS_FUSED] = "k_wide_* (fp64 state, one kernel per step)";
