@@ -14,7 +14,7 @@ EV, PR = os.path.join(REPO, "gpurun_out", "ev5"), os.path.join(REPO, "profiles")
 
 
 def short(name):
-    return re.sub(r"^void ", "", name).split("(")[0]
+    return re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "").split("(")[0]
 
 
 def counters(path):
