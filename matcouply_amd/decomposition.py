@@ -654,6 +654,8 @@ def cmf_aoadmm(
     >>> len(matcouply_amd.decomposition._listify({1: 0.5}, "l1_penalty"))
     3
     """
+    if arithmetic not in ("auto", "exact", "fast"):
+        raise ValueError(f'arithmetic must be "auto", "exact" or "fast", not {arithmetic!r}')
     random_state = check_random_state(random_state)
     svd_fun = get_svd(svd)
     cmf = initialize_cmf(matrices, rank, init, svd_fun=svd_fun, random_state=random_state, init_params=init_params)
@@ -752,8 +754,6 @@ def cmf_aoadmm(
         rank_id = 0
     # the arithmetic of small problems (exact-products mode) is chosen by the size of the WHOLE problem:
     # every rank of a sharded run, and every rank layout of the same problem, then computes with the same kernels
-    if arithmetic not in ("auto", "exact", "fast"):
-        raise ValueError(f'arithmetic must be "auto", "exact" or "fast", not {arithmetic!r}')
     exact_products = {"auto": 0, "exact": 1, "fast": 2}[arithmetic]
     if world > 1 and arithmetic == "auto":
         n_el = torch.tensor([float(X.shape[0]) * float(X.shape[1])], dtype=torch.float64, device=X.device)

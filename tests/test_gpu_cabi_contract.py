@@ -262,3 +262,42 @@ def test_release_build_ignores_the_environment_switches(tmp_path):
                          capture_output=True, text=True, timeout=300)
     d2 = json.loads([l for l in dbg.stdout.splitlines() if l.startswith("RELEASE ")][0].split(" ", 1)[1])
     assert "MCL_NO_SWEEP" in d2["active"] and d2["sweep"] == "" and d2["warned"]
+
+
+def test_round5_entry_points_refuse_bad_arguments():
+    """mcl_penalty_value / mcl_svd_init / mcl_set_options(inner_tol, exact_products) / GeneralizedL2 descriptors: errors are
+    return codes with a message, never a fault"""
+    import torch
+
+    from matcouply_amd import _engine as E
+
+    orc, regs, X, row_ptr = _sweep_problem()
+    st = orc.random_state_for(X, row_ptr, 8, regs, seed=6)
+    eng = engine_from_oracle_state(st)
+    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    assert eng.lib.mcl_penalty_value(eng._h, 0, 0, out.data_ptr()) != 0          # not a GeneralizedL2 penalty
+    assert b"GeneralizedL2" in eng.lib.mcl_last_error(eng._h)
+    assert eng.lib.mcl_penalty_value(eng._h, 5, 0, out.data_ptr()) != 0 and eng.lib.mcl_penalty_value(eng._h, 0, 9, out.data_ptr()) != 0
+    opt = E.Options()
+    opt.feasibility_penalty_scale, opt.inner_n_iter_max = 1.0, 5
+    opt.exact_products = 3
+    assert eng.lib.mcl_set_options(eng._h, ctypes.byref(opt)) != 0
+    opt.exact_products, opt.inner_tol = 0, -1.0
+    assert eng.lib.mcl_set_options(eng._h, ctypes.byref(opt)) != 0
+    # a GeneralizedL2 descriptor without its matrix, or with a row count that is not the mode's
+    d = (E.PenaltyDesc * 1)()
+    d[0].kind, d[0].aux, d[0].dual = E.PEN_GL2, eng.regs[2][0].aux.data_ptr(), eng.regs[2][0].dual.data_ptr()
+    assert eng.lib.mcl_set_penalties(eng._h, 2, 1, d) != 0
+    mat = torch.zeros(2 * 9 + 3, dtype=torch.float64, device="cuda")
+    d[0].matrix, d[0].matrix_rows = mat.data_ptr(), 3
+    assert eng.lib.mcl_set_penalties(eng._h, 2, 1, d) != 0 and b"matrix_rows" in eng.lib.mcl_last_error(eng._h)
+    eng.close()
+    # the stateless svd initialiser
+    Xd = torch.rand((40, 16), device="cuda")
+    rp = np.array([0, 25, 40], dtype=np.int64)
+    with pytest.raises(E.EngineError, match="rank exceeds"):
+        E.svd_init(Xd, rp, 17)
+    with pytest.raises(E.EngineError, match="fewer rows"):
+        E.svd_init(Xd, np.array([0, 37, 40], dtype=np.int64), 5)
+    B, C, info = E.svd_init(Xd, rp, 4)
+    assert B.shape == (40, 4) and C.shape == (16, 4) and int(info.min()) > 0

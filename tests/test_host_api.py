@@ -494,3 +494,9 @@ def test_substitute_engine_needs_the_test_switch(monkeypatch):
     X, _ = get_simple_simulated_data()
     with pytest.raises(RuntimeError, match="outside the test-suite"):
         dec.cmf_aoadmm(X, 3, n_iter_max=1)
+
+
+def test_arithmetic_keyword_is_validated():
+    X, _ = get_simple_simulated_data(random_state=0)
+    with pytest.raises(ValueError, match="arithmetic"):
+        dec.cmf_aoadmm(X, 3, n_iter_max=1, arithmetic="double")
