@@ -812,6 +812,63 @@ def cmf_aoadmm(
         nat.aux.copy_(torch.cat([m.to(nat.aux.dtype) for m in reg.auxes_as_matrices(obj)], 0))
         nat.dual.copy_(eng.B - (nat.aux - nat.dual))
 
+    # host-evaluated penalties on mode 1 that act on ALL matrices at once (a user's MatricesPenalty) under group=: like PARAFAC2
+    # they may couple the B_i of different ranks, so every rank evaluates the prox on the all-gathered matrices and keeps its own
+    gathered_B = [sharded and nat.kind == _engine.PEN_EXTERNAL and not isinstance(reg, penalties.MatrixPenalty)
+                  for reg, nat in zip(regs[1], native[1])]
+    b_layout = []  # row counts of every rank's matrices, in rank order (gathered once)
+
+    def gather_matrices_B(t):
+        """all ranks' matrices of a packed mode-1 array [rows of this rank, r], in rank order, as a list"""
+        if not b_layout:
+            mine = torch.tensor([sl.stop - sl.start for sl in row_slices], dtype=torch.int64, device=t.device)
+            n_loc = torch.tensor([len(row_slices)], dtype=torch.int64, device=t.device)
+            cnt = [torch.zeros_like(n_loc) for _ in range(world)]
+            dist.all_gather(cnt, n_loc, group=group)
+            cnt = [int(c.item()) for c in cnt]
+            padded = torch.zeros((max(cnt),), dtype=torch.int64, device=t.device)
+            padded[: len(row_slices)] = mine
+            parts = [torch.empty_like(padded) for _ in range(world)]
+            dist.all_gather(parts, padded, group=group)
+            b_layout.extend([int(v) for v in p[:c].cpu().numpy()] for p, c in zip(parts, cnt))
+        rows = [sum(js) for js in b_layout]
+        padded = torch.zeros((max(rows), t.shape[1]), dtype=t.dtype, device=t.device)
+        padded[: t.shape[0]] = t
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded, group=group)
+        out = []
+        for p, js in zip(parts, b_layout):
+            o = 0
+            for j in js:
+                out.append(p[o:o + j])
+                o += j
+        return out
+
+    def sharded_gathered_prox_B(k):
+        """a MatricesPenalty on the sharded B_i (decomposition.py:276-285): its prox on ALL matrices, this rank's kept"""
+        reg, nat = regs[1][k], native[1][k]
+        obj = ext_aux[(1, k)]
+        # the object the penalty keeps must be the list of matrices itself to be split over ranks by matrix
+        if not (isinstance(obj, (list, tuple)) and len(obj) == len(row_slices)
+                and all(is_torch(o) and tuple(o.shape) == (sl.stop - sl.start, nat.aux.shape[1]) for o, sl in zip(obj, row_slices))):
+            raise NotImplementedError("a host-evaluated MatricesPenalty on mode 1 whose auxiliary variable is not the list of "
+                                      "matrices itself is not supported with group=")
+        shifted = gather_matrices_B(eng.B + nat.dual)
+        auxes = gather_matrices_B(torch.cat([o.to(nat.aux.dtype) for o in obj], 0))
+        # the feasibility penalties of all matrices (one per matrix, fp64), in the same order
+        cnt = [len(js) for js in b_layout]
+        padded = torch.zeros((max(cnt),), dtype=torch.float64, device=nat.aux.device)
+        padded[: len(row_slices)] = eng.rho(1).to(device=nat.aux.device, dtype=torch.float64)
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded, group=group)
+        rho_all = [float(v) for p, c in zip(parts, cnt) for v in p[:c].cpu().numpy()]
+        full = reg.factor_matrices_update(shifted, rho_all, auxes)
+        lo = sum(len(js) for js in b_layout[:rank_id])
+        own = [m.clone() for m in full[lo:lo + len(row_slices)]]
+        ext_aux[(1, k)] = own
+        nat.aux.copy_(torch.cat([m.to(nat.aux.dtype) for m in reg.auxes_as_matrices(own)], 0))
+        nat.dual.copy_(eng.B - (nat.aux - nat.dual))
+
     def host_prox_matrix(mode, k, F, rho_rows, constant):
         """user prox of penalty k on mode 0 / 2 (decomposition.py:197-213 / 333-338)"""
         reg, nat = regs[mode][k], native[mode][k]
@@ -864,12 +921,11 @@ def cmf_aoadmm(
             eng.B_solve()
             for k, reg in enumerate(native[1]):
                 if reg.kind == _engine.PEN_EXTERNAL:
-                    if sharded and not isinstance(regs[1][k], penalties.MatrixPenalty):
-                        # a MatricesPenalty may couple the B_i of different ranks (as PARAFAC2 does); a MatrixPenalty's prox
-                        # acts on one matrix at a time, so every rank can evaluate it on its own matrices
-                        raise NotImplementedError("host-evaluated penalties on mode 1 that act on all matrices at once "
-                                                  "(MatricesPenalty) are not supported with group=")
-                    host_prox_B(k)
+                    # a MatrixPenalty's prox acts on one matrix at a time: every rank evaluates it on its own matrices
+                    if gathered_B[k]:
+                        sharded_gathered_prox_B(k)
+                    else:
+                        host_prox_B(k)
                     continue
                 eng.B_prox_local(k)
                 if reg.kind == _engine.PEN_PARAFAC2:
@@ -1060,6 +1116,9 @@ def cmf_aoadmm(
                     continue  # read_diag takes reg_strength * sum|B| from the native slot, which is summed over the ranks already
                 if native[1][k].kind == _engine.PEN_GL2:
                     vec[_engine.DIAG_REG + (_engine.MCL_MAX_REGS + k) * 2 + 1] = float(eng.penalty_value(1, k))
+                elif gathered_B[k]:  # a value over ALL matrices (need not be a sum over them): counted once, by rank 0
+                    value = float(reg.penalty(gather_matrices_B(eng.B)))
+                    vec[_engine.DIAG_REG + (_engine.MCL_MAX_REGS + k) * 2 + 1] = value if rank_id == 0 else 0.0
                 elif native[1][k].kind in (_engine.PEN_EXTERNAL, _engine.PEN_TV):
                     vec[_engine.DIAG_REG + (_engine.MCL_MAX_REGS + k) * 2 + 1] = float(reg.penalty([eng.B[sl] for sl in row_slices]))
         all_reduce(vec)

@@ -45,7 +45,28 @@ CASES = {
     # the kinds that became native in round 5 on the replicated mode: a GeneralizedL2 penalty (its value comes from the engine,
     # mcl_penalty_value, and is counted once) and the unit simplex on C
     "gl2_simplex_on_C": dict(),
+    # a user's MatricesPenalty on the B_i whose prox and value couple ALL matrices (as PARAFAC2 does natively): under sharding
+    # every rank evaluates it on the all-gathered matrices and keeps its own; the value is counted once
+    "coupled_matrices_on_B": dict(),
 }
+
+
+def _coupled_penalty(aux, dual):
+    """every B_i scaled by ONE factor: the stacked matrix projected on a Frobenius ball whose radius follows the feasibility
+    penalties of all matrices; the value is the (non-additive) Frobenius norm of the stack.  Module level: spawned ranks import it"""
+    from matcouply_amd import penalties as pen
+
+    class SharedScale(pen.MatricesPenalty):
+        def factor_matrices_update(self, factor_matrices, feasibility_penalties, auxes):
+            total = float(sum((m ** 2).sum() for m in factor_matrices)) ** 0.5
+            radius = 2.0 + 0.1 * float(np.mean(feasibility_penalties)) + 0.05 * len(factor_matrices)
+            scale = min(1.0, radius / total)
+            return [0.9 * scale * m + 0.1 * a for m, a in zip(factor_matrices, auxes)]
+
+        def penalty(self, x):
+            return 0.01 * float(sum((m ** 2).sum() for m in x)) ** 0.5
+
+    return SharedScale(aux_init=aux, dual_init=dual)
 
 
 J_ALL = [12, 11, 9, 10, 5, 6, 3, 4, 5, 3, 4, 6, 3, 4]  # ragged: the ranks' shares are uneven in slabs AND in rows
@@ -95,6 +116,11 @@ def _explicit_state(case, mats, r, seed=9):
         regs[0] = [("nn", mk((I, r)), mk((I, r)))]
         regs[1] = [("nn", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
         regs[2] = [("gl2C", mk((K, r)), mk((K, r))), ("simplex", mk((K, r)), mk((K, r)))]
+    elif case == "coupled_matrices_on_B":
+        regs[0] = [("nn", mk((I, r)), mk((I, r)))]
+        regs[1] = [("coupled", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats]),
+                   ("nn", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
+        regs[2] = [("l1nn", mk((K, r)), mk((K, r)))]
     elif case == "tv_B_and_C":
         regs[0] = [("nn", mk((I, r)), mk((I, r)))]
         regs[1] = [("tv", [mk((m.shape[0], r)) for m in mats], [mk((m.shape[0], r)) for m in mats])]
@@ -149,6 +175,8 @@ def _build(regs_spec, lo, hi):
                                                        aux_init=aux, dual_init=dual))
             elif kind == "simplex":
                 out[m].append(pen.UnitSimplex(aux_init=aux, dual_init=dual))
+            elif kind == "coupled":
+                out[m].append(_coupled_penalty(aux, dual))
             elif kind == "tvl1":
                 out[m].append(pen.TotalVariationPenalty(0.03, l1_strength=0.02, aux_init=aux, dual_init=dual))
     return out
@@ -215,7 +243,7 @@ def _spawn(world, case, salt=0):
 
 # world size 2: every stack; 4 and 8 ranks (the driver's scaling points): the stacks with the most collectives per iteration
 SHARDED_RUNS = [(2, c) for c in sorted(CASES)] + [(w, c) for w in (4, 8) for c in ("c3_nn_l1C", "readme_stack", "inner_tol_l1B")] \
-    + [(4, "matrix_penalties_on_A")]
+    + [(4, "matrix_penalties_on_A"), (4, "coupled_matrices_on_B")]
 
 
 @pytest.mark.parametrize("world,case", SHARDED_RUNS, ids=[f"{c}-x{w}" for w, c in SHARDED_RUNS])
