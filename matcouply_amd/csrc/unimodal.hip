@@ -32,14 +32,23 @@ struct UniScratch {
 #ifndef MCL_UNI_UB
 #define MCL_UNI_UB 8
 #endif
-#ifdef MCL_UNI_DBG  // timing experiments only (wrong results): 1 no record stores, 2 no error stores, 4 no spill stores, 8 no emit
+#ifdef MCL_UNI_DBG  // timing experiments only (wrong results): 1 no record stores, 2 no error stores, 4 no spill stores, 8 no emit,
+                    // 32 no pooling loop, 64 no push (ring / spill), 128 no cooperative refill
     int dbg;
+    unsigned long long *ctr;  // event counters summed over waves (mcl_uni_dbg_counters): see UNI_CNT
 #endif
 };
 #ifdef MCL_UNI_DBG
 #define UNI_DBG(bit) (sc.dbg & (bit))
+// wave-level event counts: 0 element steps, 1 pooling trips, 2 steps with a spill, 3 cooperative refills served from prefetched
+// registers, 4 cooperative refills with a blocking load, 5 dry refills from prefetched registers, 6 dry refills with a blocking load,
+// 7 emit positions
+#define UNI_CNT(i) (st.c[i] += 1)
+#define UNI_CNT_IF(i, cond) (st.c[i] += __builtin_amdgcn_ballot_w64(cond) != 0 ? 1 : 0)
 #else
 #define UNI_DBG(bit) false
+#define UNI_CNT(i) ((void)0)
+#define UNI_CNT_IF(i, cond) ((void)0)
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
@@ -70,6 +79,8 @@ struct UniRing4 {
     int mem_n;       // entries spilled to global memory
 #ifdef MCL_UNI_DBG
     int dbg;
+    unsigned c[8];
+    long long cyc[6], tprev;  // (dbg & 256): cycles per section of a step: coop refill, push, pooling, post; between steps; total
 #endif
 };
 struct UniRec {
@@ -117,6 +128,7 @@ struct UniPrefetch {
 template <int RC, int NRF>
 static __device__ __forceinline__ void ur4_push(UniRing4 &st, UniPrefetch<NRF> &pf, int lane, bool act, double sy, int cw, double q,
                                                 double *__restrict__ sp) {
+    UNI_CNT_IF(2, act && st.cnt == RC);
     if (act) {
         if (st.cnt == RC) {
             const int b = ((st.h - RC + 1) & (RC - 1)) * 64 + lane;
@@ -200,6 +212,8 @@ static __device__ __forceinline__ void ur4_refill_coop(UniRing4 &st, UniPrefetch
     // a lane joins when its own ring is at most half full: it will run dry soon (joining whenever there was room made every
     // lane prefetch four times as often as it refilled, and most of those prefetches were invalidated by the next spill)
     const int room = st.cnt <= RC / 2 ? RC - 2 - st.cnt : 0;
+    UNI_CNT_IF(3, pf.n > 0 && room >= pf.n);
+    UNI_CNT_IF(4, pf.n <= 0 && st.mem_n > 0 && room > 0);
     if (pf.n > 0) {
         if (room >= pf.n) {
             ur4_take_prefetched<RC, NRF>(st, pf, lane);
@@ -290,6 +304,21 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
     st.sy = ring_d[0], st.q = ring_d[1], st.cw = ring_i;
 #ifdef MCL_UNI_DBG
     st.dbg = sc.dbg;
+    for (int i = 0; i < 8; ++i) st.c[i] = 0;
+    for (int i = 0; i < 6; ++i) st.cyc[i] = 0;
+    st.tprev = 0;
+    const long long t_kernel0 = (long long)__builtin_readcyclecounter();
+    struct CtrOut {  // lane 0 adds the wave's counts when the kernel returns (every exit path)
+        const UniRing4 &st; unsigned long long *ctr; int lane; long long t0;
+        __device__ ~CtrOut() {
+            if (lane == 0 && ctr) {
+                for (int i = 0; i < 8; ++i) atomicAdd(ctr + i, (unsigned long long)st.c[i]);
+                for (int i = 0; i < 5; ++i) atomicAdd(ctr + 8 + i, (unsigned long long)st.cyc[i]);
+                atomicAdd(ctr + 14, (unsigned long long)st.cyc[5]);
+                atomicAdd(ctr + 13, (unsigned long long)((long long)__builtin_readcyclecounter() - t0));
+            }
+        }
+    } ctr_out{st, sc.ctr, lane, t_kernel0};
 #endif
     // byte addresses of this lane's slot 0 in the rings (the pooling loop addresses LDS itself)
     const int lds_d = (int)lds_addr(&ring_d[0][0]) + lane * 8, lds_i = (int)lds_addr(&ring_i[0]) + lane * 4;
@@ -298,6 +327,10 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
     double tsy, tcw, tQ;          // cached top of the stack below it
     int ht;  // 1: there is a cached top
     float levf;
+    // (Round 5, measured and dropped: a sentinel entry (sum -inf, count 1, Q 0) at the bottom of every stack takes `ht` out of
+    // the pooling loop - 23 instead of 27 instructions per trip, ~8 fewer per element step, bit-identical fits - and is 1.5 %
+    // SLOWER on the steady-state iterates of config 5 (9.85 against 9.70 ms, same box): the kernel is not bound by the count of
+    // its cheap vector instructions, see profiles/r5_uni_anatomy.txt.)
     auto reset = [&]() {
         st.h = 0, st.cnt = 0, st.mem_n = 0, pf.n = 0;
         cum2 = 0.0, csy = 0.0, ccw = 1.0, curQ = 0.0;
@@ -306,10 +339,29 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
     };
     // one element: returns the prefix error; leaves (levf, ccw) = record of the block ending at this element
     auto step = [&](double v, bool first) -> double {
-        if (sc.coop) ur4_refill_coop<RC, NRF>(st, pf, lane, sp);
+        UNI_CNT(0);
+#ifdef MCL_UNI_DBG
+        long long tk0 = 0;
+        if (sc.dbg & 256) {
+            tk0 = (long long)__builtin_readcyclecounter();
+            if (st.tprev) st.cyc[4] += tk0 - st.tprev;
+        }
+        auto tick = [&](int sec) {
+            if (sc.dbg & 256) {
+                const long long t1 = (long long)__builtin_readcyclecounter();
+                st.cyc[sec] += t1 - tk0;
+                tk0 = t1;
+            }
+        };
+#else
+        auto tick = [](int) {};
+#endif
+        if (sc.coop && !UNI_DBG(128)) ur4_refill_coop<RC, NRF>(st, pf, lane, sp);
+        tick(0);
         cum2 += v * v;
         // the finished block becomes the cached top; the previous top moves into the ring
-        ur4_push<RC, NRF>(st, pf, lane, !first && ht != 0, tsy, (int)tcw, tQ, sp);
+        if (!UNI_DBG(64)) ur4_push<RC, NRF>(st, pf, lane, !first && ht != 0, tsy, (int)tcw, tQ, sp);
+        tick(1);
         if (!first) {
             tsy = csy, tcw = ccw, tQ = curQ;
             ht = 1;
@@ -321,7 +373,10 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
         // per trip, most of them copies and mask algebra; this one 27): its exits - no lane pools / a pooling lane has run dry -
         // are decided wave-wide, what remains under the lane predicate is the straight-line pop.  With an empty ring the pop
         // reads a slot whose contents are not used (ht = 0) and moves h, which is as good a position as any other.
-        while (true) {
+#ifdef MCL_UNI_DBG
+        unsigned trips = 0;
+#endif
+        while (!UNI_DBG(32)) {
             int dry_exit;
             double t0, t1;
             unsigned long long m_need, m_b, m_save;
@@ -341,6 +396,9 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                 "s_and_b64 vcc, vcc, %[mn]\n"
                 "s_cbranch_scc1 L_dry_%=\n"
                 "s_and_saveexec_b64 %[ms], %[mn]\n"
+#ifdef MCL_UNI_DBG
+                "s_add_u32 %[trips], %[trips], 1\n"
+#endif
                 "v_add_f64 %[csy], %[csy], %[tsy]\n"
                 "v_add_f64 %[ccw], %[ccw], %[tcw]\n"
                 "v_lshl_add_u32 %[a1], %[h], 9, %[ldsd]\n"
@@ -364,19 +422,33 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                 : [flag] "=&s"(dry_exit), [t0] "=&v"(t0), [t1] "=&v"(t1), [mn] "=&s"(m_need), [mb] "=&s"(m_b), [ms] "=&s"(m_save),
                   [a1] "=&v"(a1), [a2] "=&v"(a2), [icw] "=&v"(icw), [csy] "+v"(csy), [ccw] "+v"(ccw), [tsy] "+v"(tsy),
                   [tcw] "+v"(tcw), [tq] "+v"(tQ), [ht] "+v"(ht), [h] "+v"(st.h), [cnt] "+v"(st.cnt)
+#ifdef MCL_UNI_DBG
+                  , [trips] "+s"(trips)
+#endif
                 : [memn] "v"(st.mem_n), [ldsd] "v"(lds_d), [ldsi] "v"(lds_i), [qoff] "n"(RC * 64 * 8), [msk] "n"(RC - 1)
                 : "vcc", "scc", "memory");
             if (dry_exit == 0) break;  // wave-uniform
-            if (ht != 0 && csy * tcw <= tsy * ccw && st.cnt == 0 && st.mem_n > 0)
-                ur4_refill_dry<RC, NRF>(st, pf, lane, sp);
+            const bool dry = ht != 0 && csy * tcw <= tsy * ccw && st.cnt == 0 && st.mem_n > 0;
+            UNI_CNT_IF(5, dry && pf.n > 0);
+            UNI_CNT_IF(6, dry && pf.n <= 0);
+            if (dry) ur4_refill_dry<RC, NRF>(st, pf, lane, sp);
         }
+#ifdef MCL_UNI_DBG
+        st.c[1] += trips;
+#endif
+        tick(2);
         // a block with a negative mean is clamped to level 0 and contributes q = 0; every block below it has a smaller
         // mean, so their Q is exactly 0 too and the prefix error comes out as cum2 without a special case
         const double lev = csy * rcp_count(ccw);
         const double levc = nonneg ? fmax(lev, 0.0) : lev;
         curQ = (ht != 0 ? tQ : 0.0) + csy * levc;
         levf = (float)levc;
-        return cum2 - curQ;
+        const double err_out = cum2 - curQ;
+        tick(3);
+#ifdef MCL_UNI_DBG
+        if (sc.dbg & 256) st.tprev = tk0;
+#endif
+        return err_out;
     };
 
     constexpr int UB = MCL_UNI_UB;  // elements per load batch; the NEXT batch is in flight while the current one is pooled
@@ -473,14 +545,33 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                 bool done = false;
                 for (int i0 = 0; i0 < n && !done; i0 += UB) {
                     double vb[UB], eb_l[UB];
+#ifdef MCL_UNI_DBG
+                    long long tb0 = (sc.dbg & 512) ? (long long)__builtin_readcyclecounter() : 0;
+#endif
 #pragma unroll
                     for (int j = 0; j < UB; ++j) vb[j] = (double)(fb[j] + ub[j]), eb_l[j] = eb_n[j];
+#ifdef MCL_UNI_DBG
+                    if (sc.dbg & 512) {  // force the batch's loaded values here: the wait for the loads is then this section's
+#pragma unroll
+                        for (int j = 0; j < UB; ++j) asm volatile("" : "+v"(vb[j]), "+v"(eb_l[j]));
+                        const long long t1 = (long long)__builtin_readcyclecounter();
+                        st.cyc[5] += t1 - tb0;
+                        tb0 = t1;
+                    }
+#endif
 #pragma unroll
                     for (int j = 0; j < UB; ++j) {
                         const int i = min(i0 + UB + j, n - 1);
                         fb[j] = fp[-(long)i * rs], ub[j] = up[-(long)i * rs];
                         eb_n[j] = __builtin_nontemporal_load(eLp + (long)min(n - 1 - i, m) * rs);  // (not read when t > m)
                     }
+#ifdef MCL_UNI_DBG
+                    if (sc.dbg & 512) {
+                        asm volatile("" ::: "memory");
+                        st.cyc[3] += (long long)__builtin_readcyclecounter() - tb0;  // (section 3 re-used: issue of the batch's loads)
+                        st.c[7] += 1;  // batches of phase B
+                    }
+#endif
 #pragma unroll
                     for (int j = 0; j < UB; ++j) {
                         const int i = i0 + j;
@@ -772,6 +863,19 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
 // =========================================================================================================
 // host side
 // =========================================================================================================
+#ifdef MCL_UNI_DBG
+static unsigned long long *uni_dbg_ctr() {
+    static unsigned long long *p = nullptr;
+    if (!p && hipMalloc(&p, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(p, 0, 16 * sizeof(unsigned long long));
+    return p;
+}
+// debug builds only: read and clear the event counters of the unimodal kernels (UNI_CNT)
+extern "C" int mcl_uni_dbg_counters(unsigned long long *out16) {  // [0..8) events, [8..13) section cycles, [13] kernel cycles
+    if (hipDeviceSynchronize() != hipSuccess || !uni_dbg_ctr()) return 1;
+    if (hipMemcpy(out16, uni_dbg_ctr(), 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    return hipMemset(uni_dbg_ctr(), 0, 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 static UniScratch uni_scratch(mcl_context *c) {
     const int64_t maxrows = std::max<int64_t>(c->N, std::max<int64_t>(c->I, c->K));
     const int64_t n1 = (maxrows + std::max<int64_t>(c->I, 1)) * c->r;
@@ -783,6 +887,7 @@ static UniScratch uni_scratch(mcl_context *c) {
     s.coop = c->sw.no_uni_coop ? 0 : 1;
 #ifdef MCL_UNI_DBG
     s.dbg = getenv("MCL_UNI_DBG") ? atoi(getenv("MCL_UNI_DBG")) : 0;
+    s.ctr = uni_dbg_ctr();
 #endif
     return s;
 }
@@ -805,7 +910,11 @@ int mcl_launch_unimodal(mcl_context *c, const int *ext, int n_slabs, float *F, c
     } else if (c->sw.uni_noprune) {
         hipLaunchKernelGGL(k_slab_unimodal_v4<0>, dim3(nwav), dim3(64), 0, c->stream, ext, n_slabs, F, rs, k, c->r, sc);
     } else {
-        hipLaunchKernelGGL(k_slab_unimodal_v4<3>, dim3(nwav), dim3(64), 0, c->stream, ext, n_slabs, F, rs, k, c->r, sc);
+        size_t pad = 0;
+#ifdef MCL_UNI_DBG  // occupancy experiments: unused dynamic LDS limits the workgroups a CU holds (tools/uni_occ.py)
+        pad = getenv("MCL_UNI_PAD_LDS") ? (size_t)atoi(getenv("MCL_UNI_PAD_LDS")) : 0;
+#endif
+        hipLaunchKernelGGL(k_slab_unimodal_v4<3>, dim3(nwav), dim3(64), pad, c->stream, ext, n_slabs, F, rs, k, c->r, sc);
     }
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
