@@ -102,7 +102,16 @@ README_STACK = os.environ.get("STACK") == "readme"  # README.rst:66-91 of the re
 TV_STACK = os.environ.get("STACK") == "tv"
 EXT_STACK = os.environ.get("STACK") == "ext"
 MATA_STACK = os.environ.get("STACK") == "matA"  # matrix penalties on the sharded A: evaluated on the all-gathered A + U
+COUPLED_STACK = os.environ.get("STACK") == "coupledB"  # a user's MatricesPenalty that couples the B_i of ALL ranks
 auxA2, dualA2 = mk((6, 4)), mk((6, 4))
+class SharedScale(pen.MatricesPenalty):
+    """one scale factor for all B_i (the stack projected on a Frobenius ball); the value is the norm of the stack: neither splits over ranks"""
+    def factor_matrices_update(self, factor_matrices, feasibility_penalties, auxes):
+        total = float(sum((m ** 2).sum() for m in factor_matrices)) ** 0.5
+        scale = min(1.0, (2.0 + 0.1 * float(np.mean(feasibility_penalties))) / total)
+        return [0.9 * scale * m + 0.1 * a for m, a in zip(factor_matrices, auxes)]
+    def penalty(self, x):
+        return 0.01 * float(sum((m ** 2).sum() for m in x)) ** 0.5
 class Ridge(pen.MatrixPenalty):
     """alpha * ||x||^2: prox x / (1 + 2 alpha / rho)"""
     def __init__(self, alpha, aux_init="random_uniform", dual_init="random_uniform"):
@@ -126,6 +135,9 @@ def run(lo, hi, group):
         regs[2] = [pen.TotalVariationPenalty(0.03, l1_strength=0.02, aux_init=auxC.copy(), dual_init=dualC.copy())]
     if EXT_STACK:  # a user-defined MatrixPenalty on the B_i: prox and value evaluated on the host, per matrix, on every rank
         regs[1] = [Ridge(0.3, aux_init=[a.copy() for a in auxL[lo:hi]], dual_init=[d.copy() for d in dualL[lo:hi]])]
+    if COUPLED_STACK:
+        regs[1] = [SharedScale(aux_init=[a.copy() for a in auxL[lo:hi]], dual_init=[d.copy() for d in dualL[lo:hi]]),
+                   pen.NonNegativity(aux_init=[a.copy() for a in auxU[lo:hi]], dual_init=[d.copy() for d in dualU[lo:hi]])]
     if MATA_STACK:
         regs[0] = [pen.Unimodality(non_negativity=True, aux_init=auxA[lo:hi].copy(), dual_init=dualA[lo:hi].copy()),
                    pen.TotalVariationPenalty(0.04, aux_init=auxA2[lo:hi].copy(), dual_init=dualA2[lo:hi].copy())]
@@ -134,7 +146,7 @@ def run(lo, hi, group):
         regs[1].insert(1, pen.Unimodality(non_negativity=True, aux_init=[a.copy() for a in auxU[lo:hi]],
                                           dual_init=[d.copy() for d in dualU[lo:hi]]))
     return dec.cmf_aoadmm(mats[lo:hi], 4, init=(None, (A0[lo:hi].copy(), [b.copy() for b in B0[lo:hi]], C0.copy())), regs=regs,
-                          return_errors=True, constant_feasibility_penalty=not (TV_STACK or EXT_STACK), group=group, **STOP)
+                          return_errors=True, constant_feasibility_penalty=not (TV_STACK or EXT_STACK or COUPLED_STACK), group=group, **STOP)
 bounds = [0, 2, 6]
 cmf, diag = run(bounds[rank], bounds[rank + 1], dist.group.WORLD)
 if rank == 0:
@@ -153,7 +165,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("stack", ["pf2", "readme", "pf2_stop", "tv", "ext", "matA"])
+@pytest.mark.parametrize("stack", ["pf2", "readme", "pf2_stop", "tv", "ext", "matA", "coupledB"])
 def test_two_ranks_sharing_the_gpu_equal_single_process(tmp_path, stack):
     """cmf_aoadmm(group=) with the REAL engine: 2 processes share cuda:0, collectives over gloo (RCCL refuses two ranks on one
     device); PARAFAC2 + constant feasibility penalty exercise every reduction of the step path; the "readme" stack adds the
