@@ -4,6 +4,7 @@ os.environ["MCL_SWEEP_DBG"] = os.environ.get("MCL_SWEEP_DBG", "32")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
+from matcouply_amd import _engine
 
 cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c3"]
 dev = torch.device("cuda:0")
