@@ -9,7 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(float *out, int iters, float seed) {
+__global__ __launch_bounds__(512) void k(float *out, int iters, float seed) {
     f32x4 acc[16];
     float v[12];
     for (int i = 0; i < 16; ++i) acc[i] = f32x4{seed, seed, seed, seed};
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed) {
     float s = 0.f;
     for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     for (int i = 0; i < 12; ++i) s += v[i];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
+    out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k32(float *out, int iters, float seed) {
     for (int i = 0; i < 8; ++i)
         for (int e = 0; e < 16; ++e) s += acc[i][e];
     for (int i = 0; i < 12; ++i) s += v[i];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
+    out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
 // The same question for the bf16 matrix core (v_mfma_f32_16x16x32_bf16, 16 cycles each): 64 of them = 1024 busy cycles, with the
@@ -105,7 +105,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MFB(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void kb(float *out, int iters, float seed) {
+__global__ __launch_bounds__(512) void kb(float *out, int iters, float seed) {
     f32x4 acc[16];
     float v[12];
     for (int i = 0; i < 16; ++i) acc[i] = f32x4{seed, seed, seed, seed};
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void kb(float *out, int iters, float seed) {
     float s = 0.f;
     for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     for (int i = 0; i < 12; ++i) s += v[i];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
+    out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
 template <int MODE>
@@ -160,6 +160,20 @@ void runb(float *out) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("bf16 16x16x32 mode %d: %.1f us per 2000 iterations -> %.0f cycles/iter at 2.4 GHz (64 MFMA = 1024 busy, 192 VALU = 768 issue)\n", MODE,
            ms * 1e3, ms * 1e-3 / 2000 * 2.4e9);
+}
+
+// two waves per SIMD (512 threads per workgroup, one workgroup per CU): does one wave's vector work run beside the OTHER wave's MFMAs?
+template <int MODE, bool BF>
+void run2(float *out) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    if (BF) kb<MODE><<<256, 512>>>(out, 10, 1.f); else k<MODE><<<256, 512>>>(out, 10, 1.f);
+    hipEventRecord(e0);
+    if (BF) kb<MODE><<<256, 512>>>(out, 2000, 1.f); else k<MODE><<<256, 512>>>(out, 2000, 1.f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("TWO waves per SIMD, %s mode %d: %.0f cycles per iteration of BOTH waves (each: 64 MFMA + 192 VALU in modes 0 / 1)\n",
+           BF ? "bf16 16x16x32" : "fp32 16x16x4", MODE, ms * 1e-3 / 2000 * 2.4e9);
 }
 
 template <int MODE>
@@ -189,9 +203,11 @@ void run(float *out) {
 }
 
 int main() {
-    float *out; hipMalloc(&out, 256 * 256 * 4);
+    float *out; hipMalloc(&out, 256 * 512 * 4);
     run<2>(out); run<3>(out); run<0>(out); run<1>(out);
     run32<2>(out); run32<3>(out); run32<0>(out); run32<1>(out);
     runb<2>(out); runb<3>(out); runb<0>(out); runb<1>(out);
+    run2<2, false>(out); run2<3, false>(out); run2<0, false>(out); run2<1, false>(out);
+    run2<2, true>(out); run2<3, true>(out); run2<0, true>(out); run2<1, true>(out);
     return 0;
 }
