@@ -32,9 +32,10 @@ typedef struct mcl_context mcl_context;
  * 400 this header: named indices (enum mcl_buffer_id, enum mcl_profile_slot, MCL_VARIANT_EXACT_MODE - the exact-mode query
  *     moved from index 4 to 100), twelve profile slots, mcl_profile_launches, a failed state after mcl_run's watchdog,
  *     mcl_options.inner_tol / exact_products, native GeneralizedL2 / UnitSimplex kinds (mcl_penalty_desc grew two fields),
- *     mcl_penalty_value, mcl_svd_init.
+ *     mcl_penalty_value, mcl_svd_init;
+ * 410 mcl_condition_probe (nothing else changed).
  * A host MUST compare mcl_version() with the MCL_ABI_VERSION it was built against before any other call. */
-#define MCL_ABI_VERSION 400
+#define MCL_ABI_VERSION 410
 
 #define MCL_MAX_REGS 4   /* penalties per mode */
 #define MCL_MAX_RANK 64
@@ -137,6 +138,15 @@ int mcl_flush_diagnostics(mcl_context *ctx);
 /* Value of penalty k of `mode` on the current factor, for the kinds whose value is not a column of the diagnostics vector:
  * GeneralizedL2 - sum over the mode's matrices of trace(F^T M F) (penalties.py:737-745).  One fp64 to device memory `out`. */
 int mcl_penalty_value(mcl_context *ctx, int32_t mode, int32_t k, double *out);
+/* Condition estimates of the r x r normal equations the PENALTY-FREE modes among `mode_mask` (bit m = mode m) would solve from
+ * the CURRENT factors - the systems the reference solves with an fp64 SVD (decomposition.py:155-172 mode 0, :240-256 mode 1,
+ * :312-321 mode 2; l2_penalty included): out[m] = ||M||_F ||M^-1||_F (between cond_2 and r cond_2; modes 0 / 1: the largest
+ * over the matrices; 1e300: singular), 0 for a mode that has penalties or is not in the mask.  Computed from the factors alone
+ * (fp64 Gram matrices of the B_i, no pass over X), three fp64 to DEVICE memory `out`, enqueued like everything else.  The
+ * fp32 kernels leave 1e-8 .. 4e-7 relative in what such a solve sees and the solve multiplies it by this number: a host that
+ * wants the reference's results on an ill-conditioned penalty-free mode switches to mcl_options.exact_products = 1 when the
+ * estimate is large (matcouply_amd does so between 2^20 and 2^24 elements of X above 1e3, and warns beyond). */
+int mcl_condition_probe(mcl_context *ctx, int32_t mode_mask, double *out);
 /* n outer iterations B -> C -> A on ONE device (decomposition.py:945-988); if diag_ring != NULL,
  * MCL_DIAG_LEN doubles are appended per iteration (device memory, n * MCL_DIAG_LEN doubles). */
 int mcl_iterate(mcl_context *ctx, int32_t n_iter, int32_t update_A, int32_t update_B, int32_t update_C,

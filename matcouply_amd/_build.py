@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmatcouply_hip.so")
-SOURCES = ["contract.hip", "admm.hip", "generic.hip", "unimodal.hip", "sweep.hip", "reconstruct.hip", "wide.hip", "svdinit.hip", "api.hip"]
+SOURCES = ["contract.hip", "admm.hip", "generic.hip", "unimodal.hip", "sweep.hip", "reconstruct.hip", "wide.hip", "svdinit.hip", "cond.hip", "api.hip"]
 # per-file compiler options.  The kernel files: let small MFMA results live in VGPRs - by default the register allocator parks
 # the 4-register accumulators of e.g. the sweep's inner loop / X C product in AGPRs and copies them back for every VALU use
 # (468 v_accvgpr_* instructions in the config-3 sweep, 129 with the option; no scratch either way)
@@ -36,14 +36,17 @@ def build_library(force=False, verbose=True, defs=None, out_lib=None, build_dir=
     objs = []
     procs = []
     os.makedirs(build_dir, exist_ok=True)
-    # an in-tree object older than a source or header may have another idea of the context's layout: never link it
-    newest_dep = max(os.path.getmtime(d) for d in [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-                     + [os.path.join(HERE, "..", "include", "matcouply_hip.h")])
+    # an object is current when it is newer than ITS source and every header (the headers define the context's layout: an
+    # object compiled against an older one may have another idea of it and is never linked); the other sources do not matter
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "matcouply_hip.h")]
+    newest_header = max(os.path.getmtime(h) for h in headers)
     for src in SOURCES:
         name = src.replace(".hip", ".o")
         tree_obj = os.path.join(tree_dir, name)
-        if only is not None and src not in only and os.path.exists(tree_obj) and os.path.getmtime(tree_obj) >= newest_dep:
-            objs.append(tree_obj)  # unchanged by `defs` and not older than any source / header: the in-tree object
+        newest_dep = max(newest_header, os.path.getmtime(os.path.join(CSRC, src)))
+        current = os.path.exists(tree_obj) and os.path.getmtime(tree_obj) >= newest_dep
+        if current and ((only is not None and src not in only) or (only is None and not force and not defs and build_dir == tree_dir)):
+            objs.append(tree_obj)  # unchanged by `defs` and not older than its source / any header: the in-tree object
             continue
         obj = os.path.join(build_dir, name)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + list(defs) + EXTRA_FLAGS.get(src, []) + [

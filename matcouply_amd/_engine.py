@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmatcouply_hip.so")
 
-MCL_ABI_VERSION = 400  # include/matcouply_hip.h; checked against mcl_version() when the library is loaded
+MCL_ABI_VERSION = 410  # include/matcouply_hip.h; checked against mcl_version() when the library is loaded
 MCL_MAX_REGS = 4
 MCL_MAX_RANK = 64
 DIAG_NORM_SQ, DIAG_INNER, DIAG_MODEL_SQ, DIAG_X_SQ, DIAG_REG = 0, 3, 4, 5, 8
@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "mcl_create", "mcl_destroy", "mcl_last_error", "mcl_version", "mcl_set_problem", "mcl_set_options",
     "mcl_set_factors", "mcl_set_penalties", "mcl_workspace_bytes", "mcl_set_workspace", "mcl_update_B",
     "mcl_update_C_local", "mcl_c_normal_equations", "mcl_update_C_finish", "mcl_update_A", "mcl_diagnostics",
-    "mcl_diagnostics_deferred", "mcl_flush_diagnostics", "mcl_penalty_value",
+    "mcl_diagnostics_deferred", "mcl_flush_diagnostics", "mcl_penalty_value", "mcl_condition_probe",
     "mcl_iterate", "mcl_run", "mcl_gate_begin", "mcl_verdict", "mcl_gate_end", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_B_end", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
     "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
@@ -105,6 +105,7 @@ def load_library():
         "mcl_diagnostics_deferred": (ctypes.c_int, [P, P, I32]),
         "mcl_flush_diagnostics": (ctypes.c_int, [P]),
         "mcl_penalty_value": (ctypes.c_int, [P, I32, I32, P]),
+        "mcl_condition_probe": (ctypes.c_int, [P, I32, P]),
         "mcl_iterate": (ctypes.c_int, [P, I32, I32, I32, I32, P]),
         "mcl_run": (ctypes.c_int, [P, I32, I32, I32, I32, ctypes.POINTER(StopRule), P, P, P]),
         "mcl_gate_begin": (ctypes.c_int, [P, ctypes.POINTER(StopRule), P]),
@@ -263,6 +264,7 @@ class HipEngine:
         opt.constant_A, opt.constant_B = int(bool(constant_A)), int(bool(constant_B))
         opt.inner_tol = float(inner_tol or 0.0)  # > 0: the inner stopping test of decomposition.py:90-117, evaluated on the device
         opt.exact_products = int(exact_products)  # 0: by this context's size; 1 / 2: forced on / off (sharded hosts: by the WHOLE problem)
+        self._opt = opt
         self._check(self.lib.mcl_set_options(self._h, ctypes.byref(opt)))
         self._check(self.lib.mcl_set_factors(self._h, A.data_ptr(), B.data_ptr(), C.data_ptr()))
         for mode in range(3):
@@ -367,6 +369,33 @@ class HipEngine:
         out = self._torch.empty(1, dtype=self._torch.float64, device=self.device)
         self._check(self.lib.mcl_penalty_value(self._h, int(mode), int(k), out.data_ptr()))
         return out
+
+    def condition_probe(self, update_A=True, update_B=True, update_C=True):
+        """mcl_condition_probe: kappa = ||M||_F ||M^-1||_F of the normal equations every PENALTY-FREE mode among the updated
+        ones would solve from the current factors (modes 0 / 1: the worst matrix; 0.0 for modes with penalties); a float64
+        device tensor of 3 - reading it synchronises"""
+        out = self._torch.zeros(3, dtype=self._torch.float64, device=self.device)
+        mask = int(bool(update_A)) | int(bool(update_B)) << 1 | int(bool(update_C)) << 2
+        self._check(self.lib.mcl_condition_probe(self._h, mask, out.data_ptr()))
+        return out
+
+    def set_exact(self, exact=True):
+        """Switch the context's arithmetic (mcl_options.exact_products = 1 / 2) between two outer iterations: the workspace is
+        planned and installed anew (a larger one is allocated when the mode needs it); factors and ADMM variables live in the
+        caller's tensors and are untouched, every cached by-product is recomputed by the next phase."""
+        want = 1 if exact else 2
+        if int(self._opt.exact_products) == want:
+            return
+        self._opt.exact_products = want
+        self._check(self.lib.mcl_set_options(self._h, ctypes.byref(self._opt)))
+        nbytes = self.lib.mcl_workspace_bytes(self._h)
+        if nbytes < 0:
+            raise EngineError("mcl_workspace_bytes failed")
+        if int(nbytes) + 256 > self.workspace.numel():
+            self._torch.cuda.synchronize(self.device)  # kernels of the old installation may still be reading the old buffer
+            self.workspace = self._torch.empty(int(nbytes) + 256, dtype=self._torch.uint8, device=self.device)
+            self._ws_off = (-self.workspace.data_ptr()) % 256
+        self._check(self.lib.mcl_set_workspace(self._h, self.workspace.data_ptr() + self._ws_off, nbytes))
 
     def iterate(self, n_iter, update_A=True, update_B=True, update_C=True, diag_ring=None):
         ptr = diag_ring.data_ptr() if diag_ring is not None else None

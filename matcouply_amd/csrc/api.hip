@@ -131,6 +131,7 @@ int64_t plan(mcl_context *c, char *base) {
     c->diag_sums = b.take<double>(3 * DIAG_COLS + 2);
     c->xsq_part = b.take<double>(1024);
     c->x_sq = b.take<double>(1);
+    c->cond_part = b.take<double>(mcl_cond_part_doubles(c));
     c->inner_gate = b.take<int>(2);
     {
         const int64_t max_tiles = std::max<int64_t>(std::max<int64_t>(c->tilesB.n_tiles, c->tilesC.n_tiles), std::max<int64_t>(c->tilesA.n_tiles, 1));
@@ -1191,6 +1192,17 @@ int mcl_penalty_value(mcl_context *c, int32_t mode, int32_t k, double *out) {
     if (mode < 0 || mode > 2 || k < 0 || k >= c->regs[mode].n || !out) return fail(c, "mcl_penalty_value: bad arguments");
     if (c->regs[mode].kind[k] != MCL_PEN_GL2) return fail(c, "mcl_penalty_value: only GeneralizedL2 penalties have a separate value");
     return mcl_launch_gl2_value(c, mode, k, out);
+}
+
+int mcl_condition_probe(mcl_context *c, int32_t mode_mask, double *out) {
+    if (!c) return 1;
+    if (!out) return fail(c, "mcl_condition_probe: out is NULL");
+    if (int rc = ready(c)) return rc;
+    int want = 0;
+    for (int m = 0; m < 3; ++m)
+        if ((mode_mask >> m & 1) && c->regs[m].n == 0) want |= 1 << m;  // a mode WITH penalties solves shifted, well-conditioned systems
+    if (int rc = ensure_ctc(c)) return rc;
+    return mcl_launch_cond_probe(c, want, out);
 }
 
 int mcl_iterate(mcl_context *c, int32_t n_iter, int32_t update_A, int32_t update_B, int32_t update_C,

@@ -186,6 +186,7 @@ struct mcl_context {
     double *xsq_part = nullptr;    // [1024]
     int *ext_A = nullptr, *ext_C = nullptr;  // int32[2] slab extents {0, I} / {0, K} for the single-slab modes
     double *x_sq = nullptr;     // [1]
+    double *cond_part = nullptr;  // [256, r*r + 2] mcl_condition_probe: per group of matrices the a-weighted Gram sum and the worst kappa of modes 0 / 1
     // deferred diagnostics (mcl_diagnostics_deferred): the reduction of the tables rides on a spare workgroup of the NEXT
     // C-phase reduction kernel instead of a launch of its own; the sweep alternates between two B tables so that the
     // tables of iteration t stay intact while the sweep of t + 1 writes its own
@@ -370,3 +371,5 @@ int mcl_launch_exact_xc(mcl_context *c);                         // contract.hip
 int mcl_launch_exact_gr(mcl_context *c);                         // contract.hip: GR = [G | R] of this rank's slabs, exact products
 int mcl_launch_unimodal(mcl_context *c, const int *ext, int n_slabs, float *F, const RegSet &rs, int mode, int k);  // unimodal.hip
 int mcl_launch_gl2_value(mcl_context *c, int mode, int k, double *out);  // generic.hip: sum over slabs of trace(F^T M F)
+int64_t mcl_cond_part_doubles(const mcl_context *c);                    // cond.hip
+int mcl_launch_cond_probe(mcl_context *c, int want, double *out);      // cond.hip: kappa of the penalty-free modes' systems -> out[3]

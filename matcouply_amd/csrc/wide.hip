@@ -236,7 +236,12 @@ __global__ __launch_bounds__(64) void k_wide_solve(WideRows W, WideState S, cons
     extern __shared__ double wsm[];
     double *Ls = wsm, *Ds = Ls + r * r, *ts = Ds + (S.kpf2 >= 0 ? r * r : 0);
     const RowGroup R(W, r);
-    if (!R.any()) return;
+    if (!R.any()) {
+        // a workgroup past the end of its tile: k_inner_check still sums EVERY entry of the table, which modes 0 / 1 / 2 and
+        // the non-wide checked loop share - a stale value of another phase would inflate this one's change term
+        if (change_part != nullptr && threadIdx.x == 0) change_part[blockIdx.x] = 0.0;
+        return;
+    }
     for (int e = threadIdx.x; e < r * r; e += 64) {
         Ls[e] = Linv64[(long)R.slab * r * r + e];
         if (S.kpf2 >= 0) Ds[e] = S.D[e];

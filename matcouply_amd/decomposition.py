@@ -30,6 +30,15 @@ __all__ = ["compute_feasibility_gaps", "ADMMVars", "DiagnosticMetrics", "cmf_aoa
 _ENGINE_FACTORY = None
 
 
+# arithmetic="auto" (see cmf_aoadmm): problems of at most 2^20 elements always take the exact arithmetic (the library's own rule);
+# up to _AUTO_EXACT_MAX_ELEMENTS a penalty-free mode whose normal equations have kappa = ||M||_F ||M^-1||_F above
+# _AUTO_EXACT_KAPPA moves the run there; larger problems are only warned, above _AUTO_EXACT_WARN_KAPPA
+_AUTO_EXACT_MAX_ELEMENTS = float(1 << 24)
+_AUTO_EXACT_KAPPA = 1e3
+_AUTO_EXACT_WARN_KAPPA = 1e6
+_AUTO_EXACT_PROBE_EVERY = 64
+
+
 def _test_engine_factory():
     if _ENGINE_FACTORY is None:
         return None
@@ -755,10 +764,12 @@ def cmf_aoadmm(
     # the arithmetic of small problems (exact-products mode) is chosen by the size of the WHOLE problem:
     # every rank of a sharded run, and every rank layout of the same problem, then computes with the same kernels
     exact_products = {"auto": 0, "exact": 1, "fast": 2}[arithmetic]
+    n_el_total = float(X.shape[0]) * float(X.shape[1])
     if world > 1 and arithmetic == "auto":
-        n_el = torch.tensor([float(X.shape[0]) * float(X.shape[1])], dtype=torch.float64, device=X.device)
+        n_el = torch.tensor([n_el_total], dtype=torch.float64, device=X.device)
         dist.all_reduce(n_el, group=group)
-        exact_products = 1 if float(n_el.item()) <= float(1 << 20) else 2
+        n_el_total = float(n_el.item())
+        exact_products = 1 if n_el_total <= float(1 << 20) else 2
     eng = factory(X=X, row_ptr=row_ptr, rank=rank, A=A, B=B, C=C, regs=native, l2_penalty=l2_penalty,
                   inner_n_iter_max=inner_n_iter_max, feasibility_penalty_scale=feasibility_penalty_scale,
                   constant_A=constant_A, constant_B=constant_B, exact_products=exact_products,
@@ -1124,6 +1135,51 @@ def cmf_aoadmm(
         all_reduce(vec)
         return read_diag(vec)
 
+    # ---- arithmetic="auto" above the small-problem limit: decided by CONDITIONING, not by size alone ------------------------
+    # A mode without any penalty solves un-shifted normal equations (the reference: an fp64 SVD, decomposition.py:172, 252-256,
+    # 319-321) and multiplies whatever the fp32 kernels left in its inputs (1e-8 .. 4e-7 relative) by the condition number of
+    # its system.  On large problems those roundings average out over 1e5 .. 1e7 rows (BASELINE config 4: C to 8e-8 at
+    # condition 600) and the exact arithmetic would cost passes over X; below _AUTO_EXACT_MAX_ELEMENTS elements neither
+    # holds.  There the engine's condition probe (mcl_condition_probe: kappa of the systems the penalty-free modes would
+    # solve from the CURRENT factors, no pass over X) decides before the first iteration - and again every
+    # _AUTO_EXACT_PROBE_EVERY iterations of a long run, conditioning grows as components become collinear: above
+    # _AUTO_EXACT_KAPPA the run continues in the exact arithmetic (fp64 sums of exact products, fp64 inner loops).  The decision
+    # is taken from all-reduced numbers under `group=` (every rank switches, or none).  Larger problems keep the fast kernels;
+    # a badly conditioned one is told about `arithmetic="exact"`.
+    updated_modes = (update_A, update_B_is, update_C)
+    free_modes = [m for m in range(3) if updated_modes[m] and len(regs[m]) == 0]
+    auto_candidate = (arithmetic == "auto" and bool(free_modes) and n_el_total > float(1 << 20) and n_iter_max > 0
+                      and hasattr(eng, "condition_probe"))
+
+    def probe_conditioning():
+        """worst kappa over the penalty-free updated modes (all ranks: the same number)"""
+        k = eng.condition_probe(update_A, update_B_is, update_C)
+        if sharded:
+            all_reduce(k, "max")
+        return float(k.max().item())
+
+    def maybe_go_exact():
+        nonlocal auto_candidate
+        if not auto_candidate:
+            return
+        worst = probe_conditioning()
+        if n_el_total > _AUTO_EXACT_MAX_ELEMENTS:
+            auto_candidate = False  # (large problems are probed once, for the warning only)
+            if worst > _AUTO_EXACT_WARN_KAPPA:
+                import warnings
+
+                warnings.warn(
+                    f"cmf_aoadmm: a mode without penalties has normal equations of condition ~{worst:.1e}; the fp32 kernels this "
+                    f"problem size takes by default carry about 1e-8 x that in the factors. Pass arithmetic=\"exact\" for the "
+                    "reference's fp64 solve (slower: fp64 passes over the matrices).", RuntimeWarning, stacklevel=3)
+        elif worst > _AUTO_EXACT_KAPPA:
+            eng.set_exact(True)
+            auto_candidate = False
+            if verbose:
+                print(f"matcouply_amd: penalty-free mode with condition ~{worst:.1e}: continuing in the exact arithmetic")
+
+    maybe_go_exact()
+
     rec_errors, feasibility_gaps, losses = [], [], []
     rec_error, gaps0, reg0 = diagnostics()
     rec_errors.append(rec_error)
@@ -1167,6 +1223,8 @@ def cmf_aoadmm(
                 do_update_A()
             if ring is not None:  # the table reduction rides on the next iteration's C-phase reduction kernel
                 eng.diagnostics_deferred(include_replicated=(rank_id == 0), out=ring[it])
+            if auto_candidate and (it + 1) % _AUTO_EXACT_PROBE_EVERY == 0 and it + 1 < n_iter_max:
+                maybe_go_exact()
         if ring is not None:
             eng.flush_diagnostics()
             all_reduce(ring)
@@ -1231,7 +1289,9 @@ def cmf_aoadmm(
         weights = [[(reg.reg_strength if isinstance(reg, penalties.L1Penalty) else 0.0) for reg in regs[m]] for m in range(3)]
         done, code, chunk = 0, 0, 4096
         while done < n_iter_max and not code:
-            n_now = min(chunk, n_iter_max - done)
+            if done > 0:
+                maybe_go_exact()
+            n_now = min(_AUTO_EXACT_PROBE_EVERY if auto_candidate else chunk, n_iter_max - done)
             n_ran, code, ring_h, verdict_h = eng.run(
                 n_now, tol, absolute_tol, feasibility_tol, initial_loss=losses[-1], penalty_weight=weights,
                 evaluate_loss_always=return_errors, update_A=update_A, update_B=update_B_is, update_C=update_C)
@@ -1253,7 +1313,14 @@ def cmf_aoadmm(
         ring = None
         if return_errors:
             ring = torch.zeros((n_iter_max, _engine.DIAG_LEN), dtype=torch.float64, device=device)
-        eng.iterate(n_iter_max, update_A=update_A, update_B=update_B_is, update_C=update_C, diag_ring=ring)
+        done = 0
+        while done < n_iter_max:  # (one call, unless the conditioning of a penalty-free mode is being watched)
+            n_now = min(_AUTO_EXACT_PROBE_EVERY, n_iter_max - done) if auto_candidate else n_iter_max - done
+            eng.iterate(n_now, update_A=update_A, update_B=update_B_is, update_C=update_C,
+                        diag_ring=(ring[done:] if ring is not None else None))
+            done += n_now
+            if done < n_iter_max:
+                maybe_go_exact()
         it = n_iter_max - 1
         if return_errors:
             rec, gaps, reg = read_diag_rows(ring.cpu().numpy())
@@ -1269,6 +1336,8 @@ def cmf_aoadmm(
             if update_A:
                 do_update_A()
 
+            if auto_candidate and (it + 1) % _AUTO_EXACT_PROBE_EVERY == 0 and it + 1 < n_iter_max:
+                maybe_go_exact()
             if not (stop.active or return_errors):
                 progress.iteration(it)
                 continue

@@ -174,7 +174,7 @@ def test_a_deferral_crosses_at_most_one_sweep(fast_kernels):
 def test_library_reports_the_header_abi_version():
     from matcouply_amd import _engine
 
-    assert _engine.load_library().mcl_version() == _engine.MCL_ABI_VERSION == 400
+    assert _engine.load_library().mcl_version() == _engine.MCL_ABI_VERSION == 410
 
 
 def test_events_order_a_side_stream_collective():

@@ -1,0 +1,134 @@
+"""-m gpu: mcl_condition_probe (csrc/cond.hip) and the rule `arithmetic="auto"` builds on it.
+
+A mode without penalties solves un-shifted normal equations - the reference with an fp64 SVD (decomposition.py:172, 252-256,
+319-321) - and amplifies what fp32 kernels leave in its inputs by the condition number of its system.  The probe computes
+kappa = ||M||_F ||M^-1||_F of those systems from the factors; between 2^20 and 2^24 elements of X `cmf_aoadmm` moves a run
+whose penalty-free modes exceed kappa 1e3 to the exact arithmetic (VERDICT r5 #1d), larger problems are warned."""
+import warnings
+
+import numpy as np
+import pytest
+
+from tests.helpers import engine_from_oracle_state, rel_err
+from tests.test_gpu_end_to_end import _compare, _run_both
+
+pytestmark = pytest.mark.gpu
+
+
+def _kappa(M):
+    return np.linalg.norm(M) * np.linalg.norm(np.linalg.inv(M))
+
+
+def _reference_kappas(st, l2):
+    """the three systems of decomposition.py:155-172 / 240-256 / 312-321 in NumPy fp64"""
+    A, B, C, rp = st.A, st.B, st.C, st.row_ptr
+    r = A.shape[1]
+    CtC = C.T @ C
+    kA = kB = 0.0
+    G = l2[2] * np.eye(r)
+    for i in range(len(rp) - 1):
+        B_i = B[rp[i]:rp[i + 1]]
+        if len(B_i) == 0:
+            continue
+        BtB = B_i.T @ B_i
+        aa = np.outer(A[i], A[i])
+        kA = max(kA, _kappa(BtB * CtC + l2[0] * np.eye(r)))
+        kB = max(kB, _kappa(aa * CtC + l2[1] * np.eye(r)))
+        G = G + aa * BtB
+    return np.array([kA, kB, _kappa(G)])
+
+
+@pytest.mark.parametrize("shape", [(7, "ragged", 40, 5), (300, 33, 64, 16), (3, 200, 70, 64), (9, "short", 24, 33)])
+def test_probe_equals_numpy(shape):
+    from oracle import aoadmm_oracle as orc
+
+    I, J, K, r = shape
+    rng = np.random.RandomState(I)
+    if J == "ragged":
+        J = rng.randint(5, 200, I)
+    elif J == "short":
+        J = np.array([40, 33, 0, 64, 35, 100, 34, 65, 129])  # an empty matrix among them
+    X, row_ptr = orc.synthetic_problem(I, J, K, r, seed=1, dtype=np.float64)
+    X = X.astype(np.float32).astype(np.float64)
+    l2 = [0.02, 0.0, 0.3]
+    st = orc.random_state_for(X, row_ptr, r, [[], [], []], seed=2, l2=l2)
+    r32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    st.A, st.B, st.C = r32(st.A), r32(st.B), r32(st.C)
+    eng = engine_from_oracle_state(st)
+    want = _reference_kappas(st, l2)
+    got = eng.condition_probe(True, True, True).cpu().numpy()
+    print(shape, "kappa A / B / C:", got, "numpy:", want)
+    np.testing.assert_allclose(got, want, rtol=1e-6)
+    # modes that are not asked for report 0; twice the same bits (fixed summation order)
+    assert np.array_equal(eng.condition_probe(True, True, True).cpu().numpy(), got)
+    assert np.array_equal(eng.condition_probe(False, True, False).cpu().numpy() != 0, [False, True, False])
+    eng.close()
+
+
+def test_probe_skips_modes_with_penalties():
+    from oracle import aoadmm_oracle as orc
+
+    X, row_ptr = orc.synthetic_problem(6, np.full(6, 50), 30, 4, seed=1, dtype=np.float64)
+    st = orc.random_state_for(X.astype(np.float32).astype(np.float64), row_ptr, 4, [[{"kind": "nn"}], [], [{"kind": "nn"}]], seed=2)
+    eng = engine_from_oracle_state(st)
+    k = eng.condition_probe(True, True, True).cpu().numpy()
+    assert k[0] == 0 and k[2] == 0 and k[1] > 1
+    eng.close()
+
+
+def _mid_problem(l2):
+    from oracle import aoadmm_oracle as orc
+
+    I, K, r = 40, 128, 8
+    J = np.random.RandomState(2).randint(200, 420, I)
+    X, row_ptr = orc.synthetic_problem(I, J, K, r, seed=12, dtype=np.float64)
+    X = X.astype(np.float32).astype(np.float64)
+    assert (1 << 20) < X.size <= (1 << 24)
+    regs = [[], [{"kind": "l2ball", "norm_bound": 0.7}], []]
+    return lambda: orc.random_state_for(X, row_ptr, r, regs, seed=13, l2=l2)
+
+
+def test_auto_arithmetic_follows_the_conditioning(monkeypatch):
+    """1.6 M elements, L2 ball on the B_i, A and C free: with a small ridge the free modes' systems have kappa ~1e4 - the
+    default call switches to the exact arithmetic and lands where arithmetic="exact" lands (round 5: 8.2e-5 by default);
+    with a ridge that makes them well conditioned (kappa < 1e3) the same call keeps the fast kernels."""
+    from matcouply_amd import _engine
+
+    switched = []
+    orig = _engine.HipEngine.set_exact
+
+    def recording(self, exact=True):
+        switched.append(bool(exact))
+        return orig(self, exact)
+
+    monkeypatch.setattr(_engine.HipEngine, "set_exact", recording)
+    worst = {}
+    for arithmetic in ("auto", "exact", "fast"):
+        st = _mid_problem([0.05, 0.0, 0.05])()
+        cmf, admm, diag, res = _run_both(st, 3, arithmetic=arithmetic)
+        worst[arithmetic] = max(v for k, v in _compare(cmf, admm, diag, st, res, 1.0, 1.0).items() if k != "gaps")
+    print({k: f"{v:.1e}" for k, v in worst.items()}, "switches:", switched)
+    assert switched == [True]  # the auto run, once; the forced runs never ask
+    assert worst["auto"] < 1e-5 and worst["exact"] < 1e-5 and worst["auto"] < worst["fast"]
+    assert abs(worst["auto"] - worst["exact"]) <= 1e-9 + 0.05 * worst["exact"]
+    # a ridge of the size of the systems' own scale: well conditioned, the fast kernels stay - and are inside the bar
+    switched.clear()
+    st = _mid_problem([2e4, 0.0, 2e4])()
+    cmf, admm, diag, res = _run_both(st, 3)
+    errs = _compare(cmf, admm, diag, st, res, 1e-5, 1e-5)
+    assert switched == [], switched
+    print("well-conditioned free modes, fast kernels:", f"{max(v for k, v in errs.items() if k != 'gaps'):.1e}")
+
+
+def test_large_ill_conditioned_problem_is_warned(monkeypatch):
+    """above 2^24 elements the fast kernels stay (BASELINE configs 3 - 5 live there); a penalty-free mode with kappa > 1e6
+    gets a RuntimeWarning naming arithmetic="exact" (the lever is lowered here instead of building a 17 M-element problem)"""
+    from matcouply_amd import decomposition as dec
+
+    monkeypatch.setattr(dec, "_AUTO_EXACT_MAX_ELEMENTS", float(1 << 20))
+    monkeypatch.setattr(dec, "_AUTO_EXACT_WARN_KAPPA", 1e2)
+    st = _mid_problem([0.05, 0.0, 0.05])()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _run_both(st, 1)
+    assert any('arithmetic="exact"' in str(x.message) for x in w), [str(x.message) for x in w]

@@ -59,10 +59,32 @@ def _run_both(st, n_iter, **kw):
     return cmf, admm, diag, res
 
 
+GAP_RTOL, GAP_ATOL = 1e-4, 2e-7
+
+
+def gap_error(got_hist, ref_hist, rtol=GAP_RTOL):
+    """Feasibility gaps ||aux - x|| / ||x|| (decomposition.py:351-417) of every iteration, penalty and mode against reference
+    values: worst |got - ref| / (GAP_ATOL + GAP_RTOL |ref|), i.e. <= 1 passes.  A gap is a DIFFERENCE of two fp32-stored
+    arrays over the norm of one of them: its absolute error sits at the storage level (6e-8 per element, relative to the
+    factor) however small the gap itself is - hence the absolute floor beside the relative bar."""
+    worst = 0.0
+    assert len(got_hist) == len(ref_hist), (len(got_hist), len(ref_hist))
+    for got_it, ref_it in zip(got_hist, ref_hist):
+        for m in range(3):
+            g, r = np.asarray([float(v) for v in got_it[m]]), np.asarray([float(v) for v in ref_it[m]])
+            assert g.shape == r.shape, (m, g.shape, r.shape)
+            if g.size:
+                assert np.isfinite(g).all(), got_it
+                worst = max(worst, float(np.max(np.abs(g - r) / (GAP_ATOL + rtol * np.abs(r)))))
+    return worst
+
+
 def _compare(cmf, admm, diag, st, res, tol, tol_rec=1e-5):
     errs = {"A": rel_err(cmf[1][0], st.A), "B": rel_err(np.concatenate(cmf[1][1]), st.B), "C": rel_err(cmf[1][2], st.C)}
     errs["rec"] = max(abs(a - b) / b for a, b in zip(diag.rec_errors, res["rec_errors"]))
     errs["loss"] = max(abs(a - b) / abs(b) for a, b in zip(diag.regularized_loss, res["losses"]))
+    # the VALUES of the feasibility gaps the device's diagnostics tables produce (SURVEY 8 row a7), every iteration
+    errs["gaps"] = gap_error(diag.feasibility_gaps, res["gaps"])
     for m in range(3):
         for k, d in enumerate(st.regs[m]):
             z, u = admm.auxes[m][k], admm.duals[m][k]
@@ -83,7 +105,8 @@ def _compare(cmf, admm, diag, st, res, tol, tol_rec=1e-5):
             errs[f"dual{m}{k}"] = np.linalg.norm(un - st.dual[m][k]) / scale
     # loss = rec^2 / 2 + penalties: its relative error is up to twice the rec error's
     p_tol = max(tol, 1e-8 * res.get("polar_cond", 1.0))
-    bound = lambda k: tol_rec if k == "rec" else (2 * tol_rec if k == "loss" else (p_tol if k[0] == "P" and k[1] != "D" else tol))
+    bound = lambda k: 1.0 if k == "gaps" else (
+        tol_rec if k == "rec" else (2 * tol_rec if k == "loss" else (p_tol if k[0] == "P" and k[1] != "D" else tol)))
     bad = {k: v for k, v in errs.items() if not (v < bound(k))}
     assert not bad, (bad, errs)
     return errs
@@ -106,8 +129,14 @@ def test_golden_trajectories(fname, kernel_paths):
     np.testing.assert_allclose(diag.regularized_loss, arrs["regularized_loss"], rtol=1e-5)
     e = {"A": rel_err(cmf[1][0], arrs["A"]), "B": rel_err(np.concatenate(cmf[1][1]), arrs["B"]),
          "C": rel_err(cmf[1][2], arrs["C"])}
-    print(fname, "20 it vs reference:", {k: f"{v:.1e}" for k, v in e.items()})
+    # the reference's own feasibility gaps, all 21 read-outs of every penalty (gaps_m{m}: [n_iter + 1, n_regs of the mode])
+    ref_gaps = [[arrs[f"gaps_m{m}"][it] if f"gaps_m{m}" in arrs else [] for m in range(3)] for it in range(len(arrs["rec_errors"]))]
+    # (relative error of a gap = error of the factor / the gap: the full stack's free-running B sits at 1.2e-6 after 20 iterations
+    # where the other six trajectories sit at 1e-7, its gaps at 0.04 .. 0.08 - held to 1e-3 there)
+    e_gap = gap_error(diag.feasibility_gaps, ref_gaps, rtol=(1e-3 if "c5_full" in fname else GAP_RTOL))
+    print(fname, "20 it vs reference:", {k: f"{v:.1e}" for k, v in e.items()}, f"gaps {e_gap:.2f} of the bar")
     if max(e.values()) < 3e-6:  # measured: <= 1e-7 on six of the seven trajectories, 1.2e-6 on the full stack (default path)
+        assert e_gap <= 1.0, (fname, e_gap)
         return
     # Round 5: on the DEFAULT path (fp64 inner loops of small problems, csrc/wide.hip) every one of the seven free-running
     # trajectories stays inside that bar - the full stack included, whose re-pooled column the fp32 row arithmetic used to
@@ -122,6 +151,37 @@ def test_golden_trajectories(fname, kernel_paths):
     # the reference chooses on the same input; the trajectories differ only in which side of a tie their inputs fell.
     assert any(d["kind"] == "unimodal" for d in spec["regs"][1]), (fname, e)
     _assert_stepwise_equivalence(_traj_state(arrs, spec), spec["n_iter_max"], fname)
+
+
+@pytest.mark.parametrize("fname", ["traj_c3_nn_l1C.npz", "traj_c4_pf2_ball.npz", "traj_c5_full.npz"])
+def test_public_compute_feasibility_gaps(fname):
+    """`compute_feasibility_gaps(cmf, regs, A_aux_list, B_aux_list, C_aux_list)` (reference decomposition.py:351-417) on the
+    DEVICE tensors a run returns: equal to the gaps the engine's own diagnostics tables reported for that state, and - after
+    the reference's 20 iterations - to the reference's last read-out."""
+    import torch
+
+    from matcouply_amd import decomposition as dec
+    from tests.test_oracle_golden import _traj_state
+
+    arrs = load_npz(fname)
+    spec = json.loads(str(arrs["spec"]))
+    st = _traj_state(arrs, spec)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+    rp = st.row_ptr
+    regs = _regs_from_state(st)
+    cmf, admm, diag = dec.cmf_aoadmm(
+        [t(m) for m in split_rows(st.X, rp)], st.A.shape[1], init=(None, (t(st.A), [t(b) for b in split_rows(st.B, rp)], t(st.C))),
+        regs=regs, n_iter_max=spec["n_iter_max"], tol=None, absolute_tol=None, return_errors=True, return_admm_vars=True,
+        l2_penalty=list(st.l2), feasibility_penalty_scale=st.scale, constant_feasibility_penalty=bool(st.constant_A))
+    assert cmf[1][0].is_cuda and all(b.is_cuda for b in cmf[1][1])  # device in, device out
+    gaps = dec.compute_feasibility_gaps(cmf, regs, *admm.auxes)
+    ref = [arrs[f"gaps_m{m}"][-1] for m in range(3)]
+    e_self, e_ref = gap_error([gaps], [diag.feasibility_gaps[-1]]), gap_error([gaps], [ref])
+    print(fname, "public gaps:", [[f"{float(g):.3e}" for g in m] for m in gaps], f"vs diagnostics {e_self:.2f}, vs reference {e_ref:.2f} of the bar")
+    assert e_self <= 1.0
+    if fname != "traj_c5_full.npz":  # (the full stack's free-running trajectory is held step-wise, see above)
+        assert e_ref <= 1.0
 
 
 def _state_from_gpu(st, cmf, admm):
@@ -204,7 +264,14 @@ SCALE_CASES = {
     "c2_full": dict(I=256, J=256, K=128, r=8, regs=[[{"kind": "nn"}], [{"kind": "nn"}], [{"kind": "nn"}]]),
     "c3_quarter": dict(I=256, J=512, K=256, r=16,
                        regs=[[{"kind": "nn"}], [{"kind": "nn"}], [{"kind": "l1", "reg_strength": 0.1, "non_negativity": True}]]),
-    "c4_ragged": dict(I=48, J="ragged", K=256, r=16, regs=[[], [{"kind": "parafac2"}, {"kind": "l2ball", "norm_bound": 1.0}], []]),
+    # config 4 down-scaled (7 M elements): A and C carry no penalty and the A systems have condition up to 1.5e5 - since round 6
+    # the default call moves such a mid-size problem to the exact arithmetic by itself (mcl_condition_probe); the fast kernels
+    # forced onto it (what rounds 1-5 tested here: A at 4.0 / 6.6 / 9.4e-6 in three builds that differ in the association of
+    # fp64 sums) keep their own case with the bar that margin warrants
+    "c4_ragged": dict(I=48, J="ragged", K=256, r=16, regs=[[], [{"kind": "parafac2"}, {"kind": "l2ball", "norm_bound": 1.0}], []],
+                      tol=2e-6),
+    "c4_ragged_fast": dict(I=48, J="ragged", K=256, r=16, regs=[[], [{"kind": "parafac2"}, {"kind": "l2ball", "norm_bound": 1.0}], []],
+                           tol=3e-5, arithmetic="fast"),
     "c5_stack": dict(I=24, J=160, K=192, r=32,
                      regs=[[{"kind": "nn"}],
                            [{"kind": "parafac2"}, {"kind": "unimodal", "non_negativity": True},
@@ -255,8 +322,9 @@ def test_scale_parity_vs_oracle(name):
     st = orc.random_state_for(X, row_ptr, cfg["r"], cfg["regs"], seed=1)
     # flat bar, penalty-free modes included: their un-shifted normal equations are built and solved in fp64
     # ([G | R], the per-slab Grams and right-hand sides carry fp64 across tiles)
-    cmf, admm, diag, res = _run_both(st, 2 if name.endswith("_full") else 3)
-    errs = _compare(cmf, admm, diag, st, res, 1e-5, 1e-5)
+    kw = {"arithmetic": cfg["arithmetic"]} if "arithmetic" in cfg else {}
+    cmf, admm, diag, res = _run_both(st, 2 if name.endswith("_full") else 3, **kw)
+    errs = _compare(cmf, admm, diag, st, res, cfg.get("tol", 1e-5), min(1e-5, cfg.get("tol", 1e-5) * 5))
     print(name, {k: f"{v:.1e}" for k, v in errs.items()})
 
 

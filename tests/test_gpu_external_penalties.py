@@ -169,3 +169,105 @@ def test_custom_penalty_written_against_the_reference_docs():
             col = Z[:, c]
             p = int(np.argmax(col))
             assert np.all(np.diff(col[: p + 1]) >= -1e-6) and np.all(np.diff(col[p:]) <= 1e-6)
+
+
+# ---- the EXTERNAL path against the REFERENCE's own trajectories -------------------------------------------------
+def _user_classes():
+    """Penalties a user would write against the plugin classes (penalties.py:369-463 of the reference): none of them has a
+    native descriptor, so every proximal step below runs through these Python methods on device tensors."""
+    import torch
+    from matcouply_amd import penalties as pen
+
+    class UserNonNeg(pen.RowVectorPenalty):
+        def factor_matrix_row_update(self, row, feasibility_penalty, aux_row):
+            return torch.clamp(row, min=0)
+
+        def factor_matrix_update(self, factor_matrix, feasibility_penalty, aux):
+            return torch.clamp(factor_matrix, min=0)
+
+        def penalty(self, x):
+            return 0
+
+    class UserNonNegL1(pen.RowVectorPenalty):
+        def __init__(self, strength, **kw):
+            super().__init__(**kw)
+            self.strength = strength
+
+        def factor_matrix_row_update(self, row, feasibility_penalty, aux_row):
+            return torch.clamp(row - self.strength / feasibility_penalty, min=0)
+
+        def factor_matrix_update(self, factor_matrix, feasibility_penalty, aux):
+            return torch.clamp(factor_matrix - self.strength / feasibility_penalty, min=0)
+
+        def penalty(self, x):
+            xs = x if isinstance(x, list) else [x]
+            return self.strength * sum(float(xi.double().abs().sum()) for xi in xs)
+
+    class UserBall(pen.HardConstraintMixin, pen.MatrixPenalty):
+        def __init__(self, bound, **kw):
+            super().__init__(**kw)
+            self.bound = bound
+
+        def factor_matrix_update(self, factor_matrix, feasibility_penalty, aux):
+            norms = torch.linalg.norm(factor_matrix.double(), dim=0, keepdim=True)
+            return (factor_matrix.double() * (self.bound / torch.clamp(norms, min=self.bound))).to(factor_matrix.dtype)
+
+    class UserParafac2(pen.Parafac2):
+        """the class's own Python sweep (an override of the prox takes the penalty off the native kernel)"""
+
+        def factor_matrices_update(self, factor_matrices, feasibility_penalties, auxes):
+            return super().factor_matrices_update(factor_matrices, feasibility_penalties, auxes)
+
+    return dict(nn=UserNonNeg, l1=UserNonNegL1, l2ball=UserBall, parafac2=UserParafac2)
+
+
+@pytest.mark.parametrize("fname", ["traj_c3_nn_l1C.npz", "traj_c4_pf2_ball.npz"])
+def test_user_written_penalties_follow_the_reference_trajectory(fname):
+    """The reference's 20-iteration trajectories (tests/golden/traj_*.npz, generated from the imported reference) with EVERY
+    penalty replaced by a user-written class: factors, errors, losses and feasibility gaps at the bar of the native path."""
+    import json
+
+    from matcouply_amd import decomposition as dec
+    from matcouply_amd import penalties as pen
+    from tests.helpers import load_npz
+    from tests.test_gpu_end_to_end import gap_error
+
+    arrs = load_npz(fname)
+    spec = json.loads(str(arrs["spec"]))
+    c1 = load_npz("c1_data.npz")
+    X, rp = c1["X"], c1["row_ptr"]
+    user = _user_classes()
+    regs = [[], [], []]
+    for m in range(3):
+        for s, d in enumerate(spec["regs"][m]):
+            dual = split_rows(arrs[f"dual_in_m{m}_{s}"], rp) if m == 1 else arrs[f"dual_in_m{m}_{s}"].copy()
+            if d["kind"] == "parafac2":
+                reg = user["parafac2"](aux_init=(split_rows(arrs[f"aux_in_m{m}_{s}_P"], rp), arrs[f"aux_in_m{m}_{s}_Delta"].copy()),
+                                       dual_init=dual)
+            else:
+                aux = split_rows(arrs[f"aux_in_m{m}_{s}"], rp) if m == 1 else arrs[f"aux_in_m{m}_{s}"].copy()
+                if d["kind"] == "nn":
+                    reg = user["nn"](aux_init=aux, dual_init=dual)
+                elif d["kind"] == "l1":
+                    assert d.get("non_negativity", False)
+                    reg = user["l1"](d["reg_strength"], aux_init=aux, dual_init=dual)
+                elif d["kind"] == "l2ball":
+                    assert not d.get("non_negativity", False)
+                    reg = user["l2ball"](d["norm_bound"], aux_init=aux, dual_init=dual)
+                else:
+                    raise AssertionError(d)
+            assert pen.native_descriptor_of(reg) is None, reg  # host-evaluated: the engine only solves
+            regs[m].append(reg)
+    kw = spec["kwargs"]
+    cmf, admm, diag = dec.cmf_aoadmm(
+        split_rows(X, rp), arrs["A0"].shape[1], init=(None, (arrs["A0"].copy(), split_rows(arrs["B0"], rp), arrs["C0"].copy())),
+        regs=regs, n_iter_max=spec["n_iter_max"], tol=None, absolute_tol=None, return_errors=True, return_admm_vars=True,
+        l2_penalty=kw.get("l2_penalty", None), feasibility_penalty_scale=kw.get("feasibility_penalty_scale", 1),
+        constant_feasibility_penalty=kw.get("constant_feasibility_penalty", False))
+    e = {"A": rel_err(cmf[1][0], arrs["A"]), "B": rel_err(np.concatenate(cmf[1][1]), arrs["B"]), "C": rel_err(cmf[1][2], arrs["C"])}
+    ref_gaps = [[arrs[f"gaps_m{m}"][it] for m in range(3)] for it in range(len(arrs["rec_errors"]))]
+    e["gaps"] = gap_error(diag.feasibility_gaps, ref_gaps)
+    print(fname, "user-written penalties, 20 it vs reference:", {k: f"{v:.1e}" for k, v in e.items()})
+    np.testing.assert_allclose(diag.rec_errors, arrs["rec_errors"], rtol=1e-5)
+    np.testing.assert_allclose(diag.regularized_loss, arrs["regularized_loss"], rtol=1e-5)
+    assert max(e["A"], e["B"], e["C"]) < 1e-5 and e["gaps"] <= 1.0, e

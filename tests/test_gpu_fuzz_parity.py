@@ -77,6 +77,84 @@ def test_residue_of_the_extended_sweep(seed):
     test_random_configuration(seed)
 
 
+# Round 5's 6000-draw sweep left four draws outside the flat bar (1.2e-5 .. 7.2e-5): pinned here so that the
+# suite carries them - strict: the day one of them passes, the pin has to be turned into a plain test.
+OUTSIDE_SEEDS = [2191, 2970, 3930, 4742]
+
+
+@pytest.mark.parametrize("seed", OUTSIDE_SEEDS)
+@pytest.mark.xfail(strict=True, reason="known residue of the 6000-draw sweep: conditioning of the comparison at fp32 state storage")
+def test_known_outside_draws(seed):
+    test_random_configuration(seed)
+
+
+# ---- the MID-SIZE leg: 2^20 < elements of X <= 2^23 -------------------------------------------------------------------------
+# The draws above have at most 0.62 M elements: all of them run the exact-products / fp64 path of small problems.  Between 2^20
+# and 2^23 elements (BASELINE config 2 is exactly 2^23) the kernels of the BASELINE configurations are the DEFAULT - the MFMA
+# contractions, the one-pass sweep, the chained row passes - unless the condition trigger moves a problem with an
+# ill-conditioned penalty-free mode to the exact arithmetic (csrc/api.hip: mcl_auto_exact).  Nothing is forced here: no
+# `arithmetic=` keyword, no MCL_EXACT.
+def _draw_mid_case(rng):
+    r = int(rng.choice([2, 3, 4, 5, 8, 12, 16, 24, 32]))
+    K = int(rng.choice([64, 100, 128, 200, 256, 300, 512, 1024]))
+    total = min(2.0 ** rng.uniform(20.05, 23.0), 64 * 800 * K)  # elements of X (at most 64 matrices of at most 1024 rows)
+    n_rows = total / K
+    I = int(rng.randint(max(4, int(np.ceil(n_rows / 800))), 65))
+    J = rng.randint(max(r, 8), 1025, size=I).astype(np.float64)
+    J = np.clip(np.round(J * n_rows / J.sum()), max(r, 2), 1024).astype(np.int64)
+    for _ in range(4 * I):  # the clips can leave a draw just outside the range: nudge single matrices
+        if J.sum() * K <= (1 << 20):
+            J[np.argmin(J)] = 1024
+        elif J.sum() * K > (1 << 23):
+            J[np.argmax(J)] = max(r, 2, J.max() // 2)
+        else:
+            break
+    const = bool(rng.rand() < 0.3)
+    regs = [[], [], []]
+    regs[0] = [dict(ROWSEP[rng.randint(len(ROWSEP))])] if rng.rand() < 0.7 else []
+    if const and rng.rand() < 0.5:
+        regs[0].append(dict(MATRIX[rng.randint(2)]))
+    if rng.rand() < 0.4:
+        regs[1].append({"kind": "parafac2"})
+    pool = ROWSEP + MATRIX
+    for _ in range(rng.randint(0, 3)):
+        regs[1].append(dict(pool[rng.randint(len(pool))]))
+    regs[1] = regs[1][:3]
+    for _ in range(rng.randint(0, 3)):
+        regs[2].append(dict(pool[rng.randint(len(pool))]))
+    l2 = [0.0 if regs[m] else float(rng.uniform(0.05, 0.5)) for m in range(3)]
+    if rng.rand() < 0.3:
+        l2 = [v + float(rng.uniform(0, 0.3)) for v in l2]
+    return dict(I=I, J=J, K=K, r=r, regs=regs, l2=l2, const=const, scale=float(rng.choice([0.5, 1.0, 2.0])),
+                inner=int(rng.choice([1, 3, 5])))
+
+
+def _mid_state(seed):
+    from oracle import aoadmm_oracle as orc
+
+    case = _draw_mid_case(np.random.RandomState(50000 + seed))
+    X, row_ptr = orc.synthetic_problem(case["I"], case["J"], case["K"], case["r"], seed=seed, dtype=np.float64)
+    X = X.astype(np.float32).astype(np.float64)
+    assert (1 << 20) < X.size <= (1 << 23), X.size
+    st = orc.random_state_for(X, row_ptr, case["r"], case["regs"], seed=seed + 1, l2=case["l2"],
+                              inner_n_iter_max=case["inner"], feasibility_penalty_scale=case["scale"],
+                              constant_A=case["const"], constant_B=case["const"])
+    return case, st
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MCL_FUZZ_MID_SEEDS", 48))))  # MCL_FUZZ_MID_SEEDS=400: extended sweep
+def test_random_mid_size_configuration(seed):
+    """Flat 1e-5 after two outer iterations, default arithmetic, on problems of the size range where the fast kernels are
+    the default (reference: decomposition.py:945-1053 through the oracle)."""
+    case, st = _mid_state(seed)
+    cmf, admm, diag, res = _run_both(st, 2)
+    strict = os.environ.get("MCL_FUZZ_REPORT_ONLY") is None
+    errs = _compare(cmf, admm, diag, st, res, 1e-5 if strict else 1.0, 1e-5 if strict else 1.0)
+    print("mid", seed, {k: case[k] for k in ("I", "K", "r", "const", "inner")}, f"rows {int(case['J'].sum())}",
+          [[d["kind"] for d in m] for m in case["regs"]],
+          f"worst {max(v for k, v in errs.items() if k != 'gaps'):.1e} gaps {errs['gaps']:.2f} polar cond {res['polar_cond']:.0e}")
+
+
 @pytest.mark.parametrize("seed", [45, 135, 142, 237])
 def test_ill_conditioned_penalty_free_modes(seed):
     """Draws whose penalty-free modes have normal equations of condition 2e3 .. 5e5 (tools/parity_probe.py fuzz:<seed>): the
@@ -213,10 +291,12 @@ def test_exact_arithmetic_can_be_forced_on_a_larger_problem():
     assert X.size > (1 << 20)
     regs = [[], [{"kind": "l2ball", "norm_bound": 0.7}], []]
     worst = {}
-    for arithmetic in ("exact", "fast"):
+    for arithmetic in ("exact", "fast", "auto"):
         st = orc.random_state_for(X, row_ptr, r, regs, seed=13, l2=[0.05, 0.0, 0.05])
         cmf, admm, diag, res = _run_both(st, 3, arithmetic=arithmetic)
         errs = _compare(cmf, admm, diag, st, res, 1.0, 1.0)
-        worst[arithmetic] = max(errs.values())
-    print(f"exact {worst['exact']:.1e}   fast {worst['fast']:.1e}")
+        worst[arithmetic] = max(v for k, v in errs.items() if k != "gaps")
+    print(f"exact {worst['exact']:.1e}   fast {worst['fast']:.1e}   auto (the default) {worst['auto']:.1e}")
     assert worst["exact"] < 1e-5 and worst["exact"] < worst["fast"], worst
+    # round 6: the DEFAULT call finds the ill-conditioned penalty-free modes itself (mcl_condition_probe) and is inside the bar
+    assert worst["auto"] < 1e-5, worst

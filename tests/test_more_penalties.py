@@ -360,7 +360,7 @@ def test_solver_inner_tol_matches_reference(kernel_paths, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("stack", ["pf2_ball", "uni_tv_constant", "rowsep"])
+@pytest.mark.parametrize("stack", ["pf2_ball", "uni_tv_constant", "rowsep", "stale_partials"])
 def test_device_inner_tol_on_generic_stacks(stack, kernel_paths):
     """the device-side inner stopping test with slab-wise penalties in the loop (PARAFAC2 + L2 ball; unimodality + total
     variation with matrix penalties on A under a constant feasibility penalty; row-separable stacks with per-row rho on A):
@@ -375,12 +375,24 @@ def test_device_inner_tol_on_generic_stacks(stack, kernel_paths):
         I, J, K, r, kw = 8, rng.randint(30, 80, 8), 40, 3, dict(constant_A=True, constant_B=True)
         regs = [[{"kind": "l2ball", "norm_bound": 2.0, "non_negativity": True}], [{"kind": "unimodal", "non_negativity": True}],
                 [{"kind": "tv", "reg_strength": 0.01, "l1_strength": 0.0}]]
+    elif stack == "stale_partials":
+        # tiles of fewer than 64 rows leave row-less workgroups in the fp64 solve pass, whose entries of the shared
+        # table of ||x - x_old||^2 partials used to keep another phase's values.  K = 37 and J_i <= 60 (no multiple of 64),
+        # rank 4 (16 rows per workgroup) and B on 1e3 times the scale of C: a stale B-phase partial in the C-phase's sum would
+        # keep the C loop running where the reference (decomposition.py:100-107) stops.
+        I, J, K, r, kw = 5, np.array([60, 23, 37, 5, 49]), 37, 4, {}
+        regs = [[{"kind": "nn"}], [{"kind": "l2ball", "norm_bound": 40.0}], [{"kind": "l2ball", "norm_bound": 0.5}]]
     else:
         I, J, K, r, kw = 7, rng.randint(30, 80, 7), 64, 5, {}
         regs = [[{"kind": "l1", "reg_strength": 0.05}, {"kind": "nn"}], [{"kind": "nn"}], [{"kind": "box", "min_val": 0.0, "max_val": 0.9}]]
     X, row_ptr = orc.synthetic_problem(I, J, K, r, seed=4, dtype=np.float64)
     X = X.astype(np.float32).astype(np.float64)
     st = orc.random_state_for(X, row_ptr, r, regs, seed=8, inner_n_iter_max=15, **kw)
+    if stack == "stale_partials":
+        st.B *= 30.0
+        st.aux[1][0] *= 30.0
+        st.C *= 0.03
+        st.aux[2][0] *= 0.03
     st.inner_tol = 5e-2
     cmf, admm, diag, res = _run_both(st, 3, inner_tol=5e-2)
     assert min(st.inner_iters) < 15, st.inner_iters  # an early exit is actually taken somewhere
