@@ -586,6 +586,22 @@ def main():
 
     pmc_kernels, pmc_source = pmc_table()
 
+    def achievable_gbps():
+        """the read bandwidth THIS box delivers to a pure streaming kernel (mcl_read_bandwidth), measured in this process after
+        the timed regions: over up to 2 GiB of X when X exceeds the 256 MB last-level cache, else over a 1 GiB scratch buffer"""
+        try:
+            n_bytes = X.numel() * 4
+            if n_bytes >= (600 << 20):
+                buf = X.view(-1)[: min(X.numel(), (2 << 30) // 4)]
+            else:
+                buf = torch.empty((1 << 30) // 4, dtype=torch.float32, device=device).zero_()
+            return E.read_bandwidth(buf, repeats=10)
+        except Exception as exc:  # a measurement aid: its failure must not cost the line
+            print(f"[bench] read-bandwidth probe failed: {exc}", file=sys.stderr)
+            return None
+
+    hbm_achievable = achievable_gbps() if rank == 0 else None
+
     def pmc_traffic(kernel_variant):
         if not pmc_kernels:
             return None
@@ -615,6 +631,7 @@ def main():
                  algorithmic_bytes=int(ab) if ab else None,
                  achieved_gbps=round(ab / (net_us * 1e-6) / 1e9, 1) if ab and net_us > 0 else None,
                  frac=round(ab / (net_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if ab and net_us > 0 else None,
+                 frac_achievable=(round(ab / (net_us * 1e-6) / 1e9 / hbm_achievable, 4) if ab and net_us > 0 and hbm_achievable else None),
                  traffic=pmc_traffic(eng.kernel_variant(slot)), bound=bound_of.get(slot, "hbm"), slot=slot)
         per_kernel.append(e)
     per_kernel.sort(key=lambda e: -e["us_per_step"])
@@ -643,6 +660,10 @@ def main():
         dom = timed_sites[0]  # the largest share of the step among the sites with an algorithmic byte count
         slot = dom["slot"]
         roofline = dict(bound="hbm", achieved=dom["achieved_gbps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=dom["frac"],
+                        peak_achievable=round(hbm_achievable, 1) if hbm_achievable else None,
+                        frac_achievable=dom["frac_achievable"],
+                        peak_achievable_is=("streaming-read GB/s measured in this process by mcl_read_bandwidth (the data-sheet "
+                                            "8 TB/s is `peak`)"),
                         traffic=dom["traffic"],
                         traffic_source=("static: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in separate "
                                         "passes, not measured in this run)" % pmc_source) if dom["traffic"] is not None else None,

@@ -33,7 +33,7 @@ typedef struct mcl_context mcl_context;
  *     moved from index 4 to 100), twelve profile slots, mcl_profile_launches, a failed state after mcl_run's watchdog,
  *     mcl_options.inner_tol / exact_products, native GeneralizedL2 / UnitSimplex kinds (mcl_penalty_desc grew two fields),
  *     mcl_penalty_value, mcl_svd_init;
- * 410 mcl_condition_probe (nothing else changed).
+ * 410 mcl_condition_probe, mcl_condition_monitor, mcl_read_bandwidth (nothing else changed).
  * A host MUST compare mcl_version() with the MCL_ABI_VERSION it was built against before any other call. */
 #define MCL_ABI_VERSION 410
 
@@ -147,6 +147,15 @@ int mcl_penalty_value(mcl_context *ctx, int32_t mode, int32_t k, double *out);
  * wants the reference's results on an ill-conditioned penalty-free mode switches to mcl_options.exact_products = 1 when the
  * estimate is large (matcouply_amd does so between 2^20 and 2^24 elements of X above 1e3, and warns beyond). */
 int mcl_condition_probe(mcl_context *ctx, int32_t mode_mask, double *out);
+/* The same estimate taken WHERE IT MATTERS: the phases are Gauss-Seidel - the A-phase of an iteration solves systems built
+ * from the B_i and C of the same iteration - so the numbers that count are those at the start of each phase.  While a monitor is
+ * installed (out != NULL: device fp64[4], zeroed by the caller), every phase of a penalty-free mode in `mode_mask` (mcl_update_B,
+ * mcl_update_C_local, mcl_update_A / mcl_A_begin) first launches the probe for ITS system and keeps the running maximum in
+ * out[mode]; out[3] collects the worst conditioning of the PARAFAC2 polar factors (~ ||sigma|| / sigma_min of Y_i Delta^T,
+ * penalties.py:1233-1235; 1e8 for a matrix the Newton-Schulz route had to hand on) of every inner iteration, for ranks <= 32;
+ * out = NULL removes it.  Two small launches per monitored phase: meant for a short trial (matcouply_amd runs two
+ * iterations under the monitor, restores the initial state and then chooses the arithmetic) and for an occasional check. */
+int mcl_condition_monitor(mcl_context *ctx, double *out, int32_t mode_mask);
 /* n outer iterations B -> C -> A on ONE device (decomposition.py:945-988); if diag_ring != NULL,
  * MCL_DIAG_LEN doubles are appended per iteration (device memory, n * MCL_DIAG_LEN doubles). */
 int mcl_iterate(mcl_context *ctx, int32_t n_iter, int32_t update_A, int32_t update_B, int32_t update_C,
@@ -332,6 +341,10 @@ double mcl_profile_overhead_us(mcl_context *ctx);
  * (matcouply_amd.cmf_aoadmm issues a RuntimeWarning).  A library built with -DMCL_NO_ENV_SWITCHES
  * (MCL_BUILD_DEFS=-DMCL_NO_ENV_SWITCHES python -c "import __graft_entry__ as g; g.build()") never consults the
  * environment: every switch keeps its default and mcl_active_switches() is always "". */
+/* What the box's memory system delivers to a pure streaming READ of `bytes` of device memory at `buf` (>= 1 MiB; take more than
+ * the 256 MB last-level cache for an HBM figure): the better of two access geometries, `repeats` timed launches each, GB/s to
+ * HOST `gbps`.  Stateless measurement helper (bench.py: roofline.frac_achievable); `scratch`: one device float; synchronises. */
+int mcl_read_bandwidth(const void *buf, int64_t bytes, int32_t repeats, float *scratch, void *hip_stream, double *gbps);
 int mcl_reload_switches(mcl_context *ctx);
 const char *mcl_active_switches(const mcl_context *ctx);
 

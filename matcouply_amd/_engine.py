@@ -39,13 +39,13 @@ EXPORTED_SYMBOLS = [
     "mcl_create", "mcl_destroy", "mcl_last_error", "mcl_version", "mcl_set_problem", "mcl_set_options",
     "mcl_set_factors", "mcl_set_penalties", "mcl_workspace_bytes", "mcl_set_workspace", "mcl_update_B",
     "mcl_update_C_local", "mcl_c_normal_equations", "mcl_update_C_finish", "mcl_update_A", "mcl_diagnostics",
-    "mcl_diagnostics_deferred", "mcl_flush_diagnostics", "mcl_penalty_value", "mcl_condition_probe",
+    "mcl_diagnostics_deferred", "mcl_flush_diagnostics", "mcl_penalty_value", "mcl_condition_probe", "mcl_condition_monitor",
     "mcl_iterate", "mcl_run", "mcl_gate_begin", "mcl_verdict", "mcl_gate_end", "mcl_B_begin", "mcl_B_rho_max", "mcl_B_factor", "mcl_B_solve", "mcl_B_prox_local",
     "mcl_B_prox_reduce_buffer", "mcl_B_prox_finish", "mcl_B_end", "mcl_A_begin", "mcl_A_rho_max", "mcl_A_finish",
     "mcl_A_factor", "mcl_A_solve", "mcl_A_end", "mcl_C_begin", "mcl_C_solve", "mcl_C_end",
     "mcl_internal_buffer", "mcl_kernel_variant", "mcl_profile_enable", "mcl_profile_set_stride", "mcl_profile_read", "mcl_profile_launches", "mcl_profile_overhead_us",
     "mcl_reload_switches", "mcl_active_switches", "mcl_record_event", "mcl_wait_event", "mcl_cmf_to_packed",
-    "mcl_svd_init_workspace_bytes", "mcl_svd_init", "mcl_svd_init_last_error",
+    "mcl_svd_init_workspace_bytes", "mcl_svd_init", "mcl_svd_init_last_error", "mcl_read_bandwidth",
 ]
 
 
@@ -106,6 +106,7 @@ def load_library():
         "mcl_flush_diagnostics": (ctypes.c_int, [P]),
         "mcl_penalty_value": (ctypes.c_int, [P, I32, I32, P]),
         "mcl_condition_probe": (ctypes.c_int, [P, I32, P]),
+        "mcl_condition_monitor": (ctypes.c_int, [P, P, I32]),
         "mcl_iterate": (ctypes.c_int, [P, I32, I32, I32, I32, P]),
         "mcl_run": (ctypes.c_int, [P, I32, I32, I32, I32, ctypes.POINTER(StopRule), P, P, P]),
         "mcl_gate_begin": (ctypes.c_int, [P, ctypes.POINTER(StopRule), P]),
@@ -143,6 +144,7 @@ def load_library():
         "mcl_svd_init_workspace_bytes": (I64, [ctypes.POINTER(I64), I64, I64, I32]),
         "mcl_svd_init": (ctypes.c_int, [P, ctypes.POINTER(I64), I64, I64, I32, I32, P, P, P, I64, P, P]),
         "mcl_svd_init_last_error": (ctypes.c_char_p, []),
+        "mcl_read_bandwidth": (ctypes.c_int, [P, I64, I32, P, P, ctypes.POINTER(ctypes.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -182,6 +184,22 @@ def cmf_to_packed(A, B, C, row_ptr, weights=None):
     if rc != 0:
         raise EngineError("mcl_cmf_to_packed failed")
     return out
+
+
+def read_bandwidth(buf, repeats=10):
+    """GB/s a pure streaming read of the CUDA tensor `buf` reaches on this box (mcl_read_bandwidth; synchronises)"""
+    import torch
+
+    lib = load_library()
+    scratch = torch.zeros(1, dtype=torch.float32, device=buf.device)
+    out = ctypes.c_double()
+    with torch.cuda.device(buf.device):
+        stream = torch.cuda.current_stream(buf.device).cuda_stream
+        rc = lib.mcl_read_bandwidth(buf.data_ptr(), buf.numel() * buf.element_size(), int(repeats), scratch.data_ptr(),
+                                    ctypes.c_void_p(stream), ctypes.byref(out))
+    if rc != 0:
+        raise EngineError("mcl_read_bandwidth failed")
+    return out.value
 
 
 def svd_init(X, row_ptr, rank, threshold=False):
@@ -378,6 +396,24 @@ class HipEngine:
         mask = int(bool(update_A)) | int(bool(update_B)) << 1 | int(bool(update_C)) << 2
         self._check(self.lib.mcl_condition_probe(self._h, mask, out.data_ptr()))
         return out
+
+    def condition_monitor(self, on, update_A=True, update_B=True, update_C=True):
+        """mcl_condition_monitor: while on, every phase of a penalty-free mode among the updated ones first measures the kappa of
+        the system it is about to solve, and every PARAFAC2 inner iteration the conditioning of its polar factors; returns the
+        float64 device tensor of 4 that collects the running maxima (modes 0, 1, 2, polar factors) (on) / None"""
+        if not on:
+            self._check(self.lib.mcl_condition_monitor(self._h, None, 0))
+            self._monitor = None
+            return None
+        self._monitor = self._torch.zeros(4, dtype=self._torch.float64, device=self.device)
+        mask = int(bool(update_A)) | int(bool(update_B)) << 1 | int(bool(update_C)) << 2
+        self._check(self.lib.mcl_condition_monitor(self._h, self._monitor.data_ptr(), mask))
+        return self._monitor
+
+    def invalidate(self):
+        """the caller has written the factor / ADMM tensors behind the engine's back: every cached by-product is forgotten
+        (mcl_set_factors with the same pointers)"""
+        self._check(self.lib.mcl_set_factors(self._h, self.A.data_ptr(), self.B.data_ptr(), self.C.data_ptr()))
 
     def set_exact(self, exact=True):
         """Switch the context's arithmetic (mcl_options.exact_products = 1 / 2) between two outer iterations: the workspace is

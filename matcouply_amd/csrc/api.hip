@@ -311,6 +311,14 @@ int ensure_ctc(mcl_context *c) {
     return 0;
 }
 
+// mcl_condition_monitor: before a penalty-free mode's phase, the condition estimate of the system it is about to solve (from the
+// factors as they are NOW: the phases are Gauss-Seidel, the A-phase of an iteration sees the B and C of the same iteration)
+int monitor_condition(mcl_context *c, int mode) {
+    if (!c->cond_monitor || !(c->cond_monitor_mask >> mode & 1) || c->regs[mode].n != 0) return 0;
+    if (int rc = ensure_ctc(c)) return rc;
+    return mcl_launch_cond_probe(c, 1 << mode, c->cond_monitor, true);
+}
+
 int ensure_xc(mcl_context *c) {
     if (!c->xc_valid && c->exact) {  // exact-products mode: fp64 sums of exact products, rounded once for the fp32 image
         if (int rc = mcl_launch_exact_xc(c)) return rc;
@@ -477,6 +485,8 @@ int mcl_set_problem(mcl_context *c, const float *X, const int64_t *row_ptr, int6
     c->X = X;
     c->row_ptr.assign(row_ptr, row_ptr + I + 1);
     c->I = I, c->K = K, c->N = N, c->r = rank;
+    c->max_slab_rows = 0;
+    for (int64_t i = 0; i < I; ++i) c->max_slab_rows = std::max<int64_t>(c->max_slab_rows, row_ptr[i + 1] - row_ptr[i]);
     c->RP = mcl_pad_rank(rank);
     c->NB = (rank + 15) / 16;
     if (c->NB == 3) c->NB = 4;
@@ -772,6 +782,8 @@ int mcl_set_workspace(mcl_context *c, void *workspace, int64_t bytes) {
 int mcl_B_begin(mcl_context *c) {
     if (int rc = ready(c)) return rc;
     if (int rc = round_complete(c, "mcl_B_begin")) return rc;
+    if (c->cond_monitor && c->regs[1].n == 0)  // (a stack WITH penalties comes here from mcl_update_B, which has looked already)
+        if (int rc = monitor_condition(c, 1)) return rc;
     if (int rc = ensure_ctc(c)) return rc;
     if (int rc = ensure_xc(c)) return rc;
     if (c->opt.constant_B)
@@ -873,6 +885,8 @@ int mcl_update_B(mcl_context *c) {
     } else if (int rc = ready(c)) {
         return rc;
     }
+    if (c->cond_monitor)
+        if (int rc = monitor_condition(c, 1)) return rc;
     if (mcl_sweep_eligible(c)) {
         // one pass over X: B-phase fused with the per-bseg X^T B / B^T B that the C- and A-phases need (sweep.hip)
         if (int rc = ensure_ctc(c)) return rc;
@@ -926,6 +940,8 @@ int mcl_update_B(mcl_context *c) {
 
 // ---- C-phase -------------------------------------------------------------------------------------------
 int mcl_update_C_local(mcl_context *c) {
+    if (c && c->cond_monitor && ready_noflush(c) == 0 && !c->b_finish_pending)
+        if (int rc = monitor_condition(c, 2)) return rc;
     if (c && c->diag_pending && ready_noflush(c) == 0 && !c->b_finish_pending && c->mseg_valid && c->grpart_valid)
         return mcl_launch_reduce_weighted(c);  // ... with the deferred diagnostics reduction on its spare workgroup
     if (int rc = ready(c)) return rc;
@@ -994,6 +1010,8 @@ int mcl_update_C_finish(mcl_context *c) {
 // ---- A-phase -------------------------------------------------------------------------------------------
 int mcl_A_begin(mcl_context *c) {
     if (int rc = ready(c)) return rc;
+    if (c->cond_monitor)
+        if (int rc = monitor_condition(c, 0)) return rc;
     // C^T C still in the partial blocks of k_C_finish_multi: the rows kernels of the A-phase finish sum them themselves (and
     // write the totals); anything else - the constant-rho pre-pass, the column-layout finish - gets them folded first
     const bool rows_finish = !(c->RP == 64 || c->RP == 4 || c->sw.a_finish_cols) && !c->opt.constant_A;
@@ -1205,6 +1223,13 @@ int mcl_condition_probe(mcl_context *c, int32_t mode_mask, double *out) {
     return mcl_launch_cond_probe(c, want, out);
 }
 
+int mcl_condition_monitor(mcl_context *c, double *out, int32_t mode_mask) {
+    if (!c) return 1;
+    c->cond_monitor = out;
+    c->cond_monitor_mask = out ? mode_mask : 0;
+    return 0;
+}
+
 int mcl_iterate(mcl_context *c, int32_t n_iter, int32_t update_A, int32_t update_B, int32_t update_C,
                 double *diag_ring) {
     if (int rc = ready(c)) return rc;
@@ -1250,6 +1275,10 @@ int mcl_run(mcl_context *c, int32_t n_iter_max, int32_t update_A, int32_t update
     if (!rule || !status) return fail(c, "mcl_run: rule and status must not be NULL (fixed iteration counts: mcl_iterate)");
     if (n_iter_max > 0 && (!diag_ring || !verdict_ring)) return fail(c, "mcl_run: diag_ring / verdict_ring is NULL");
     if (int rc = ready(c)) return rc;
+    if (has_kind(c, MCL_PEN_GL2))  //  its value trace(F^T M F) is no column of the diagnostics vector
+        return fail(c, "mcl_run: a GeneralizedL2 penalty's value is not part of the diagnostics vector, so the device-side stopping "
+                       "rule would evaluate the loss without it (decomposition.py:1016-1023): drive the iterations with mcl_iterate / "
+                       "the phase calls and add mcl_penalty_value to the loss on the host");
     int *status_dev = nullptr;
     if (hipHostGetDevicePointer(reinterpret_cast<void **>(&status_dev), (void *)status, 0) != hipSuccess || !status_dev) {
         (void)hipGetLastError();
@@ -1357,6 +1386,10 @@ int mcl_gate_begin(mcl_context *c, const mcl_stop_rule *rule, mcl_run_status *st
     if (!c) return 1;
     if (!rule || !status) return fail(c, "mcl_gate_begin: rule and status must not be NULL");
     if (int rc = ready(c)) return rc;
+    if (has_kind(c, MCL_PEN_GL2))
+        return fail(c, "mcl_gate_begin: a GeneralizedL2 penalty's value is not part of the diagnostics vector (see mcl_run): write it "
+                       "into the penalty-value slot of the vector on the host before mcl_verdict is NOT supported either - evaluate "
+                       "the rule on the host");
     int *status_dev = nullptr;
     if (hipHostGetDevicePointer(reinterpret_cast<void **>(&status_dev), (void *)status, 0) != hipSuccess || !status_dev) {
         (void)hipGetLastError();

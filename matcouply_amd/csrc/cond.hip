@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_cond_slabs(const float *__restrict__ A,
 }
 
 __global__ __launch_bounds__(256) void k_cond_final(const double *__restrict__ part, int n_g, int r, double l2C, int want,
-                                                    double *__restrict__ out) {
+                                                    int accumulate, double *__restrict__ out) {
     extern __shared__ double csm[];
     double *W = csm, *red = csm + r * r;
     const int t = threadIdx.x, r2 = r * r;
@@ -156,24 +156,124 @@ __global__ __launch_bounds__(256) void k_cond_final(const double *__restrict__ p
     if (t == 0) {
         double kA = 0.0, kB = 0.0;
         for (int g = 0; g < n_g; ++g) kA = fmax(kA, part[(long)g * (r2 + 2) + r2]), kB = fmax(kB, part[(long)g * (r2 + 2) + r2 + 1]);
-        out[0] = (want & 1) ? kA : 0.0;
-        out[1] = (want & 2) ? kB : 0.0;
-        out[2] = kC;
+        if (accumulate) {  // monitoring (mcl_condition_monitor): the running maximum of the modes asked for, the others untouched
+            if (want & 1) out[0] = fmax(out[0], kA);
+            if (want & 2) out[1] = fmax(out[1], kB);
+            if (want & 4) out[2] = fmax(out[2], kC);
+        } else {
+            out[0] = (want & 1) ? kA : 0.0;
+            out[1] = (want & 2) ? kB : 0.0;
+            out[2] = kC;
+        }
     }
 }
 
 }  // namespace
 
+// While a monitor is installed: the worst conditioning the PARAFAC2 polar factors of the inner iteration just enqueued have met.
+// The Newton-Schulz kernel leaves x_i = 1 / ||(G_i / tr G_i)^-1/2||_F per matrix (G_i = (Y_i Delta^T)^T (Y_i Delta^T)), i.e.
+// 1 / x_i ~ ||sigma|| / sigma_min of Y_i Delta^T, and flags the matrices it had to hand to the Jacobi / QR routes (status > 0:
+// no convergence, rank-deficient, lambda_min <= 1e-10 lambda_max) - those count as 1e8.  out[3] keeps the running maximum.
+namespace {
+__global__ __launch_bounds__(256) void k_pf2_cond_track(const float *__restrict__ xmin, const int *__restrict__ status, int I,
+                                                        double *__restrict__ out) {
+    __shared__ double red[4];
+    double worst = 0.0;
+    for (int i = threadIdx.x; i < I; i += 256) {
+        const float x = xmin[i];
+        const double k = status[i] > 0 ? 1e8 : (x > 0.f ? 1.0 / (double)x : 0.0);
+        worst = fmax(worst, k);
+    }
+    for (int off = 32; off > 0; off >>= 1) worst = fmax(worst, __shfl_xor(worst, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = worst;
+    __syncthreads();
+    if (threadIdx.x == 0) out[3] = fmax(out[3], fmax(fmax(red[0], red[1]), fmax(red[2], red[3])));
+}
+}  // namespace
+
+int mcl_launch_pf2_cond_track(mcl_context *c) {
+    if (!c->cond_monitor || !c->pf2_xmin || !c->pf2_status || c->I == 0) return 0;
+    hipLaunchKernelGGL(k_pf2_cond_track, dim3(1), dim3(256), 0, c->stream, c->pf2_xmin, c->pf2_status, (int)c->I, c->cond_monitor);
+    MCL_CHECK_HIP(c, hipGetLastError());
+    return 0;
+}
+
 int64_t mcl_cond_part_doubles(const mcl_context *c) { return (int64_t)COND_GROUPS * ((int64_t)c->r * c->r + 2); }
 
 // CtC64 must be current (api.hip: ensure_ctc).  `want`: bit m set = report mode m.
-int mcl_launch_cond_probe(mcl_context *c, int want, double *out) {
+int mcl_launch_cond_probe(mcl_context *c, int want, double *out, bool accumulate) {
     const int r = c->r;
     const int n_g = (int)std::max<int64_t>(1, std::min<int64_t>(COND_GROUPS, c->I));
     const size_t lds = ((size_t)r * r + 8) * sizeof(double);
     hipLaunchKernelGGL(k_cond_slabs, dim3(n_g), dim3(256), lds, c->stream, c->A, c->B, c->row_ptr_dev, c->CtC64, (int)c->I, r,
                        c->opt.l2_penalty[0], c->opt.l2_penalty[1], want, c->cond_part);
-    hipLaunchKernelGGL(k_cond_final, dim3(1), dim3(256), lds, c->stream, c->cond_part, n_g, r, c->opt.l2_penalty[2], want, out);
+    hipLaunchKernelGGL(k_cond_final, dim3(1), dim3(256), lds, c->stream, c->cond_part, n_g, r, c->opt.l2_penalty[2], want, accumulate ? 1 : 0, out);
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// mcl_read_bandwidth: what this box's memory system delivers to a pure streaming read (bench.py prices its kernels against
+// the 8 TB/s data-sheet peak AND against this: roofline.frac_achievable).  Two access geometries, the better one counts:
+// grid-stride 16-byte reads (consecutive lanes / waves / workgroups read consecutive memory) and one contiguous chunk per
+// wave, 16 KB in flight per wave in both.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+typedef float bw_f4 __attribute__((ext_vector_type(4)));
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_read_bw(const bw_f4 *__restrict__ p, long n_f4, long chunk_f4, float *__restrict__ out) {
+    constexpr int U = 16;
+    bw_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0) {
+        const long stride = (long)gridDim.x * 256;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i + (U - 1) * stride < n_f4; i += U * stride) {
+            bw_f4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + i + u * stride);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += v[u];
+        }
+    } else {
+        const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6), base = w * chunk_f4;
+        const int lane = threadIdx.x & 63;
+        for (long s = 0; s + U <= chunk_f4 / 64; s += U) {
+            bw_f4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + base + (s + u) * 64 + lane);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += v[u];
+        }
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = acc[0];  // (keeps the loads)
+}
+}  // namespace
+
+extern "C" int mcl_read_bandwidth(const void *buf, int64_t bytes, int32_t repeats, float *scratch, void *hip_stream, double *gbps) {
+    if (!buf || !scratch || !gbps || bytes < (int64_t(1) << 20) || repeats < 1) return 1;
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    const long n_f4 = bytes / 16;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
+    double best = 0.0;
+    for (int mode = 0; mode < 2; ++mode) {
+        const int blocks = 2048;
+        const long chunk_f4 = (n_f4 / ((long)blocks * 4)) / (64 * 16) * (64 * 16);
+        const double moved = mode == 0 ? 16.0 * ((n_f4 / ((long)blocks * 256 * 16)) * ((long)blocks * 256 * 16)) : 16.0 * chunk_f4 * blocks * 4;
+        if (moved <= 0) continue;
+        for (int rep = 0; rep < repeats + 2; ++rep) {
+            if (rep == 2) (void)hipEventRecord(e0, s);
+            if (mode == 0) hipLaunchKernelGGL(k_read_bw<0>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const bw_f4 *>(buf), n_f4, chunk_f4, scratch);
+            else hipLaunchKernelGGL(k_read_bw<1>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const bw_f4 *>(buf), n_f4, chunk_f4, scratch);
+        }
+        (void)hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess) return 1;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms > 0.f) best = std::max(best, moved * repeats / (ms * 1e-3) / 1e9);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *gbps = best;
+    return hipGetLastError() == hipSuccess && best > 0.0 ? 0 : 1;
 }

@@ -615,10 +615,12 @@ __global__ __launch_bounds__(256) void k_gl2_pass(const int *__restrict__ ext, c
     //  BACK: Z[j][c] = sum_e U^T[e][j] T[e][c] / (s_e + rho / 2), then the dual step D = F - (Z - D)
     MCL_GATE(gate);
     __shared__ double ins[16][64];
-    const int slab = blockIdx.y;
+    // (the slab index is folded into blockIdx.x: gridDim.y stops at 65535, a GeneralizedL2 penalty on the B_i may see more matrices)
+    const int tps = (n + 63) >> 6;
+    const int slab = (int)(blockIdx.x / (unsigned)tps);
     const long s0 = ext[slab];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int a = blockIdx.x * 64 + tx;
+    const int a = (int)(blockIdx.x - (unsigned)slab * (unsigned)tps) * 64 + tx;
     const double half_rho = 0.5 * (double)rho_arr[slab];
     double acc[16];
 #pragma unroll
@@ -2080,6 +2082,8 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                     else MCL_NS(2, false);
                 }
 #undef MCL_NS
+                if (c->cond_monitor)  // (mcl_condition_monitor: a trial / an occasional monitored iteration only)
+                    if (int rc = mcl_launch_pf2_cond_track(c)) return rc;
             }
             if (status == nullptr) c->variant[MCL_PROF_PF2] = "k_pf2_algebra (Jacobi) + k_pf2_polar_qr";
             // rank <= 16: the Newton-Schulz kernel runs the Jacobi route itself and flags the slabs whose Gram matrix is too
@@ -2114,7 +2118,7 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
         case MCL_PEN_GL2: {
             const int n = rs.mat_rows[k];
             const double *U = rs.mat[k], *eig = U + (long)n * n, *UT = eig + n;
-            const dim3 g((unsigned)((n + 63) / 64), (unsigned)mv.n_slabs);
+            const dim3 g((unsigned)((n + 63) / 64) * (unsigned)mv.n_slabs);
             hipLaunchKernelGGL((k_gl2_pass<float, false>), g, dim3(256), 0, c->stream, mv.ext, U, eig, n, c->r, mv.rho, (const float *)mv.F,
                                (const float *)rs.dual[k], c->gl2_T, (float *)nullptr, (float *)nullptr, (double *)nullptr, (double *)nullptr,
                                mv.gate);
@@ -2149,7 +2153,7 @@ int mcl_launch_gl2_value(mcl_context *c, int mode, int k, double *out) {
         MCL_CHECK_HIP(c, hipMemsetAsync(out, 0, sizeof(double), c->stream));
         return 0;
     }
-    hipLaunchKernelGGL((k_gl2_pass<float, false>), dim3((unsigned)((n + 63) / 64), (unsigned)mv.n_slabs), dim3(256), 0, c->stream, mv.ext,
+    hipLaunchKernelGGL((k_gl2_pass<float, false>), dim3((unsigned)((n + 63) / 64) * (unsigned)mv.n_slabs), dim3(256), 0, c->stream, mv.ext,
                        U, eig, n, c->r, mv.rho, (const float *)mv.F, (const float *)nullptr, c->gl2_T, (float *)nullptr, (float *)nullptr,
                        (double *)nullptr, (double *)nullptr, (const int *)nullptr);
     hipLaunchKernelGGL(k_gl2_value, dim3(1), dim3(256), 0, c->stream, (const double *)c->gl2_T, eig, rows, n, c->r, out);
@@ -2163,7 +2167,7 @@ int mcl_launch_gl2_wide(mcl_context *c, int mode, int k, const double *F64, doub
     const RegSet &rs = c->regs[mode];
     const int n = rs.mat_rows[k];
     const double *U = rs.mat[k], *eig = U + (long)n * n, *UT = eig + n;
-    const dim3 g((unsigned)((n + 63) / 64), (unsigned)mv.n_slabs);
+    const dim3 g((unsigned)((n + 63) / 64) * (unsigned)mv.n_slabs);
     hipLaunchKernelGGL((k_gl2_pass<double, false>), g, dim3(256), 0, c->stream, mv.ext, U, eig, n, c->r, mv.rho, F64, (const double *)D64,
                        c->gl2_T, (float *)nullptr, (float *)nullptr, (double *)nullptr, (double *)nullptr, mv.gate);
     hipLaunchKernelGGL((k_gl2_pass<double, true>), g, dim3(256), 0, c->stream, mv.ext, UT, eig, n, c->r, mv.rho, F64, (const double *)D64,

@@ -94,6 +94,7 @@ struct mcl_context {
     const float *X = nullptr;
     std::vector<int64_t> row_ptr;  // host
     int64_t I = 0, K = 0, N = 0;
+    int64_t max_slab_rows = 0;  // longest matrix (rows)
     int r = 0;
     int RP = 0;  // rank padded to 4/8/16/32/64 (register tiles)
     int NB = 0;  // number of 16-wide MFMA column blocks = ceil(r/16)
@@ -186,6 +187,8 @@ struct mcl_context {
     double *xsq_part = nullptr;    // [1024]
     int *ext_A = nullptr, *ext_C = nullptr;  // int32[2] slab extents {0, I} / {0, K} for the single-slab modes
     double *x_sq = nullptr;     // [1]
+    double *cond_monitor = nullptr;  // mcl_condition_monitor: device fp64[4] running maxima (modes 0-2, PARAFAC2 polar factors), NULL = off
+    int cond_monitor_mask = 0;
     double *cond_part = nullptr;  // [256, r*r + 2] mcl_condition_probe: per group of matrices the a-weighted Gram sum and the worst kappa of modes 0 / 1
     // deferred diagnostics (mcl_diagnostics_deferred): the reduction of the tables rides on a spare workgroup of the NEXT
     // C-phase reduction kernel instead of a launch of its own; the sweep alternates between two B tables so that the
@@ -371,5 +374,6 @@ int mcl_launch_exact_xc(mcl_context *c);                         // contract.hip
 int mcl_launch_exact_gr(mcl_context *c);                         // contract.hip: GR = [G | R] of this rank's slabs, exact products
 int mcl_launch_unimodal(mcl_context *c, const int *ext, int n_slabs, float *F, const RegSet &rs, int mode, int k);  // unimodal.hip
 int mcl_launch_gl2_value(mcl_context *c, int mode, int k, double *out);  // generic.hip: sum over slabs of trace(F^T M F)
+int mcl_launch_pf2_cond_track(mcl_context *c);                         // cond.hip: monitor slot 3 <- worst polar-factor conditioning of the last PARAFAC2 inner iteration
 int64_t mcl_cond_part_doubles(const mcl_context *c);                    // cond.hip
-int mcl_launch_cond_probe(mcl_context *c, int want, double *out);      // cond.hip: kappa of the penalty-free modes' systems -> out[3]
+int mcl_launch_cond_probe(mcl_context *c, int want, double *out, bool accumulate = false);  // cond.hip: kappa of the penalty-free modes' systems -> out[3]

@@ -232,7 +232,19 @@ __global__ __launch_bounds__(256) void k_svd_subspace(const double *__restrict__
         }
     }
     for (int k = tid; k < m; k += 256) theta[k] = prev[k];
-    if (tid == 0) info[info0 + b] = it_used;
+    if (tid == 0) {
+        // numerical rank below `rank` (an all-zero matrix, fewer independent rows than components): the Ritz vectors of the
+        // null eigenvalues were set to zero above, where LAPACK returns an orthonormal completion - a zero column in the initial
+        // B_i / C makes that component's normal equations singular from the first iteration on.  Reported as -(1000 + number of
+        // such vectors): the host falls back to its LAPACK path
+        int deficient = 0;
+        const double lam_max = lam[order[0]];
+        for (int k = 0; k < rank && k < m; ++k) {
+            const double l = lam[order[k]];
+            deficient += !(l > 1e-28 * lam_max && l > 0.0);
+        }
+        info[info0 + b] = deficient > 0 ? -(1000 + deficient) : it_used;
+    }
 }
 
 // B_b = X_b V_b with unit columns, the entry of largest magnitude of every column positive (threshold: clipped at 0)

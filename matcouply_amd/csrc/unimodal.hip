@@ -250,6 +250,11 @@ static __device__ __forceinline__ double rcp_count(double w) {
     return x;
 }
 
+// Offset (in elements) of row `idx` of a lane's column inside its slab: idx * r with both factors below 2^24 (the launcher checks
+// the rows) - ONE full-rate instruction, and as an unsigned 32-bit index the address is one v_lshl_add_u64 away; the 64-bit
+// products `(long)idx * rs` of rounds 3-5 cost 6-8 instructions per load (24 loads per batch of 8 steps in the sweeps).
+static __device__ __forceinline__ unsigned row_off(int idx, int r) { return __umul24((unsigned)idx, (unsigned)r); }
+
 static __device__ __forceinline__ int wave_max_i(int v) {
     for (int o = 32; o; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
     return v;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                 float fb[UB], ub[UB];
 #pragma unroll
                 for (int j = 0; j < UB; ++j) {
-                    const long o = (long)min(j, m - 1) * rs;
+                    const unsigned o = row_off(min(j, m - 1), r);
                     fb[j] = fp[o], ub[j] = up[o];
                 }
                 for (int i0 = 0; i0 < m; i0 += UB) {
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                     for (int j = 0; j < UB; ++j) vb[j] = (double)(fb[j] + ub[j]);
 #pragma unroll
                     for (int j = 0; j < UB; ++j) {
-                        const long o = (long)min(i0 + UB + j, m - 1) * rs;
+                        const unsigned o = row_off(min(i0 + UB + j, m - 1), r);
                         fb[j] = fp[o], ub[j] = up[o];
                     }
 #pragma unroll
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
             double best = (m == n) ? eLm : __builtin_inf();
             split3 = n;
             {
-                const float *fp = F + ((long)e - 1) * rs + col, *up = U + ((long)e - 1) * rs + col;
+                const float *fp = F + (long)s * rs + col, *up = U + (long)s * rs + col;  // indexed by POSITION n - 1 - i
                 const double *eLp = errL + eb * rs + col;  // eL[t] at eLp[t * rs]
                 double *eRp = errR + eb * rs + col;        // eR[t] at eRp[t * rs], stored for t > m only
                 UniRec *rp = recR + ((long)e - 1) * rs + col;
@@ -538,9 +543,10 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                 double eb_n[UB];
 #pragma unroll
                 for (int j = 0; j < UB; ++j) {
-                    const long o = (long)min(j, n - 1) * rs;
-                    fb[j] = fp[-o], ub[j] = up[-o];
-                    eb_n[j] = __builtin_nontemporal_load(eLp + (long)min(max(n - 1 - j, 0), m) * rs);
+                    const int pos = max(n - 1 - j, 0);
+                    const unsigned o = row_off(pos, r);
+                    fb[j] = fp[o], ub[j] = up[o];
+                    eb_n[j] = __builtin_nontemporal_load(eLp + row_off(min(pos, m), r));
                 }
                 bool done = false;
                 for (int i0 = 0; i0 < n && !done; i0 += UB) {
@@ -561,9 +567,10 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
 #endif
 #pragma unroll
                     for (int j = 0; j < UB; ++j) {
-                        const int i = min(i0 + UB + j, n - 1);
-                        fb[j] = fp[-(long)i * rs], ub[j] = up[-(long)i * rs];
-                        eb_n[j] = __builtin_nontemporal_load(eLp + (long)min(n - 1 - i, m) * rs);  // (not read when t > m)
+                        const int pos = max(n - 1 - (i0 + UB + j), 0);
+                        const unsigned o = row_off(pos, r);
+                        fb[j] = fp[o], ub[j] = up[o];
+                        eb_n[j] = __builtin_nontemporal_load(eLp + row_off(min(pos, m), r));  // (not read when t > m)
                     }
 #ifdef MCL_UNI_DBG
                     if (sc.dbg & 512) {
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                             rp -= rs;
                             const int tt = n - 1 - i;
                             if (tt > m) {
-                                if (!UNI_DBG(2)) __builtin_nontemporal_store(er, eRp + (long)tt * rs);
+                                if (!UNI_DBG(2)) __builtin_nontemporal_store(er, eRp + row_off(tt, r));
                             } else {
                                 const double tot = eb_l[j] + er;
                                 if (tot <= best) {
@@ -610,9 +617,9 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                 double er_n[UB];
 #pragma unroll
                 for (int j = 0; j < UB; ++j) {
-                    const long o = (long)min(j, nc - 1) * rs;
+                    const unsigned o = row_off(min(j, nc - 1), r);
                     fb[j] = fp[o], ub[j] = up[o];
-                    er_n[j] = __builtin_nontemporal_load(eRp + (long)min(j, max(nc - 2, 0)) * rs);
+                    er_n[j] = __builtin_nontemporal_load(eRp + row_off(min(j, max(nc - 2, 0)), r));
                 }
                 bool done = false;
                 for (int i0 = 0; i0 < nc && !done; i0 += UB) {
@@ -621,9 +628,9 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                     for (int j = 0; j < UB; ++j) vb[j] = (double)(fb[j] + ub[j]), er_l[j] = er_n[j];
 #pragma unroll
                     for (int j = 0; j < UB; ++j) {
-                        const long o = (long)min(i0 + UB + j, nc - 1) * rs;
+                        const unsigned o = row_off(min(i0 + UB + j, nc - 1), r);
                         fb[j] = fp[o], ub[j] = up[o];
-                        er_n[j] = __builtin_nontemporal_load(eRp + (long)min(i0 + UB + j, max(nc - 2, 0)) * rs);
+                        er_n[j] = __builtin_nontemporal_load(eRp + row_off(min(i0 + UB + j, max(nc - 2, 0)), r));
                     }
 #pragma unroll
                     for (int j = 0; j < UB; ++j) {
@@ -808,13 +815,13 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
         const int jtop = wave_max_i(split) - 1;
         UniRec rn[EB];
 #pragma unroll
-        for (int u = 0; u < EB; ++u) rn[u] = ld_rec_nt(rp + (long)min(max(jtop - u, 0), nm1) * rs);
+        for (int u = 0; u < EB; ++u) rn[u] = ld_rec_nt(rp + row_off(min(max(jtop - u, 0), nm1), r));
         for (int j0 = jtop; j0 >= 0; j0 -= EB) {
             UniRec rb[EB];
 #pragma unroll
             for (int u = 0; u < EB; ++u) rb[u] = rn[u];
 #pragma unroll
-            for (int u = 0; u < EB; ++u) rn[u] = ld_rec_nt(rp + (long)min(max(j0 - EB - u, 0), nm1) * rs);
+            for (int u = 0; u < EB; ++u) rn[u] = ld_rec_nt(rp + row_off(min(max(j0 - EB - u, 0), nm1), r));
 #pragma unroll
             for (int u = 0; u < EB; ++u) {  // branch-free (a branch around the stores would turn the counted waits on
                 const int j = j0 - u;       // the next batch's loads into waits for every store of this one)
@@ -822,7 +829,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                 const bool take = on && rem == 0;
                 z = take ? rb[u].lev : z;
                 rem = take ? rb[u].len : rem;
-                *(on ? zp + (long)j * rs : sink) = z;
+                *(on ? zp + row_off(min(max(j, 0), nm1), r) : sink) = z;
                 rem -= on ? 1 : 0;
             }
         }
@@ -838,14 +845,14 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
         UniRec rn[EB];
         if (jbot < jend) {
 #pragma unroll
-            for (int u = 0; u < EB; ++u) rn[u] = ld_rec_nt(rp + (long)min(jbot + u, nm1) * rs);
+            for (int u = 0; u < EB; ++u) rn[u] = ld_rec_nt(rp + row_off(min(jbot + u, nm1), r));
         }
         for (int j0 = jbot; j0 < jend; j0 += EB) {
             UniRec rb[EB];
 #pragma unroll
             for (int u = 0; u < EB; ++u) rb[u] = rn[u];
 #pragma unroll
-            for (int u = 0; u < EB; ++u) rn[u] = ld_rec_nt(rp + (long)min(j0 + EB + u, nm1) * rs);
+            for (int u = 0; u < EB; ++u) rn[u] = ld_rec_nt(rp + row_off(min(j0 + EB + u, nm1), r));
 #pragma unroll
             for (int u = 0; u < EB; ++u) {
                 const int j = j0 + u;
@@ -853,7 +860,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
                 const bool take = on && rem == 0;
                 z = take ? rb[u].lev : z;
                 rem = take ? rb[u].len : rem;
-                *(on ? zp + (long)j * rs : sink) = z;
+                *(on ? zp + row_off(min(max(j, 0), nm1), r) : sink) = z;
                 rem -= on ? 1 : 0;
             }
         }
@@ -896,7 +903,12 @@ static UniScratch uni_scratch(mcl_context *c) {
 int mcl_launch_unimodal(mcl_context *c, const int *ext, int n_slabs, float *F, const RegSet &rs, int mode, int k) {
     const long nthreads = (long)n_slabs * c->r;
     if (nthreads == 0) return 0;
-    (void)mode;
+    // the kernels index a column by 24-bit row numbers (row_off): a single matrix of 2^24 rows under this constraint is refused
+    const int64_t longest = mode == 1 ? c->max_slab_rows : (mode == 0 ? c->I : c->K);
+    if (longest >= (int64_t(1) << 24)) {
+        c->err = "unimodality: a factor matrix of 2^24 or more rows is not supported";
+        return 1;
+    }
     UniScratch sc = uni_scratch(c);
     const unsigned nwav = (unsigned)((nthreads + 63) / 64);
     // fewer columns than about one wave per SIMD: the two sweeps run concurrently in different waves

@@ -35,8 +35,10 @@ _ENGINE_FACTORY = None
 # _AUTO_EXACT_KAPPA moves the run there; larger problems are only warned, above _AUTO_EXACT_WARN_KAPPA
 _AUTO_EXACT_MAX_ELEMENTS = float(1 << 24)
 _AUTO_EXACT_KAPPA = 1e3
+_AUTO_EXACT_POLAR = 1e5  # ... or a PARAFAC2 polar factor (||sigma|| / sigma_min of Y_i Delta^T) above this
 _AUTO_EXACT_WARN_KAPPA = 1e6
 _AUTO_EXACT_PROBE_EVERY = 64
+_AUTO_EXACT_TRIAL_ITERATIONS = 2
 
 
 def _test_engine_factory():
@@ -120,6 +122,22 @@ def _data_on_device(matrices):
         return False
 
 
+_DEVICE_SVD_MAX_K = 2048  # the device initialiser keeps K x K fp64 Gram matrices per matrix in flight (32 MB each at this K)
+
+
+def _device_svd_applies(matrices, rank):
+    """The device form of init="svd" serves the shapes its subspace iteration covers: rank > K, a matrix with fewer rows than
+    components, or a K whose Gram matrices would not fit the initialiser's workspace take the host path, as the reference does
+    (ADVICE r5).  (`svd=` only names the driver: every valid name is the same thin LAPACK SVD on the host, _utils.get_svd.)"""
+    try:
+        K = int(shape(matrices[0])[1])
+        rows = [int(shape(m)[0]) for m in matrices] if not isinstance(matrices, PackedMatrices) else \
+            [int(matrices.row_ptr[i + 1] - matrices.row_ptr[i]) for i in range(len(matrices))]
+    except Exception:
+        return False
+    return rank <= K <= _DEVICE_SVD_MAX_K and min(rows) >= rank
+
+
 def initialize_cmf(matrices, rank, init, svd_fun, random_state=None, init_params=None):
     random_state = check_random_state(random_state)
     if isinstance(init, (tuple, list, CoupledMatrixFactorization)):
@@ -135,25 +153,35 @@ def initialize_cmf(matrices, rank, init, svd_fun, random_state=None, init_params
         C = random_state.uniform(size=(K, rank))
         B_is = [random_state.uniform(size=(shape(matrix)[0], rank)) for matrix in matrices]
         return CoupledMatrixFactorization((None, [A, B_is, C]))
-    if (init == "svd" or init == "threshold_svd") and _data_on_device(matrices):
+    if (init == "svd" or init == "threshold_svd") and _data_on_device(matrices) and _device_svd_applies(matrices, rank):
         # data resident in HBM: the singular vectors on the device, no copy of X to the host (mcl_svd_init: fp64 subspace
         # iteration on the Gram matrices).  The vectors are LAPACK's up to their SIGNS (largest-magnitude entry positive here):
         # B_i and C come from independent decompositions, so the reference's trajectory from this initialiser is reproduced
         # by the host path below only - which host-resident data keeps taking.
         X, row_ptr = _pack(matrices, _device())
         B, C, info = _engine.svd_init(X, row_ptr, rank, threshold=(init == "threshold_svd"))
-        if int(info.min().item()) < 0:
+        info_min = int(info.min().item())
+        if info_min <= -1000:
             import warnings
 
-            warnings.warn("svd initialisation on the device: the subspace iteration of some matrices had not settled after 400 "
-                          "iterations (no gap behind the leading singular values); the vectors are approximate", RuntimeWarning)
-        A = torch.ones((len(row_ptr) - 1, rank), dtype=torch.float32, device=X.device)
-        B_is = [B[int(row_ptr[i]): int(row_ptr[i + 1])] for i in range(len(row_ptr) - 1)]
-        return CoupledMatrixFactorization((None, [A, B_is, C]))
+            warnings.warn("svd initialisation on the device: a matrix has numerical rank below `rank` (its trailing singular "
+                          "vectors are not determined by the data); taking the host (LAPACK) path, which completes the basis",
+                          RuntimeWarning)
+        else:
+            if info_min < 0:
+                import warnings
+
+                warnings.warn("svd initialisation on the device: the subspace iteration of some matrices had not settled after 400 "
+                              "iterations (no gap behind the leading singular values); the vectors are approximate", RuntimeWarning)
+            A = torch.ones((len(row_ptr) - 1, rank), dtype=torch.float32, device=X.device)
+            B_is = [B[int(row_ptr[i]): int(row_ptr[i + 1])] for i in range(len(row_ptr) - 1)]
+            return CoupledMatrixFactorization((None, [A, B_is, C]))
     if init == "svd" or init == "threshold_svd":
         # one-off set-up on the host (decomposition.py:42-53)
         from ._utils import to_numpy
 
+        if svd_fun is None:
+            svd_fun = get_svd("truncated_svd")
         mats = [np.asarray(to_numpy(m), dtype=np.float64) for m in matrices]
         A = np.ones((len(mats), rank))
         B_is = [svd_fun(m, n_eigenvecs=rank)[0] for m in mats]
@@ -1140,45 +1168,79 @@ def cmf_aoadmm(
     # 319-321) and multiplies whatever the fp32 kernels left in its inputs (1e-8 .. 4e-7 relative) by the condition number of
     # its system.  On large problems those roundings average out over 1e5 .. 1e7 rows (BASELINE config 4: C to 8e-8 at
     # condition 600) and the exact arithmetic would cost passes over X; below _AUTO_EXACT_MAX_ELEMENTS elements neither
-    # holds.  There the engine's condition probe (mcl_condition_probe: kappa of the systems the penalty-free modes would
-    # solve from the CURRENT factors, no pass over X) decides before the first iteration - and again every
-    # _AUTO_EXACT_PROBE_EVERY iterations of a long run, conditioning grows as components become collinear: above
-    # _AUTO_EXACT_KAPPA the run continues in the exact arithmetic (fp64 sums of exact products, fp64 inner loops).  The decision
-    # is taken from all-reduced numbers under `group=` (every rank switches, or none).  Larger problems keep the fast kernels;
-    # a badly conditioned one is told about `arithmetic="exact"`.
+    # holds.  The condition numbers that matter are those AT THE START OF EACH PHASE (Gauss-Seidel: the A-phase of an
+    # iteration solves systems built from the B_i and C of the same iteration - a random start has kappa ~30 where the first
+    # A-phase meets 3e4), so they are measured there: a TRIAL of _AUTO_EXACT_TRIAL_ITERATIONS iterations runs under the engine's
+    # condition monitor (mcl_condition_monitor: per phase of a penalty-free mode, kappa = ||M||_F ||M^-1||_F of its system, from
+    # the factors, no pass over X), the initial state is restored, and with a kappa above _AUTO_EXACT_KAPPA the run takes the
+    # exact arithmetic (fp64 sums of exact products, fp64 inner loops) from its first iteration - the result is that of one
+    # arithmetic from start to end.  Long runs look again every _AUTO_EXACT_PROBE_EVERY iterations (one monitored iteration) and
+    # switch forward.  Under `group=` the maxima are all-reduced (every rank switches, or none).  Larger problems keep the fast
+    # kernels; a badly conditioned one is told about `arithmetic="exact"`.
     updated_modes = (update_A, update_B_is, update_C)
     free_modes = [m for m in range(3) if updated_modes[m] and len(regs[m]) == 0]
-    auto_candidate = (arithmetic == "auto" and bool(free_modes) and n_el_total > float(1 << 20) and n_iter_max > 0
-                      and hasattr(eng, "condition_probe"))
+    all_native = not any(r.kind == _engine.PEN_EXTERNAL for m in range(3) for r in native[m])
+    has_pf2 = update_B_is and any(r_.kind == _engine.PEN_PARAFAC2 for r_ in native[1]) and rank <= 32
+    auto_candidate = (arithmetic == "auto" and (bool(free_modes) or (has_pf2 and n_el_total <= _AUTO_EXACT_MAX_ELEMENTS))
+                      and n_el_total > float(1 << 20) and n_iter_max > 0 and all_native and hasattr(eng, "condition_monitor"))
 
-    def probe_conditioning():
-        """worst kappa over the penalty-free updated modes (all ranks: the same number)"""
-        k = eng.condition_probe(update_A, update_B_is, update_C)
+    def plain_iterations(n):
+        """n outer iterations without diagnostics, on whichever path this run takes"""
         if sharded:
-            all_reduce(k, "max")
-        return float(k.max().item())
+            for _ in range(n):
+                if update_B_is:
+                    do_update_B()
+                if update_C:
+                    do_update_C()
+                if update_A:
+                    do_update_A()
+        else:
+            eng.iterate(n, update_A=update_A, update_B=update_B_is, update_C=update_C)
 
-    def maybe_go_exact():
+    def monitored_kappa(n):
+        """worst kappa the penalty-free phases of the next n iterations meet (all ranks: the same number); the iterations RUN"""
+        mon = eng.condition_monitor(True, update_A, update_B_is, update_C)
+        try:
+            plain_iterations(n)
+        finally:
+            eng.condition_monitor(False)
+        if sharded:
+            all_reduce(mon, "max")
+        return kappa_of(mon)
+
+    def kappa_of(mon):
+        """monitor vector -> the number the rule looks at: the worst kappa of a penalty-free mode's system, or - on the same
+        footing, _AUTO_EXACT_KAPPA / _AUTO_EXACT_POLAR apart - the worst conditioning of a PARAFAC2 polar factor (the Gram route of
+        the fast kernels squares it: a factor of condition 1e5 sits at the edge of what fp32 statistics resolve)"""
+        m = mon.cpu().numpy()
+        return max(float(m[:3].max()), float(m[3]) * (_AUTO_EXACT_KAPPA / _AUTO_EXACT_POLAR))
+
+    def decide_arithmetic(worst):
         nonlocal auto_candidate
-        if not auto_candidate:
-            return
-        worst = probe_conditioning()
         if n_el_total > _AUTO_EXACT_MAX_ELEMENTS:
-            auto_candidate = False  # (large problems are probed once, for the warning only)
+            auto_candidate = False  # (large problems are looked at once, for the warning only)
             if worst > _AUTO_EXACT_WARN_KAPPA:
                 import warnings
 
                 warnings.warn(
                     f"cmf_aoadmm: a mode without penalties has normal equations of condition ~{worst:.1e}; the fp32 kernels this "
                     f"problem size takes by default carry about 1e-8 x that in the factors. Pass arithmetic=\"exact\" for the "
-                    "reference's fp64 solve (slower: fp64 passes over the matrices).", RuntimeWarning, stacklevel=3)
+                    "reference's fp64 solve (slower: fp64 passes over the matrices).", RuntimeWarning, stacklevel=4)
         elif worst > _AUTO_EXACT_KAPPA:
             eng.set_exact(True)
             auto_candidate = False
             if verbose:
-                print(f"matcouply_amd: penalty-free mode with condition ~{worst:.1e}: continuing in the exact arithmetic")
+                print(f"matcouply_amd: penalty-free mode with condition ~{worst:.1e}: the exact arithmetic from here on")
 
-    maybe_go_exact()
+    if auto_candidate:
+        state = [eng.A, eng.B, eng.C] + [t for m in range(3) for r_ in native[m] for t in (r_.aux, r_.dual, r_.aux2) if t is not None]
+        saved = [t.clone() for t in state]
+        worst = monitored_kappa(min(_AUTO_EXACT_TRIAL_ITERATIONS, n_iter_max))
+        for t, t0 in zip(state, saved):
+            t.copy_(t0)
+        del saved
+        eng.invalidate()  # the factors changed behind the engine's back
+        decide_arithmetic(worst)
 
     rec_errors, feasibility_gaps, losses = [], [], []
     rec_error, gaps0, reg0 = diagnostics()
@@ -1215,6 +1277,8 @@ def cmf_aoadmm(
         # on the device and are all-reduced once for all iterations (one collective per iteration remains: [G | R])
         ring = torch.zeros((n_iter_max, _engine.DIAG_LEN), dtype=torch.float64, device=device) if return_errors else None
         for it in range(n_iter_max):
+            mon = (eng.condition_monitor(True, update_A, update_B_is, update_C)
+                   if (auto_candidate and it > 0 and it % _AUTO_EXACT_PROBE_EVERY == 0) else None)
             if update_B_is:
                 do_update_B()
             if update_C:
@@ -1223,8 +1287,10 @@ def cmf_aoadmm(
                 do_update_A()
             if ring is not None:  # the table reduction rides on the next iteration's C-phase reduction kernel
                 eng.diagnostics_deferred(include_replicated=(rank_id == 0), out=ring[it])
-            if auto_candidate and (it + 1) % _AUTO_EXACT_PROBE_EVERY == 0 and it + 1 < n_iter_max:
-                maybe_go_exact()
+            if mon is not None:
+                eng.condition_monitor(False)
+                all_reduce(mon, "max")
+                decide_arithmetic(kappa_of(mon))
         if ring is not None:
             eng.flush_diagnostics()
             all_reduce(ring)
@@ -1288,11 +1354,10 @@ def cmf_aoadmm(
         # the factors returned are exactly those of the stopping iteration.  Chunked so that the rings stay small.
         weights = [[(reg.reg_strength if isinstance(reg, penalties.L1Penalty) else 0.0) for reg in regs[m]] for m in range(3)]
         done, code, chunk = 0, 0, 4096
-        while done < n_iter_max and not code:
-            if done > 0:
-                maybe_go_exact()
-            n_now = min(_AUTO_EXACT_PROBE_EVERY if auto_candidate else chunk, n_iter_max - done)
-            n_ran, code, ring_h, verdict_h = eng.run(
+
+        def run_chunk(n_now):
+            nonlocal done, feasibility_criterion
+            n_ran, code_, ring_h, verdict_h = eng.run(
                 n_now, tol, absolute_tol, feasibility_tol, initial_loss=losses[-1], penalty_weight=weights,
                 evaluate_loss_always=return_errors, update_A=update_A, update_B=update_B_is, update_C=update_C)
             feasibility_gaps.extend(read_diag_rows(ring_h)[1])
@@ -1303,6 +1368,19 @@ def cmf_aoadmm(
                 rec_errors.extend(verdict_h[evaluated, 0].tolist())
                 losses.extend(verdict_h[evaluated, 1].tolist())
             done += n_ran
+            return code_
+
+        while done < n_iter_max and not code:
+            n_now = min(_AUTO_EXACT_PROBE_EVERY if auto_candidate else chunk, n_iter_max - done)
+            if auto_candidate and done > 0:  # the first iteration of every further chunk runs under the condition monitor
+                mon = eng.condition_monitor(True, update_A, update_B_is, update_C)
+                code = run_chunk(1)
+                eng.condition_monitor(False)
+                decide_arithmetic(kappa_of(mon))
+                n_now -= 1
+                if code or n_now == 0:
+                    continue
+            code = run_chunk(n_now)
         it = done - 1
         if code:
             satisfied_stopping_condition = True
@@ -1316,11 +1394,16 @@ def cmf_aoadmm(
         done = 0
         while done < n_iter_max:  # (one call, unless the conditioning of a penalty-free mode is being watched)
             n_now = min(_AUTO_EXACT_PROBE_EVERY, n_iter_max - done) if auto_candidate else n_iter_max - done
-            eng.iterate(n_now, update_A=update_A, update_B=update_B_is, update_C=update_C,
+            mon = eng.condition_monitor(True, update_A, update_B_is, update_C) if (auto_candidate and done > 0) else None
+            eng.iterate(1 if mon is not None else n_now, update_A=update_A, update_B=update_B_is, update_C=update_C,
                         diag_ring=(ring[done:] if ring is not None else None))
+            if mon is not None:  # the first iteration of every further chunk ran under the monitor
+                eng.condition_monitor(False)
+                decide_arithmetic(kappa_of(mon))
+                if n_now > 1:
+                    eng.iterate(n_now - 1, update_A=update_A, update_B=update_B_is, update_C=update_C,
+                                diag_ring=(ring[done + 1:] if ring is not None else None))
             done += n_now
-            if done < n_iter_max:
-                maybe_go_exact()
         it = n_iter_max - 1
         if return_errors:
             rec, gaps, reg = read_diag_rows(ring.cpu().numpy())
@@ -1329,15 +1412,19 @@ def cmf_aoadmm(
             losses.extend(0.5 * rec ** 2 + reg)
     else:
         for it in range(n_iter_max):
+            mon = (eng.condition_monitor(True, update_A, update_B_is, update_C)
+                   if (auto_candidate and it > 0 and it % _AUTO_EXACT_PROBE_EVERY == 0) else None)
             if update_B_is:
                 do_update_B()
             if update_C:
                 do_update_C()
             if update_A:
                 do_update_A()
+            if mon is not None:
+                eng.condition_monitor(False)
+                all_reduce(mon, "max")
+                decide_arithmetic(kappa_of(mon))
 
-            if auto_candidate and (it + 1) % _AUTO_EXACT_PROBE_EVERY == 0 and it + 1 < n_iter_max:
-                maybe_go_exact()
             if not (stop.active or return_errors):
                 progress.iteration(it)
                 continue

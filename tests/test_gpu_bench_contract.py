@@ -67,6 +67,10 @@ def test_single_rank_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None or str(r["traffic_source"]).startswith("static: profiles/")
+    # ... and against what the box's memory system delivers to a pure streaming read, measured in the same process
+    # (mcl_read_bandwidth): between 4 and 8 TB/s on an MI355X, the fraction against it above the one against the spec
+    assert 4000.0 < r["peak_achievable"] <= 8000.0, r["peak_achievable"]
+    assert abs(r["frac_achievable"] - r["achieved"] / r["peak_achievable"]) < 2e-3 and r["frac_achievable"] >= r["frac"]
     _check_per_kernel(d, most_of_the_step=False)
     m = r["mfma"]
     assert m["unit"] == "TFLOP/s" and m["peak"] == 157.3 and 0 < m["frac"] < 1 and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-3

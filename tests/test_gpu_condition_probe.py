@@ -2,8 +2,10 @@
 
 A mode without penalties solves un-shifted normal equations - the reference with an fp64 SVD (decomposition.py:172, 252-256,
 319-321) - and amplifies what fp32 kernels leave in its inputs by the condition number of its system.  The probe computes
-kappa = ||M||_F ||M^-1||_F of those systems from the factors; between 2^20 and 2^24 elements of X `cmf_aoadmm` moves a run
-whose penalty-free modes exceed kappa 1e3 to the exact arithmetic (VERDICT r5 #1d), larger problems are warned."""
+kappa = ||M||_F ||M^-1||_F of those systems from the factors; between 2^20 and 2^24 elements of X `cmf_aoadmm` runs a two-iteration
+trial under the per-phase monitor (the numbers that matter are those at the start of each phase: a random start has kappa ~30
+where the first A-phase meets 3e4), restores the initial state and moves a run whose penalty-free modes exceeded kappa 1e3 to the
+exact arithmetic (VERDICT r5 #1d); larger problems are warned."""
 import warnings
 
 import numpy as np
@@ -58,7 +60,9 @@ def test_probe_equals_numpy(shape):
     want = _reference_kappas(st, l2)
     got = eng.condition_probe(True, True, True).cpu().numpy()
     print(shape, "kappa A / B / C:", got, "numpy:", want)
-    np.testing.assert_allclose(got, want, rtol=1e-6)
+    ok = want < 1e12  # (K < rank: the B systems are singular - "huge" on both sides, the digits are rounding)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=1e-6)
+    assert (got[~ok] > 1e12).all()
     # modes that are not asked for report 0; twice the same bits (fixed summation order)
     assert np.array_equal(eng.condition_probe(True, True, True).cpu().numpy(), got)
     assert np.array_equal(eng.condition_probe(False, True, False).cpu().numpy() != 0, [False, True, False])
@@ -111,13 +115,32 @@ def test_auto_arithmetic_follows_the_conditioning(monkeypatch):
     assert switched == [True]  # the auto run, once; the forced runs never ask
     assert worst["auto"] < 1e-5 and worst["exact"] < 1e-5 and worst["auto"] < worst["fast"]
     assert abs(worst["auto"] - worst["exact"]) <= 1e-9 + 0.05 * worst["exact"]
-    # a ridge of the size of the systems' own scale: well conditioned, the fast kernels stay - and are inside the bar
+    # a ridge that keeps the free modes' systems well conditioned (kappa <= 17 over these iterations in the reference's arithmetic):
+    # the fast kernels stay - and are inside the bar
     switched.clear()
-    st = _mid_problem([2e4, 0.0, 2e4])()
+    st = _mid_problem([500.0, 0.0, 500.0])()
     cmf, admm, diag, res = _run_both(st, 3)
     errs = _compare(cmf, admm, diag, st, res, 1e-5, 1e-5)
     assert switched == [], switched
     print("well-conditioned free modes, fast kernels:", f"{max(v for k, v in errs.items() if k != 'gaps'):.1e}")
+
+
+def test_ill_conditioned_polar_factors_move_a_mid_size_parafac2_run(monkeypatch):
+    """every mode penalised, PARAFAC2 on the B_i of a mid-size problem: the monitor's fourth slot (worst ||sigma|| / sigma_min of
+    Y_i Delta^T over the trial's inner iterations) decides - draw 41 of the mid-size fuzz leg (3e7 in the first inner iteration
+    from its random dual: B at 4.6e-5 with the fast kernels) runs in the exact arithmetic by default and is inside the bar"""
+    from matcouply_amd import _engine
+    from tests.test_gpu_fuzz_parity import _mid_state
+
+    switched = []
+    orig = _engine.HipEngine.set_exact
+    monkeypatch.setattr(_engine.HipEngine, "set_exact", lambda self, exact=True: (switched.append(bool(exact)), orig(self, exact))[1])
+    case, st = _mid_state(41)
+    assert all(len(m) > 0 for m in case["regs"]) and case["regs"][1][0]["kind"] == "parafac2"
+    cmf, admm, diag, res = _run_both(st, 2)
+    errs = _compare(cmf, admm, diag, st, res, 1e-5, 1e-5)
+    print("mid 41:", {k: f"{v:.1e}" for k, v in errs.items()}, f"polar cond {res['polar_cond']:.0e}", "switches:", switched)
+    assert switched == [True]
 
 
 def test_large_ill_conditioned_problem_is_warned(monkeypatch):
