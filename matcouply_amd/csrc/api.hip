@@ -132,6 +132,7 @@ int64_t plan(mcl_context *c, char *base) {
     c->xsq_part = b.take<double>(1024);
     c->x_sq = b.take<double>(1);
     c->cond_part = b.take<double>(mcl_cond_part_doubles(c));
+    c->row_sink = b.take<float>(64 * 64 * 4);
     c->inner_gate = b.take<int>(2);
     {
         const int64_t max_tiles = std::max<int64_t>(std::max<int64_t>(c->tilesB.n_tiles, c->tilesC.n_tiles), std::max<int64_t>(c->tilesA.n_tiles, 1));
@@ -215,6 +216,7 @@ void read_switches(mcl_switches &w) {
     w.sweep_dbg = num("MCL_SWEEP_DBG", 0), w.reduce_el = num("MCL_REDUCE_EL", 0), w.uni_split = num("MCL_UNI_SPLIT", -1);
     w.exact = num("MCL_EXACT", -1);
     w.no_wide = flag("MCL_NO_WIDE");
+    w.no_row_prefetch = flag("MCL_NO_ROW_PREFETCH");
     w.test_mute_verdict = flag("MCL_TEST_MUTE_VERDICT");  // test hook of the mcl_run watchdog, not a kernel form
     if (const char *e = getenv("MCL_RUN_SPINS")) w.run_spins = atol(e);  // operating parameter of mcl_run's wait (see there)
     if (const char *e = getenv("MCL_RUN_WATCHDOG_S")) {  // an operating parameter, not a kernel form (not listed by mcl_active_switches)
@@ -231,7 +233,7 @@ std::string switches_in_env() {
         "MCL_UNI_NOPRUNE", "MCL_STATS_REDUCE", "MCL_NO_ROWS64", "MCL_NO_UNI_COOP", "MCL_NO_A_FUSION", "MCL_NO_A_WIDE", "MCL_NO_BSEG_GROUPS",
         "MCL_NO_SWEEP_HALF", "MCL_NO_X_NT", "MCL_X_NT_MB", "MCL_NO_MULTI_C", "MCL_NO_DIAG_DEFER", "MCL_XC_DEPTH1", "MCL_SEG_ROWS",
         "MCL_BSEG_ROWS", "MCL_XC_WAVES", "MCL_XT_WAVES", "MCL_SWEEP_WAVES", "MCL_XC_DBG", "MCL_XT_DBG", "MCL_XT_DEPTH",
-        "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT", "MCL_EXACT", "MCL_NO_WIDE"};
+        "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT", "MCL_EXACT", "MCL_NO_WIDE", "MCL_NO_ROW_PREFETCH"};
     std::string out;
 #ifdef MCL_NO_ENV_SWITCHES
     return out;

@@ -35,16 +35,6 @@ static __device__ __forceinline__ double prox_elem_g(int kind, int nonneg, doubl
     }
 }
 
-struct ModeView {
-    const int *tile_slab, *tile_row0, *tile_nrows;
-    int n_tiles;
-    const int *ext;        // slab extents (row_ptr)
-    int n_slabs;
-    const float *rho;      // [n_slabs]
-    float *F;              // factor [rows, r]
-    const int *gate;       // stop flag of a gated run (mcl_run with a stopping rule), else NULL: see MCL_GATE
-};
-
 static ModeView view_of(mcl_context *c, int mode) {
     ModeView v{};
     v.gate = c->gate_active;
@@ -2291,7 +2281,9 @@ int mcl_launch_rows_finish_solve_stats(mcl_context *c) {
                        (const float *)c->A, (const float *)c->LinvB, c->regs[1], c->r, (const float *)c->pf2_T,        \
                        (const double *)c->colsq, c->stat_gram, c->stat_colsq, (const double *)c->LinvB64,              \
                        (const double *)c->pf2_T64)
-    if (mcl_rows64(c)) {
+    if (mcl_try_rows_chain_mid(c, mv, rhs, vec, mcl_rows64(c))) {
+        // (rowchain.hip: the same pass with its loads software-pipelined, for the stacks it is instantiated for)
+    } else if (mcl_rows64(c)) {
         if (vec) MCL_FSS(1, true, true);
         else MCL_FSS(1, false, true);
     } else if (c->NB == 1) {

@@ -65,13 +65,24 @@ struct TileMap {
     int *nrows = nullptr;  // device int32[n_tiles]
 };
 
+// One mode's factor as the row kernels see it (generic.hip: view_of; passed by value)
+struct ModeView {
+    const int *tile_slab, *tile_row0, *tile_nrows;
+    int n_tiles;
+    const int *ext;        // slab extents (row_ptr)
+    int n_slabs;
+    const float *rho;      // [n_slabs]
+    float *F;              // factor [rows, r]
+    const int *gate;       // stop flag of a gated run (mcl_run with a stopping rule), else NULL: see MCL_GATE
+};
+
 // MCL_* environment switches (A/B experiments, debug paths): read ONCE per context in mcl_create(), never on a launch
 // path - a getenv() is a linear scan of the environment and is not safe against a concurrent setenv().
 struct mcl_switches {
     bool no_sweep = false, no_pass_chain = false, no_pf2_delta_fusion = false, ns_plain = false, pf2_jacobi = false;
     bool no_stack_fusion = false, no_solve_stats = false, no_next_b = false, no_fused_gram = false, no_fused_c = false;
     bool a_finish_cols = false, xc_norow = false, uni_noprune = false, stats_reduce = false;
-    bool no_rows64 = false, no_uni_coop = false, no_wide = false;
+    bool no_rows64 = false, no_uni_coop = false, no_wide = false, no_row_prefetch = false;
     bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_x_nt = false, no_sweep_half = false, no_multi_c = false, no_diag_defer = false, xc_depth1 = false;
     int x_nt_mb = 0, seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
     int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
@@ -189,6 +200,7 @@ struct mcl_context {
     double *x_sq = nullptr;     // [1]
     double *cond_monitor = nullptr;  // mcl_condition_monitor: device fp64[4] running maxima (modes 0-2, PARAFAC2 polar factors), NULL = off
     int cond_monitor_mask = 0;
+    float *row_sink = nullptr;  // [64 waves, 64 lanes, 4] where the software-pipelined row passes (rowchain.hip) send the stores of lanes outside the matrix
     double *cond_part = nullptr;  // [256, r*r + 2] mcl_condition_probe: per group of matrices the a-weighted Gram sum and the worst kappa of modes 0 / 1
     // deferred diagnostics (mcl_diagnostics_deferred): the reduction of the tables rides on a spare workgroup of the NEXT
     // C-phase reduction kernel instead of a launch of its own; the sweep alternates between two B tables so that the
@@ -374,6 +386,7 @@ int mcl_launch_exact_xc(mcl_context *c);                         // contract.hip
 int mcl_launch_exact_gr(mcl_context *c);                         // contract.hip: GR = [G | R] of this rank's slabs, exact products
 int mcl_launch_unimodal(mcl_context *c, const int *ext, int n_slabs, float *F, const RegSet &rs, int mode, int k);  // unimodal.hip
 int mcl_launch_gl2_value(mcl_context *c, int mode, int k, double *out);  // generic.hip: sum over slabs of trace(F^T M F)
+int mcl_try_rows_chain_mid(mcl_context *c, const ModeView &mv, const float *rhs, bool vec, bool rows64);  // rowchain.hip
 int mcl_launch_pf2_cond_track(mcl_context *c);                         // cond.hip: monitor slot 3 <- worst polar-factor conditioning of the last PARAFAC2 inner iteration
 int64_t mcl_cond_part_doubles(const mcl_context *c);                    // cond.hip
 int mcl_launch_cond_probe(mcl_context *c, int want, double *out, bool accumulate = false);  // cond.hip: kappa of the penalty-free modes' systems -> out[3]
