@@ -809,51 +809,71 @@ static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const fl
         G[e] = sum;
     }
     __syncthreads();
-    // cyclic Jacobi eigen-decomposition of the symmetric G (fp64); V accumulates the eigenvectors
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0, dg = 0.0;
-        for (int e = lane; e < n2; e += 64) {
-            const int a = e / r, b = e - a * r;
-            if (a == b) dg += G[e] * G[e];
-            else off += G[e] * G[e];
-        }
-        off = wave_sum_d(off);
-        dg = wave_sum_d(dg);
-        if (off <= 1e-30 * dg) break;
-        for (int p = 0; p < r - 1; ++p) {
-            for (int q = p + 1; q < r; ++q) {
+    // Jacobi eigen-decomposition of the symmetric G (fp64); V accumulates the eigenvectors.  Round 6: PARALLEL ordering - in
+    // each of the n - 1 steps of a sweep the n / 2 disjoint index pairs of a round-robin tournament are rotated at once
+    // (Brent-Luk), where rounds 2-5 walked the r (r - 1) / 2 pairs of a cyclic sweep one after the other: every rotation is two
+    // barriers and a division / square-root chain (~1000 cycles), so a rank-16 matrix took ~1 M cycles - 436 us per call on the
+    // 48-matrix problems of the exact arithmetic, 75 % of their iteration (rocprof, gpurun_out/r6).  A lane keeps ONE pair for the
+    // whole step (its rotation computed redundantly by the lanes that share it, from the same LDS values: identical bits), applies
+    // it to its rows of G J and V J, then to its columns of J^T (G J).
+    {
+        const int n = r + (r & 1);      // an odd rank plays with a bye (index r)
+        const int npairs = n >> 1;
+        int P = 1;
+        while (P < npairs) P <<= 1;     // lanes per row group: pair i = lane % P (P <= 32 for rank <= 64)
+        const int pi = lane % P, kstep = 64 / P, k0 = lane / P;
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            double off = 0.0, dg = 0.0;
+            for (int e = lane; e < n2; e += 64) {
+                const int a = e / r, b = e - a * r;
+                if (a == b) dg += G[e] * G[e];
+                else off += G[e] * G[e];
+            }
+            off = wave_sum_d(off);
+            dg = wave_sum_d(dg);
+            if (off <= 1e-30 * dg) break;
+            for (int st = 0; st < n - 1; ++st) {
+                // the pair of this lane in step st: (n - 1, st) for i = 0, ((st + i) mod (n - 1), (st - i) mod (n - 1)) otherwise
+                int p = -1, q = -1;
+                if (pi < npairs) {
+                    int a = pi == 0 ? n - 1 : (st + pi) % (n - 1), b = pi == 0 ? st : (st - pi + (n - 1)) % (n - 1);
+                    p = min(a, b), q = max(a, b);
+                    if (q >= r) p = -1;  // the bye
+                }
                 __syncthreads();
-                const double apq = G[p * r + q], app = G[p * r + p], aqq = G[q * r + q];
-                if (fabs(apq) > 1e-300) {
-                    const double tau = (aqq - app) / (2.0 * apq);
-                    const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = tt * cs;
-                    double gkp = 0.0, gkq = 0.0, vkp = 0.0, vkq = 0.0;
-                    const int k = lane;
-                    if (k < r) {
-                        gkp = G[k * r + p], gkq = G[k * r + q];
-                        vkp = V[k * r + p], vkq = V[k * r + q];
-                    }
-                    __syncthreads();
-                    if (k < r) {
-                        V[k * r + p] = cs * vkp - sn * vkq;
-                        V[k * r + q] = sn * vkp + cs * vkq;
-                        if (k != p && k != q) {
-                            const double np = cs * gkp - sn * gkq, nq = sn * gkp + cs * gkq;
-                            G[k * r + p] = np, G[p * r + k] = np;
-                            G[k * r + q] = nq, G[q * r + k] = nq;
-                        }
-                    }
-                    if (lane == 0) {
-                        G[p * r + p] = app - tt * apq;
-                        G[q * r + q] = aqq + tt * apq;
-                        G[p * r + q] = 0.0;
-                        G[q * r + p] = 0.0;
+                double cs = 1.0, sn = 0.0, dpp = 0.0, dqq = 0.0;
+                bool rot = false;
+                if (p >= 0) {
+                    const double apq = G[p * r + q], app = G[p * r + p], aqq = G[q * r + q];
+                    if (fabs(apq) > 1e-300) {
+                        const double tau = (aqq - app) / (2.0 * apq);
+                        const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        cs = 1.0 / sqrt(1.0 + tt * tt), sn = tt * cs;
+                        dpp = app - tt * apq, dqq = aqq + tt * apq;
+                        rot = true;
                     }
                 }
+                __syncthreads();
+                if (rot)  // columns p, q of G and V:  X <- X J
+                    for (int k = k0; k < r; k += kstep) {
+                        const double gkp = G[k * r + p], gkq = G[k * r + q], vkp = V[k * r + p], vkq = V[k * r + q];
+                        G[k * r + p] = cs * gkp - sn * gkq, G[k * r + q] = sn * gkp + cs * gkq;
+                        V[k * r + p] = cs * vkp - sn * vkq, V[k * r + q] = sn * vkp + cs * vkq;
+                    }
+                __syncthreads();
+                if (rot)  // rows p, q of G:  G <- J^T G
+                    for (int k = k0; k < r; k += kstep) {
+                        const double gpk = G[p * r + k], gqk = G[q * r + k];
+                        G[p * r + k] = cs * gpk - sn * gqk, G[q * r + k] = sn * gpk + cs * gqk;
+                    }
+                __syncthreads();
+                if (rot && k0 == 0) {  // the rotated 2 x 2 block in closed form (exact zero off the diagonal)
+                    G[p * r + p] = dpp, G[q * r + q] = dqq;
+                    G[p * r + q] = 0.0, G[q * r + p] = 0.0;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     __syncthreads();
     double lmax = 0.0, lmin = 1e300;
@@ -2240,7 +2260,9 @@ int mcl_launch_rows_finish_fused(mcl_context *c, int mode, bool want_diag) {
     double *diag = (mode == 1) ? c->diagB_tile : c->diagC_tile;
     ProfScope prof(c, mode == 1 ? MCL_PROF_ROWS_CHAIN : MCL_PROF_OTHER);
     if (mode == 1) c->variant[MCL_PROF_ROWS_CHAIN] = mcl_rows64(c) ? "k_rows_finish_solve_stats<R64> chain (solve_stats -> finish_solve_stats x (n-1) -> finish_fused)" : "k_rows_finish_solve_stats chain (solve_stats -> finish_solve_stats x (n-1) -> finish_fused)";
-    if (mode == 1 && mcl_rows64(c)) {  // rank <= 16 with a PARAFAC2 member: fp64 row algebra
+    if (mode == 1 && mcl_try_rows_chain_last(c, mv, vec, mcl_rows64(c), diag, want_diag ? 1 : 0)) {
+        // (rowchain.hip: software-pipelined form)
+    } else if (mode == 1 && mcl_rows64(c)) {  // rank <= 16 with a PARAFAC2 member: fp64 row algebra
         if (vec)
             hipLaunchKernelGGL((k_rows_finish_fused<1, true, true>), grid, block, 0, c->stream, mv, rs, c->r, (const float *)c->pf2_T,
                                (const double *)c->colsq, diag, want_diag ? 1 : 0, (const double *)c->pf2_T64);
@@ -2315,7 +2337,9 @@ int mcl_launch_rows_solve_stats(mcl_context *c) {
 #define MCL_SS(NBR_, VEC_, R64_)                                                                                     \
     hipLaunchKernelGGL((k_rows_solve_stats<NBR_, VEC_, R64_>), grid, block, 0, c->stream, mv, rhs, (const float *)c->A, \
                        (const float *)c->LinvB, c->regs[1], c->r, c->stat_gram, c->stat_colsq, (const double *)c->LinvB64)
-    if (mcl_rows64(c)) {
+    if (mcl_try_rows_chain_first(c, mv, rhs, vec, mcl_rows64(c))) {
+        // (rowchain.hip: software-pipelined form)
+    } else if (mcl_rows64(c)) {
         if (vec) MCL_SS(1, true, true);
         else MCL_SS(1, false, true);
     } else if (c->NB == 1) {

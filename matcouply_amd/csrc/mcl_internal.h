@@ -387,6 +387,8 @@ int mcl_launch_exact_gr(mcl_context *c);                         // contract.hip
 int mcl_launch_unimodal(mcl_context *c, const int *ext, int n_slabs, float *F, const RegSet &rs, int mode, int k);  // unimodal.hip
 int mcl_launch_gl2_value(mcl_context *c, int mode, int k, double *out);  // generic.hip: sum over slabs of trace(F^T M F)
 int mcl_try_rows_chain_mid(mcl_context *c, const ModeView &mv, const float *rhs, bool vec, bool rows64);  // rowchain.hip
+int mcl_try_rows_chain_first(mcl_context *c, const ModeView &mv, const float *rhs, bool vec, bool rows64);
+int mcl_try_rows_chain_last(mcl_context *c, const ModeView &mv, bool vec, bool rows64, double *diag, int want_diag);
 int mcl_launch_pf2_cond_track(mcl_context *c);                         // cond.hip: monitor slot 3 <- worst polar-factor conditioning of the last PARAFAC2 inner iteration
 int64_t mcl_cond_part_doubles(const mcl_context *c);                    // cond.hip
 int mcl_launch_cond_probe(mcl_context *c, int want, double *out, bool accumulate = false);  // cond.hip: kappa of the penalty-free modes' systems -> out[3]

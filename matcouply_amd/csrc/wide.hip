@@ -408,12 +408,27 @@ __global__ __launch_bounds__(256) void k_wide_colsq(WideRows W, WideState S, int
     const int s = W.ext[slab], e = W.ext[slab + 1];
     const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
     double acc = 0.0;
-    if (col < r)
-        for (long j = (long)s + rl; j < e; j += 4) {
-            double y = S.F[j * r + col] + S.U[k][j * r + col];
-            if (nonneg) y = fmax(y, 0.0);
-            acc = fma(y, y, acc);
+    if (col < r) {
+        // eight rows' loads in flight per step (round 6: one dependent load pair per row made this kernel 40 us on the 576-row
+        // matrices of a mid-size problem - the exact arithmetic serves up to 2^24 elements since the condition monitor); the
+        // squares are added in the order of the rows, as before
+        constexpr int UB = 8;
+        for (long j0 = (long)s + rl; j0 < e; j0 += 4 * UB) {
+            double yv[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const long j = min(j0 + 4 * u, (long)e - 1);
+                yv[u] = S.F[j * r + col] + S.U[k][j * r + col];
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (j0 + 4 * u < e) {
+                    double y = yv[u];
+                    if (nonneg) y = fmax(y, 0.0);
+                    acc = fma(y, y, acc);
+                }
         }
+    }
     sm[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x < 64 && col < r) colsq[(long)slab * r + col] = (sm[col] + sm[64 + col]) + (sm[128 + col] + sm[192 + col]);
@@ -594,9 +609,10 @@ __global__ __launch_bounds__(64) void k_wide_tv(WideRows W, WideState S, RegSet 
 // PARAFAC2 (penalties.py:1224-1250, 1280-1281) on the fp64 state: S_i = Y_i^T Y_i, Y = F + U; the polar factors through the
 // Jacobi / QR kernels of generic.hip (fp64 throughout; mcl_launch_pf2_jacobi_wide); P_i = Y_i T_i; Delta; dual step
 // ---------------------------------------------------------------------------------------------------------
+constexpr int WIDE_GRAM_ROWS = 64;
 __global__ __launch_bounds__(256) void k_wide_gram(WideRows W, WideState S, int k, int r, double *__restrict__ Sout) {
     MCL_GATE(W.gate);
-    extern __shared__ double wsm[];  // 16 rows x r of Y
+    extern __shared__ double wsm[];  // WIDE_GRAM_ROWS rows x r of Y
     const int slab = blockIdx.x;
     const long s = W.ext[slab];
     const int n = W.ext[slab + 1] - W.ext[slab];
@@ -605,8 +621,8 @@ __global__ __launch_bounds__(256) void k_wide_gram(WideRows W, WideState S, int 
     double acc[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) acc[q] = 0.0;
-    for (int j0 = 0; j0 < n; j0 += 16) {
-        const int nr = min(16, n - j0);
+    for (int j0 = 0; j0 < n; j0 += WIDE_GRAM_ROWS) {  // (64 rows per stage since round 6: a quarter of the barriers and load round trips; same order of the sums)
+        const int nr = min(WIDE_GRAM_ROWS, n - j0);
         __syncthreads();
         for (int e = threadIdx.x; e < nr * r; e += 256) wsm[e] = S.F[(s + j0) * r + e] + S.U[k][(s + j0) * r + e];
         __syncthreads();
@@ -860,7 +876,7 @@ int mcl_wide_phase(mcl_context *c, int mode) {
                         c->err = "PARAFAC2 constraint can only be imposed with mode=1";
                         return 1;
                     }
-                    hipLaunchKernelGGL(k_wide_gram, dim3((unsigned)c->I), dim3(256), sizeof(double) * 16 * r, c->stream, W, S, k, r, c->pf2_S);
+                    hipLaunchKernelGGL(k_wide_gram, dim3((unsigned)c->I), dim3(256), sizeof(double) * WIDE_GRAM_ROWS * r, c->stream, W, S, k, r, c->pf2_S);
                     if (int rc = mcl_launch_pf2_jacobi_wide(c, k, S.F, S.U[k], S.D)) return rc;
                     hipLaunchKernelGGL(k_wide_pf2_apply, dim3(wide_grid(W, r)), dim3(64), sm_one, c->stream, W, S, k, r,
                                        (const double *)c->pf2_T64, rs.aux[k]);

@@ -206,7 +206,7 @@ def test_ill_conditioned_penalty_free_modes(seed):
                 os.environ["MCL_EXACT"] = old
 
     exact, fast = run(True), run(False)
-    worst = lambda e: max(v for k, v in e.items() if not (k[0] == "P" and k[1] != "D"))
+    worst = lambda e: max(v for k, v in e.items() if k != "gaps" and not (k[0] == "P" and k[1] != "D"))
     print(seed, f"exact products {worst(exact):.1e}   fast kernels {worst(fast):.1e}")
     assert worst(exact) < 1e-5, exact
     assert worst(fast) > worst(exact)

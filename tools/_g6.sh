@@ -1,0 +1,15 @@
+mkdir -p gpurun_out/r6
+python -m pytest tests/test_gpu_end_to_end.py tests/test_gpu_phase_parity.py -m gpu -q -x > gpurun_out/r6/t6_e2e.log 2>&1; echo "rc e2e $?" >> gpurun_out/r6/t6_e2e.log; tail -3 gpurun_out/r6/t6_e2e.log
+for cfg in c4 c5s; do
+  python bench.py --config $cfg --steps 20 --warmup 3 --no-api --no-cpu-baseline > gpurun_out/r6/t6_bench_${cfg}_new.json 2> gpurun_out/r6/t6_bench_${cfg}_new.err
+  MCL_NO_ROW_PREFETCH=1 python bench.py --config $cfg --steps 20 --warmup 3 --no-api --no-cpu-baseline > gpurun_out/r6/t6_bench_${cfg}_old.json 2> gpurun_out/r6/t6_bench_${cfg}_old.err
+done
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r6/t6_bench_*.json')):
+    try:
+        d=json.load(open(f)); ch=[e for e in d['roofline']['per_kernel'] if 'chained' in e['role']]
+        print(f.split('t6_bench_')[1], d['value'], d['ms_per_step'], [(e['kernel'][:40], e['launches_per_step'], e['avg_us'], e['frac']) for e in ch])
+    except Exception as e: print(f, 'ERR', e)
+PY
+bash tools/evidence_round.sh 6 c5 5 sq 30 > gpurun_out/r6/t6_ev_c5.log 2>&1; echo "rc $?" >> gpurun_out/r6/t6_ev_c5.log; tail -5 gpurun_out/r6/t6_ev_c5.log

@@ -23,7 +23,8 @@ READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 # the kernels the iteration time of the BASELINE configurations is made of: held to the committed baseline
 HOT = [r"^k_sweep<", r"^k_contract_x", r"^k_rows_finish_solve_stats<", r"^k_rows_finish_fused<", r"^k_rows_solve_stats<",
-       r"^k_pf2_algebra_ns<", r"^k_slab_unimodal_v4<", r"^k_rows_fused<", r"^k_reduce_frag", r"^k_A_finish_rows", r"^k_C_finish_multi"]
+       r"^k_pf2_algebra_ns<", r"^k_slab_unimodal_v4<", r"^k_rows_fused<", r"^k_reduce_frag", r"^k_A_finish_rows", r"^k_C_finish_multi",
+       r"k_rows_chain_(first|mid|last)<"]
 
 
 def code_objects(lib=LIB):
@@ -71,7 +72,7 @@ def resources(lib=LIB):
                              scratch_bytes=get("private_segment_fixed_size"), lds_bytes=get("group_segment_fixed_size"),
                              max_workgroup=get("max_flat_workgroup_size")))
     for r, n in zip(rows, demangle([r["mangled"] for r in rows])):
-        r["kernel"] = re.sub(r"^void ", "", n).split("(")[0]
+        r["kernel"] = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "").split("(")[0]
         r["occupancy"] = min(8, 512 // max(8, -(-r["vgpr_count"] // 8) * 8))
     return sorted(rows, key=lambda r: r["kernel"])
 
