@@ -6,11 +6,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmatcouply_hip.so")
-SOURCES = ["contract.hip", "admm.hip", "generic.hip", "unimodal.hip", "sweep.hip", "reconstruct.hip", "wide.hip", "svdinit.hip", "cond.hip", "rowchain.hip", "api.hip"]
+SOURCES = ["contract.hip", "admm.hip", "generic.hip", "unimodal.hip", "sweep.hip", "reconstruct.hip", "wide.hip", "svdinit.hip", "cond.hip", "rowchain.hip", "xclds.hip", "api.hip"]
 # per-file compiler options.  The kernel files: let small MFMA results live in VGPRs - by default the register allocator parks
 # the 4-register accumulators of e.g. the sweep's inner loop / X C product in AGPRs and copies them back for every VALU use
 # (468 v_accvgpr_* instructions in the config-3 sweep, 129 with the option; no scratch either way)
-EXTRA_FLAGS = {f: ["-mllvm", "-amdgpu-mfma-vgpr-form=1"] for f in ("sweep.hip", "contract.hip", "generic.hip", "admm.hip", "unimodal.hip", "rowchain.hip")}
+EXTRA_FLAGS = {f: ["-mllvm", "-amdgpu-mfma-vgpr-form=1"] for f in ("sweep.hip", "contract.hip", "generic.hip", "admm.hip", "unimodal.hip", "rowchain.hip", "xclds.hip")}
 
 
 def _stale():

@@ -956,7 +956,7 @@ static int launch_xt(mcl_context *c) {
     } while (0)
     if (vec) {
         if (depth == 2) MCL_XT(4, 2, RMODE, grid);
-        else MCL_XT(4, 4, RMODE, grid);
+        else MCL_XT(4, 4, RMODE, grid);  // (round 6: eight groups in flight measured 13.57 against 13.91 ms at config 5 - not taken)
     } else {
         MCL_XT(1, 2, RMODE, grid);
     }
@@ -1042,6 +1042,15 @@ static int launch_xc(mcl_context *c) {
         if (c->x_streams) MCL_XCR_(CREG_, GRAM_, true);                                                               \
         else MCL_XCR_(CREG_, GRAM_, false);                                                                           \
     } while (0)
+        if (n_segs > 0 && !creg && mcl_try_contract_xc_lds(c, gram)) {
+            // K % 512 == 0 with the fragment image of C resident in LDS and four X tiles in flight per wave (xclds.hip)
+            c->xc_did_gram = gram != 0;
+            char bufl[96];
+            snprintf(bufl, sizeof bufl, "k_contract_xc_lds<NB=%d,GRAM=%d>", NB, gram);
+            c->variant[MCL_PROF_XC] = bufl;
+            MCL_CHECK_HIP(c, hipGetLastError());
+            return 0;
+        }
         if (n_segs > 0) {
             if constexpr (NB == 1) {  // resident C fragments: K = 256, rank <= 16 only
                 if (creg && !c->sw.xc_depth1) {  // two blocks of X in flight per wave

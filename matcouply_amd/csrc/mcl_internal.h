@@ -82,10 +82,10 @@ struct mcl_switches {
     bool no_sweep = false, no_pass_chain = false, no_pf2_delta_fusion = false, ns_plain = false, pf2_jacobi = false;
     bool no_stack_fusion = false, no_solve_stats = false, no_next_b = false, no_fused_gram = false, no_fused_c = false;
     bool a_finish_cols = false, xc_norow = false, uni_noprune = false, stats_reduce = false;
-    bool no_rows64 = false, no_uni_coop = false, no_wide = false, no_row_prefetch = false;
+    bool no_rows64 = false, no_uni_coop = false, no_wide = false, no_row_prefetch = false, no_xc_lds = false;
     bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_x_nt = false, no_sweep_half = false, no_multi_c = false, no_diag_defer = false, xc_depth1 = false;
     int x_nt_mb = 0, seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
-    int xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
+    int xc_lds_depth = 0, xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
     int exact = -1;  // MCL_EXACT: 1 / 0 force the exact-products mode on / off (default -1: by problem size, mcl_exact_mode)
     long run_spins = 2000;          // mcl_run: polite spins of a wait before it starts to sleep (MCL_RUN_SPINS)
     bool test_mute_verdict = false;  // MCL_TEST_MUTE_VERDICT: mcl_run's verdict kernels report into scratch (watchdog test)
@@ -386,6 +386,7 @@ int mcl_launch_exact_xc(mcl_context *c);                         // contract.hip
 int mcl_launch_exact_gr(mcl_context *c);                         // contract.hip: GR = [G | R] of this rank's slabs, exact products
 int mcl_launch_unimodal(mcl_context *c, const int *ext, int n_slabs, float *F, const RegSet &rs, int mode, int k);  // unimodal.hip
 int mcl_launch_gl2_value(mcl_context *c, int mode, int k, double *out);  // generic.hip: sum over slabs of trace(F^T M F)
+int mcl_try_contract_xc_lds(mcl_context *c, int gram);  // xclds.hip: X C with the fragment image of C resident in LDS
 int mcl_try_rows_chain_mid(mcl_context *c, const ModeView &mv, const float *rhs, bool vec, bool rows64);  // rowchain.hip
 int mcl_try_rows_chain_first(mcl_context *c, const ModeView &mv, const float *rhs, bool vec, bool rows64);
 int mcl_try_rows_chain_last(mcl_context *c, const ModeView &mv, bool vec, bool rows64, double *diag, int want_diag);
