@@ -577,7 +577,7 @@ def main():
         exists; counters are collected in separate runs, never inside this one."""
         if world != 1:
             return None, None
-        for rnd in ("r5", "r4", "r3", "r2", "r1"):
+        for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
             path = os.path.join(REPO, "profiles", f"{rnd}_{args.config}_pmc_traffic.json")
             if os.path.exists(path):
                 with open(path) as f:
@@ -608,7 +608,8 @@ def main():
         base = kernel_variant.split("<")[0].split(" ")[0]
         # a site that launches several kernel forms (chained row passes): the launch-weighted mean of its kernels
         hits = [v for name, v in pmc_kernels.items() if name.split("<")[0] == base or
-                (base == "k_rows_finish_solve_stats" and name.split("<")[0] in ("k_rows_solve_stats", "k_rows_finish_fused"))]
+                (base == "k_rows_finish_solve_stats" and name.split("<")[0] in ("k_rows_solve_stats", "k_rows_finish_fused")) or
+                (base == "k_rows_chain_first" and name.split("<")[0].startswith("k_rows_chain_"))]
         if not hits:
             return None
         n = sum(v["launches"] for v in hits)

@@ -2262,6 +2262,8 @@ int mcl_launch_rows_finish_fused(mcl_context *c, int mode, bool want_diag) {
     if (mode == 1) c->variant[MCL_PROF_ROWS_CHAIN] = mcl_rows64(c) ? "k_rows_finish_solve_stats<R64> chain (solve_stats -> finish_solve_stats x (n-1) -> finish_fused)" : "k_rows_finish_solve_stats chain (solve_stats -> finish_solve_stats x (n-1) -> finish_fused)";
     if (mode == 1 && mcl_try_rows_chain_last(c, mv, vec, mcl_rows64(c), diag, want_diag ? 1 : 0)) {
         // (rowchain.hip: software-pipelined form)
+        c->variant[MCL_PROF_ROWS_CHAIN] = mcl_rows64(c) ? "k_rows_chain_first<R64> -> k_rows_chain_mid x (n-1) -> k_rows_chain_last (software-pipelined chain)"
+                                                         : "k_rows_chain_first -> k_rows_chain_mid x (n-1) -> k_rows_chain_last (software-pipelined chain)";
     } else if (mode == 1 && mcl_rows64(c)) {  // rank <= 16 with a PARAFAC2 member: fp64 row algebra
         if (vec)
             hipLaunchKernelGGL((k_rows_finish_fused<1, true, true>), grid, block, 0, c->stream, mv, rs, c->r, (const float *)c->pf2_T,

@@ -143,12 +143,15 @@ def _mid_state(seed):
 
 
 # Round 6, 400 draws (MCL_FUZZ_MID_SEEDS=400 MCL_FUZZ_REPORT_ONLY=1): 398 inside the flat bar with the default call - round 5's
-# kernels alone (no condition monitor): 364 of 400; every draw the fast kernels leave outside has a penalty-free mode or an
+# kernels alone (no condition monitor): 25 of the 400 had a quantity above 1e-5; every draw the fast kernels leave outside has a penalty-free mode or an
 # ill-conditioned PARAFAC2 polar factor.  The two left: 18 (A and B free, unimodality on C: A at 1.4e-5 in the exact arithmetic
 # too - fp32 storage of B and C between the phases in front of A systems of condition ~1e5) and 327 (a PARAFAC2 basis P_i at
 # 1.6e-5 where its bound max(1e-5, 1e-8 cond) is 1e-5: conditioning 1e3, just under the polar trigger).  18 lies in the suite's
 # range: pinned, strictly.
 MID_OUTSIDE = {18: "A at 1.4e-5 in either arithmetic: fp32 state storage in front of penalty-free A systems of condition ~1e5"}
+
+
+_MID_ARITHMETIC = {}  # seed -> which arithmetic the default call chose (filled by the runs of this module)
 
 
 def _mid_params(n):
@@ -157,12 +160,16 @@ def _mid_params(n):
 
 
 @pytest.mark.parametrize("seed", _mid_params(int(os.environ.get("MCL_FUZZ_MID_SEEDS", 48))))  # MCL_FUZZ_MID_SEEDS=400: extended sweep
-def test_random_mid_size_configuration(seed):
+def test_random_mid_size_configuration(seed, monkeypatch):
     """Flat 1e-5 after two outer iterations, default arithmetic, on problems of the size range where the fast kernels are
     the default (reference: decomposition.py:945-1053 through the oracle)."""
+    switched = []
+    orig = _engine_mod.HipEngine.set_exact
+    monkeypatch.setattr(_engine_mod.HipEngine, "set_exact", lambda self, exact=True: (switched.append(bool(exact)), orig(self, exact))[1])
     case, st = _mid_state(seed)
     cmf, admm, diag, res = _run_both(st, 2)
-    label = f"mid {seed} " + str({k: case[k] for k in ("I", "K", "r", "const", "inner")}) + f" rows {int(case['J'].sum())} " + \
+    _MID_ARITHMETIC[seed] = "exact" if switched else "fast"
+    label = f"mid {seed} [{_MID_ARITHMETIC[seed]}] " + str({k: case[k] for k in ("I", "K", "r", "const", "inner")}) + f" rows {int(case['J'].sum())} " + \
         str([[d["kind"] for d in m] for m in case["regs"]])
     try:
         errs = _compare(cmf, admm, diag, st, res, 1e-5, 1e-5)
@@ -175,6 +182,18 @@ def test_random_mid_size_configuration(seed):
         return
     flat = max(v for k, v in errs.items() if k != "gaps" and not (k[0] == "P" and k[1] != "D"))
     print(label, f"inside: worst {flat:.1e} gaps {errs['gaps']:.2f} polar cond {res['polar_cond']:.0e}")
+
+
+def test_mid_size_leg_runs_both_arithmetics():
+    """The leg above must keep covering the kernels of the BASELINE configurations: the condition monitor moves the draws with
+    an ill-conditioned penalty-free mode or PARAFAC2 polar factor to the exact arithmetic, the others stay on the fast
+    kernels - of the suite's 48 draws at least a third each way (the small-problem fuzz never touched the
+    benchmarked kernels)."""
+    if len(_MID_ARITHMETIC) < 40:
+        pytest.skip("needs the mid-size leg of this module to have run in the same session")
+    n_fast = sum(v == "fast" for v in _MID_ARITHMETIC.values())
+    print(f"mid-size leg: {n_fast} draws on the fast kernels, {len(_MID_ARITHMETIC) - n_fast} in the exact arithmetic")
+    assert n_fast >= len(_MID_ARITHMETIC) // 3 and len(_MID_ARITHMETIC) - n_fast >= len(_MID_ARITHMETIC) // 6
 
 
 @pytest.mark.parametrize("seed", [45, 135, 142, 237])
