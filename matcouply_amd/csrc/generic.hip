@@ -783,6 +783,17 @@ __global__ __launch_bounds__(256) void k_pf2_gram(const int *__restrict__ ext, c
     }
 }
 
+// Synchronisation of ONE wave with itself around its LDS traffic.  The LDS operations of a wave are executed in the order
+// they were issued, so a value written by one lane is there for the next read of another lane of the same wave: what is needed is
+// that the compiler keeps that order.  (A workgroup barrier would also do in a one-wave workgroup - where the compiler drops it -
+// but the Newton-Schulz kernel runs FOUR independent slabs per workgroup at rank <= 16, each wave on its own way through the
+// fallbacks: a real barrier there would wait for waves that never come.)
+static __device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // One slab through the Jacobi route (one wave; `smd` = 4 r^2 + r doubles of LDS, `Ssrc` = the slab's S in any address
 // space).  Called by the stand-alone kernel below and by k_pf2_algebra_ns for the slabs it cannot handle.
 static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const float *__restrict__ Delta, double rh, int r,
@@ -796,7 +807,7 @@ static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const fl
         D[e] = Delta64 != nullptr ? Delta64[e] : (double)Delta[e];  // (the fp64 state of wide.hip, or the caller's fp32 matrix)
         V[e] = ((e / r) == (e % r)) ? 1.0 : 0.0;
     }
-    __syncthreads();
+    wave_sync_lds();
     // G = D S D^T  (via tmp = S D^T stored in V's place is not possible: V must stay I) -> two-step through lam-free loop
     for (int e = lane; e < n2; e += 64) {
         const int a = e / r, b = e - a * r;
@@ -808,7 +819,7 @@ static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const fl
         }
         G[e] = sum;
     }
-    __syncthreads();
+    wave_sync_lds();
     // Jacobi eigen-decomposition of the symmetric G (fp64); V accumulates the eigenvectors.  Round 6: PARALLEL ordering - in
     // each of the n - 1 steps of a sweep the n / 2 disjoint index pairs of a round-robin tournament are rotated at once
     // (Brent-Luk), where rounds 2-5 walked the r (r - 1) / 2 pairs of a cyclic sweep one after the other: every rotation is two
@@ -840,7 +851,7 @@ static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const fl
                     p = min(a, b), q = max(a, b);
                     if (q >= r) p = -1;  // the bye
                 }
-                __syncthreads();
+                wave_sync_lds();
                 double cs = 1.0, sn = 0.0, dpp = 0.0, dqq = 0.0;
                 bool rot = false;
                 if (p >= 0) {
@@ -853,29 +864,29 @@ static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const fl
                         rot = true;
                     }
                 }
-                __syncthreads();
+                wave_sync_lds();
                 if (rot)  // columns p, q of G and V:  X <- X J
                     for (int k = k0; k < r; k += kstep) {
                         const double gkp = G[k * r + p], gkq = G[k * r + q], vkp = V[k * r + p], vkq = V[k * r + q];
                         G[k * r + p] = cs * gkp - sn * gkq, G[k * r + q] = sn * gkp + cs * gkq;
                         V[k * r + p] = cs * vkp - sn * vkq, V[k * r + q] = sn * vkp + cs * vkq;
                     }
-                __syncthreads();
+                wave_sync_lds();
                 if (rot)  // rows p, q of G:  G <- J^T G
                     for (int k = k0; k < r; k += kstep) {
                         const double gpk = G[p * r + k], gqk = G[q * r + k];
                         G[p * r + k] = cs * gpk - sn * gqk, G[q * r + k] = sn * gpk + cs * gqk;
                     }
-                __syncthreads();
+                wave_sync_lds();
                 if (rot && k0 == 0) {  // the rotated 2 x 2 block in closed form (exact zero off the diagonal)
                     G[p * r + p] = dpp, G[q * r + q] = dqq;
                     G[p * r + q] = 0.0, G[q * r + p] = 0.0;
                 }
             }
-            __syncthreads();
+            wave_sync_lds();
         }
     }
-    __syncthreads();
+    wave_sync_lds();
     double lmax = 0.0, lmin = 1e300;
     for (int k = 0; k < r; ++k) lmax = fmax(lmax, G[k * r + k]), lmin = fmin(lmin, G[k * r + k]);
     // G = (Y Delta^T)^T (Y Delta^T) squares the condition number: beyond cond(Y Delta^T) ~ 1e5 its small eigenvalues are
@@ -887,7 +898,7 @@ static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const fl
         const double l = G[lane * r + lane];
         lam[lane] = (l > 1e-14 * lmax && l > 0.0) ? 1.0 / sqrt(l) : 0.0;  // pseudo-inverse square root
     }
-    __syncthreads();
+    wave_sync_lds();
     // W = V diag(lam) V^T -> G
     for (int e = lane; e < n2; e += 64) {
         const int a = e / r, b = e - a * r;
@@ -895,7 +906,7 @@ static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const fl
         for (int k = 0; k < r; ++k) sum += V[a * r + k] * lam[k] * V[b * r + k];
         G[e] = sum;
     }
-    __syncthreads();
+    wave_sync_lds();
     // T = D^T W -> V
     for (int e = lane; e < n2; e += 64) {
         const int a = e / r, b = e - a * r;
@@ -903,7 +914,7 @@ static __device__ void pf2_jacobi_slab(double *smd, const double *Ssrc, const fl
         for (int k = 0; k < r; ++k) sum += D[k * r + a] * G[k * r + b];
         V[e] = sum;
     }
-    __syncthreads();
+    wave_sync_lds();
     for (int e = lane; e < n2; e += 64) {
         const int a = e / r, b = e - a * r;
         double sum = 0.0;
@@ -1156,34 +1167,52 @@ struct TileStats {
 #else
 #define NS_STAMP(i) do { } while (0)
 #endif
+// Slabs per workgroup.  Rank <= 16 (config 4: 1024 slabs = one per SIMD, the kernel lasts as long as its slowest slab): FOUR, one
+// wave each.  The waves of a workgroup are placed on the four SIMDs of its CU in turn, whereas the SIMD of a one-wave workgroup is
+// the dispatcher's choice - and with 4 such workgroups per CU it put two Newton-Schulz waves on one SIMD for 140 of 1024 slabs
+// (in-kernel HW_ID stamps, tools/ns_stamps.py: 70 SIMDs with two waves, 70 idle), where two fp64-MFMA chains run 1.3-1.5 x
+// slower each (2520 against 1900 cycles per step; tools/ns_valu_probe.hip: 1355 -> 1980 for the bare step).
+template <int NB>
+struct NsShape {
+    static constexpr int SPW = NB == 1 ? 4 : 1;
+};
 template <int NB, bool TILES>
-__global__ __launch_bounds__((TILES && NB == 1) ? 128 : 64) __attribute__((amdgpu_waves_per_eu(2))) void k_pf2_algebra_ns(double *__restrict__ S, const float *__restrict__ Delta,
+__global__ __launch_bounds__(64 * NsShape<NB>::SPW + ((TILES && NB == 1) ? 64 : 0)) __attribute__((amdgpu_waves_per_eu(2))) void k_pf2_algebra_ns(double *__restrict__ S, const float *__restrict__ Delta,
                                                        const float *__restrict__ rho, const int *__restrict__ ext, int r,
                                                        float *__restrict__ T, double *__restrict__ acc_out,
                                                        int *__restrict__ status, TileStats ts, RegSet regs,
                                                        float *__restrict__ xmin_est, int scaled, double *__restrict__ T64) {
     MCL_GATE(regs.gate);
     // S_i while the system is formed (TILES), then the scratch of the LDS transposes (the epilogue re-reads S_i from memory)
-    __shared__ double Ssm[(16 * NB) * (16 * NB + 1)];
-    __shared__ float Dsm[256 * NB * NB];
+    constexpr int SPW = NsShape<NB>::SPW;
+    __shared__ double Ssm_w[SPW][(16 * NB) * (16 * NB + 1)];
+    __shared__ float Dsm_w[SPW][256 * NB * NB];
     // rank <= 16: the Jacobi route of a slab this iteration cannot handle runs right here (8 KB of LDS; saves the launch of
     // the stand-alone kernel in every inner iteration); rank 32 would need 33 KB and lose a wave per CU, so those slabs are
     // left to k_pf2_algebra (status = 1)
     constexpr bool INK = NB == 1;
-    __shared__ double Jsm[INK ? 4 * 256 + 16 : 1];
-    const int slab = blockIdx.x, lane = threadIdx.x & 63;
+    __shared__ double Jsm_w[INK ? SPW : 1][INK ? 4 * 256 + 16 : 1];
+    const int wave = SPW == 1 ? 0 : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // (the column-sum wave has its own slabs below)
+    const int slab = SPW == 1 ? (int)blockIdx.x : min((int)blockIdx.x * SPW + (wave < SPW ? wave : 0), ts.n_slabs - 1);
+    auto &Ssm = Ssm_w[wave < SPW ? wave : 0];
+    auto &Dsm = Dsm_w[wave < SPW ? wave : 0];
+    auto &Jsm = Jsm_w[(INK && wave < SPW) ? wave : 0];
     const int q = lane >> 4, c16 = lane & 15;
     const int n2 = r * r;
     const double *Ss = S + (long)slab * n2;
     // The L2-ball column sums of the slab's tiles, in k_stats_reduce's order: two more memory round trips.  Rank <= 16 (one
     // slab per SIMD at config 4: the chain's latency is the kernel's duration): a SECOND wave takes them and is done; rank 32
     // (register-bound at two waves per SIMD: a second wave would halve the resident slabs) keeps them in front of the chain.
+    // (round 6: that wave is the FIFTH of the workgroup and takes the column sums of its four slabs, 16 lanes each)
     constexpr bool COLSQ_WAVE = TILES && NB == 1;
-    if (TILES && (COLSQ_WAVE ? threadIdx.x >= 64 : true)) {
-        const int t0 = ts.slab_tile_ptr[slab], t1 = ts.slab_tile_ptr[slab + 1];
+    if (TILES && (COLSQ_WAVE ? wave == SPW : true)) {
+        const int cslab = COLSQ_WAVE ? blockIdx.x * SPW + (lane >> 4) : slab;
+        const bool cs_ok = cslab < ts.n_slabs;
+        const int t0 = cs_ok ? ts.slab_tile_ptr[cslab] : 0, t1 = cs_ok ? ts.slab_tile_ptr[cslab + 1] : 0;
         for (int k = 0; k < regs.n; ++k) {
             if (regs.kind[k] != MCL_PEN_L2BALL) continue;
-            for (int col = lane; col < r; col += 64) {
+            for (int col = COLSQ_WAVE ? (lane & 15) : lane; col < r; col += (COLSQ_WAVE ? 16 : 64)) {
                 double sq = 0.0;
                 for (int tb = t0; tb < t1; tb += 8) {  // ascending order, 8 loads in flight
                     double v[8];
@@ -1193,15 +1222,22 @@ __global__ __launch_bounds__((TILES && NB == 1) ? 128 : 64) __attribute__((amdgp
                     for (int u = 0; u < 8; ++u)
                         if (tb + u < t1) sq += v[u];
                 }
-                ts.colsq[((long)k * ts.n_slabs + slab) * r + col] = sq;
+                if (cs_ok) ts.colsq[((long)k * ts.n_slabs + cslab) * r + col] = sq;
             }
         }
         if (COLSQ_WAVE) return;
     }
+    if (SPW > 1 && (int)blockIdx.x * SPW + wave >= ts.n_slabs) return;  // the last workgroup's spare waves (nothing below is a workgroup barrier)
 #ifdef MCL_NS_STAMPS
-    long long *stamps = reinterpret_cast<long long *>(xmin_est + gridDim.x);  // the plan reserves 8 int64 per slab behind pf2_xmin
+    long long *stamps = reinterpret_cast<long long *>(xmin_est + ts.n_slabs);  // the plan reserves 8 int64 per slab behind pf2_xmin
 #endif
     NS_STAMP(0);
+#ifdef MCL_NS_STAMPS  // where the wave runs: HW_REG_HW_ID (wave, SIMD, CU, SH, SE) and HW_REG_XCC_ID
+    if (lane == 0) {
+        stamps[(long)slab * 8 + 6] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        stamps[(long)slab * 8 + 7] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
     // everything this wave needs besides the statistics is requested up front, so its latency overlaps the tile loop:
     // the slab's extent and weight, and Delta (staged in LDS; every product below reads it from there)
     const int slab_rows = ext[slab + 1] - ext[slab];
@@ -1255,7 +1291,8 @@ __global__ __launch_bounds__((TILES && NB == 1) ? 128 : 64) __attribute__((amdgp
             }
         }
     }
-    __syncthreads();
+    if constexpr (SPW == 1) __syncthreads();  // (a one-wave workgroup: the compiler drops the barrier instruction)
+    else wave_sync_lds();
     NS_STAMP(1);
     auto Sat = [&](int i, int j) -> double {
         if (TILES) return (i < r && j < r) ? Ssm[i * r + j] : 0.0;
@@ -2080,7 +2117,8 @@ int mcl_launch_generic_prox_local(mcl_context *c, int mode, int k) {
                 TileStats ts{c->slab_tile_ptr, c->stat_gram, c->stat_colsq, c->colsq, 16 * c->NB, (int)c->I};
                 const bool tiles = c->stats_in_solve && mcl_stats_reduce_in_algebra(c);
 #define MCL_NS(NB_, TILES_)                                                                                          \
-    hipLaunchKernelGGL((k_pf2_algebra_ns<NB_, TILES_>), dim3((unsigned)c->I), dim3(((TILES_) && (NB_) == 1) ? 128 : 64), 0, c->stream, c->pf2_S, \
+    hipLaunchKernelGGL((k_pf2_algebra_ns<NB_, TILES_>), dim3((unsigned)((c->I + NsShape<NB_>::SPW - 1) / NsShape<NB_>::SPW)),                   \
+                       dim3(64 * NsShape<NB_>::SPW + (((TILES_) && (NB_) == 1) ? 64 : 0)), 0, c->stream, c->pf2_S,                  \
                        rs.aux2[k], c->rhoB, mv.ext, r, c->pf2_T, c->pf2_acc, c->pf2_status, ts, rs, c->pf2_xmin,     \
                        c->sw.ns_plain ? 0 : 1, c->pf2_T64)
                 c->variant[MCL_PROF_PF2] = std::string("k_pf2_algebra_ns<NB=") + std::to_string(c->NB) + (tiles ? ",TILES> (+ k_pf2_sum_delta)" : "> (+ k_pf2_sum_delta)");

@@ -36,3 +36,20 @@ for i in fast:
 print("corr(steps, ticks/step) = %.2f; corr(J, prologue) = %.2f" % (np.corrcoef(steps, d[:, 2] / np.maximum(steps, 1))[0, 1], np.corrcoef(J, d[:, 0])[0, 1]))
 t0 = st[:, 0].min()
 print("kernel span: first entry -> last exit %.0f ticks; entries spread %.0f; exits spread %.0f" % (st[:, 4].max() - t0, st[:, 0].max() - t0, st[:, 4].max() - st[:, 4].min()))
+
+# where the waves ran (HW_REG_HW_ID: wave [3:0], SIMD [5:4], pipe [7:6], CU [11:8], SH [12], SE [15:13]; HW_REG_XCC_ID [3:0])
+hw, xcc = st[:, 6], st[:, 7] & 0xf
+simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 0xf, (hw >> 12) & 1, (hw >> 13) & 7
+key = ((((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd)
+uniq, cnt = np.unique(key, return_counts=True)
+print("SIMDs used: %d; with 1 / 2 / 3+ Newton-Schulz waves: %d / %d / %d" % (len(uniq), (cnt == 1).sum(), (cnt == 2).sum(), (cnt >= 3).sum()))
+cukey = (((xcc * 8 + se) * 2 + sh) * 16 + cu)
+cu_u, cu_c = np.unique(cukey, return_counts=True)
+print("CUs used: %d; waves per CU histogram: %s" % (len(cu_u), dict(zip(*np.unique(cu_c, return_counts=True)))))
+per_simd = dict(zip(uniq, cnt))
+shared = np.array([per_simd[k] for k in key])
+tps = d[:, 2] / np.maximum(steps, 1)
+for n in sorted(set(shared)):
+    m = shared == n
+    print("  waves on a SIMD with %d such wave(s): %d, loop ticks per step mean %.0f, whole-slab ticks mean %.0f" % (n, m.sum(), tps[m].mean(), tot[m].mean()))
+print("per XCD, (SE, SH) -> CUs used:", {int(x): sorted(set(zip(se[xcc == x].tolist(), sh[xcc == x].tolist()))) for x in np.unique(xcc)[:2]})
