@@ -218,6 +218,7 @@ void read_switches(mcl_switches &w) {
     w.no_wide = flag("MCL_NO_WIDE");
     w.no_row_prefetch = flag("MCL_NO_ROW_PREFETCH");
     w.no_xc_lds = flag("MCL_NO_XC_LDS");
+    w.uni_wpb = num("MCL_UNI_WPB", 0);
     w.xc_lds_depth = num("MCL_XC_LDS_DEPTH", 0);
     w.test_mute_verdict = flag("MCL_TEST_MUTE_VERDICT");  // test hook of the mcl_run watchdog, not a kernel form
     if (const char *e = getenv("MCL_RUN_SPINS")) w.run_spins = atol(e);  // operating parameter of mcl_run's wait (see there)
@@ -235,7 +236,7 @@ std::string switches_in_env() {
         "MCL_UNI_NOPRUNE", "MCL_STATS_REDUCE", "MCL_NO_ROWS64", "MCL_NO_UNI_COOP", "MCL_NO_A_FUSION", "MCL_NO_A_WIDE", "MCL_NO_BSEG_GROUPS",
         "MCL_NO_SWEEP_HALF", "MCL_NO_X_NT", "MCL_X_NT_MB", "MCL_NO_MULTI_C", "MCL_NO_DIAG_DEFER", "MCL_XC_DEPTH1", "MCL_SEG_ROWS",
         "MCL_BSEG_ROWS", "MCL_XC_WAVES", "MCL_XT_WAVES", "MCL_SWEEP_WAVES", "MCL_XC_DBG", "MCL_XT_DBG", "MCL_XT_DEPTH",
-        "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT", "MCL_EXACT", "MCL_NO_WIDE", "MCL_NO_ROW_PREFETCH", "MCL_NO_XC_LDS", "MCL_XC_LDS_DEPTH"};
+        "MCL_SWEEP_DBG", "MCL_REDUCE_EL", "MCL_UNI_SPLIT", "MCL_EXACT", "MCL_NO_WIDE", "MCL_NO_ROW_PREFETCH", "MCL_NO_XC_LDS", "MCL_XC_LDS_DEPTH", "MCL_UNI_WPB"};
     std::string out;
 #ifdef MCL_NO_ENV_SWITCHES
     return out;

@@ -1395,8 +1395,10 @@ __global__ __launch_bounds__(64 * NsShape<NB>::SPW + ((TILES && NB == 1) ? 64 : 
         double ca = 1.5, cb = 0.5;
         const bool watch = !scaled || (1.f - flo) < 1e-2f;  // the end is near: measure the residual from here on
         if (scaled && (1.f - flo) >= 1e-3f) {
-            const float ss = fhi * fhi + fhi * flo + flo * flo, sq = __builtin_sqrtf(ss * (1.f / 3.f));
-            const float fb = 2.f / ((2.f / 3.f) * ss * sq + flo * fhi * (flo + fhi));
+            // (the hardware's own square root and reciprocal - one instruction each, 1 ulp - where the library forms spent ~45
+            // instructions per step on correct rounding and denormals: these coefficients only steer the speed of convergence)
+            const float ss = fhi * fhi + fhi * flo + flo * flo, sq = __builtin_amdgcn_sqrtf(ss * (1.f / 3.f));
+            const float fb = 2.f * __builtin_amdgcn_rcpf((2.f / 3.f) * ss * sq + flo * fhi * (flo + fhi));
             const float fa = fb * ss;
             const float e = (2.f / 3.f) * fa * sq - 1.f;
             ca = (double)fa, cb = (double)fb;
@@ -1445,7 +1447,7 @@ __global__ __launch_bounds__(64 * NsShape<NB>::SPW + ((TILES && NB == 1) ? 64 : 
             // a lower bound that was too optimistic (an eigenvalue below the assumed lo): the prediction is ahead of the
             // iterate - fall back to measuring, i.e. keep the predicted interval no tighter than the certified one
             // (|1 - x^2| <= ||I - Z Y||_F for every eigenvalue x^2 of Z Y, so x >= 1 - ||I - Z Y||_F)
-            if (scaled) flo = fminf(flo, res < 1.0 ? 1.f - __builtin_sqrtf((float)res) : 0.1f);
+            if (scaled) flo = fminf(flo, res < 1.0 ? 1.f - __builtin_amdgcn_sqrtf((float)res) : 0.1f);
         }
         mm_t<NB>(Yt, Tm, N1);            // Y  <- Y T
         mm_t<NB>(Tmt, Z, N3);            // Z  <- T Z

@@ -85,7 +85,7 @@ struct mcl_switches {
     bool no_rows64 = false, no_uni_coop = false, no_wide = false, no_row_prefetch = false, no_xc_lds = false;
     bool no_a_fusion = false, no_a_wide = false, no_bseg_groups = false, no_x_nt = false, no_sweep_half = false, no_multi_c = false, no_diag_defer = false, xc_depth1 = false;
     int x_nt_mb = 0, seg_rows = 0, bseg_rows = 0, xc_waves = 0, xt_waves = 0, sweep_waves = 0;  // 0: default
-    int xc_lds_depth = 0, xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
+    int uni_wpb = 0, xc_lds_depth = 0, xc_dbg = 0, xt_dbg = 0, xt_depth = 0, sweep_dbg = 0, reduce_el = 0, uni_split = -1;
     int exact = -1;  // MCL_EXACT: 1 / 0 force the exact-products mode on / off (default -1: by problem size, mcl_exact_mode)
     long run_spins = 2000;          // mcl_run: polite spins of a wait before it starts to sleep (MCL_RUN_SPINS)
     bool test_mute_verdict = false;  // MCL_TEST_MUTE_VERDICT: mcl_run's verdict kernels report into scratch (watchdog test)

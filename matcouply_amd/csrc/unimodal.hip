@@ -268,19 +268,34 @@ static __device__ __forceinline__ int wave_min_i(int v) {
 // MODE 1 + MODE 2: few columns (less than about one wave per SIMD) - the two sweeps run concurrently in different waves
 // (direction = block parity; the right-to-left one stores its errors instead of searching the split), then a second
 // launch searches the split with the same comparisons in the same order and emits.  Halves the serial chain.
-template <int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const int *__restrict__ ext, int n_slabs, float *__restrict__ F,
+// WPB (MODE 3): independent waves per workgroup.  With one-wave workgroups the SIMD of every wave is the dispatcher's choice, and
+// eight of them per CU (the LDS rings allow two per SIMD) do not land two per SIMD (round 6: the PARAFAC2 Newton-Schulz kernel
+// had 14 % of its waves doubled up on a SIMD with another SIMD idle, HW_ID stamps); the waves of ONE workgroup are placed on the
+// four SIMDs in turn.  WPB = 4: four column groups per workgroup, rings in dynamic LDS (80 KB), two workgroups per CU.
+// (Round 6, measured and dropped: a PERSISTENT form - as many workgroups as the device holds, every wave drawing column groups from a
+// counter, so that four waves do not wait for the slowest of them before the next four start - is no faster: 95.2 / 97.7 ms per
+// config-5 iteration against 94.2 / 96.9, same box; two waves per workgroup, which the dispatcher puts on SIMD pairs, 104-105.)
+template <int MODE, int WPB = 1>
+__global__ __launch_bounds__(MODE == 2 ? 256 : 64 * WPB) __attribute__((amdgpu_waves_per_eu(2))) void k_slab_unimodal_v4(const int *__restrict__ ext, int n_slabs, float *__restrict__ F,
                                                          RegSet regs, int k, int r, UniScratch sc) {
     MCL_GATE(regs.gate);
+    static_assert(WPB == 1 || MODE == 3, "several independent waves per workgroup: the throughput form only");
     // ring entries per lane and entries per refill (see the defaults above; round 4 re-measured RC = 8 / NRF = 4 / UB = 4 at
     // three waves per SIMD: 14.5 ms against 10.2 ms per call at config 5 - the depth of the load batches matters more)
     constexpr int RC = MCL_UNI_RC, NRF = MCL_UNI_NRF;
-    __shared__ double ring_d[2][MODE == 2 ? 1 : RC * 64];
-    __shared__ int ring_i[MODE == 2 ? 1 : RC * 64];
+    __shared__ double ring_d_st[2][(MODE == 2 || WPB > 1) ? 1 : RC * 64];
+    __shared__ int ring_i_st[(MODE == 2 || WPB > 1) ? 1 : RC * 64];
+    extern __shared__ double ring_dyn[];  // WPB > 1: per wave [2][RC * 64] doubles + [RC * 64] ints
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;  // MODE 2: four waves work on the same 64 columns
+    double (*ring_d)[(MODE == 2 || WPB > 1) ? 1 : RC * 64] = ring_d_st;
+    int *ring_i = ring_i_st;
+    double *ring_sy = WPB > 1 ? ring_dyn + (long)wv * (2 * RC * 64 + RC * 32) : &ring_d[0][0];
+    double *ring_q = WPB > 1 ? ring_sy + RC * 64 : &ring_d[1][0];
+    int *ring_cw = WPB > 1 ? reinterpret_cast<int *>(ring_sy + 2 * RC * 64) : ring_i;
+    const unsigned wblk = WPB > 1 ? blockIdx.x * WPB + wv : blockIdx.x;  // this wave's column group
     const bool do_L = MODE == 0 || (MODE == 1 && (blockIdx.x & 1) == 0);  // (MODE 3 has its own schedule below)
     const bool do_R = MODE == 0 || (MODE == 1 && (blockIdx.x & 1) == 1);
-    const long t = (long)(MODE == 1 ? blockIdx.x >> 1 : blockIdx.x) * 64 + lane;
+    const long t = (long)(MODE == 1 ? blockIdx.x >> 1 : wblk) * 64 + lane;
     const bool live = t < (long)n_slabs * r;  // no early exit: the emit loops use wave-wide reductions
     const int slab = live ? (int)(t / r) : 0, col = live ? (int)(t - (long)slab * r) : 0;
     const int s = ext[slab], e = ext[slab + 1];
@@ -306,7 +321,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
 
     UniRing4 st;
     UniPrefetch<NRF> pf;
-    st.sy = ring_d[0], st.q = ring_d[1], st.cw = ring_i;
+    st.sy = ring_sy, st.q = ring_q, st.cw = ring_cw;
 #ifdef MCL_UNI_DBG
     st.dbg = sc.dbg;
     for (int i = 0; i < 8; ++i) st.c[i] = 0;
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
     } ctr_out{st, sc.ctr, lane, t_kernel0};
 #endif
     // byte addresses of this lane's slot 0 in the rings (the pooling loop addresses LDS itself)
-    const int lds_d = (int)lds_addr(&ring_d[0][0]) + lane * 8, lds_i = (int)lds_addr(&ring_i[0]) + lane * 4;
+    const int lds_d = (int)lds_addr(ring_sy) + lane * 8, lds_i = (int)lds_addr(ring_cw) + lane * 4;
     static_assert((RC & (RC - 1)) == 0, "ring indices wrap by masking");
     double csy, ccw, curQ, cum2;  // block being built (count kept as a double), Q including it, sum of y^2
     double tsy, tcw, tQ;          // cached top of the stack below it
@@ -806,7 +821,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_slab_unimodal_v4(const
     constexpr int EB = 16;
     const int nm1 = max(n - 1, 0);
     // stores of lanes that have nothing to write at a position go to a per-lane sink (an unused scratch array)
-    float *sink = sc.sink + ((long)blockIdx.x * 64 + lane) * 2 + (MODE == 2 ? wv : 0);
+    float *sink = sc.sink + ((long)wblk * 64 + lane) * 2 + (MODE == 2 ? wv : 0);
     if (MODE != 2 || wv == 0) {
         const UniRec *rp = recL + (long)s * rs + col;
         float *zp = Z + (long)s * rs + col;
@@ -926,7 +941,28 @@ int mcl_launch_unimodal(mcl_context *c, const int *ext, int n_slabs, float *F, c
 #ifdef MCL_UNI_DBG  // occupancy experiments: unused dynamic LDS limits the workgroups a CU holds (tools/uni_occ.py)
         pad = getenv("MCL_UNI_PAD_LDS") ? (size_t)atoi(getenv("MCL_UNI_PAD_LDS")) : 0;
 #endif
-        hipLaunchKernelGGL(k_slab_unimodal_v4<3>, dim3(nwav), dim3(64), pad, c->stream, ext, n_slabs, F, rs, k, c->r, sc);
+        constexpr size_t wave_lds = (size_t)(2 * MCL_UNI_RC * 64) * sizeof(double) + (size_t)(MCL_UNI_RC * 64) * sizeof(int);
+        // waves per workgroup: 4 (see the kernel), MCL_UNI_WPB = 1 / 2 / 4 for the A/B; the padded debug launches keep the one-wave form
+        int wpb = c->sw.uni_wpb > 0 ? c->sw.uni_wpb : 4;
+        if (pad != 0 || (wpb != 2 && wpb != 4)) wpb = 1;
+        static int attr_set[5] = {0, 0, 0, 0, 0};  // 0: not tried, 1: set, -1: refused
+        if (wpb > 1 && attr_set[wpb] == 0) {
+            const void *fn = wpb == 4 ? reinterpret_cast<const void *>(k_slab_unimodal_v4<3, 4>) : reinterpret_cast<const void *>(k_slab_unimodal_v4<3, 2>);
+            attr_set[wpb] = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpb * wave_lds)) == hipSuccess ? 1 : -1;
+            if (attr_set[wpb] < 0) (void)hipGetLastError();
+        }
+        if (wpb > 1 && attr_set[wpb] < 0) wpb = 1;
+#ifdef MCL_UNI_DBG
+        wpb = 1;  // the instrumented kernel has early exits: one-wave form only
+#endif
+        if (wpb == 4) {
+            c->variant[MCL_PROF_UNIMODAL] = "k_slab_unimodal_v4<3, WPB=4>";
+            hipLaunchKernelGGL((k_slab_unimodal_v4<3, 4>), dim3((nwav + 3) / 4), dim3(256), 4 * wave_lds, c->stream, ext, n_slabs, F, rs, k, c->r, sc);
+        } else if (wpb == 2) {
+            c->variant[MCL_PROF_UNIMODAL] = "k_slab_unimodal_v4<3, WPB=2>";
+            hipLaunchKernelGGL((k_slab_unimodal_v4<3, 2>), dim3((nwav + 1) / 2), dim3(128), 2 * wave_lds, c->stream, ext, n_slabs, F, rs, k, c->r, sc);
+        } else
+            hipLaunchKernelGGL(k_slab_unimodal_v4<3>, dim3(nwav), dim3(64), pad, c->stream, ext, n_slabs, F, rs, k, c->r, sc);
     }
     MCL_CHECK_HIP(c, hipGetLastError());
     return 0;

@@ -54,6 +54,10 @@ def test_the_kernels_of_the_baseline_configurations_fit_their_design_points(now)
     # rank-32 Newton-Schulz (config 5): TWO waves per SIMD - one wave issues an fp64 MFMA every ~143 cycles, the pipe takes one per 64
     assert now["k_pf2_algebra_ns<2, true>"]["occupancy"] >= 2
     # unimodal regressions, throughput forms: two waves per SIMD (the 20 KB LDS ring allows no more)
-    for mode in (0, 3):
-        u = now[f"k_slab_unimodal_v4<{mode}>"]
+    # (the default form, <3, 4>: four independent waves per workgroup with their rings in 80 KB of DYNAMIC LDS - two workgroups per CU)
+    for form in ("0, 1", "3, 1", "3, 4"):
+        u = now[f"k_slab_unimodal_v4<{form}>"]
         assert u["occupancy"] >= 2 and u["scratch_bytes"] == 0 and u["lds_bytes"] <= 20480
+    # rank <= 16 Newton-Schulz (config 4): four slabs per workgroup, one per SIMD - at most 256 registers, no scratch
+    ns = now["k_pf2_algebra_ns<1, true>"]
+    assert ns["occupancy"] >= 2 and ns["scratch_bytes"] == 0
