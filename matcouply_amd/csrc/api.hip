@@ -166,7 +166,7 @@ int64_t plan(mcl_context *c, char *base) {
         c->pf2_red = b.take<float>(r * r + 1);
         c->pf2_status = b.take<int>(I);
         c->pf2_qr = b.take<double>(N * r);  // Y_i Delta^T of the slabs k_pf2_polar_qr takes
-#ifdef MCL_NS_STAMPS
+#if defined(MCL_NS_STAMPS) || defined(MCL_UNI_STAMPS)
         c->pf2_xmin = b.take<float>(I + 16 * I + 64);  // + 8 int64 stamps per slab (tools/ns_stamps.py)
 #else
         c->pf2_xmin = b.take<float>(I);  // zeroed with the workspace: "no estimate yet"
@@ -402,6 +402,10 @@ int generic_inner_loop(mcl_context *c, int mode) {
         c->stats_in_solve = stats;
         c->pf2_delta_fused = !c->sw.no_pf2_delta_fusion;
         int rc = 0;
+        // (Round 6, measured and dropped: the PARAFAC2 algebra of an inner iteration does not depend on the unimodal regressions of
+        // the same iteration, and a launch of the regressions leaves 13-16 % of the device's wave slots idle - two rounds of long
+        // waves, tools/uni_stamps.py.  Run on a low-priority stream of the library's own beside the regressions, the algebra's
+        // waves do not wait for those gaps: the regressions take 10.3 instead of 7.6 ms, config 5 106 instead of 96 ms per iteration.)
         for (int k = 0; k < c->regs[mode].n && rc == 0; ++k) {
             rc = mcl_launch_generic_prox_local(c, mode, k);
             if (rc == 0) rc = mcl_launch_generic_prox_finish(c, mode, k);
@@ -1447,7 +1451,7 @@ float *mcl_internal_buffer(mcl_context *c, int32_t which, int64_t *count) {
         case MCL_BUF_PF2_GRAM: p = reinterpret_cast<float *>(c->pf2_S), n = c->pf2_S ? 2 * c->I * (int64_t)c->r * c->r : 0; break;
         case MCL_BUF_SWEEP_CYCLES: p = reinterpret_cast<float *>(c->sweep_cycles), n = c->sweep_cycles ? (int64_t)2048 * 6 * 2 : 0; break;
         case MCL_BUF_PF2_STATUS: p = reinterpret_cast<float *>(c->pf2_status), n = c->pf2_status ? c->I : 0; break;  // int32 bits
-#ifdef MCL_NS_STAMPS
+#if defined(MCL_NS_STAMPS) || defined(MCL_UNI_STAMPS)
         case MCL_BUF_NS_STAMPS: p = c->pf2_xmin, n = c->pf2_xmin ? 17 * c->I : 0; break;
 #endif
         // the planner's work-unit tables (int32 bits): segments of the X passes, bsegs of the sweep, and the first

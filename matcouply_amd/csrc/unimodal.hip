@@ -20,6 +20,9 @@
 struct UniScratch {
     double *lvL, *lvR, *eL, *eR;
     float *sink;  // two floats per lane: target of the emit loops' predicated-off stores
+#ifdef MCL_UNI_STAMPS  // instrumented builds (tools/uni_stamps.py): per column group [start, end (100 MHz), HW_ID, XCC_ID, sweeps done]
+    long long *stamps;
+#endif
     int coop;     // cooperative ring refill (ur4_refill_coop); 0: MCL_NO_UNI_COOP (A/B switch)
     double *spL, *spR;  // packed spill areas (3 doubles per entry) of the left-to-right / right-to-left sweep
 // ring entries per lane / entries per refill / elements per load batch (build-time; the defaults are the measured best)
@@ -293,6 +296,10 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64 * WPB) __attribute__((amdgpu_w
     double *ring_q = WPB > 1 ? ring_sy + RC * 64 : &ring_d[1][0];
     int *ring_cw = WPB > 1 ? reinterpret_cast<int *>(ring_sy + 2 * RC * 64) : ring_i;
     const unsigned wblk = WPB > 1 ? blockIdx.x * WPB + wv : blockIdx.x;  // this wave's column group
+#ifdef MCL_UNI_STAMPS
+    const long long stamp_t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    long long stamp_t1 = 0;
+#endif
     const bool do_L = MODE == 0 || (MODE == 1 && (blockIdx.x & 1) == 0);  // (MODE 3 has its own schedule below)
     const bool do_R = MODE == 0 || (MODE == 1 && (blockIdx.x & 1) == 1);
     const long t = (long)(MODE == 1 ? blockIdx.x >> 1 : wblk) * 64 + lane;
@@ -816,6 +823,9 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64 * WPB) __attribute__((amdgpu_w
         }
     }
     if (UNI_DBG(8)) return;
+#ifdef MCL_UNI_STAMPS
+    stamp_t1 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     // emit, positions in lockstep over the wave (EB records per batch, the next batch in flight).
     // Left fit: chain from position split-1 downwards.
     constexpr int EB = 16;
@@ -880,6 +890,14 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64 * WPB) __attribute__((amdgpu_w
             }
         }
     }
+#ifdef MCL_UNI_STAMPS
+    if (MODE == 3 && lane == 0 && sc.stamps != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long *o = sc.stamps + (long)wblk * 8;
+        o[0] = stamp_t0, o[1] = (long long)__builtin_amdgcn_s_memrealtime(), o[4] = stamp_t1;
+        o[2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4), o[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
 }
 
 // =========================================================================================================
@@ -898,6 +916,14 @@ extern "C" int mcl_uni_dbg_counters(unsigned long long *out16) {  // [0..8) even
     return hipMemset(uni_dbg_ctr(), 0, 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
 #endif
+// Round 6, per-wave stamps of a config-5 launch (tools/uni_stamps.py, profiles/r6_uni_stamps.txt): 4096 waves on 2048 slots, every
+// SIMD runs exactly four of them two at a time; a wave takes 2.2 ... 4.2 ms (mean 3.1-3.2) and the launch 7.5-7.7 ms where twice
+// the mean would be 6.3: 16 % of the slot time is idle - the second workgroup of a CU slot starts when the slowest of the first
+// four waves is done, and the launch ends with its slowest CU.  Measured and dropped: launching the column groups longest-first
+// (durations of the previous launch, ranked on the device: k_uni_order) - the CUs end closer together (p10-p90 of their last ends
+// 423 -> 228 us) but a wave's duration follows its neighbours as much as its data (the same group one iteration apart: correlation
+// 0.94 in index order, 0.47 reordered), the waves take 3 % longer out of their memory order, and the launch is 2 % SLOWER
+// (98.1-99.2 against 96.3-96.4 ms per config-5 iteration, same box).
 static UniScratch uni_scratch(mcl_context *c) {
     const int64_t maxrows = std::max<int64_t>(c->N, std::max<int64_t>(c->I, c->K));
     const int64_t n1 = (maxrows + std::max<int64_t>(c->I, 1)) * c->r;
@@ -906,6 +932,9 @@ static UniScratch uni_scratch(mcl_context *c) {
     s.lvL = d, s.lvR = d + n1, s.eL = d + 2 * n1, s.eR = d + 3 * n1;
     s.spL = d + 4 * n1, s.spR = d + 7 * n1;  // 3 n1 doubles each
     s.sink = c->uni_sink;
+#ifdef MCL_UNI_STAMPS
+    s.stamps = c->pf2_xmin ? reinterpret_cast<long long *>(c->pf2_xmin + c->I) : nullptr;
+#endif
     s.coop = c->sw.no_uni_coop ? 0 : 1;
 #ifdef MCL_UNI_DBG
     s.dbg = getenv("MCL_UNI_DBG") ? atoi(getenv("MCL_UNI_DBG")) : 0;
