@@ -102,12 +102,16 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
     const int wr_lo = HALF ? (((lane & 15) ^ hi) << 2) : ((lane & 15) << 2);
     const int wr_hi = HALF ? (hi * KW + (((lane & 31) >> 4) << 6)) : ((lane >> 4) << 6);
 
+    const long long wall_entry = (dbg & 64) ? (long long)wall_clock64() : 0;
     for (int e = threadIdx.x * 4; e < MS; e += 4 * NT)
         *reinterpret_cast<f32x4 *>(Cs + e) = *reinterpret_cast<const f32x4 *>(Cfrag + e);
     __syncthreads();
 
-    long long cyc[6] = {0, 0, 0, 0, 0, 0};  // (dbg & 32): cycles per section, per wave; [5] = 100 MHz wall ticks
-    const long long wall0 = (dbg & 32) ? (long long)wall_clock64() : 0;
+    // (dbg & 32): cycles per section, per wave; [5] = 100 MHz wall ticks.  (dbg & 64), tools/sweep_stamps.py: [0] entry, [1] start of
+    // the block loop, [2] end (absolute 100 MHz ticks), [3] HW_ID, [4] XCC_ID
+    long long cyc[6] = {0, 0, 0, 0, 0, 0};
+    const long long wall0 = (dbg & (32 | 64)) ? (long long)wall_clock64() : 0;
+    const long long core0 = (dbg & 64) ? (long long)__builtin_readcyclecounter() : 0;  // (dbg & 64): [5] = core clock cycles of the block loop
     auto tick = [&](int sec, long long &t0) {
         if (dbg & 32) {
             const long long t1 = __builtin_readcyclecounter();
@@ -645,7 +649,12 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(const float *__restrict__ X, 
     }
 
     if (dbg & 32) cyc[5] = (long long)wall_clock64() - wall0;
-    if ((dbg & 32) && lane == 0) {
+    if (dbg & 64) {
+        cyc[0] = wall_entry, cyc[1] = wall0, cyc[2] = (long long)wall_clock64();
+        cyc[5] = (long long)__builtin_readcyclecounter() - core0;
+        cyc[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4), cyc[4] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+    if ((dbg & (32 | 64)) && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) cyc_out[((long)blockIdx.x * NW + wave) * 6 + i] = cyc[i];
     }
