@@ -149,7 +149,7 @@ int64_t plan(mcl_context *c, char *base) {
     c->gl2_T = has_kind(c, MCL_PEN_GL2) ? b.take<double>(maxrows * r) : nullptr;
     if (has_kind(c, MCL_PEN_UNIMODAL)) {
         c->uni_f64 = b.take<double>(10 * (maxrows + std::max<int64_t>(I, 1)) * r);
-        c->uni_sink = b.take<float>(2 * 64 * ((std::max<int64_t>(I, 1) * r + 63) / 64));
+        c->uni_sink = b.take<float>(2 * 64 * ((std::max<int64_t>(I, 1) * r + 63) / 64 + 3));  // (+3: the spare waves of the last four-wave workgroup)
     } else {
         c->uni_f64 = nullptr;
         c->uni_sink = nullptr;

@@ -59,9 +59,11 @@ def test_unimodal_kernel_forms_agree_with_oracle(shape, nonneg, data):
     B0, U0 = eng.B.clone(), eng.regs[1][0].dual.clone()
     Y = (B0 + U0).cpu().numpy().astype(np.float64)  # the fp32 sum the kernels form, as exact doubles
     want = np.concatenate([orc.unimodal_columns(Y[row_ptr[i]: row_ptr[i + 1]], nonneg) for i in range(len(J))])
-    saved = {k: os.environ.get(k) for k in ("MCL_UNI_SPLIT", "MCL_UNI_NOPRUNE")}
+    saved = {k: os.environ.get(k) for k in ("MCL_UNI_SPLIT", "MCL_UNI_NOPRUNE", "MCL_UNI_WPB")}
     try:
-        for env in ({"MCL_UNI_SPLIT": "0"}, {"MCL_UNI_SPLIT": "0", "MCL_UNI_NOPRUNE": "1"}, {"MCL_UNI_SPLIT": "1"}):
+        # (the throughput form runs four independent waves per workgroup since round 6; MCL_UNI_WPB=1: the one-wave workgroups)
+        for env in ({"MCL_UNI_SPLIT": "0"}, {"MCL_UNI_SPLIT": "0", "MCL_UNI_WPB": "1"}, {"MCL_UNI_SPLIT": "0", "MCL_UNI_NOPRUNE": "1"},
+                    {"MCL_UNI_SPLIT": "1"}):
             for k in saved:
                 os.environ.pop(k, None)
             os.environ.update(env)
