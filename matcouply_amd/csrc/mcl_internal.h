@@ -231,6 +231,7 @@ struct mcl_context {
     double *gl2_T = nullptr;    // [max rows, r] fp64: U^T Y of the GeneralizedL2 prox / U^T F of its value
     double *colsq = nullptr;    // [max(I,1), r]   per-slab column sums of squares (L2Ball)
     double *uni_f64 = nullptr;  // unimodal regression scratch: 10 fp64 arrays of (rows + slabs) * r
+    int uni_attr_set[5] = {0, 0, 0, 0, 0};  // dynamic-LDS attribute of the multi-wave unimodal kernels on this context's device
     float *uni_sink = nullptr;  // two floats per lane of the unimodal kernels: where predicated-off stores of the emit loops go
     double *pf2_S = nullptr;    // [I, r, r]  Y_i^T Y_i (fp64)
     float *pf2_T = nullptr;     // [I, r, r]  P_i = Y_i T_i

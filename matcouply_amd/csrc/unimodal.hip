@@ -974,7 +974,7 @@ int mcl_launch_unimodal(mcl_context *c, const int *ext, int n_slabs, float *F, c
         // waves per workgroup: 4 (see the kernel), MCL_UNI_WPB = 1 / 2 / 4 for the A/B; the padded debug launches keep the one-wave form
         int wpb = c->sw.uni_wpb > 0 ? c->sw.uni_wpb : 4;
         if (pad != 0 || (wpb != 2 && wpb != 4)) wpb = 1;
-        static int attr_set[5] = {0, 0, 0, 0, 0};  // 0: not tried, 1: set, -1: refused
+        int (&attr_set)[5] = c->uni_attr_set;  // per context (= per device): 0 not tried, 1 set, -1 refused
         if (wpb > 1 && attr_set[wpb] == 0) {
             const void *fn = wpb == 4 ? reinterpret_cast<const void *>(k_slab_unimodal_v4<3, 4>) : reinterpret_cast<const void *>(k_slab_unimodal_v4<3, 2>);
             attr_set[wpb] = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpb * wave_lds)) == hipSuccess ? 1 : -1;
