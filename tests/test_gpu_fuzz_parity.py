@@ -341,3 +341,36 @@ def test_exact_arithmetic_can_be_forced_on_a_larger_problem():
     assert worst["exact"] < 1e-5 and worst["exact"] < worst["fast"], worst
     # round 6: the DEFAULT call finds the ill-conditioned penalty-free modes itself (mcl_condition_probe) and is inside the bar
     assert worst["auto"] < 1e-5, worst
+
+
+# Round 6: the PARAFAC2 Newton-Schulz kernel of rank <= 16 runs FOUR slabs per workgroup (one wave each; a fifth wave takes the
+# L2-ball column sums of the four).  Slab counts that leave spare waves in the last workgroup, ranks below and at the tile width,
+# slabs shorter than a tile and longer than sixteen tiles (the column sums' second batch), on the FAST kernels.
+@pytest.mark.parametrize("I,r", [(1, 3), (2, 16), (3, 5), (5, 16), (6, 9), (7, 16), (9, 12)])
+def test_four_slab_newton_schulz_workgroups(I, r):
+    from oracle import aoadmm_oracle as orc
+
+    rng = np.random.RandomState(700 + 31 * I + r)
+    J = rng.randint(max(r, 20), 400, size=I)
+    J[rng.randint(I)] = 1100  # more than sixteen 64-row tiles
+    if I > 1:
+        J[(int(np.argmax(J)) + 1) % I] = max(r, 17)  # a slab inside one tile
+    K = 96
+    regs = [[{"kind": "nn"}], [{"kind": "parafac2"}, {"kind": "l2ball", "norm_bound": 1.2}], [{"kind": "nn"}]]
+    X, row_ptr = orc.synthetic_problem(I, J, K, r, seed=I + r, dtype=np.float64)
+    X = X.astype(np.float32).astype(np.float64)
+    st = orc.random_state_for(X, row_ptr, r, regs, seed=I + r + 1, l2=[0.0, 0.0, 0.0], inner_n_iter_max=5,
+                              feasibility_penalty_scale=1.0, constant_A=False, constant_B=False)
+    old = os.environ.get("MCL_EXACT")
+    os.environ["MCL_EXACT"] = "0"  # the kernels of the BASELINE configurations (the problem is small enough for the exact mode)
+    try:
+        cmf, admm, diag, res = _run_both(st, 2)
+    finally:
+        os.environ.pop("MCL_EXACT", None)
+        if old is not None:
+            os.environ["MCL_EXACT"] = old
+    # (1e-4: small problems on the fp32 kernels are what the exact-products mode exists for - DESIGN.md section 4; a slab or a
+    # column sum taken from the wrong place shows as O(0.1))
+    errs = _compare(cmf, admm, diag, st, res, 1e-4, 1e-4)
+    print(I, r, [int(j) for j in J], "worst factor / variable error %.1e" % max(v for k, v in errs.items() if k != "gaps"),
+          f"polar cond {res['polar_cond']:.0e}")
