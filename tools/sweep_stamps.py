@@ -19,6 +19,8 @@ for it in range(8):
 torch.cuda.synchronize()
 c = eng.internal(_engine.BUF_SWEEP_CYCLES).view(torch.int64).view(-1, 6).cpu().numpy()
 c = c[c[:, 2] > 0]
+if len(c) == 0:
+    sys.exit(f"no stamps: the instrumented twin exists for the K = 256 / rank <= 16 sweep only (variant {eng.kernel_variant(_engine.PROF_SWEEP)})")
 if len(sys.argv) > 2:
     np.savez_compressed(sys.argv[2], stamps=c)
 T0 = c[:, 0].min()
