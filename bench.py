@@ -247,7 +247,9 @@ def cpu_baseline(cfg, budget_s=15.0):
     t_probe = timed(I_probe, 1, "probe")
     per_slab = t_probe / I_probe
     I_s = int(min(I, max(I_probe, budget_s / 3.0 / max(per_slab, 1e-9))))
-    iters = 2
+    # about two thirds of the budget in timed iterations (the brief: a bounded sample of roughly 10 s or more of CPU work): 2 of
+    # them when one iteration of the sample already takes a third of the budget (configs 4 / 5), up to 20 on the small ones
+    iters = int(max(2, min(20, (budget_s * 0.67) / max(per_slab * I_s, 1e-9))))
     t_iter = timed(I_s, iters, "sample")
     value = 1.0 / (t_iter * I / I_s)
     survey = {"c3": 0.41, "c2": 7.5}.get(cfg.get("name"))
