@@ -1390,6 +1390,11 @@ __global__ __launch_bounds__(64 * NsShape<NB>::SPW + ((TILES && NB == 1) ? 64 : 
         const float est = xmin_est[slab];
         flo = est > 0.f ? fminf(0.5f * est, 1.f) : 1e-2f;
     }
+    // (the interval, the residual and everything decided from them are the same in all lanes: kept in scalar registers, so that the
+    // branches of a step are scalar branches and not the exec-mask sequences of a divergent one)
+    // (rank <= 16 only: the rank-32 kernel sits at its 256-register budget and the extra scalar traffic costs it spills)
+    auto uni_f = [](float v) { return NB == 1 ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))) : v; };
+    flo = uni_f(flo);
     for (int it = 0; it < 100; ++it) {
         it_used = it;
         double ca = 1.5, cb = 0.5;
@@ -1397,15 +1402,19 @@ __global__ __launch_bounds__(64 * NsShape<NB>::SPW + ((TILES && NB == 1) ? 64 : 
         if (scaled && (1.f - flo) >= 1e-3f) {
             // (the hardware's own square root and reciprocal - one instruction each, 1 ulp - where the library forms spent ~45
             // instructions per step on correct rounding and denormals: these coefficients only steer the speed of convergence)
-            const float ss = fhi * fhi + fhi * flo + flo * flo, sq = __builtin_amdgcn_sqrtf(ss * (1.f / 3.f));
-            const float fb = 2.f * __builtin_amdgcn_rcpf((2.f / 3.f) * ss * sq + flo * fhi * (flo + fhi));
+            // (rank <= 16, where the step's latency is the kernel's; the rank-32 kernel keeps the forms its register allocation was
+            // tuned with)
+            const float ss = fhi * fhi + fhi * flo + flo * flo;
+            const float sq = NB == 1 ? __builtin_amdgcn_sqrtf(ss * (1.f / 3.f)) : __builtin_sqrtf(ss * (1.f / 3.f));
+            const float den = (2.f / 3.f) * ss * sq + flo * fhi * (flo + fhi);
+            const float fb = NB == 1 ? 2.f * __builtin_amdgcn_rcpf(den) : 2.f / den;
             const float fa = fb * ss;
             const float e = (2.f / 3.f) * fa * sq - 1.f;
             ca = (double)fa, cb = (double)fb;
-            flo = 1.f - e, fhi = 1.f + e;
+            flo = uni_f(1.f - e), fhi = uni_f(1.f + e);
         } else if (scaled) {
             const float e = 1.f - flo;
-            flo = 1.f - 1.5f * e * e, fhi = 1.f;  // plain Newton-Schulz: x -> x (3 - x^2) / 2 <= 1, error 1.5 e^2
+            flo = uni_f(1.f - 1.5f * e * e), fhi = 1.f;  // plain Newton-Schulz: x -> x (3 - x^2) / 2 <= 1, error 1.5 e^2
         }
         mm_t<NB>(Zt, Y, P);             // P  = Z Y
         tr_lds<NB>(P, Pt, Ssm, q, c16);  // Pt = P^T
@@ -1424,6 +1433,8 @@ __global__ __launch_bounds__(64 * NsShape<NB>::SPW + ((TILES && NB == 1) ? 64 : 
                         res += d * d;
                     }
             res = wave_sum_d(res);
+            if constexpr (NB == 1)
+                res = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(res)), __builtin_amdgcn_readfirstlane(__double2loint(res)));
         }
 #pragma unroll
         for (int a = 0; a < NB; ++a)
@@ -1447,7 +1458,7 @@ __global__ __launch_bounds__(64 * NsShape<NB>::SPW + ((TILES && NB == 1) ? 64 : 
             // a lower bound that was too optimistic (an eigenvalue below the assumed lo): the prediction is ahead of the
             // iterate - fall back to measuring, i.e. keep the predicted interval no tighter than the certified one
             // (|1 - x^2| <= ||I - Z Y||_F for every eigenvalue x^2 of Z Y, so x >= 1 - ||I - Z Y||_F)
-            if (scaled) flo = fminf(flo, res < 1.0 ? 1.f - __builtin_amdgcn_sqrtf((float)res) : 0.1f);
+            if (scaled) flo = uni_f(fminf(flo, res < 1.0 ? 1.f - (NB == 1 ? __builtin_amdgcn_sqrtf((float)res) : __builtin_sqrtf((float)res)) : 0.1f));
         }
         mm_t<NB>(Yt, Tm, N1);            // Y  <- Y T
         mm_t<NB>(Tmt, Z, N3);            // Z  <- T Z
