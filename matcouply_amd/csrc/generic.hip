@@ -1196,6 +1196,13 @@ __global__ __launch_bounds__(64 * NsShape<NB>::SPW + ((TILES && NB == 1) ? 64 : 
     // (the column-sum wave has its own slabs below)
     const int slab = SPW == 1 ? (int)blockIdx.x : min((int)blockIdx.x * SPW + (wave < SPW ? wave : 0), ts.n_slabs - 1);
     auto &Ssm = Ssm_w[wave < SPW ? wave : 0];
+    // scratch of the LDS transposes.  Rank <= 16: an area of its own, so that S_i stays in LDS for the epilogue's T^T S (its re-read
+    // from memory was a round trip at the end of every slab's chain); rank 32 has no LDS to spare (8 workgroups per CU) and uses
+    // S_i's area once U1 has consumed it
+    __shared__ double Wsm_w[NB == 1 ? SPW : 1][NB == 1 ? 16 * 17 : 1];
+    double *Wtr;
+    if constexpr (NB == 1) Wtr = Wsm_w[wave < SPW ? wave : 0];
+    else Wtr = Ssm;
     auto &Dsm = Dsm_w[wave < SPW ? wave : 0];
     auto &Jsm = Jsm_w[(INK && wave < SPW) ? wave : 0];
     const int q = lane >> 4, c16 = lane & 15;
@@ -1345,7 +1352,7 @@ __global__ __launch_bounds__(64 * NsShape<NB>::SPW + ((TILES && NB == 1) ? 64 : 
             }
         }
     tr = wave_sum_d(tr);
-    tr_lds<NB>(G, Gt, Ssm, q, c16);  // G^T (S_i has been consumed by U1: its LDS copy is free; the fallbacks below read memory)
+    tr_lds<NB>(G, Gt, Wtr, q, c16);  // G^T (S_i has been consumed by U1: its LDS copy is free; the fallbacks below read memory)
     if (!(tr > 0.0)) {
         if (lane == 0) status[slab] = 1;
         if (INK) pf2_jacobi_slab(Jsm, Ss, Delta, rh, r, slab, lane, T, acc_out, T64, status, true);  // may flag the slab (2)
@@ -1417,7 +1424,7 @@ __global__ __launch_bounds__(64 * NsShape<NB>::SPW + ((TILES && NB == 1) ? 64 : 
             flo = uni_f(1.f - 1.5f * e * e), fhi = 1.f;  // plain Newton-Schulz: x -> x (3 - x^2) / 2 <= 1, error 1.5 e^2
         }
         mm_t<NB>(Zt, Y, P);             // P  = Z Y
-        tr_lds<NB>(P, Pt, Ssm, q, c16);  // Pt = P^T
+        tr_lds<NB>(P, Pt, Wtr, q, c16);  // Pt = P^T
         double res = 1.0;
         if (watch) {
             res = 0.0;
@@ -1462,8 +1469,8 @@ __global__ __launch_bounds__(64 * NsShape<NB>::SPW + ((TILES && NB == 1) ? 64 : 
         }
         mm_t<NB>(Yt, Tm, N1);            // Y  <- Y T
         mm_t<NB>(Tmt, Z, N3);            // Z  <- T Z
-        tr_lds<NB>(N1, N2, Ssm, q, c16);  // Yt <- Y^T
-        tr_lds<NB>(N3, N4, Ssm, q, c16);  // Zt <- Z^T
+        tr_lds<NB>(N1, N2, Wtr, q, c16);  // Yt <- Y^T
+        tr_lds<NB>(N3, N4, Wtr, q, c16);  // Zt <- Z^T
         Y = N1;
         Yt = N2;
         Z = N3;
@@ -1492,7 +1499,10 @@ __global__ __launch_bounds__(64 * NsShape<NB>::SPW + ((TILES && NB == 1) ? 64 : 
     }
     // S_i for the epilogue: from memory (this wave wrote it above when it summed the tiles; its LDS copy has been the scratch of
     // the transposes since)
-    auto Smem = [&](int i, int j) -> double { return (i < r && j < r) ? Ss[i * r + j] : 0.0; };
+    auto Smem = [&](int i, int j) -> double {
+        if constexpr (NB == 1 && TILES) return (i < r && j < r) ? Ssm[i * r + j] : 0.0;  // (still in LDS: see Wtr)
+        else return (i < r && j < r) ? Ss[i * r + j] : 0.0;
+    };
     const double wscale = 1.0 / sqrt(tr);  // W = Z / sqrt(tr)
     // T = Delta^T W  (A[i][k] = Delta[k][i];  B = W in D layout), then acc = rho T^T S (A = T^T: A[i][k] = T[k][i] = D layout of T)
     SymTiles<NB> Tt;
